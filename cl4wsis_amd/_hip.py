@@ -1,0 +1,98 @@
+"""ctypes binding of libcl4wsis_hip.so (the C ABI declared in include/cl4wsis.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcl4wsis_hip.so")
+
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("cin", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32),
+        ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+        ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32),
+        ("hout", C.c_int32), ("wout", C.c_int32),
+        ("in_ctot", C.c_int32), ("in_coff", C.c_int32),
+        ("out_ctot", C.c_int32), ("out_coff", C.c_int32),
+        ("act1", C.c_int32), ("slope1", C.c_float),
+        ("act2", C.c_int32), ("slope2", C.c_float),
+        ("precision", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_L = C.c_long
+
+# name -> argtypes; every function returns int (0 = ok). Mirrors include/cl4wsis.h.
+PROTOTYPES = {}
+
+
+def _decl(name, *argtypes):
+    PROTOTYPES[name] = list(argtypes)
+
+
+_decl("cl4_pack_conv_weight", _P, _P, _I, _I, _I, _I, _P)
+_decl("cl4_conv2d_fwd", C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P)
+_decl("cl4_conv2d_wgrad", C.POINTER(ConvDesc), _P, _P, _P, _P)
+_decl("cl4_bn_fold", _P, _P, _P, _P, _F, _P, _P, _I, _P)
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once). Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). cl4wsis_amd has no CPU or PyTorch fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.cl4_abi_version.restype = C.c_int
+    lib.cl4_last_error.restype = C.c_char_p
+    for name, args in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc == 0:
+        return
+    lib = load()
+    if rc < 0:
+        raise RuntimeError(f"{name}: invalid argument: {lib.cl4_last_error().decode()}")
+    raise RuntimeError(f"{name}: HIP launch failed with hipError_t={rc}")
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    check(rc, name)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). The tensor must be a contiguous CUDA tensor."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("cl4wsis_amd kernels need tensors resident in HBM (device tensor expected)")
+    if not t.is_contiguous():
+        raise RuntimeError("cl4wsis_amd kernels need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

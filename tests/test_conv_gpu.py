@@ -1,0 +1,105 @@
+"""GPU parity of the implicit-GEMM conv kernels (cl4_conv2d_fwd / cl4_conv2d_wgrad) against a
+plain PyTorch fp32 CPU reference of the same op (floating-point kernel: tolerance 1e-4 relative
+to the output scale; the north-star tolerance is 1e-3)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (n, cin, h, w, cout, k, stride, pad, dil) — the layer shapes of ResNet101 / DeepLabV3 / decoder at small size
+CASES = [
+    (2, 64, 17, 17, 256, 1, 1, 0, 1),      # bottleneck 1x1 expand
+    (2, 128, 33, 33, 128, 3, 2, 1, 1),     # strided 3x3
+    (1, 96, 33, 33, 160, 3, 1, 6, 6),      # ASPP dilation 6
+    (1, 64, 33, 33, 72, 3, 1, 18, 18),     # dilation 18: most taps out of bounds
+    (2, 3, 65, 65, 64, 7, 2, 3, 1),        # stem
+    (2, 256, 9, 9, 21, 1, 1, 0, 1),        # classifier, cout < 32
+    (1, 37, 13, 11, 50, 3, 1, 1, 1),       # ragged everything
+    (1, 5, 33, 33, 5, 1, 1, 0, 1),         # PeakGenerator 5->5
+    (3, 512, 5, 5, 130, 1, 1, 0, 1),       # cout just above one M tile
+]
+
+
+def _rel_err(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_plain(gpu, case):
+    from cl4wsis_amd import ops
+    n, cin, h, w, cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    ref = F.conv2d(x.double(), wt.double(), stride=s, padding=p, dilation=d).float()
+    y = ops.conv2d(x.to(gpu), ops.pack_conv_weight(wt.to(gpu)), k, stride=s, pad=p, dil=d)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert _rel_err(y.cpu(), ref) < 1e-5
+
+
+def test_conv_fwd_fused_epilogue(gpu):
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(7)
+    n, cin, h, w, cout = 2, 48, 19, 19, 80
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    mean, var = torch.randn(cout, generator=g), torch.rand(cout, generator=g) + 0.2
+    pre = torch.randn(n, cout, h, w, generator=g)
+    post = torch.randn(n, cout, h, w, generator=g)
+    z = F.conv2d(x, wt, padding=1) + pre
+    z = F.leaky_relu(F.batch_norm(z, mean, var, gamma, beta, False, 0.0, 1e-5), 0.01)
+    ref = F.relu(z + post)
+    scale, shift = ops.bn_fold(gamma.to(gpu), beta.to(gpu), mean.to(gpu), var.to(gpu), 1e-5)
+    y = ops.conv2d(x.to(gpu), ops.pack_conv_weight(wt.to(gpu)), 3, pad=1, scale=scale, shift=shift,
+                   pre=pre.to(gpu), post=post.to(gpu), act1=ops.ACT_LEAKY, slope1=0.01, act2=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    assert _rel_err(y.cpu(), ref) < 1e-5
+
+
+def test_conv_channel_slices(gpu):
+    """Reading a channel slice of x and writing a channel slice of y (the torch.cat replacement)."""
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 40, 15, 15, generator=g)
+    w1 = torch.randn(24, 16, 1, 1, generator=g)
+    w2 = torch.randn(40, 16, 3, 3, generator=g)
+    ref = torch.cat([F.conv2d(x[:, 8:24], w1), F.conv2d(x[:, 8:24], w2, padding=2, dilation=2)], 1)
+    xd = x.to(gpu)
+    out = torch.full((2, 64, 15, 15), float("nan"), device=gpu)
+    ops.conv2d(xd, ops.pack_conv_weight(w1.to(gpu)), 1, in_coff=8, cin=16, out=out, out_coff=0)
+    ops.conv2d(xd, ops.pack_conv_weight(w2.to(gpu)), 3, pad=2, dil=2, in_coff=8, cin=16, out=out, out_coff=24)
+    torch.cuda.synchronize()
+    assert _rel_err(out.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("case", [
+    (2, 64, 17, 17, 256, 1, 1, 0, 1),
+    (2, 96, 33, 33, 160, 3, 1, 3, 3),
+    (3, 40, 21, 19, 50, 3, 1, 1, 1),
+    (2, 128, 33, 33, 2, 1, 1, 0, 1),
+])
+def test_conv_wgrad(gpu, case):
+    from cl4wsis_amd import ops
+    n, cin, h, w, cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
+    wt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, wt, stride=s, padding=p, dilation=d)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    ref = wt.grad.float()
+    dw = torch.zeros(cout, cin, k, k, device=gpu)
+    ops.conv2d_wgrad(x.float().to(gpu), dy.float().to(gpu), dw, k, stride=s, pad=p, dil=d)
+    torch.cuda.synchronize()
+    assert _rel_err(dw.cpu(), ref) < 1e-5
+
+
+def test_bad_arguments_raise(gpu):
+    from cl4wsis_amd import ops
+    x = torch.zeros(1, 4, 8, 8, device=gpu)
+    wp = torch.zeros(4 * 25, 8, device=gpu)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x, wp, 5, pad=2)  # 5x5 dense conv is not part of the path
