@@ -45,6 +45,24 @@ _decl("cl4_conv2d_fwd", C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P)
 _decl("cl4_conv2d_wgrad", C.POINTER(ConvDesc), _P, _P, _P, _P)
 _decl("cl4_bn_fold", _P, _P, _P, _P, _F, _P, _P, _I, _P)
 
+_decl("cl4_maxpool3x3s2", _P, _P, _L, _I, _I, _I, _I, _P)
+_decl("cl4_avgpool_s1", _P, _P, _L, _I, _I, _I, _I, _P)
+_decl("cl4_replicate_pad", _P, _P, _L, _I, _I, _I, _I, _I, _I, _P)
+_decl("cl4_global_mean", _P, _P, _L, _I, _P)
+_decl("cl4_resize_bilinear_fwd", _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P)
+_decl("cl4_resize_bilinear_bwd", _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P)
+_decl("cl4_flip_w", _P, _P, _L, _I, _P)
+_decl("cl4_axpy", _P, _P, _F, _L, _P)
+_decl("cl4_copy_channels", _P, _P, _I, _I, _L, _I, _I, _I, _I, _P)
+_decl("cl4_bn_train_stats", _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, C.c_size_t, _P)
+_decl("cl4_bn_apply", _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _F, _P)
+_decl("cl4_bn_train_bwd", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P, _F, _P, _P, _P, C.c_size_t, _P)
+_decl("cl4_relu_bwd", _P, _P, _P, _L, _P)
+_decl("cl4_bias_grad", _P, _P, _I, _I, _I, _I, _I, _P)
+_decl("cl4_dropout_mask", _P, _L, C.c_uint64, _F, _P)
+_decl("cl4_dwconv5_fwd", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P)
+_decl("cl4_dwconv5_wgrad", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P)
+
 _lib = None
 
 
@@ -60,6 +78,8 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.cl4_abi_version.restype = C.c_int
     lib.cl4_last_error.restype = C.c_char_p
+    lib.cl4_bn_workspace_bytes.restype = C.c_size_t
+    lib.cl4_bn_workspace_bytes.argtypes = [C.c_int]
     for name, args in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = args

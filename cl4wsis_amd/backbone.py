@@ -1,0 +1,107 @@
+"""ResNet-{50,101} body (output stride 8/16, five stage outputs) on the HIP conv kernels.
+
+Mirrors the state-dict layout of the reference (models/resnet.py:11-123, modules/residual.py:7-97):
+``mod1.conv1 / mod1.bn1``, ``mod{2..5}.block{i}.convs.{conv1,bn1,conv2,bn2,conv3,bn3}``,
+``.proj_conv / .proj_bn``. Every conv + InPlaceABN + (residual add + leaky-ReLU) group is ONE
+kernel launch (fused epilogue of cl4_conv2d_fwd).
+"""
+from collections import OrderedDict
+
+import torch.nn as nn
+
+from . import ops
+from .nn import ABN, conv_abn
+
+
+class _Holder(nn.Module):
+    """A named container of sub-modules (keeps state_dict prefixes; has no forward of its own)."""
+
+    def __init__(self, mods=None):
+        super().__init__()
+        for k, v in (mods or {}).items():
+            self.add_module(k, v)
+
+
+class ResidualBlock(nn.Module):
+    """Bottleneck residual block — modules/residual.py:31-97."""
+
+    def __init__(self, in_channels, channels, stride=1, dilation=1, norm_act=ABN):
+        super().__init__()
+        if len(channels) != 3:
+            raise ValueError("only bottleneck blocks (three channel counts) are on the CL4WSIS path")
+        bn3 = norm_act(channels[2])
+        bn3.activation = "identity"
+        self.convs = _Holder(OrderedDict([
+            ("conv1", nn.Conv2d(in_channels, channels[0], 1, bias=False)),
+            ("bn1", norm_act(channels[0])),
+            ("conv2", nn.Conv2d(channels[0], channels[1], 3, stride=stride, padding=dilation, dilation=dilation, bias=False)),
+            ("bn2", norm_act(channels[1])),
+            ("conv3", nn.Conv2d(channels[1], channels[2], 1, bias=False)),
+            ("bn3", bn3),
+        ]))
+        if stride != 1 or in_channels != channels[-1]:
+            self.proj_conv = nn.Conv2d(in_channels, channels[-1], 1, stride=stride, bias=False)
+            self.proj_bn = norm_act(channels[-1])
+            self.proj_bn.activation = "identity"
+
+    def forward(self, x):
+        if self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("train-mode InPlaceABN (step 0 / phase 1) is not built yet; phase 2 freezes the body")
+        c = self.convs
+        r = conv_abn(x, self.proj_conv, self.proj_bn) if hasattr(self, "proj_conv") else x
+        y = conv_abn(x, c.conv1, c.bn1)
+        y = conv_abn(y, c.conv2, c.bn2)
+        act, slope = c.bn1.act_code()
+        return conv_abn(y, c.conv3, c.bn3, post=r, act2=act, slope2=slope)
+
+
+class ResNet(nn.Module):
+    def __init__(self, structure, norm_act=ABN, output_stride=16, keep_outputs=False):
+        super().__init__()
+        if len(structure) != 4:
+            raise ValueError("Expected a structure with four values")
+        if output_stride not in (8, 16):
+            raise ValueError("Output stride must be 8 or 16")
+        self.structure = structure
+        self.keep_outputs = keep_outputs
+        self.dilation = [1, 1, 1, 2] if output_stride == 16 else [1, 1, 2, 4]
+        self.mod1 = _Holder(OrderedDict([
+            ("conv1", nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)),
+            ("bn1", norm_act(64)),
+        ]))
+        in_ch, channels = 64, (64, 64, 256)
+        for mod_id, num in enumerate(structure):
+            blocks = OrderedDict()
+            d = self.dilation[mod_id]
+            for b in range(num):
+                s = 2 if (d == 1 and b == 0 and mod_id > 0) else 1
+                blocks[f"block{b + 1}"] = ResidualBlock(in_ch, channels, stride=s, dilation=d, norm_act=norm_act)
+                in_ch = channels[-1]
+            self.add_module(f"mod{mod_id + 2}", nn.Sequential(blocks))
+            channels = tuple(c * 2 for c in channels)
+        self.out_channels = in_ch
+
+    def forward(self, x):
+        y = conv_abn(x, self.mod1.conv1, self.mod1.bn1)
+        outs = [ops.maxpool3x3s2(y)]
+        for m in (self.mod2, self.mod3, self.mod4, self.mod5):
+            y = outs[-1]
+            for blk in m:
+                y = blk(y)
+            outs.append(y)
+        return outs if self.keep_outputs else outs[-1]
+
+
+_NETS = {"50": [3, 4, 6, 3], "101": [3, 4, 23, 3], "152": [3, 8, 36, 3]}
+
+
+def net_resnet50(**kw):
+    return ResNet(_NETS["50"], **kw)
+
+
+def net_resnet101(**kw):
+    return ResNet(_NETS["101"], **kw)
+
+
+def net_resnet152(**kw):
+    return ResNet(_NETS["152"], **kw)

@@ -1,0 +1,125 @@
+// 5x5 depthwise convolution (stride 1, pad 2) of the Panoptic-DeepLab fuse / head blocks
+// (modules/panoptic_deeplab.py:32-47, basic_conv with groups=in_planes) — forward, input gradient
+// and weight gradient. Per-channel K=25: HBM/LDS-bound, no MFMA. A workgroup owns a 32x32 output
+// tile of one (n, c) plane; the 36x36 halo tile is staged through LDS once and every lane reads its
+// 5x5 window from LDS (row stride 37 floats: conflict-free for the 32-lane row reads).
+#include "common.h"
+
+namespace {
+
+constexpr int T = 32;        // output tile edge
+constexpr int R = 2;         // halo
+constexpr int TS = T + 2 * R;  // 36
+constexpr int LDT = TS + 1;    // 37
+
+struct DwArgs {
+  int n, c, h, w;
+  int x_ctot, x_coff, y_ctot, y_coff;
+  int flip;  // 1: correlate with the 180-degree rotated kernel (input gradient)
+};
+
+__device__ __forceinline__ void stage_tile(float (*tile)[LDT], const float* __restrict__ xp, int h, int w, int y0, int x0) {
+  for (int i = threadIdx.x; i < TS * TS; i += blockDim.x) {
+    int ty = i / TS, tx = i - ty * TS;
+    int iy = y0 - R + ty, ix = x0 - R + tx;
+    tile[ty][tx] = ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? xp[(long)iy * w + ix] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                      float* __restrict__ y, DwArgs a) {
+  __shared__ float tile[TS][LDT];
+  __shared__ float wk[25];
+  const int tiles_x = (a.w + T - 1) / T;
+  const int ty0 = (blockIdx.x / tiles_x) * T, tx0 = (blockIdx.x % tiles_x) * T;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* xp = x + ((long)n * a.x_ctot + a.x_coff + c) * a.h * a.w;
+  if (threadIdx.x < 25) wk[threadIdx.x] = wgt[c * 25 + (a.flip ? 24 - threadIdx.x : threadIdx.x)];
+  stage_tile(tile, xp, a.h, a.w, ty0, tx0);
+  __syncthreads();
+  const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;  // 8 rows per pass
+  float* yp = y + ((long)n * a.y_ctot + a.y_coff + c) * a.h * a.w;
+#pragma unroll
+  for (int pass = 0; pass < T / 8; ++pass) {
+    int ly = ly0 + pass * 8;
+    int oy = ty0 + ly, ox = tx0 + lx;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) acc = fmaf(wk[ky * 5 + kx], tile[ly + ky][lx + kx], acc);
+    if (oy < a.h && ox < a.w) yp[(long)oy * a.w + ox] = acc;
+  }
+}
+
+// dw[c][ky][kx] += sum_{n,y,x} dy[n,c,y,x] * x[n,c,y+ky-2,x+kx-2]. One workgroup per (tile, c, n):
+// 25 per-lane partial sums -> wave reduction -> one atomic per tap per workgroup.
+__global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ dw, DwArgs a) {
+  __shared__ float tile[TS][LDT];
+  __shared__ float red[4][25];
+  const int tiles_x = (a.w + T - 1) / T;
+  const int ty0 = (blockIdx.x / tiles_x) * T, tx0 = (blockIdx.x % tiles_x) * T;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* xp = x + ((long)n * a.x_ctot + a.x_coff + c) * a.h * a.w;
+  const float* dp = dy + ((long)n * a.y_ctot + a.y_coff + c) * a.h * a.w;
+  stage_tile(tile, xp, a.h, a.w, ty0, tx0);
+  __syncthreads();
+  const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;
+  float acc[25];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) acc[t] = 0.f;
+#pragma unroll
+  for (int pass = 0; pass < T / 8; ++pass) {
+    int ly = ly0 + pass * 8;
+    int oy = ty0 + ly, ox = tx0 + lx;
+    float g = (oy < a.h && ox < a.w) ? dp[(long)oy * a.w + ox] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) acc[ky * 5 + kx] = fmaf(g, tile[ly + ky][lx + kx], acc[ky * 5 + kx]);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int t = 0; t < 25; ++t) {
+    float s = cl4::wave_sum(acc[t]);
+    if (lane == 0) red[wave][t] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 25) {
+    float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(&dw[c * 25 + threadIdx.x], s);
+  }
+}
+
+int check(const DwArgs& a) {
+  CL4_REQUIRE(a.n > 0 && a.c > 0 && a.h > 0 && a.w > 0, "dwconv5: non-positive dims");
+  CL4_REQUIRE(a.n <= 65535 && a.c <= 65535, "dwconv5: n/c exceed grid limits");
+  CL4_REQUIRE(a.x_coff >= 0 && a.x_coff + a.c <= a.x_ctot && a.y_coff >= 0 && a.y_coff + a.c <= a.y_ctot,
+              "dwconv5: channel slice out of range");
+  return CL4_OK;
+}
+
+}  // namespace
+
+extern "C" int cl4_dwconv5_fwd(const float* x, const float* w, float* y, int n, int c, int h, int wd, int x_ctot, int x_coff,
+                               int y_ctot, int y_coff, int flip, void* stream) {
+  DwArgs a{n, c, h, wd, x_ctot, x_coff, y_ctot, y_coff, flip};
+  int rc = check(a);
+  if (rc) return rc;
+  CL4_REQUIRE(x && w && y, "dwconv5_fwd: null pointer");
+  dim3 g(cl4::cdiv(h, T) * cl4::cdiv(wd, T), c, n);
+  hipLaunchKernelGGL(dwconv5_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, w, y, a);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_dwconv5_wgrad(const float* x, const float* dy, float* dw, int n, int c, int h, int wd, int x_ctot,
+                                 int x_coff, int dy_ctot, int dy_coff, void* stream) {
+  DwArgs a{n, c, h, wd, x_ctot, x_coff, dy_ctot, dy_coff, 0};
+  int rc = check(a);
+  if (rc) return rc;
+  CL4_REQUIRE(x && dy && dw, "dwconv5_wgrad: null pointer");
+  dim3 g(cl4::cdiv(h, T) * cl4::cdiv(wd, T), c, n);
+  hipLaunchKernelGGL(dwconv5_wgrad_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, dy, dw, a);
+  return cl4::launch_status();
+}

@@ -1,0 +1,269 @@
+// Train-mode nn.BatchNorm2d (+ReLU) of the Panoptic-DeepLab instance decoder / heads
+// (modules/panoptic_deeplab.py:26-28,44-46,74-76,108-110,121-123,161-163) — forward statistics,
+// normalise+activation, and the backward reductions / input gradient. HBM-bound: every pass reads
+// the activation once with the pixel index on the lane; per-channel sums are kept in fp64 so the
+// single-pass variance is as accurate as PyTorch's two-pass one.
+#include "common.h"
+
+namespace {
+
+constexpr int SPLIT = 32;  // workgroups per channel for the statistics / backward reductions
+
+struct BnShape {
+  int n, c, hw, ctot, coff;  // x is a channel slice [coff, coff+c) of a tensor with ctot channels
+};
+
+__device__ __forceinline__ void block_reduce2(double& a, double& b) {
+  __shared__ double sa[4], sb[4];
+  a = cl4::wave_sum_d(a);
+  b = cl4::wave_sum_d(b);
+  if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; sb[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  a = sa[0] + sa[1] + sa[2] + sa[3];
+  b = sb[0] + sb[1] + sb[2] + sb[3];
+}
+
+// grid (c, SPLIT): partial[(c*SPLIT + s)*2 + {0,1}] = {sum x, sum x^2} over this block's share.
+__global__ void bn_stats_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, BnShape s) {
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const long per_c = (long)s.n * s.hw;
+  double a = 0.0, b = 0.0;
+  for (long i = (long)sp * blockDim.x + threadIdx.x; i < per_c; i += (long)SPLIT * blockDim.x) {
+    int n = i / s.hw;
+    int p = i - (long)n * s.hw;
+    float v = x[((long)n * s.ctot + s.coff + c) * s.hw + p];
+    a += (double)v;
+    b += (double)v * (double)v;
+  }
+  block_reduce2(a, b);
+  if (threadIdx.x == 0) {
+    partial[((long)c * SPLIT + sp) * 2 + 0] = a;
+    partial[((long)c * SPLIT + sp) * 2 + 1] = b;
+  }
+}
+
+// mean / biased var; running stats updated with the unbiased variance (PyTorch semantics, momentum m).
+__global__ void bn_stats_final_kernel(const double* __restrict__ partial, float* __restrict__ mean, float* __restrict__ var,
+                                      float* running_mean, float* running_var, float momentum, long count, int c) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < SPLIT; ++s) {
+    a += partial[((long)i * SPLIT + s) * 2 + 0];
+    b += partial[((long)i * SPLIT + s) * 2 + 1];
+  }
+  double m = a / (double)count;
+  double v = b / (double)count - m * m;
+  if (v < 0.0) v = 0.0;
+  mean[i] = (float)m;
+  var[i] = (float)v;
+  if (running_mean) {
+    double unb = count > 1 ? v * (double)count / (double)(count - 1) : v;
+    running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * (float)m;
+    running_var[i] = (1.f - momentum) * running_var[i] + momentum * (float)unb;
+  }
+}
+
+// y = act((x - mean) * rstd * gamma + beta); optional inverted-dropout mask (uint8 keep flags, scale 1/(1-p)).
+__global__ void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
+                                const float* __restrict__ var, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, int act, float slope, BnShape s, int y_ctot,
+                                int y_coff, const uint8_t* __restrict__ keep, float keep_scale) {
+  long total = (long)s.n * s.c * s.hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int p = i % s.hw;
+    long t = i / s.hw;
+    int c = t % s.c;
+    int n = t / s.c;
+    float rstd = 1.f / sqrtf(var[c] + eps);
+    float v = x[((long)n * s.ctot + s.coff + c) * s.hw + p];
+    v = (v - mean[c]) * rstd * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+    v = cl4::apply_act(v, act, slope);
+    if (keep) v = keep[i] ? v * keep_scale : 0.f;
+    y[((long)n * y_ctot + y_coff + c) * s.hw + p] = v;
+  }
+}
+
+// Backward reductions. dz = dy * keepscale * [z > 0] with z recomputed from x.
+//   partial = {sum dz, sum dz * xhat}
+__global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, double* __restrict__ partial,
+                                      const float* __restrict__ mean, const float* __restrict__ var,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
+                                      BnShape s, int dy_ctot, int dy_coff, const uint8_t* __restrict__ keep,
+                                      float keep_scale) {
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const long per_c = (long)s.n * s.hw;
+  const float mu = mean[c], rstd = 1.f / sqrtf(var[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+  double a = 0.0, b = 0.0;
+  for (long i = (long)sp * blockDim.x + threadIdx.x; i < per_c; i += (long)SPLIT * blockDim.x) {
+    int n = i / s.hw;
+    int p = i - (long)n * s.hw;
+    float xh = (x[((long)n * s.ctot + s.coff + c) * s.hw + p] - mu) * rstd;
+    float d = dy[((long)n * dy_ctot + dy_coff + c) * s.hw + p];
+    if (keep) d = keep[((long)n * s.c + c) * s.hw + p] ? d * keep_scale : 0.f;
+    if (act == CL4_ACT_RELU && !(xh * g + bb > 0.f)) d = 0.f;
+    a += (double)d;
+    b += (double)d * (double)xh;
+  }
+  block_reduce2(a, b);
+  if (threadIdx.x == 0) {
+    partial[((long)c * SPLIT + sp) * 2 + 0] = a;
+    partial[((long)c * SPLIT + sp) * 2 + 1] = b;
+  }
+}
+
+__global__ void bn_bwd_final_kernel(const double* __restrict__ partial, float* __restrict__ sum_dz, float* __restrict__ sum_dz_xh,
+                                    float* dgamma, float* dbeta, int c) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < SPLIT; ++s) {
+    a += partial[((long)i * SPLIT + s) * 2 + 0];
+    b += partial[((long)i * SPLIT + s) * 2 + 1];
+  }
+  sum_dz[i] = (float)a;
+  sum_dz_xh[i] = (float)b;
+  if (dgamma) dgamma[i] += (float)b;
+  if (dbeta) dbeta[i] += (float)a;
+}
+
+// dx = gamma * rstd * (dz - sum_dz/N - xhat * sum_dz_xh/N)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                    const float* __restrict__ mean, const float* __restrict__ var,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ sum_dz, const float* __restrict__ sum_dz_xh, float eps, int act,
+                                    BnShape s, int dy_ctot, int dy_coff, const uint8_t* __restrict__ keep, float keep_scale) {
+  long total = (long)s.n * s.c * s.hw;
+  const float invn = 1.f / (float)((long)s.n * s.hw);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int p = i % s.hw;
+    long t = i / s.hw;
+    int c = t % s.c;
+    int n = t / s.c;
+    float rstd = 1.f / sqrtf(var[c] + eps);
+    float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+    long xi = ((long)n * s.ctot + s.coff + c) * s.hw + p;
+    float xh = (x[xi] - mean[c]) * rstd;
+    float d = dy[((long)n * dy_ctot + dy_coff + c) * s.hw + p];
+    if (keep) d = keep[i] ? d * keep_scale : 0.f;
+    if (act == CL4_ACT_RELU && !(xh * g + bb > 0.f)) d = 0.f;
+    dx[xi] = g * rstd * (d - sum_dz[c] * invn - xh * sum_dz_xh[c] * invn);
+  }
+}
+
+// ReLU backward for layers without BN (ASPPPooling conv -> ReLU): dx = dy * [y > 0].
+__global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+// Per-channel sum over (n, hw) of dy -> bias gradient (accumulated). One workgroup per channel.
+__global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int n, int c, int hw, int ctot, int coff) {
+  __shared__ double part[4];
+  const int ch = blockIdx.x;
+  double a = 0.0;
+  const long per_c = (long)n * hw;
+  for (long i = threadIdx.x; i < per_c; i += blockDim.x) {
+    int nn = i / hw;
+    int p = i - (long)nn * hw;
+    a += (double)dy[((long)nn * ctot + coff + ch) * hw + p];
+  }
+  a = cl4::wave_sum_d(a);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) db[ch] += (float)(part[0] + part[1] + part[2] + part[3]);
+}
+
+// Counter-based keep mask for nn.Dropout(p): splitmix64 of (seed, element index).
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, uint64_t seed, float p) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    float u = (float)(z >> 40) * (1.f / 16777216.f);
+    keep[i] = u >= p ? 1 : 0;
+  }
+}
+
+int check_shape(const BnShape& s) {
+  CL4_REQUIRE(s.n > 0 && s.c > 0 && s.hw > 0, "bn: non-positive dims");
+  CL4_REQUIRE(s.coff >= 0 && s.coff + s.c <= s.ctot, "bn: channel slice out of range");
+  return CL4_OK;
+}
+
+}  // namespace
+
+extern "C" size_t cl4_bn_workspace_bytes(int c) { return (size_t)c * SPLIT * 2 * sizeof(double); }
+
+extern "C" int cl4_bn_train_stats(const float* x, int n, int c, int hw, int ctot, int coff, float* mean, float* var,
+                                  float* running_mean, float* running_var, float momentum, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  BnShape s{n, c, hw, ctot, coff};
+  int rc = check_shape(s);
+  if (rc) return rc;
+  CL4_REQUIRE(x && mean && var && workspace, "bn_train_stats: null pointer");
+  if (workspace_bytes < cl4_bn_workspace_bytes(c)) { cl4::set_error("bn_train_stats: workspace too small"); return CL4_ENOSPC; }
+  hipStream_t st = cl4::as_stream(stream);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, (double*)workspace, s);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)workspace, mean, var,
+                     running_mean, running_var, momentum, (long)n * hw, c);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_bn_apply(const float* x, float* y, int n, int c, int hw, int x_ctot, int x_coff, int y_ctot, int y_coff,
+                            const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act,
+                            float slope, const uint8_t* keep, float keep_scale, void* stream) {
+  BnShape s{n, c, hw, x_ctot, x_coff};
+  int rc = check_shape(s);
+  if (rc) return rc;
+  CL4_REQUIRE(x && y && mean && var, "bn_apply: null pointer");
+  CL4_REQUIRE(y_coff >= 0 && y_coff + c <= y_ctot, "bn_apply: output slice out of range");
+  long total = (long)n * c * hw;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, mean,
+                     var, gamma, beta, eps, act, slope, s, y_ctot, y_coff, keep, keep_scale);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_bn_train_bwd(const float* x, const float* dy, float* dx, int n, int c, int hw, int x_ctot, int x_coff,
+                                int dy_ctot, int dy_coff, const float* mean, const float* var, const float* gamma,
+                                const float* beta, float eps, int act, const uint8_t* keep, float keep_scale,
+                                float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+  BnShape s{n, c, hw, x_ctot, x_coff};
+  int rc = check_shape(s);
+  if (rc) return rc;
+  CL4_REQUIRE(x && dy && dx && mean && var && workspace, "bn_train_bwd: null pointer");
+  CL4_REQUIRE(dy_coff >= 0 && dy_coff + c <= dy_ctot, "bn_train_bwd: dy slice out of range");
+  size_t need = cl4_bn_workspace_bytes(c) + (size_t)2 * c * sizeof(float);
+  if (workspace_bytes < need) { cl4::set_error("bn_train_bwd: workspace too small"); return CL4_ENOSPC; }
+  double* partial = (double*)workspace;
+  float* sums = (float*)((char*)workspace + cl4_bn_workspace_bytes(c));
+  hipStream_t st = cl4::as_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
+                     s, dy_ctot, dy_coff, keep, keep_scale);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, sums + c,
+                     dgamma, dbeta, c);
+  long total = (long)n * c * hw;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, x, dy, dx, mean, var, gamma,
+                     beta, sums, sums + c, eps, act, s, dy_ctot, dy_coff, keep, keep_scale);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_relu_bwd(const float* y, const float* dy, float* dx, long n, void* stream) {
+  CL4_REQUIRE(y && dy && dx && n > 0, "relu_bwd: bad arguments");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), y, dy, dx, n);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_bias_grad(const float* dy, float* db, int n, int c, int hw, int ctot, int coff, void* stream) {
+  CL4_REQUIRE(dy && db && n > 0 && c > 0 && hw > 0 && coff >= 0 && coff + c <= ctot, "bias_grad: bad arguments");
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(c), dim3(256), 0, cl4::as_stream(stream), dy, db, n, c, hw, ctot, coff);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_dropout_mask(uint8_t* keep, long n, uint64_t seed, float p, void* stream) {
+  CL4_REQUIRE(keep && n > 0 && p >= 0.f && p < 1.f, "dropout_mask: bad arguments");
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), keep, n, seed, p);
+  return cl4::launch_status();
+}

@@ -1,0 +1,290 @@
+// HBM-bound spatial kernels of the backbone / heads: max-pool, box average pool, global mean,
+// replicate pad, bilinear resize (forward + deterministic gather backward), W-flip, axpy.
+// All tensors NCHW fp32; "planes" = n*c. One lane per output element with the fastest index
+// on the lane (coalesced), grid-stride loops sized by cl4::stream_grid.
+#include "common.h"
+
+namespace {
+
+// models/resnet.py:63 nn.MaxPool2d(3, stride=2, padding=1) (implicit -inf padding).
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int hin, int win,
+                                    int hout, int wout) {
+  long total = planes * hout * wout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int ox = i % wout;
+    long t = i / wout;
+    int oy = t % hout;
+    long pl = t / hout;
+    const float* xp = x + pl * hin * win;
+    float m = -INFINITY;
+    int iy0 = oy * 2 - 1, ix0 = ox * 2 - 1;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      int iy = iy0 + dy;
+      if ((unsigned)iy >= (unsigned)hin) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        int ix = ix0 + dx;
+        if ((unsigned)ix >= (unsigned)win) continue;
+        m = fmaxf(m, xp[iy * win + ix]);
+      }
+    }
+    y[i] = m;
+  }
+}
+
+// modules/deeplab.py:87 avg_pool2d(x, (kh,kw), stride=1): one workgroup per plane, the plane is staged
+// in LDS once and every output window is summed from LDS (planes here are <= 65x65).
+__global__ void avgpool_s1_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int kh, int kw) {
+  extern __shared__ float tile[];
+  const long pl = blockIdx.x;
+  const float* xp = x + pl * h * w;
+  for (int i = threadIdx.x; i < h * w; i += blockDim.x) tile[i] = xp[i];
+  __syncthreads();
+  const int ho = h - kh + 1, wo = w - kw + 1;
+  const float inv = 1.f / (float)(kh * kw);
+  // one wave per output window: lanes stride over the window, wave-sum at the end
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int o = wave; o < ho * wo; o += nw) {
+    int oy = o / wo, ox = o - oy * wo;
+    float s = 0.f;
+    for (int t = lane; t < kh * kw; t += 64) {
+      int dy = t / kw, dx = t - dy * kw;
+      s += tile[(oy + dy) * w + ox + dx];
+    }
+    s = cl4::wave_sum(s);
+    if (lane == 0) y[pl * ho * wo + o] = s * inv;
+  }
+}
+
+// F.pad(mode="replicate") — modules/deeplab.py:88.
+__global__ void replicate_pad_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int hin, int win,
+                                     int pad_t, int pad_l, int hout, int wout) {
+  long total = planes * hout * wout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int ox = i % wout;
+    long t = i / wout;
+    int oy = t % hout;
+    long pl = t / hout;
+    int iy = min(max(oy - pad_t, 0), hin - 1), ix = min(max(ox - pad_l, 0), win - 1);
+    y[i] = x[pl * hin * win + iy * win + ix];
+  }
+}
+
+// Global mean over H*W per plane (AdaptiveAvgPool2d(1), modules/panoptic_deeplab.py:84; deeplab.py:75).
+__global__ void global_mean_kernel(const float* __restrict__ x, float* __restrict__ y, int hw) {
+  __shared__ float part[4];
+  const long pl = blockIdx.x;
+  const float* xp = x + pl * hw;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) s += xp[i];
+  s = cl4::wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) y[pl] = (part[0] + part[1] + part[2] + part[3]) / (float)hw;
+}
+
+// PyTorch's bilinear source index (upsample_bilinear2d): align_corners=True: src = dst*(in-1)/(out-1);
+// align_corners=False: src = max((dst+0.5)*in/out - 0.5, 0). Returns i0, i1 and the weight of i1.
+__device__ __forceinline__ void src_index(int dst, float scale, int align, int in_size, int& i0, int& i1, float& l1) {
+  float src;
+  if (align) {
+    src = scale * (float)dst;
+  } else {
+    src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+__host__ __device__ inline float resize_scale(int in_size, int out_size, int align) {
+  if (align) return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+  return (float)in_size / (float)out_size;
+}
+
+struct ResizeArgs {
+  int n, c, hin, win, hout, wout, align;
+  int in_ctot, in_coff, out_ctot, out_coff;
+  float sy, sx;
+};
+
+__global__ void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, ResizeArgs a) {
+  long total = (long)a.n * a.c * a.hout * a.wout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int ox = i % a.wout;
+    long t = i / a.wout;
+    int oy = t % a.hout;
+    t /= a.hout;
+    int c = t % a.c;
+    int n = t / a.c;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(oy, a.sy, a.align, a.hin, y0, y1, ly);
+    src_index(ox, a.sx, a.align, a.win, x0, x1, lx);
+    const float* xp = x + ((long)n * a.in_ctot + a.in_coff + c) * a.hin * a.win;
+    float hy = 1.f - ly, hx = 1.f - lx;
+    float v = hy * (hx * xp[y0 * a.win + x0] + lx * xp[y0 * a.win + x1]) +
+              ly * (hx * xp[y1 * a.win + x0] + lx * xp[y1 * a.win + x1]);
+    y[(((long)n * a.out_ctot + a.out_coff + c) * a.hout + oy) * a.wout + ox] = v;
+  }
+}
+
+// Backward of the resize as a deterministic gather: input pixel (iy,ix) sums the output pixels whose
+// forward footprint touched it. The candidate output range is bounded from the scale and each
+// candidate recomputes the forward's own (i0,i1,l1), so forward and backward can never disagree.
+__global__ void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, ResizeArgs a, int accumulate) {
+  long total = (long)a.n * a.c * a.hin * a.win;
+  const float ry = a.sy > 0.f ? 1.f / a.sy : 0.f, rx = a.sx > 0.f ? 1.f / a.sx : 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int ix = i % a.win;
+    long t = i / a.win;
+    int iy = t % a.hin;
+    t /= a.hin;
+    int c = t % a.c;
+    int n = t / a.c;
+    // outputs with src in (iy-1, iy+1): dst in ((iy-1)/s - 1, (iy+1)/s + 1) (covers both align modes)
+    int oy_lo = max(0, (int)floorf(((float)iy - 1.f) * ry) - 1), oy_hi = min(a.hout - 1, (int)ceilf(((float)iy + 1.f) * ry) + 1);
+    int ox_lo = max(0, (int)floorf(((float)ix - 1.f) * rx) - 1), ox_hi = min(a.wout - 1, (int)ceilf(((float)ix + 1.f) * rx) + 1);
+    if (a.sy == 0.f) { oy_lo = 0; oy_hi = a.hout - 1; }
+    if (a.sx == 0.f) { ox_lo = 0; ox_hi = a.wout - 1; }
+    const float* dyp = dy + ((long)n * a.out_ctot + a.out_coff + c) * a.hout * a.wout;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float ly;
+      src_index(oy, a.sy, a.align, a.hin, y0, y1, ly);
+      float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float lx;
+        src_index(ox, a.sx, a.align, a.win, x0, x1, lx);
+        float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+        if (wx == 0.f) continue;
+        acc += wy * wx * dyp[oy * a.wout + ox];
+      }
+    }
+    long o = (((long)n * a.in_ctot + a.in_coff + c) * a.hin + iy) * a.win + ix;
+    dx[o] = accumulate ? dx[o] + acc : acc;
+  }
+}
+
+// y[r][w-1-x] = x[r][x] (torch.flip(-1), train.py:261).
+__global__ void flip_w_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int w) {
+  long total = rows * w;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int xx = i % w;
+    long r = i / w;
+    y[i] = x[r * w + (w - 1 - xx)];
+  }
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] += alpha * x[i];
+}
+
+// Copy a channel slice [n, c, hw] between tensors with different channel totals.
+__global__ void copy_channels_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int c, long hw,
+                                     int in_ctot, int in_coff, int out_ctot, int out_coff) {
+  long total = (long)n * c * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long p = i % hw;
+    long t = i / hw;
+    int cc = t % c;
+    int nn = t / c;
+    y[((long)nn * out_ctot + out_coff + cc) * hw + p] = x[((long)nn * in_ctot + in_coff + cc) * hw + p];
+  }
+}
+
+}  // namespace
+
+extern "C" int cl4_maxpool3x3s2(const float* x, float* y, long planes, int hin, int win, int hout, int wout, void* stream) {
+  CL4_REQUIRE(x && y && planes > 0, "maxpool: bad arguments");
+  CL4_REQUIRE(hout == (hin + 2 - 3) / 2 + 1 && wout == (win + 2 - 3) / 2 + 1, "maxpool: output size mismatch");
+  long total = planes * hout * wout;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y,
+                     planes, hin, win, hout, wout);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_avgpool_s1(const float* x, float* y, long planes, int h, int w, int kh, int kw, void* stream) {
+  CL4_REQUIRE(x && y && planes > 0 && kh >= 1 && kw >= 1 && kh <= h && kw <= w, "avgpool_s1: bad arguments");
+  CL4_REQUIRE((size_t)h * w * 4 <= 64 * 1024, "avgpool_s1: plane %dx%d does not fit the LDS staging", h, w);
+  hipLaunchKernelGGL(avgpool_s1_kernel, dim3((unsigned)planes), dim3(256), (size_t)h * w * 4, cl4::as_stream(stream), x, y, h,
+                     w, kh, kw);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_replicate_pad(const float* x, float* y, long planes, int hin, int win, int pad_t, int pad_l, int hout,
+                                 int wout, void* stream) {
+  CL4_REQUIRE(x && y && planes > 0 && pad_t >= 0 && pad_l >= 0 && hout >= hin && wout >= win, "replicate_pad: bad arguments");
+  long total = planes * hout * wout;
+  hipLaunchKernelGGL(replicate_pad_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y,
+                     planes, hin, win, pad_t, pad_l, hout, wout);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_global_mean(const float* x, float* y, long planes, int hw, void* stream) {
+  CL4_REQUIRE(x && y && planes > 0 && hw > 0, "global_mean: bad arguments");
+  hipLaunchKernelGGL(global_mean_kernel, dim3((unsigned)planes), dim3(256), 0, cl4::as_stream(stream), x, y, hw);
+  return cl4::launch_status();
+}
+
+static int fill_resize(ResizeArgs& a, int n, int c, int hin, int win, int hout, int wout, int align, int in_ctot,
+                       int in_coff, int out_ctot, int out_coff) {
+  CL4_REQUIRE(n > 0 && c > 0 && hin > 0 && win > 0 && hout > 0 && wout > 0, "resize: non-positive dims");
+  CL4_REQUIRE(in_coff >= 0 && in_coff + c <= in_ctot && out_coff >= 0 && out_coff + c <= out_ctot, "resize: channel slice out of range");
+  a.n = n; a.c = c; a.hin = hin; a.win = win; a.hout = hout; a.wout = wout; a.align = align;
+  a.in_ctot = in_ctot; a.in_coff = in_coff; a.out_ctot = out_ctot; a.out_coff = out_coff;
+  a.sy = resize_scale(hin, hout, align);
+  a.sx = resize_scale(win, wout, align);
+  return CL4_OK;
+}
+
+extern "C" int cl4_resize_bilinear_fwd(const float* x, float* y, int n, int c, int hin, int win, int hout, int wout,
+                                       int align_corners, int in_ctot, int in_coff, int out_ctot, int out_coff, void* stream) {
+  CL4_REQUIRE(x && y, "resize_fwd: null tensor");
+  ResizeArgs a;
+  int rc = fill_resize(a, n, c, hin, win, hout, wout, align_corners, in_ctot, in_coff, out_ctot, out_coff);
+  if (rc) return rc;
+  long total = (long)n * c * hout * wout;
+  hipLaunchKernelGGL(resize_fwd_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, a);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_resize_bilinear_bwd(const float* dy, float* dx, int n, int c, int hin, int win, int hout, int wout,
+                                       int align_corners, int in_ctot, int in_coff, int out_ctot, int out_coff,
+                                       int accumulate, void* stream) {
+  CL4_REQUIRE(dy && dx, "resize_bwd: null tensor");
+  ResizeArgs a;
+  int rc = fill_resize(a, n, c, hin, win, hout, wout, align_corners, in_ctot, in_coff, out_ctot, out_coff);
+  if (rc) return rc;
+  long total = (long)n * c * hin * win;
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), dy, dx, a,
+                     accumulate);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_flip_w(const float* x, float* y, long rows, int w, void* stream) {
+  CL4_REQUIRE(x && y && rows > 0 && w > 0 && x != y, "flip_w: bad arguments");
+  hipLaunchKernelGGL(flip_w_kernel, dim3(cl4::stream_grid(rows * w, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, rows, w);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_axpy(float* y, const float* x, float alpha, long n, void* stream) {
+  CL4_REQUIRE(x && y && n > 0, "axpy: bad arguments");
+  hipLaunchKernelGGL(axpy_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), y, x, alpha, n);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_copy_channels(const float* x, float* y, int n, int c, long hw, int in_ctot, int in_coff, int out_ctot,
+                                 int out_coff, void* stream) {
+  CL4_REQUIRE(x && y && n > 0 && c > 0 && hw > 0, "copy_channels: bad arguments");
+  CL4_REQUIRE(in_coff >= 0 && in_coff + c <= in_ctot && out_coff >= 0 && out_coff + c <= out_ctot, "copy_channels: slice out of range");
+  long total = (long)n * c * hw;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, n,
+                     c, hw, in_ctot, in_coff, out_ctot, out_coff);
+  return cl4::launch_status();
+}

@@ -1,0 +1,402 @@
+"""DeepLabV3 semantic head and the Panoptic-DeepLab instance decoder / heads on HIP kernels.
+
+State-dict names follow the reference:
+  head.{map_convs.N, map_bn, global_pooling_conv, global_pooling_bn, red_conv, pool_red_conv, red_bn}
+  decoder.instance_decoder.{aspp.convs.N.{0,1}, aspp.convs.4.aspp_pooling.1, aspp.project.{0,1},
+                            project.N.{0,1}, fuse.N.0.{0.0,0.1,1,2}}
+  instance_head.classifier.{center,offset}.{fuse.0.{0.0,0.1,1,2}, cls.K}
+
+The instance branch has two execution modes:
+  * eval (frozen old model): BatchNorm folded into the conv epilogues, one kernel per conv;
+  * train (phase-2 trainable sub-net): batch statistics, Dropout(0.5), and a hand-written backward
+    (`InstanceBranch.forward_train` / `.backward`) that accumulates parameter gradients — it is
+    wrapped in one autograd.Function so that ``loss.backward()`` of the reference's Trainer works.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .nn import ABN, conv_abn, conv_bias, packed_weight
+
+EPS = 1e-5
+
+
+class DeeplabV3(nn.Module):
+    """modules/deeplab.py:8-89."""
+
+    def __init__(self, in_channels, out_channels, hidden_channels=256, out_stride=16, norm_act=ABN, pooling_size=None):
+        super().__init__()
+        self.pooling_size = pooling_size
+        dil = [6, 12, 18] if out_stride == 16 else [12, 24, 32]
+        self.hidden = hidden_channels
+        self.map_convs = nn.ModuleList(
+            [nn.Conv2d(in_channels, hidden_channels, 1, bias=False)] +
+            [nn.Conv2d(in_channels, hidden_channels, 3, bias=False, dilation=d, padding=d) for d in dil])
+        self.map_bn = norm_act(hidden_channels * 4)
+        self.global_pooling_conv = nn.Conv2d(in_channels, hidden_channels, 1, bias=False)
+        self.global_pooling_bn = norm_act(hidden_channels)
+        self.red_conv = nn.Conv2d(hidden_channels * 4, out_channels, 1, bias=False)
+        self.pool_red_conv = nn.Conv2d(hidden_channels, out_channels, 1, bias=False)
+        self.red_bn = norm_act(out_channels)
+        self.reset_parameters(self.map_bn.activation, self.map_bn.activation_param)
+
+    def reset_parameters(self, activation, slope):
+        gain = nn.init.calculate_gain(activation, slope)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_normal_(m.weight.data, gain)
+
+    def forward(self, x):
+        if self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("train-mode DeepLabV3 (step 0 / phase 1) is not built yet; phase 2 freezes it")
+        n, _, h, w = x.shape
+        hid = self.hidden
+        cat = torch.empty((n, 4 * hid, h, w), dtype=torch.float32, device=x.device)
+        for i, conv in enumerate(self.map_convs):  # each branch writes its slice, map_bn folded per slice
+            conv_abn(x, conv, self.map_bn, out=cat, out_coff=i * hid, bn_lo=i * hid, bn_hi=(i + 1) * hid)
+        # eval-mode image pooling (deeplab.py:78-88): box average, stride 1, then replicate pad. The two 1x1
+        # convs + ABN are pointwise, so they commute exactly with the replicate pad: run them on the
+        # (h-k+1)x(w-k+1) map and pad afterwards.
+        ps = self.pooling_size if isinstance(self.pooling_size, (tuple, list)) else (self.pooling_size, self.pooling_size)
+        kh, kw = min(ps[0], h), min(ps[1], w)
+        pool = ops.avgpool_s1(x, kh, kw)
+        pool = conv_abn(pool, self.global_pooling_conv, self.global_pooling_bn)
+        pool = ops.conv2d(pool, packed_weight(self.pool_red_conv), 1)
+        pl, pt = (kw - 1) // 2, (kh - 1) // 2
+        pr = pl if kw % 2 == 1 else pl + 1
+        pb = pt if kh % 2 == 1 else pt + 1
+        pool = ops.replicate_pad(pool, pl, pr, pt, pb)
+        return conv_abn(cat, self.red_conv, self.red_bn, pre=pool)
+
+
+class IncrementalClassifier(nn.ModuleList):
+    """segmentation_module.py:107-113 — per-step 1x1 classifiers, concatenated on C."""
+
+    def forward(self, x):
+        n, _, h, w = x.shape
+        tot = sum(m.out_channels for m in self)
+        out = torch.empty((n, tot, h, w), dtype=torch.float32, device=x.device)
+        off = 0
+        for m in self:
+            conv_bias(x, m, out=out, out_coff=off)
+            off += m.out_channels
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Panoptic-DeepLab building blocks (parameter holders with the reference's Sequential indices)
+# ------------------------------------------------------------------------------------------------
+def _conv_bn_relu(cin, cout, k, padding=0, dilation=1, groups=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, padding=padding, dilation=dilation, groups=groups, bias=False),
+                         nn.BatchNorm2d(cout), nn.ReLU())
+
+
+def _dw_separable(cin, cout):
+    """stacked_conv(num_stack=1, depthwise_separable_conv) — modules/panoptic_deeplab.py:32-67:
+    Sequential( Sequential( Sequential(dw5x5, BN, ReLU), conv1x1, BN, ReLU ) )."""
+    inner = nn.Sequential(_conv_bn_relu(cin, cin, 5, padding=2, groups=cin),
+                          nn.Conv2d(cin, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU())
+    return nn.Sequential(inner)
+
+
+class ASPPPooling(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.aspp_pooling = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Conv2d(cin, cout, 1, bias=False), nn.ReLU())
+
+
+class ASPP(nn.Module):
+    """modules/panoptic_deeplab.py:101-133."""
+
+    def __init__(self, cin, cout, rates):
+        super().__init__()
+        mods = [_conv_bn_relu(cin, cout, 1)]
+        mods += [_conv_bn_relu(cin, cout, 3, padding=r, dilation=r) for r in rates]
+        mods.append(ASPPPooling(cin, cout))
+        self.convs = nn.ModuleList(mods)
+        self.project = nn.Sequential(nn.Conv2d(5 * cout, cout, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(),
+                                     nn.Dropout(0.5))
+
+
+class SinglePanopticDeepLabDecoder(nn.Module):
+    """modules/panoptic_deeplab.py:137-193 (parameters only; executed by InstanceBranch)."""
+
+    def __init__(self, in_channels, feature_key, low_level_channels, low_level_key, low_level_channels_project,
+                 decoder_channels, atrous_rates, aspp_channels=None):
+        super().__init__()
+        aspp_channels = aspp_channels or decoder_channels
+        self.aspp = ASPP(in_channels, aspp_channels, atrous_rates)
+        self.feature_key = feature_key
+        self.low_level_key = list(low_level_key)
+        self.decoder_stage = len(low_level_channels)
+        self.project = nn.ModuleList([_conv_bn_relu(low_level_channels[i], low_level_channels_project[i], 1)
+                                      for i in range(self.decoder_stage)])
+        fuse = []
+        for i in range(self.decoder_stage):
+            cin = (aspp_channels if i == 0 else decoder_channels) + low_level_channels_project[i]
+            fuse.append(_dw_separable(cin, decoder_channels))
+        self.fuse = nn.ModuleList(fuse)
+
+
+class IncrementalPanopticDeepLabDecoder(nn.Module):
+    """modules/panoptic_deeplab.py:381-430 — only the instance branch exists on the CL4WSIS path
+    (argparser.py:19-20 forces DeepLabV3 as the semantic branch)."""
+
+    def __init__(self, in_channels, feature_key, low_level_channels, low_level_key, low_level_channels_project,
+                 decoder_channels, atrous_rates, branch=("ins",), detach_instance=False):
+        super().__init__()
+        self.branch = list(branch)
+        if "seg" in self.branch:
+            raise NotImplementedError("Panoptic-DeepLab semantic decoder: never instantiated by the reference's CLI")
+        self.detach_instance = detach_instance
+        if "ins" in self.branch:
+            self.instance_decoder = SinglePanopticDeepLabDecoder(
+                in_channels, feature_key, low_level_channels, low_level_key, (64, 32, 16), 128, atrous_rates,
+                aspp_channels=256)
+
+
+class IncrementalSinglePanopticDeepLabHead(nn.Module):
+    """modules/panoptic_deeplab.py:432-468 (parameters only; executed by InstanceBranch)."""
+
+    def __init__(self, decoder_channels, head_channels, num_classes, class_key):
+        super().__init__()
+        classifier = {}
+        for i, key in enumerate(class_key):
+            ncls = num_classes[i] if isinstance(num_classes[i], (list, tuple)) else [num_classes[i]]
+            classifier[key] = nn.ModuleDict({
+                "fuse": _dw_separable(decoder_channels, head_channels[i]),
+                "cls": nn.ModuleList([nn.Conv2d(head_channels[i], c, 1) for c in ncls]),
+            })
+        self.classifier = nn.ModuleDict(classifier)
+        self.class_key = list(class_key)
+
+
+# ------------------------------------------------------------------------------------------------
+# Execution of the instance branch
+# ------------------------------------------------------------------------------------------------
+class _BnConvRec:
+    """Saved tensors of one conv -> BN(train) -> ReLU group for the backward pass."""
+    __slots__ = ("x", "x_coff", "cin", "z", "mean", "var", "keep", "y")
+
+
+def _bn_train(z, bn, out=None, out_coff=0, keep=None, keep_scale=1.0):
+    mean, var = ops.bn_train_stats(z, running_mean=bn.running_mean, running_var=bn.running_var, momentum=bn.momentum)
+    y = ops.bn_apply(z, mean, var, bn.weight.detach(), bn.bias.detach(), bn.eps, ops.ACT_RELU, keep=keep,
+                     keep_scale=keep_scale, out=out, out_coff=out_coff)
+    return y, mean, var
+
+
+class InstanceBranch:
+    """Runs decoder.instance_decoder + instance_head of one model.
+
+    eval: `forward_eval(feats)`; train: `forward_train(feats)` then `backward(dcenter, doffset)`.
+    """
+
+    def __init__(self, decoder, head):
+        self.dec = decoder.instance_decoder
+        self.head = head
+
+    # ------------------------------------------------------------------ eval (frozen old model)
+    def _dwsep_eval(self, x, seq):
+        blk = seq[0]
+        dw, bn0 = blk[0][0], blk[0][1]
+        y = ops.dwconv5(x, dw.weight.detach())
+        # a ReLU sits between the depthwise and the pointwise conv, so the first BN+ReLU is one affine pass
+        # over the running statistics; the second BN+ReLU is the pointwise conv's epilogue.
+        y = ops.bn_apply(y, bn0.running_mean, bn0.running_var, bn0.weight.detach(), bn0.bias.detach(), bn0.eps, ops.ACT_RELU)
+        return conv_abn(y, blk[1], blk[2])
+
+    @torch.no_grad()
+    def forward_eval(self, feats):
+        d = self.dec
+        x = feats[d.feature_key]
+        n, _, h, w = x.shape
+        aspp = d.aspp
+        cout = aspp.convs[0][0].out_channels
+        cat = torch.empty((n, 5 * cout, h, w), dtype=torch.float32, device=x.device)
+        for i in range(4):
+            conv_abn(x, aspp.convs[i][0], aspp.convs[i][1], out=cat, out_coff=i * cout)
+        g = ops.global_mean(x)
+        pconv = aspp.convs[4].aspp_pooling[1]
+        g = ops.conv2d(g, packed_weight(pconv), 1, act1=ops.ACT_RELU)
+        ops.resize_bilinear(g, (h, w), True, out=cat, out_coff=4 * cout)
+        y = conv_abn(cat, aspp.project[0], aspp.project[1])  # Dropout is identity in eval
+        for i in range(d.decoder_stage):
+            l = feats[d.low_level_key[i]]
+            cp = d.project[i][0].out_channels
+            cy = y.shape[1]
+            hh, ww = l.shape[2:]
+            cat = torch.empty((n, cy + cp, hh, ww), dtype=torch.float32, device=x.device)
+            ops.resize_bilinear(y, (hh, ww), True, out=cat, out_coff=0)
+            conv_abn(l, d.project[i][0], d.project[i][1], out=cat, out_coff=cy)
+            y = self._dwsep_eval(cat, d.fuse[i])
+        return self._head_eval(y)
+
+    def _head_eval(self, y):
+        pred = OrderedDict()
+        n, _, h, w = y.shape
+        for key in self.head.class_key:
+            mod = self.head.classifier[key]
+            z = self._dwsep_eval(y, mod["fuse"])
+            tot = sum(m.out_channels for m in mod["cls"])
+            out = torch.empty((n, tot, h, w), dtype=torch.float32, device=y.device)
+            off = 0
+            for m in mod["cls"]:
+                conv_bias(z, m, out=out, out_coff=off)
+                off += m.out_channels
+            pred[key] = out
+        return pred
+
+    # ------------------------------------------------------------------ train (phase-2 trainable sub-net)
+    def _dwsep_train(self, x, seq, tape):
+        blk = seq[0]
+        dw, bn0, pw, bn1 = blk[0][0], blk[0][1], blk[1], blk[2]
+        z0 = ops.dwconv5(x, dw.weight.detach())
+        a, m0, v0 = _bn_train(z0, bn0)
+        z1 = ops.conv2d(a, packed_weight(pw), 1)
+        y, m1, v1 = _bn_train(z1, bn1)
+        tape.append(("dwsep", blk, x, z0, m0, v0, a, z1, m1, v1))
+        return y
+
+    def forward_train(self, feats, dropout_keep=None, seed=0):
+        """Forward with batch statistics; returns (pred dict, tape). Inputs are treated as constants
+        (IncrementalPanopticDeepLabDecoder.forward detaches them, modules/panoptic_deeplab.py:422-426)."""
+        d = self.dec
+        tape = []
+        x = feats[d.feature_key]
+        n, _, h, w = x.shape
+        aspp = d.aspp
+        cout = aspp.convs[0][0].out_channels
+        cat5 = torch.empty((n, 5 * cout, h, w), dtype=torch.float32, device=x.device)
+        recs = []
+        for i in range(4):
+            conv, bn = aspp.convs[i][0], aspp.convs[i][1]
+            z = ops.conv2d(x, packed_weight(conv), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0])
+            _, m, v = _bn_train(z, bn, out=cat5, out_coff=i * cout)
+            recs.append((z, m, v))
+        g = ops.global_mean(x)
+        pconv = aspp.convs[4].aspp_pooling[1]
+        gp = ops.conv2d(g, packed_weight(pconv), 1, act1=ops.ACT_RELU)
+        ops.resize_bilinear(gp, (h, w), True, out=cat5, out_coff=4 * cout)
+        pz = ops.conv2d(cat5, packed_weight(aspp.project[0]), 1)
+        p = aspp.project[3].p
+        if dropout_keep is None:
+            dropout_keep = ops.dropout_mask((n, cout, h, w), p, seed, x.device)
+        y, pm, pv = _bn_train(pz, aspp.project[1], keep=dropout_keep, keep_scale=1.0 / (1.0 - p))
+        tape.append(("aspp", x, recs, g, gp, cat5, pz, pm, pv, dropout_keep, 1.0 / (1.0 - p)))
+        for i in range(d.decoder_stage):
+            l = feats[d.low_level_key[i]]
+            conv, bn = d.project[i][0], d.project[i][1]
+            cp, cy = conv.out_channels, y.shape[1]
+            hh, ww = l.shape[2:]
+            cat = torch.empty((n, cy + cp, hh, ww), dtype=torch.float32, device=x.device)
+            ops.resize_bilinear(y, (hh, ww), True, out=cat, out_coff=0)
+            lz = ops.conv2d(l, packed_weight(conv), 1)
+            _, lm, lv = _bn_train(lz, bn, out=cat, out_coff=cy)
+            tape.append(("stage", i, l, lz, lm, lv, cy, cp, y.shape[2:]))
+            y = self._dwsep_train(cat, d.fuse[i], tape)
+        pred = OrderedDict()
+        hn, _, hh, hw = y.shape
+        tape.append(("fork", y))
+        for key in self.head.class_key:
+            mod = self.head.classifier[key]
+            z = self._dwsep_train(y, mod["fuse"], tape)
+            tot = sum(m.out_channels for m in mod["cls"])
+            out = torch.empty((hn, tot, hh, hw), dtype=torch.float32, device=y.device)
+            off = 0
+            for m in mod["cls"]:
+                conv_bias(z, m, out=out, out_coff=off)
+                off += m.out_channels
+            tape.append(("cls", key, z))
+            pred[key] = out
+        return pred, tape
+
+    # ---- backward helpers ------------------------------------------------------------------------
+    @staticmethod
+    def _grad(param, grads):
+        g = grads.get(id(param))
+        if g is None:
+            g = torch.zeros_like(param, dtype=torch.float32)
+            grads[id(param)] = g
+        return g
+
+    def _dwsep_bwd(self, rec, dy, grads, need_dx=True):
+        _, blk, x, z0, m0, v0, a, z1, m1, v1 = rec
+        dw, bn0, pw, bn1 = blk[0][0], blk[0][1], blk[1], blk[2]
+        G = lambda p: self._grad(p, grads)
+        dz1 = ops.bn_train_bwd(z1, dy, m1, v1, bn1.weight.detach(), bn1.bias.detach(), G(bn1.weight), G(bn1.bias), bn1.eps)
+        ops.conv2d_wgrad(a, dz1, G(pw.weight), 1)
+        # input gradient of a 1x1 conv: the PyTorch weight [cout, cin] already is the packed [K=cout][M=cin] operand
+        da = ops.conv2d(dz1, pw.weight.detach().reshape(pw.out_channels, pw.in_channels), 1)
+        dz0 = ops.bn_train_bwd(z0, da, m0, v0, bn0.weight.detach(), bn0.bias.detach(), G(bn0.weight), G(bn0.bias), bn0.eps)
+        ops.dwconv5_wgrad_(G(dw.weight), x, dz0)
+        return ops.dwconv5(dz0, dw.weight.detach(), flip=True) if need_dx else None
+
+    def backward(self, tape, dpred):
+        """Back-propagates d(loss)/d(pred[key]) through the recorded forward. Returns {id(param): grad}."""
+        grads = {}
+        G = lambda p: self._grad(p, grads)
+        i = len(tape) - 1
+        dfork = None
+        # heads (recorded as dwsep, cls per key) ---------------------------------------------------
+        while tape[i][0] != "fork":
+            tag, key, z = tape[i]
+            assert tag == "cls"
+            rec = tape[i - 1]
+            mod = self.head.classifier[key]
+            dy = dpred[key]
+            dz = None
+            off = 0
+            for m in mod["cls"]:
+                co = m.out_channels
+                ops.conv2d_wgrad(z, dy, G(m.weight), 1, dy_coff=off, cout=co)
+                ops.bias_grad_(G(m.bias), dy, c=co, coff=off)
+                # dz += W^T dy_slice : conv over the dy channel slice with the natural [cout][cin] weight
+                part = ops.conv2d(dy, m.weight.detach().reshape(co, m.in_channels), 1, in_coff=off, cin=co)
+                dz = part if dz is None else ops.axpy_(dz, part)
+                off += co
+            dx = self._dwsep_bwd(rec, dz, grads)
+            dfork = dx if dfork is None else ops.axpy_(dfork, dx)
+            i -= 2
+        i -= 1
+        dy = dfork
+        d = self.dec
+        # decoder stages, last to first -----------------------------------------------------------------
+        while tape[i][0] != "aspp":
+            rec = tape[i]
+            stage = tape[i - 1]
+            _, si, l, lz, lm, lv, cy, cp, prev_hw = stage
+            dcat = self._dwsep_bwd(rec, dy, grads)
+            conv, bn = d.project[si][0], d.project[si][1]
+            dlz = ops.bn_train_bwd(lz, dcat, lm, lv, bn.weight.detach(), bn.bias.detach(), G(bn.weight), G(bn.bias), bn.eps,
+                                   dy_coff=cy)
+            ops.conv2d_wgrad(l, dlz, G(conv.weight), 1)
+            dy = ops.resize_bilinear_bwd(dcat, tuple(prev_hw), True, dy_coff=0, c=cy)
+            i -= 2
+        # ASPP ------------------------------------------------------------------------------------------
+        _, x, recs, g, gp, cat5, pz, pm, pv, keep, kscale = tape[i]
+        aspp = d.aspp
+        pbn = aspp.project[1]
+        dpz = ops.bn_train_bwd(pz, dy, pm, pv, pbn.weight.detach(), pbn.bias.detach(), G(pbn.weight), G(pbn.bias), pbn.eps,
+                               keep=keep, keep_scale=kscale)
+        pconv0 = aspp.project[0]
+        ops.conv2d_wgrad(cat5, dpz, G(pconv0.weight), 1)
+        dcat5 = ops.conv2d(dpz, pconv0.weight.detach().reshape(pconv0.out_channels, pconv0.in_channels), 1)
+        cout = aspp.convs[0][0].out_channels
+        for j in range(4):
+            conv, bn = aspp.convs[j][0], aspp.convs[j][1]
+            z, m, v = recs[j]
+            dz = ops.bn_train_bwd(z, dcat5, m, v, bn.weight.detach(), bn.bias.detach(), G(bn.weight), G(bn.bias), bn.eps,
+                                  dy_coff=j * cout)
+            ops.conv2d_wgrad(x, dz, G(conv.weight), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0])
+        h, w = x.shape[2:]
+        dgp = ops.resize_bilinear_bwd(dcat5, (1, 1), True, dy_coff=4 * cout, c=cout)
+        dgp = ops.relu_bwd(gp, dgp)
+        pconv = aspp.convs[4].aspp_pooling[1]
+        ops.conv2d_wgrad(g, dgp, G(pconv.weight), 1)
+        return grads
+
+    def trainable_parameters(self):
+        return list(self.dec.parameters()) + list(self.head.parameters())

@@ -1,0 +1,111 @@
+"""Parameter holders and kernel-call helpers shared by the network modules.
+
+The modules keep the reference's attribute names so that ``state_dict()`` keys are the
+checkpoint contract of SURVEY.md Appendix B; their ``forward`` never runs a torch compute op —
+it enqueues the HIP kernels of libcl4wsis_hip.so through :mod:`cl4wsis_amd.ops`.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+EPS = 1e-5
+
+
+class ABN(nn.Module):
+    """Parameter holder with the contract of inplace_abn.ABN / InPlaceABN(Sync)
+    (reference: segmentation_module.py:17-29; attribute use in modules/residual.py:52,65,82,92-93,
+    modules/deeplab.py:39): weight, bias, running_mean, running_var, .activation, .activation_param.
+    Eval mode is folded into the producing conv's epilogue (scale/shift + leaky-ReLU)."""
+
+    def __init__(self, num_features, eps=EPS, momentum=0.1, affine=True, activation="leaky_relu",
+                 activation_param=0.01, group=None):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = eps
+        self.momentum = momentum
+        self.activation = activation
+        self.activation_param = activation_param
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def act_code(self):
+        if self.activation == "leaky_relu":
+            return ops.ACT_LEAKY, float(self.activation_param)
+        if self.activation == "identity":
+            return ops.ACT_NONE, 0.0
+        raise NotImplementedError(f"ABN activation {self.activation!r} is not on the phase-2 path")
+
+    def forward(self, x):  # pragma: no cover - never used on the product path
+        raise RuntimeError("ABN is fused into the producing convolution; call the owning block instead")
+
+
+InPlaceABN = ABN
+InPlaceABNSync = ABN
+
+
+class _Cache:
+    """Device-side derived tensors (packed weights, folded BN) keyed by the source tensors'
+    (data_ptr, _version): an optimizer step or load_state_dict bumps _version and invalidates."""
+
+    def __init__(self):
+        self._store = {}
+
+    @staticmethod
+    def _sig(tensors):
+        return tuple((t.data_ptr(), t._version, t.device.index) for t in tensors if t is not None)
+
+    def get(self, key, tensors, build):
+        sig = self._sig(tensors)
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        val = build()
+        self._store[key] = (sig, val)
+        return val
+
+    def clear(self):
+        self._store.clear()
+
+
+CACHE = _Cache()
+
+
+def packed_weight(conv):
+    """[cout,cin,k,k] -> [cin*k*k, cout], cached until the weight changes."""
+    w = conv.weight
+    return CACHE.get(("wp", id(conv)), (w,), lambda: ops.pack_conv_weight(w.detach()))
+
+
+def folded_bn(bn, lo=0, hi=None):
+    """(scale, shift) of an eval-mode ABN / BatchNorm2d, optionally for a channel slice."""
+    ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+    def build():
+        return ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+
+    scale, shift = CACHE.get(("bn", id(bn)), ts, build)
+    if lo == 0 and hi is None:
+        return scale, shift
+    return scale[lo:hi], shift[lo:hi]
+
+
+def conv_abn(x, conv, bn, post=None, act2=ops.ACT_NONE, slope2=0.01, out=None, out_coff=0, bn_lo=0, bn_hi=None,
+             pre=None):
+    """conv -> eval ABN (affine + its activation) [-> + post -> act2], one kernel."""
+    scale, shift = folded_bn(bn, bn_lo, bn_hi)
+    act1, slope1 = bn.act_code() if isinstance(bn, ABN) else (ops.ACT_RELU, 0.0)
+    k = conv.kernel_size[0]
+    return ops.conv2d(x, packed_weight(conv), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0],
+                      scale=scale, shift=shift, pre=pre, post=post, act1=act1, slope1=slope1, act2=act2, slope2=slope2,
+                      out=out, out_coff=out_coff)
+
+
+def conv_bias(x, conv, out=None, out_coff=0, act=ops.ACT_NONE):
+    """conv (+bias) with no normalisation (classifier heads)."""
+    k = conv.kernel_size[0]
+    shift = conv.bias.detach() if conv.bias is not None else None
+    return ops.conv2d(x, packed_weight(conv), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0],
+                      shift=shift, act1=act, out=out, out_coff=out_coff)

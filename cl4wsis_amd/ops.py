@@ -103,3 +103,183 @@ def conv2d_wgrad(x, dy, dw, k, stride=1, pad=0, dil=1, in_coff=0, cin=None, dy_c
         raise RuntimeError("conv2d_wgrad: dy spatial shape does not match the convolution geometry")
     call("cl4_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), stream())
     return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# spatial / streaming kernels
+# ---------------------------------------------------------------------------------------------
+def maxpool3x3s2(x):
+    n, c, h, w = x.shape
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+    call("cl4_maxpool3x3s2", ptr(x), ptr(y), n * c, h, w, ho, wo, stream())
+    return y
+
+
+def avgpool_s1(x, kh, kw):
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h - kh + 1, w - kw + 1), dtype=torch.float32, device=x.device)
+    call("cl4_avgpool_s1", ptr(x), ptr(y), n * c, h, w, kh, kw, stream())
+    return y
+
+
+def replicate_pad(x, pad_l, pad_r, pad_t, pad_b):
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h + pad_t + pad_b, w + pad_l + pad_r), dtype=torch.float32, device=x.device)
+    call("cl4_replicate_pad", ptr(x), ptr(y), n * c, h, w, pad_t, pad_l, y.shape[2], y.shape[3], stream())
+    return y
+
+
+def global_mean(x):
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, 1, 1), dtype=torch.float32, device=x.device)
+    call("cl4_global_mean", ptr(x), ptr(y), n * c, h * w, stream())
+    return y
+
+
+def resize_bilinear(x, size, align_corners, out=None, out_coff=0, in_coff=0, c=None):
+    n, in_ctot, hin, win = x.shape
+    if c is None:
+        c = in_ctot - in_coff
+    ho, wo = size
+    if out is None:
+        out = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
+        out_coff = 0
+    call("cl4_resize_bilinear_fwd", ptr(x), ptr(out), n, c, hin, win, ho, wo, int(bool(align_corners)),
+         in_ctot, in_coff, out.shape[1], out_coff, stream())
+    return out
+
+
+def resize_bilinear_bwd(dy, in_size, align_corners, dy_coff=0, c=None, dx=None, dx_coff=0, accumulate=False):
+    n, dy_ctot, ho, wo = dy.shape
+    if c is None:
+        c = dy_ctot - dy_coff
+    hin, win = in_size
+    if dx is None:
+        dx = torch.empty((n, c, hin, win), dtype=torch.float32, device=dy.device)
+        dx_coff = 0
+        accumulate = False
+    call("cl4_resize_bilinear_bwd", ptr(dy), ptr(dx), n, c, hin, win, ho, wo, int(bool(align_corners)),
+         dx.shape[1], dx_coff, dy_ctot, dy_coff, int(bool(accumulate)), stream())
+    return dx
+
+
+def flip_w(x, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    w = x.shape[-1]
+    call("cl4_flip_w", ptr(x), ptr(out), x.numel() // w, w, stream())
+    return out
+
+
+def axpy_(y, x, alpha=1.0):
+    if y.numel() != x.numel():
+        raise RuntimeError("axpy_: size mismatch")
+    call("cl4_axpy", ptr(y), ptr(x), C.c_float(alpha), y.numel(), stream())
+    return y
+
+
+def copy_channels(x, out, c, in_coff=0, out_coff=0):
+    n, in_ctot = x.shape[:2]
+    hw = x.shape[2] * x.shape[3]
+    call("cl4_copy_channels", ptr(x), ptr(out), n, c, hw, in_ctot, in_coff, out.shape[1], out_coff, stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# train-mode BatchNorm / dropout / depthwise conv
+# ---------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.type, device.index)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def bn_workspace_bytes(c):
+    return _hip.load().cl4_bn_workspace_bytes(c) + 2 * c * 4
+
+
+def bn_train_stats(x, c=None, coff=0, running_mean=None, running_var=None, momentum=0.1):
+    n, ctot, h, w = x.shape
+    if c is None:
+        c = ctot - coff
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    var = torch.empty_like(mean)
+    ws = _workspace(x.device, bn_workspace_bytes(c))
+    call("cl4_bn_train_stats", ptr(x), n, c, h * w, ctot, coff, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+         C.c_float(momentum), ptr(ws), ws.numel(), stream())
+    return mean, var
+
+
+def bn_apply(x, mean, var, gamma, beta, eps=1e-5, act=ACT_RELU, slope=0.01, keep=None, keep_scale=1.0,
+             c=None, x_coff=0, out=None, out_coff=0):
+    n, x_ctot, h, w = x.shape
+    if c is None:
+        c = x_ctot - x_coff
+    if out is None:
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        out_coff = 0
+    call("cl4_bn_apply", ptr(x), ptr(out), n, c, h * w, x_ctot, x_coff, out.shape[1], out_coff, ptr(mean), ptr(var),
+         ptr(gamma), ptr(beta), C.c_float(eps), act, C.c_float(slope), ptr(keep), C.c_float(keep_scale), stream())
+    return out
+
+
+def bn_train_bwd(x, dy, mean, var, gamma, beta, dgamma, dbeta, eps=1e-5, act=ACT_RELU, keep=None, keep_scale=1.0,
+                 c=None, x_coff=0, dy_coff=0):
+    """Returns dx with the layout of x (only the [x_coff, x_coff+c) slice is written when x is a slice)."""
+    n, x_ctot, h, w = x.shape
+    if c is None:
+        c = x_ctot - x_coff
+    dx = torch.empty_like(x)
+    ws = _workspace(x.device, bn_workspace_bytes(c))
+    call("cl4_bn_train_bwd", ptr(x), ptr(dy), ptr(dx), n, c, h * w, x_ctot, x_coff, dy.shape[1], dy_coff, ptr(mean), ptr(var),
+         ptr(gamma), ptr(beta), C.c_float(eps), act, ptr(keep), C.c_float(keep_scale), ptr(dgamma), ptr(dbeta),
+         ptr(ws), ws.numel(), stream())
+    return dx
+
+
+def relu_bwd(y, dy):
+    dx = torch.empty_like(dy)
+    call("cl4_relu_bwd", ptr(y), ptr(dy), ptr(dx), y.numel(), stream())
+    return dx
+
+
+def bias_grad_(db, dy, c=None, coff=0):
+    n, ctot, h, w = dy.shape
+    if c is None:
+        c = ctot - coff
+    call("cl4_bias_grad", ptr(dy), ptr(db), n, c, h * w, ctot, coff, stream())
+    return db
+
+
+def dropout_mask(shape, p, seed, device):
+    keep = torch.empty(shape, dtype=torch.uint8, device=device)
+    call("cl4_dropout_mask", ptr(keep), keep.numel(), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_float(p), stream())
+    return keep
+
+
+def dwconv5(x, w, flip=False, c=None, x_coff=0, out=None, out_coff=0):
+    n, x_ctot, h, wd = x.shape
+    if c is None:
+        c = x_ctot - x_coff
+    if tuple(w.shape) != (c, 1, 5, 5):
+        raise RuntimeError(f"dwconv5: weight shape {tuple(w.shape)} != {(c, 1, 5, 5)}")
+    if out is None:
+        out = torch.empty((n, c, h, wd), dtype=torch.float32, device=x.device)
+        out_coff = 0
+    call("cl4_dwconv5_fwd", ptr(x), ptr(w), ptr(out), n, c, h, wd, x_ctot, x_coff, out.shape[1], out_coff, int(flip), stream())
+    return out
+
+
+def dwconv5_wgrad_(dw, x, dy, c=None, x_coff=0, dy_coff=0):
+    n, x_ctot, h, wd = x.shape
+    if c is None:
+        c = x_ctot - x_coff
+    call("cl4_dwconv5_wgrad", ptr(x), ptr(dy), ptr(dw), n, c, h, wd, x_ctot, x_coff, dy.shape[1], dy_coff, stream())
+    return dw

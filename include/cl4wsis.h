@@ -90,6 +90,64 @@ int cl4_conv2d_wgrad(const cl4_conv_desc* d, const float* x, const float* dy, fl
 int cl4_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                 float eps, float* scale, float* shift, int c, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Spatial / streaming kernels (HBM-bound). "planes" = n*c of an NCHW tensor.
+ * ------------------------------------------------------------------------ */
+/* nn.MaxPool2d(3, stride=2, padding=1) — models/resnet.py:63. */
+int cl4_maxpool3x3s2(const float* x, float* y, long planes, int hin, int win, int hout, int wout, void* stream);
+/* F.avg_pool2d(x, (kh,kw), stride=1) -> [planes, h-kh+1, w-kw+1] — modules/deeplab.py:87. */
+int cl4_avgpool_s1(const float* x, float* y, long planes, int h, int w, int kh, int kw, void* stream);
+/* F.pad(mode="replicate") — modules/deeplab.py:88 (pad_b/pad_r implied by hout/wout). */
+int cl4_replicate_pad(const float* x, float* y, long planes, int hin, int win, int pad_t, int pad_l, int hout, int wout, void* stream);
+/* mean over H*W per plane — AdaptiveAvgPool2d(1), modules/panoptic_deeplab.py:84; deeplab.py:75-76. */
+int cl4_global_mean(const float* x, float* y, long planes, int hw, void* stream);
+/* F.interpolate(mode="bilinear") in both align_corners conventions; x and y may be
+ * channel slices. Backward is a deterministic gather (no atomics); accumulate!=0 adds into dx. */
+int cl4_resize_bilinear_fwd(const float* x, float* y, int n, int c, int hin, int win, int hout, int wout,
+                            int align_corners, int in_ctot, int in_coff, int out_ctot, int out_coff, void* stream);
+int cl4_resize_bilinear_bwd(const float* dy, float* dx, int n, int c, int hin, int win, int hout, int wout,
+                            int align_corners, int in_ctot, int in_coff, int out_ctot, int out_coff,
+                            int accumulate, void* stream);
+/* y[r, w-1-i] = x[r, i] — torch.flip(-1), train.py:261,263. */
+int cl4_flip_w(const float* x, float* y, long rows, int w, void* stream);
+int cl4_axpy(float* y, const float* x, float alpha, long n, void* stream);
+int cl4_copy_channels(const float* x, float* y, int n, int c, long hw, int in_ctot, int in_coff, int out_ctot, int out_coff, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Train-mode nn.BatchNorm2d (+ReLU, + nn.Dropout keep mask) of the instance decoder / heads —
+ * modules/panoptic_deeplab.py:26-28,44-46,74-76,108-110,121-123,161-163.
+ * ------------------------------------------------------------------------ */
+size_t cl4_bn_workspace_bytes(int c);
+/* batch mean / biased variance of a channel slice; running stats (may be NULL) are updated in place
+ * with the unbiased variance and `momentum` (PyTorch semantics). */
+int cl4_bn_train_stats(const float* x, int n, int c, int hw, int ctot, int coff, float* mean, float* var,
+                       float* running_mean, float* running_var, float momentum,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* y = dropout(act((x-mean)/sqrt(var+eps)*gamma+beta)); keep: uint8 [n,c,hw] or NULL. */
+int cl4_bn_apply(const float* x, float* y, int n, int c, int hw, int x_ctot, int x_coff, int y_ctot, int y_coff,
+                 const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                 int act, float slope, const uint8_t* keep, float keep_scale, void* stream);
+/* Backward of the above: dx (same layout as x); dgamma/dbeta (may be NULL) are accumulated into.
+ * workspace_bytes >= cl4_bn_workspace_bytes(c) + 2*c*sizeof(float). */
+int cl4_bn_train_bwd(const float* x, const float* dy, float* dx, int n, int c, int hw, int x_ctot, int x_coff,
+                     int dy_ctot, int dy_coff, const float* mean, const float* var, const float* gamma,
+                     const float* beta, float eps, int act, const uint8_t* keep, float keep_scale,
+                     float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+int cl4_relu_bwd(const float* y, const float* dy, float* dx, long n, void* stream);
+/* db[c] += sum_{n,hw} dy — bias gradient of the classifier convs. */
+int cl4_bias_grad(const float* dy, float* db, int n, int c, int hw, int ctot, int coff, void* stream);
+/* Counter-based keep mask for nn.Dropout(p) — modules/panoptic_deeplab.py:123. */
+int cl4_dropout_mask(uint8_t* keep, long n, uint64_t seed, float p, void* stream);
+
+/* ------------------------------------------------------------------------
+ * 5x5 depthwise conv, stride 1, pad 2 — modules/panoptic_deeplab.py:39-40. w: [c,1,5,5].
+ * flip=1 correlates with the rotated kernel (= input gradient). wgrad accumulates into dw.
+ * ------------------------------------------------------------------------ */
+int cl4_dwconv5_fwd(const float* x, const float* w, float* y, int n, int c, int h, int wd,
+                    int x_ctot, int x_coff, int y_ctot, int y_coff, int flip, void* stream);
+int cl4_dwconv5_wgrad(const float* x, const float* dy, float* dw, int n, int c, int h, int wd,
+                      int x_ctot, int x_coff, int dy_ctot, int dy_coff, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
