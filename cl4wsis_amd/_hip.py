@@ -27,6 +27,35 @@ class ConvDesc(C.Structure):
     ]
 
 
+
+class LabelIO(C.Structure):
+    _fields_ = [
+        ("b", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("cnew", C.c_int32), ("old_classes", C.c_int32),
+        ("hc", C.c_int32), ("wc", C.c_int32), ("center_ctot", C.c_int32),
+        ("K", C.c_int32), ("sigma", C.c_int32), ("nms_kernel", C.c_int32), ("run_refine", C.c_int32),
+        ("pseudo_thresh", C.c_float), ("refine_thresh", C.c_float), ("beta", C.c_float),
+        ("seg_gt", C.c_void_p), ("prob_win", C.c_void_p), ("label_new", C.c_void_p),
+        ("peak_conf", C.c_void_p), ("peak_y", C.c_void_p), ("peak_x", C.c_void_p),
+        ("center_lo", C.c_void_p), ("offset_lo", C.c_void_p), ("gauss", C.c_void_p),
+        ("p_center", C.c_void_p), ("p_offset", C.c_void_p), ("p_weight", C.c_void_p),
+        ("r_center", C.c_void_p), ("r_offset", C.c_void_p), ("r_weight", C.c_void_p),
+    ]
+
+
+class P2LossIO(C.Structure):
+    _fields_ = [
+        ("b", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("hc", C.c_int32), ("wc", C.c_int32),
+        ("cold", C.c_int32), ("cnew", C.c_int32),
+        ("center", C.c_void_p), ("offset", C.c_void_p), ("old_center", C.c_void_p), ("old_offset", C.c_void_p),
+        ("old_w", C.c_void_p),
+        ("p_center", C.c_void_p), ("p_offset", C.c_void_p), ("p_weight", C.c_void_p),
+        ("r_center", C.c_void_p), ("r_offset", C.c_void_p), ("r_weight", C.c_void_p),
+        ("center_weight", C.c_float), ("offset_weight", C.c_float),
+        ("losses", C.c_void_p), ("d_center", C.c_void_p), ("d_offset", C.c_void_p),
+    ]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -63,6 +92,17 @@ _decl("cl4_dropout_mask", _P, _L, C.c_uint64, _F, _P)
 _decl("cl4_dwconv5_fwd", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_dwconv5_wgrad", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 
+_decl("cl4_cam_smooth", _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P)
+_decl("cl4_peak_extract", _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.c_size_t, _P)
+_decl("cl4_seg_pseudo_gt", _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P)
+_decl("cl4_ccl", _P, _I, _I, _I, _I, _P, _P)
+_decl("cl4_cc_stats", _P, _I, _I, _I, _P, _P, _P, _P)
+_decl("cl4_label_generation", C.POINTER(LabelIO), _P, C.c_size_t, _P)
+_decl("cl4_label_counters", _P, _I, _I, _I, _P, _P)
+_decl("cl4_p2_loss", C.POINTER(P2LossIO), _P, C.c_size_t, _P)
+_decl("cl4_adam_step", _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P)
+_decl("cl4_fill_zero", _P, C.c_size_t, _P)
+
 _lib = None
 
 
@@ -80,6 +120,10 @@ def load():
     lib.cl4_last_error.restype = C.c_char_p
     lib.cl4_bn_workspace_bytes.restype = C.c_size_t
     lib.cl4_bn_workspace_bytes.argtypes = [C.c_int]
+    for nm, at in (("cl4_peak_workspace_bytes", [C.c_int, C.c_int]), ("cl4_label_workspace_bytes", [C.c_int] * 3),
+                   ("cl4_p2_loss_workspace_bytes", [C.c_int] * 6)):
+        getattr(lib, nm).restype = C.c_size_t
+        getattr(lib, nm).argtypes = at
     for name, args in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = args

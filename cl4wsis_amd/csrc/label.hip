@@ -1,0 +1,407 @@
+// Label-stage kernels, part 1: CAM normalisation + smoothing, peak extraction, the flip-TTA semantic
+// pseudo ground truth, and connected-component labelling with per-component statistics.
+// All HBM/LDS-bound integer/float work; results feed the bit-exact index outputs (argmax maps, peak
+// coordinates), so every formula follows the reference's operation order.
+#include "label_common.h"
+
+namespace {
+
+using cl4::Bilin;
+using cl4::bilin_half_pixel;
+using cl4::bilin_sample;
+
+// ---------------------------------------------------------------------------------------------
+// PeakGenerator (eval) + cam_normalize + 3x3 smoothing — wss/modules.py:354-368,390-434; wss/utils.py:28-32.
+// One workgroup per image; everything lives in LDS (cnew*h*w floats twice).
+// ---------------------------------------------------------------------------------------------
+__device__ float block_max(float v, float* red) {
+  v = cl4::wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void cam_smooth_kernel(const float* __restrict__ int_masks, int ctot, int h, int w,
+                                                         const float* __restrict__ pg_w, const float* __restrict__ pg_b,
+                                                         const float* __restrict__ label, int cnew, float alpha,
+                                                         float* __restrict__ cam) {
+  extern __shared__ float lds[];
+  __shared__ float red[4];
+  const int hw = h * w;
+  float* xs = lds;              // [cnew][hw] PAM output
+  float* ys = lds + cnew * hw;  // [cnew][hw] normalised cam
+  const int b = blockIdx.x;
+  const float* src = int_masks + ((long)b * ctot + (ctot - cnew)) * hw;
+  for (int i = threadIdx.x; i < cnew * hw; i += blockDim.x) xs[i] = fmaxf(src[i], 0.f);
+  __syncthreads();
+  // PAM: zero everything below alpha * per-channel max
+  for (int c = 0; c < cnew; ++c) {
+    float m = 0.f;  // relu output >= 0; AdaptiveMaxPool2d(1)
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) m = fmaxf(m, xs[c * hw + i]);
+    m = block_max(m, red);
+    const float thr = m * alpha;
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+      float v = xs[c * hw + i];
+      xs[c * hw + i] = (v < thr) ? 0.f : v;
+    }
+  }
+  __syncthreads();
+  // extra_conv4 (1x1, cnew -> cnew, bias) then relu * label
+  for (int i = threadIdx.x; i < cnew * hw; i += blockDim.x) {
+    int c = i / hw, p = i - c * hw;
+    float acc = 0.f;
+    for (int k = 0; k < cnew; ++k) acc += pg_w[c * cnew + k] * xs[k * hw + p];
+    acc += pg_b[c];
+    ys[i] = fmaxf(acc, 0.f) * label[b * cnew + c];
+  }
+  __syncthreads();
+  // cam /= (max_hw + 1e-5)
+  for (int c = 0; c < cnew; ++c) {
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) m = fmaxf(m, ys[c * hw + i]);
+    m = block_max(m, red);
+    const float den = m + 1e-5f;
+    for (int i = threadIdx.x; i < hw; i += blockDim.x) ys[c * hw + i] = ys[c * hw + i] / den;
+  }
+  __syncthreads();
+  // 3x3 average, zero padding, divisor 9
+  for (int i = threadIdx.x; i < cnew * hw; i += blockDim.x) {
+    int c = i / hw, p = i - c * hw;
+    int y = p / w, x = p - y * w;
+    float s = 0.f;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        int yy = y + dy, xx = x + dx;
+        if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) s += ys[c * hw + yy * w + xx];
+      }
+    cam[((long)b * cnew + c) * hw + p] = s / 9.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// peak_extract — wss/utils.py:3-25, fused with the bilinear upsample of train.py:431:
+// the full-resolution CAM is never written to HBM. Tile = 32x32 outputs + halo R=(kernel-1)/2.
+// ---------------------------------------------------------------------------------------------
+constexpr int PT = 32;
+constexpr int PMAXR = 7;                      // kernel 15
+constexpr int PTS = PT + 2 * PMAXR;           // 46
+constexpr int CAND_CAP = 8192;
+
+struct PeakCand {
+  float v;
+  int idx;
+};
+
+__global__ __launch_bounds__(256) void peak_nms_kernel(const float* __restrict__ cam, int h, int w, int H, int W, int R,
+                                                       const float* __restrict__ label, PeakCand* __restrict__ cand,
+                                                       int* __restrict__ cand_cnt) {
+  extern __shared__ float lds[];
+  float* lo = lds;                 // [h*w]
+  float* val = lds + h * w;        // [PTS][PTS]
+  float* rmax = val + PTS * PTS;   // [PTS][PT]
+  const int tiles_x = (W + PT - 1) / PT;
+  const int ty0 = (blockIdx.x / tiles_x) * PT, tx0 = (blockIdx.x % tiles_x) * PT;
+  const int c = blockIdx.y, b = blockIdx.z, C = gridDim.y;
+  if (label[b * C + c] == 0.f) return;  // unlabelled class: its CAM is identically zero, no positive peak
+  const float* plane = cam + ((long)b * C + c) * h * w;
+  for (int i = threadIdx.x; i < h * w; i += blockDim.x) lo[i] = plane[i];
+  __syncthreads();
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const int TS = PT + 2 * R;
+  for (int i = threadIdx.x; i < TS * TS; i += blockDim.x) {
+    int ty = i / TS, tx = i - ty * TS;
+    int Y = ty0 - R + ty, X = tx0 - R + tx;
+    float v = -INFINITY;  // max_pool2d pads with -inf
+    if ((unsigned)Y < (unsigned)H && (unsigned)X < (unsigned)W) {
+      Bilin by = bilin_half_pixel(Y, sy, h), bx = bilin_half_pixel(X, sx, w);
+      v = bilin_sample(lo, w, by, bx);
+    }
+    val[ty * PTS + tx] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TS * PT; i += blockDim.x) {
+    int ty = i / PT, x = i - ty * PT;
+    float m = -INFINITY;
+    for (int d = 0; d <= 2 * R; ++d) m = fmaxf(m, val[ty * PTS + x + d]);
+    rmax[ty * PT + x] = m;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PT * PT; i += blockDim.x) {
+    int y = i / PT, x = i - y * PT;
+    int Y = ty0 + y, X = tx0 + x;
+    if (Y >= H || X >= W) continue;
+    float m = -INFINITY;
+    for (int d = 0; d <= 2 * R; ++d) m = fmaxf(m, rmax[(y + d) * PT + x]);
+    float v = val[(y + R) * PTS + x + R];
+    if (v == m && v > 0.f) {
+      int slot = atomicAdd(&cand_cnt[b * C + c], 1);
+      if (slot < CAND_CAP) {
+        cand[((long)(b * C + c)) * CAND_CAP + slot].v = v;
+        cand[((long)(b * C + c)) * CAND_CAP + slot].idx = Y * W + X;
+      }
+    }
+  }
+}
+
+// top-K of the candidates of one (b, c): value descending, ties by ascending flat index.
+__global__ __launch_bounds__(256) void peak_topk_kernel(PeakCand* __restrict__ cand, const int* __restrict__ cand_cnt, int W,
+                                                        int K, float* __restrict__ conf, int* __restrict__ ys,
+                                                        int* __restrict__ xs) {
+  __shared__ unsigned long long best[4];
+  const int bc = blockIdx.x;
+  int n = cand_cnt[bc];
+  if (n > CAND_CAP) n = CAND_CAP;
+  PeakCand* cl = cand + (long)bc * CAND_CAP;
+  for (int k = 0; k < K; ++k) {
+    // key = (value bits << 32) | (0xFFFFFFFF - idx): max key = largest value, then smallest index
+    unsigned long long key = 0ull;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      float v = cl[i].v;
+      if (v > 0.f) {
+        unsigned long long kk = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)cl[i].idx);
+        key = kk > key ? kk : key;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long other = __shfl_xor(key, o, 64);
+      key = other > key ? other : key;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = key;
+    __syncthreads();
+    key = best[0];
+    for (int q = 1; q < 4; ++q) key = best[q] > key ? best[q] : key;
+    float v = 0.f;
+    int idx = 0;
+    if (key != 0ull) {
+      v = __uint_as_float((unsigned)(key >> 32));
+      idx = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
+      for (int i = threadIdx.x; i < n; i += blockDim.x)
+        if (cl[i].idx == idx) cl[i].v = -1.f;  // remove the winner
+    }
+    if (threadIdx.x == 0) {
+      conf[(long)bc * K + k] = v;
+      ys[(long)bc * K + k] = idx / W;
+      xs[(long)bc * K + k] = idx % W;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Semantic pseudo ground truth — train.py:263,438-449. One workgroup per 16 output rows of one image.
+// ---------------------------------------------------------------------------------------------
+constexpr int SEG_ROWS = 16;
+constexpr int SEG_MAXC = 32;
+
+__global__ __launch_bounds__(256) void seg_pseudo_gt_kernel(const float* __restrict__ seg2b, const float* __restrict__ l1h,
+                                                            int bs, int C, int h, int w, int H, int W, int old_classes,
+                                                            int no_mask, int band, uint8_t* __restrict__ seg_gt,
+                                                            float* __restrict__ old_w, float* __restrict__ prob_win) {
+  extern __shared__ float lds[];  // [C][band][w] flip-TTA mean of the logits
+  const int b = blockIdx.y;
+  const int Y0 = blockIdx.x * SEG_ROWS;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  const int ylo = bilin_half_pixel(Y0, sy, h).i0;
+  const long plane = (long)h * w;
+  for (int i = threadIdx.x; i < C * band * w; i += blockDim.x) {
+    int x = i % w;
+    int t = i / w;
+    int r = t % band;
+    int c = t / band;
+    int y = min(ylo + r, h - 1);
+    float a = seg2b[((long)b * C + c) * plane + y * w + x];
+    float f = seg2b[((long)(bs + b) * C + c) * plane + y * w + (w - 1 - x)];
+    lds[i] = (a + f) / 2.f;
+  }
+  __syncthreads();
+  float mask[SEG_MAXC];
+  for (int c = 0; c < C; ++c) {
+    float m = 1.f;
+    if (no_mask) { if (c >= 1) m = l1h[b * (C - 1) + c - 1]; }
+    else if (c >= old_classes) m = l1h[b * (C - 1) + c - 1];
+    mask[c] = m;
+  }
+  const int rows = min(SEG_ROWS, H - Y0);
+  for (int i = threadIdx.x; i < rows * W; i += blockDim.x) {
+    int yy = i / W, X = i - yy * W;
+    int Y = Y0 + yy;
+    Bilin by = bilin_half_pixel(Y, sy, h), bx = bilin_half_pixel(X, sx, w);
+    by.i0 -= ylo; by.i1 -= ylo;  // band-relative rows
+    float v[SEG_MAXC];
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+      v[c] = bilin_sample(lds + c * band * w, w, by, bx);
+      mx = fmaxf(mx, v[c]);
+    }
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - mx); sum += v[c]; }
+    int arg = 0;
+    float best = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+      float p = (v[c] / sum) * mask[c];
+      if (p > best) { best = p; arg = c; }
+    }
+    long o = ((long)b * H + Y) * W + X;
+    old_w[o] = (arg < old_classes && arg != 0) ? 1.f : 0.f;
+    seg_gt[o] = (uint8_t)(arg < old_classes ? 0 : arg);
+    prob_win[o] = best;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Connected-component labelling (union-find with atomicMin) on a uint8 class map: pixels are
+// connected iff they are neighbours (4- or 8-way) and carry the same non-zero value.
+// label = smallest flat index (b*H*W + y*W + x) of the component, -1 for background.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int uf_find(const int* L, int a) {
+  int p = L[a];
+  while (p != a) { a = p; p = L[a]; }
+  return a;
+}
+
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+  while (true) {
+    a = uf_find(L, a);
+    b = uf_find(L, b);
+    if (a == b) return;
+    if (a < b) { int t = a; a = b; b = t; }  // a > b: link a under b
+    int old = atomicMin(&L[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+__global__ void ccl_init_kernel(const uint8_t* __restrict__ cls, int* __restrict__ L, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    L[i] = cls[i] ? (int)i : -1;
+}
+
+__global__ void ccl_merge_kernel(const uint8_t* __restrict__ cls, int* __restrict__ L, int H, int W, long total, int conn8) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    uint8_t v = cls[i];
+    if (!v) continue;
+    int x = i % W;
+    int y = (i / W) % H;
+    if (x > 0 && cls[i - 1] == v) uf_union(L, (int)i, (int)i - 1);
+    if (y > 0) {
+      if (cls[i - W] == v) uf_union(L, (int)i, (int)i - W);
+      if (conn8) {
+        if (x > 0 && cls[i - W - 1] == v) uf_union(L, (int)i, (int)i - W - 1);
+        if (x < W - 1 && cls[i - W + 1] == v) uf_union(L, (int)i, (int)i - W + 1);
+      }
+    }
+  }
+}
+
+__global__ void ccl_compress_kernel(int* __restrict__ L, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int l = L[i];
+    if (l >= 0) L[i] = uf_find(L, (int)i);
+  }
+}
+
+// area / sum_x / sum_y per component root. Each thread walks 8 consecutive pixels of a row and flushes one
+// set of atomics per run of equal roots (cuts same-address atomic traffic ~8x on large components).
+constexpr int RUN = 8;
+__global__ void cc_stats_kernel(const int* __restrict__ L, int H, int W, long total_runs, int runs_per_row,
+                                unsigned* __restrict__ area, unsigned* __restrict__ sumx, unsigned* __restrict__ sumy) {
+  for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < total_runs; r += (long)gridDim.x * blockDim.x) {
+    int xr = r % runs_per_row;
+    long row = r / runs_per_row;  // b*H + y
+    int y = row % H;
+    int x0 = xr * RUN;
+    const int* lp = L + row * W;
+    int cur = -1;
+    unsigned a = 0, sx = 0;
+    for (int x = x0; x < min(x0 + RUN, W); ++x) {
+      int l = lp[x];
+      if (l != cur) {
+        if (cur >= 0) { atomicAdd(&area[cur], a); atomicAdd(&sumx[cur], sx); atomicAdd(&sumy[cur], a * (unsigned)y); }
+        cur = l; a = 0; sx = 0;
+      }
+      if (l >= 0) { ++a; sx += (unsigned)x; }
+    }
+    if (cur >= 0) { atomicAdd(&area[cur], a); atomicAdd(&sumx[cur], sx); atomicAdd(&sumy[cur], a * (unsigned)y); }
+  }
+}
+
+}  // namespace
+
+extern "C" int cl4_cam_smooth(const float* int_masks, int b, int ctot, int h, int w, const float* pg_w, const float* pg_b,
+                              const float* label_new, int cnew, float alpha, float* cam, void* stream) {
+  CL4_REQUIRE(int_masks && pg_w && pg_b && label_new && cam, "cam_smooth: null pointer");
+  CL4_REQUIRE(b > 0 && cnew > 0 && cnew <= ctot && h > 0 && w > 0, "cam_smooth: bad dims");
+  size_t lds = (size_t)2 * cnew * h * w * sizeof(float);
+  CL4_REQUIRE(lds <= 64 * 1024, "cam_smooth: %d x %dx%d does not fit LDS", cnew, h, w);
+  hipLaunchKernelGGL(cam_smooth_kernel, dim3(b), dim3(256), lds, cl4::as_stream(stream), int_masks, ctot, h, w, pg_w, pg_b,
+                     label_new, cnew, alpha, cam);
+  return cl4::launch_status();
+}
+
+extern "C" size_t cl4_peak_workspace_bytes(int b, int c) {
+  return (size_t)b * c * (CAND_CAP * sizeof(PeakCand) + sizeof(int));
+}
+
+extern "C" int cl4_peak_extract(const float* cam, const float* label_new, int b, int c, int h, int w, int H, int W, int kernel,
+                                int K, float* conf, int* ys, int* xs, void* workspace, size_t workspace_bytes, void* stream) {
+  CL4_REQUIRE(cam && label_new && conf && ys && xs && workspace, "peak_extract: null pointer");
+  CL4_REQUIRE(b > 0 && c > 0 && h > 0 && w > 0 && H > 0 && W > 0 && K > 0, "peak_extract: bad dims");
+  CL4_REQUIRE(kernel % 2 == 1 && kernel >= 1 && (kernel - 1) / 2 <= PMAXR, "peak_extract: kernel %d unsupported (odd, <= 15)", kernel);
+  if (workspace_bytes < cl4_peak_workspace_bytes(b, c)) { cl4::set_error("peak_extract: workspace too small"); return CL4_ENOSPC; }
+  size_t lds = ((size_t)h * w + PTS * PTS + PTS * PT) * sizeof(float);
+  CL4_REQUIRE(lds <= 64 * 1024, "peak_extract: low-res map %dx%d does not fit LDS", h, w);
+  hipStream_t st = cl4::as_stream(stream);
+  int* cnt = (int*)workspace;
+  PeakCand* cand = (PeakCand*)((char*)workspace + (((size_t)b * c * sizeof(int) + 15) / 16) * 16);
+  CL4_REQUIRE((char*)(cand + (size_t)b * c * CAND_CAP) <= (char*)workspace + workspace_bytes + 16, "peak_extract: workspace layout");
+  hipMemsetAsync(cnt, 0, (size_t)b * c * sizeof(int), st);
+  dim3 g(cl4::cdiv(H, PT) * cl4::cdiv(W, PT), c, b);
+  hipLaunchKernelGGL(peak_nms_kernel, g, dim3(256), lds, st, cam, h, w, H, W, (kernel - 1) / 2, label_new, cand, cnt);
+  hipLaunchKernelGGL(peak_topk_kernel, dim3(b * c), dim3(256), 0, st, cand, cnt, W, K, conf, ys, xs);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_seg_pseudo_gt(const float* seg2b, const float* l1h, int bs, int C, int h, int w, int H, int W,
+                                 int old_classes, int no_mask, uint8_t* seg_gt, float* old_w, float* prob_win, void* stream) {
+  CL4_REQUIRE(seg2b && l1h && seg_gt && old_w && prob_win, "seg_pseudo_gt: null pointer");
+  CL4_REQUIRE(bs > 0 && C > 1 && C <= SEG_MAXC && h > 0 && w > 0 && H > 0 && W > 0, "seg_pseudo_gt: bad dims (C <= %d)", SEG_MAXC);
+  CL4_REQUIRE(old_classes >= 1 && old_classes <= C, "seg_pseudo_gt: old_classes out of range");
+  int band = (int)((float)SEG_ROWS * (float)h / (float)H) + 3;
+  if (band > h) band = h;
+  size_t lds = (size_t)C * band * w * sizeof(float);
+  CL4_REQUIRE(lds <= 64 * 1024, "seg_pseudo_gt: low-res band does not fit LDS");
+  dim3 g(cl4::cdiv(H, SEG_ROWS), bs);
+  hipLaunchKernelGGL(seg_pseudo_gt_kernel, g, dim3(256), lds, cl4::as_stream(stream), seg2b, l1h, bs, C, h, w, H, W,
+                     old_classes, no_mask, band, seg_gt, old_w, prob_win);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_ccl(const uint8_t* cls_map, int b, int H, int W, int connectivity, int* labels, void* stream) {
+  CL4_REQUIRE(cls_map && labels && b > 0 && H > 0 && W > 0, "ccl: bad arguments");
+  CL4_REQUIRE(connectivity == 4 || connectivity == 8, "ccl: connectivity must be 4 or 8");
+  long total = (long)b * H * W;
+  CL4_REQUIRE(total < 2147483647L, "ccl: index overflow");
+  hipStream_t st = cl4::as_stream(stream);
+  int g = cl4::stream_grid(total, 256);
+  hipLaunchKernelGGL(ccl_init_kernel, dim3(g), dim3(256), 0, st, cls_map, labels, total);
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3(g), dim3(256), 0, st, cls_map, labels, H, W, total, connectivity == 8);
+  hipLaunchKernelGGL(ccl_compress_kernel, dim3(g), dim3(256), 0, st, labels, total);
+  return cl4::launch_status();
+}
+
+// area/sumx/sumy: uint32 [b*H*W], indexed by component root; zeroed here.
+extern "C" int cl4_cc_stats(const int* labels, int b, int H, int W, unsigned* area, unsigned* sumx, unsigned* sumy, void* stream) {
+  CL4_REQUIRE(labels && area && sumx && sumy && b > 0 && H > 0 && W > 0, "cc_stats: bad arguments");
+  hipStream_t st = cl4::as_stream(stream);
+  size_t bytes = (size_t)b * H * W * sizeof(unsigned);
+  hipMemsetAsync(area, 0, bytes, st);
+  hipMemsetAsync(sumx, 0, bytes, st);
+  hipMemsetAsync(sumy, 0, bytes, st);
+  int rpr = cl4::cdiv(W, RUN);
+  long runs = (long)b * H * rpr;
+  hipLaunchKernelGGL(cc_stats_kernel, dim3(cl4::stream_grid(runs, 256)), dim3(256), 0, st, labels, H, W, runs, rpr, area, sumx, sumy);
+  return cl4::launch_status();
+}

@@ -283,3 +283,144 @@ def dwconv5_wgrad_(dw, x, dy, c=None, x_coff=0, dy_coff=0):
         c = x_ctot - x_coff
     call("cl4_dwconv5_wgrad", ptr(x), ptr(dy), ptr(dw), n, c, h, wd, x_ctot, x_coff, dy.shape[1], dy_coff, stream())
     return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# label stage / losses / optimiser
+# ---------------------------------------------------------------------------------------------
+def cam_smooth(int_masks, pg_weight, pg_bias, label_new, alpha=0.7):
+    """PeakGenerator eval + cam_normalize + smoothing; returns the new-class CAM [b, cnew, h, w]."""
+    b, ctot, h, w = int_masks.shape
+    cnew = pg_weight.shape[0]
+    cam = torch.empty((b, cnew, h, w), dtype=torch.float32, device=int_masks.device)
+    call("cl4_cam_smooth", ptr(int_masks), b, ctot, h, w, ptr(pg_weight.reshape(cnew, cnew)), ptr(pg_bias), ptr(label_new),
+         cnew, C.c_float(alpha), ptr(cam), stream())
+    return cam
+
+
+def peak_extract(cam, label_new, size, kernel=15, K=25):
+    """Upsample-to-`size` + NMS + top-K. Returns device tensors conf f32, ys i32, xs i32 of shape [b, c, K]."""
+    b, c, h, w = cam.shape
+    H, W = size
+    conf = torch.empty((b, c, K), dtype=torch.float32, device=cam.device)
+    ys = torch.empty((b, c, K), dtype=torch.int32, device=cam.device)
+    xs = torch.empty_like(ys)
+    nbytes = _hip.load().cl4_peak_workspace_bytes(b, c) + 64
+    ws = _workspace(cam.device, nbytes)
+    call("cl4_peak_extract", ptr(cam), ptr(label_new), b, c, h, w, H, W, kernel, K, ptr(conf), ptr(ys), ptr(xs), ptr(ws),
+         ws.numel(), stream())
+    return conf, ys, xs
+
+
+def seg_pseudo_gt(seg2b, l1h, old_classes, size, no_mask=False):
+    n2, Cc, h, w = seg2b.shape
+    bs = n2 // 2
+    H, W = size
+    dev = seg2b.device
+    seg_gt = torch.empty((bs, H, W), dtype=torch.uint8, device=dev)
+    old_w = torch.empty((bs, 1, H, W), dtype=torch.float32, device=dev)
+    prob_win = torch.empty((bs, H, W), dtype=torch.float32, device=dev)
+    call("cl4_seg_pseudo_gt", ptr(seg2b), ptr(l1h), bs, Cc, h, w, H, W, old_classes, int(no_mask), ptr(seg_gt), ptr(old_w),
+         ptr(prob_win), stream())
+    return seg_gt, old_w, prob_win
+
+
+def ccl(cls_map, connectivity=8):
+    b, H, W = cls_map.shape
+    labels = torch.empty((b, H, W), dtype=torch.int32, device=cls_map.device)
+    call("cl4_ccl", ptr(cls_map), b, H, W, connectivity, ptr(labels), stream())
+    return labels
+
+
+def cc_stats(labels):
+    b, H, W = labels.shape
+    area = torch.empty((b, H, W), dtype=torch.int32, device=labels.device)
+    sumx = torch.empty_like(area)
+    sumy = torch.empty_like(area)
+    call("cl4_cc_stats", ptr(labels), b, H, W, ptr(area), ptr(sumx), ptr(sumy), stream())
+    return area, sumx, sumy
+
+
+_label_ws = {}
+
+
+def label_generation(seg_gt, prob_win, label_new, peaks, center_lo, offset_lo, gauss, old_classes, sigma=6,
+                     pseudo_thresh=0.7, refine_thresh=0.3, nms_kernel=41, beta=3.0, run_refine=True):
+    """Batch pseudo_label_generation + refine_label_generation. Returns (pseudo, refined) dicts of device tensors
+    with keys center [b,cnew,H,W], offset [b,2,H,W], weight [b,1,H,W]; refined is None when run_refine is False."""
+    b, H, W = seg_gt.shape
+    cnew = label_new.shape[1]
+    dev = seg_gt.device
+    conf, ys, xs = peaks
+    new = lambda c: torch.empty((b, c, H, W), dtype=torch.float32, device=dev)
+    pseudo = {"center": new(cnew), "offset": new(2), "weight": new(1)}
+    refined = {"center": new(cnew), "offset": new(2), "weight": new(1)} if run_refine else None
+    d = _hip.LabelIO()
+    d.b, d.H, d.W, d.cnew, d.old_classes = b, H, W, cnew, old_classes
+    d.hc, d.wc, d.center_ctot = center_lo.shape[2], center_lo.shape[3], center_lo.shape[1]
+    d.K, d.sigma, d.nms_kernel, d.run_refine = conf.shape[2], sigma, nms_kernel, int(run_refine)
+    d.pseudo_thresh, d.refine_thresh, d.beta = pseudo_thresh, refine_thresh, beta
+    pv = lambda t: ptr(t).value if t is not None else None
+    d.seg_gt, d.prob_win, d.label_new = pv(seg_gt), pv(prob_win), pv(label_new)
+    d.peak_conf, d.peak_y, d.peak_x = pv(conf), pv(ys), pv(xs)
+    d.center_lo, d.offset_lo, d.gauss = pv(center_lo), pv(offset_lo), pv(gauss)
+    d.p_center, d.p_offset, d.p_weight = pv(pseudo["center"]), pv(pseudo["offset"]), pv(pseudo["weight"])
+    if run_refine:
+        d.r_center, d.r_offset, d.r_weight = pv(refined["center"]), pv(refined["offset"]), pv(refined["weight"])
+    nbytes = _hip.load().cl4_label_workspace_bytes(b, H, W)
+    key = (dev.index, nbytes)
+    ws = _label_ws.get(key)
+    if ws is None:
+        _label_ws.clear()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _label_ws[key] = ws
+    call("cl4_label_generation", C.byref(d), ptr(ws), ws.numel(), stream())
+    return pseudo, refined
+
+
+def label_counters(b, H, W, device):
+    """{n_contour, n_psplat, n_center, n_cand, overflow} of the last label_generation (forces a sync)."""
+    nbytes = _hip.load().cl4_label_workspace_bytes(b, H, W)
+    ws = _label_ws[(device.index, nbytes)]
+    out = torch.empty(5, dtype=torch.int32, device=device)
+    call("cl4_label_counters", ptr(ws), b, H, W, ptr(out), stream())
+    return dict(zip(("n_contour", "n_psplat", "n_center", "n_cand", "overflow"), out.cpu().tolist()))
+
+
+def p2_loss(center, offset, old_center, old_offset, old_w, pseudo, refined, size, center_weight=200.0,
+            offset_weight=0.01, with_grad=True):
+    """Returns (losses [4] device tensor: center_old, offset_old, center_new, offset_new; d_center; d_offset)."""
+    b, ctot, hc, wc = center.shape
+    cnew = pseudo["center"].shape[1]
+    cold = ctot - cnew
+    H, W = size
+    dev = center.device
+    losses = torch.empty(4, dtype=torch.float32, device=dev)
+    dcen = torch.empty_like(center) if with_grad else None
+    doff = torch.empty_like(offset) if with_grad else None
+    d = _hip.P2LossIO()
+    d.b, d.H, d.W, d.hc, d.wc, d.cold, d.cnew = b, H, W, hc, wc, cold, cnew
+    pv = lambda t: ptr(t).value if t is not None else None
+    d.center, d.offset, d.old_center, d.old_offset, d.old_w = pv(center), pv(offset), pv(old_center), pv(old_offset), pv(old_w)
+    d.p_center, d.p_offset, d.p_weight = pv(pseudo["center"]), pv(pseudo["offset"]), pv(pseudo["weight"])
+    if refined is not None:
+        d.r_center, d.r_offset, d.r_weight = pv(refined["center"]), pv(refined["offset"]), pv(refined["weight"])
+    d.center_weight, d.offset_weight = center_weight, offset_weight
+    d.losses, d.d_center, d.d_offset = pv(losses), pv(dcen), pv(doff)
+    nbytes = _hip.load().cl4_p2_loss_workspace_bytes(b, H, W, cold, cnew, int(with_grad))
+    ws = _workspace(dev, nbytes)
+    call("cl4_p2_loss", C.byref(d), ptr(ws), ws.numel(), stream())
+    return losses, dcen, doff
+
+
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    n = p.numel()
+    if not (g.numel() == n and m.numel() == n and v.numel() == n):
+        raise RuntimeError("adam_step_: size mismatch")
+    call("cl4_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), n, C.c_float(lr), C.c_float(beta1), C.c_float(beta2),
+         C.c_float(eps), C.c_float(weight_decay), int(step), stream())
+
+
+def zero_(t):
+    call("cl4_fill_zero", ptr(t), t.numel() * t.element_size(), stream())
+    return t

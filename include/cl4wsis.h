@@ -148,6 +148,82 @@ int cl4_dwconv5_fwd(const float* x, const float* w, float* y, int n, int c, int 
 int cl4_dwconv5_wgrad(const float* x, const float* dy, float* dw, int n, int c, int h, int wd,
                       int x_ctot, int x_coff, int dy_ctot, int dy_coff, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Label stage of the phase-2 step (train.py:418-522). HBM/LDS-bound integer / float work.
+ * ------------------------------------------------------------------------ */
+/* PeakGenerator eval (PAM -> 1x1 conv -> relu*label -> /max) + 3x3 smoothing — wss/modules.py:354-368,390-434,
+ * wss/utils.py:28-32. int_masks [b,ctot,h,w] (the last cnew channels are used), pg_w [cnew,cnew], pg_b [cnew],
+ * label_new [b,cnew] -> cam [b,cnew,h,w] (new-class channels only; old-class channels are identically zero). */
+int cl4_cam_smooth(const float* int_masks, int b, int ctot, int h, int w, const float* pg_w, const float* pg_b,
+                   const float* label_new, int cnew, float alpha, float* cam, void* stream);
+/* Bilinear upsample (align_corners=False) to HxW fused with peak_extract (wss/utils.py:3-25): kernel x kernel max-pool
+ * NMS + top-K per (b,c). conf/ys/xs: [b,c,K]; slots beyond the positive peaks hold conf=0,y=x=0. Ties: lowest index. */
+size_t cl4_peak_workspace_bytes(int b, int c);
+int cl4_peak_extract(const float* cam, const float* label_new, int b, int c, int h, int w, int H, int W, int kernel, int K,
+                     float* conf, int* ys, int* xs, void* workspace, size_t workspace_bytes, void* stream);
+/* train.py:263,438-449: flip-TTA mean of seg2b [2b,C,h,w] -> upsample -> softmax -> label mask -> argmax.
+ * seg_gt uint8 [b,H,W] (old classes zeroed), old_w f32 [b,H,W], prob_win f32 [b,H,W] (masked prob of the argmax). */
+int cl4_seg_pseudo_gt(const float* seg2b, const float* l1h, int bs, int C, int h, int w, int H, int W, int old_classes,
+                      int no_mask, uint8_t* seg_gt, float* old_w, float* prob_win, void* stream);
+/* Connected components of equal non-zero values (connectivity 4 or 8): labels int32 [b,H,W] = smallest flat index
+ * (b*H*W + y*W + x) of the component, -1 on background. Replaces cv2.connectedComponentsWithStats
+ * (modules/utils.py:224,307,627); cl4_cc_stats gives area / sum_x / sum_y at the root index. */
+int cl4_ccl(const uint8_t* cls_map, int b, int H, int W, int connectivity, int* labels, void* stream);
+int cl4_cc_stats(const int* labels, int b, int H, int W, unsigned* area, unsigned* sumx, unsigned* sumy, void* stream);
+
+/* pseudo_label_generation (modules/utils.py:179-253) + refine_label_generation (:257-385) for the whole batch. */
+typedef struct cl4_label_io {
+  int32_t b, H, W;
+  int32_t cnew, old_classes;      /* new classes; old classes INCLUDING background */
+  int32_t hc, wc, center_ctot;    /* low-res size / channel count of center_lo */
+  int32_t K, sigma, nms_kernel, run_refine;
+  float pseudo_thresh, refine_thresh, beta;
+  const uint8_t* seg_gt;          /* [b,H,W] */
+  const float* prob_win;          /* [b,H,W] */
+  const float* label_new;         /* [b,cnew] */
+  const float* peak_conf;         /* [b,cnew,K] */
+  const int32_t* peak_y;
+  const int32_t* peak_x;
+  const float* center_lo;         /* [b,center_ctot,hc,wc] new model; class c is channel old_classes-1+c */
+  const float* offset_lo;         /* [b,2,hc,wc] */
+  const float* gauss;             /* [(6*sigma+3)^2] float32 of modules/utils.py:49-59 */
+  float* p_center;                /* [b,cnew,H,W] */
+  float* p_offset;                /* [b,2,H,W] (channel 0 = y) */
+  float* p_weight;                /* [b,1,H,W] */
+  float* r_center;
+  float* r_offset;
+  float* r_weight;
+} cl4_label_io;
+size_t cl4_label_workspace_bytes(int b, int H, int W);
+int cl4_label_generation(const cl4_label_io* d, void* workspace, size_t workspace_bytes, void* stream);
+/* {n_contour, n_psplat, n_center, n_cand, overflow} of the last call on this workspace -> out5 (device). */
+int cl4_label_counters(const void* workspace, int b, int H, int W, int* out5, void* stream);
+
+/* train.py:503-522 with utils/loss.py:228-275: blending + four weighted losses, fused with the bilinear upsample of
+ * the low-resolution maps; optionally the gradient w.r.t. center / offset (low resolution). */
+typedef struct cl4_p2_loss_io {
+  int32_t b, H, W, hc, wc;
+  int32_t cold, cnew;             /* old classes WITHOUT background (15), new classes (5) */
+  const float* center;            /* [b,cold+cnew,hc,wc] */
+  const float* offset;            /* [b,2,hc,wc] */
+  const float* old_center;        /* [b,cold,hc,wc] */
+  const float* old_offset;        /* [b,2,hc,wc] */
+  const float* old_w;             /* [b,H,W] */
+  const float* p_center; const float* p_offset; const float* p_weight;
+  const float* r_center; const float* r_offset; const float* r_weight;   /* all NULL when run_refine is off */
+  float center_weight, offset_weight;   /* 200, 0.01 (train.py:100-101) */
+  float* losses;                  /* [4] device: center_old, offset_old, center_new, offset_new */
+  float* d_center;                /* [b,cold+cnew,hc,wc] d(sum of the four)/d(center), or NULL */
+  float* d_offset;
+} cl4_p2_loss_io;
+size_t cl4_p2_loss_workspace_bytes(int b, int H, int W, int cold, int cnew, int with_grad);
+int cl4_p2_loss(const cl4_p2_loss_io* d, void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch.optim.Adam step (train.py:181-182,538) over flat buffers; `step` is the 1-based step count. */
+int cl4_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, void* stream);
+int cl4_fill_zero(void* p, size_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
