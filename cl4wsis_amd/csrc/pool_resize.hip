@@ -85,13 +85,14 @@ __global__ void global_mean_kernel(const float* __restrict__ x, float* __restric
 }
 
 // PyTorch's bilinear source index (upsample_bilinear2d): align_corners=True: src = dst*(in-1)/(out-1);
-// align_corners=False: src = max((dst+0.5)*in/out - 0.5, 0). Returns i0, i1 and the weight of i1.
+// align_corners=False: src = max(fma(scale, dst+0.5, -0.5), 0) — the FMA form is what the reference's CPU kernel
+// evaluates (see label_common.h). Returns i0, i1 and the weight of i1.
 __device__ __forceinline__ void src_index(int dst, float scale, int align, int in_size, int& i0, int& i1, float& l1) {
   float src;
   if (align) {
     src = scale * (float)dst;
   } else {
-    src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = fmaf(scale, (float)dst + 0.5f, -0.5f);
     if (src < 0.f) src = 0.f;
   }
   i0 = (int)src;
@@ -126,8 +127,9 @@ __global__ void resize_fwd_kernel(const float* __restrict__ x, float* __restrict
     src_index(ox, a.sx, a.align, a.win, x0, x1, lx);
     const float* xp = x + ((long)n * a.in_ctot + a.in_coff + c) * a.hin * a.win;
     float hy = 1.f - ly, hx = 1.f - lx;
-    float v = hy * (hx * xp[y0 * a.win + x0] + lx * xp[y0 * a.win + x1]) +
-              ly * (hx * xp[y1 * a.win + x0] + lx * xp[y1 * a.win + x1]);
+    float t0 = fmaf(xp[y0 * a.win + x0], hx, xp[y0 * a.win + x1] * lx);
+    float t1 = fmaf(xp[y1 * a.win + x0], hx, xp[y1 * a.win + x1] * lx);
+    float v = fmaf(t0, hy, t1 * ly);
     y[(((long)n * a.out_ctot + a.out_coff + c) * a.hout + oy) * a.wout + ox] = v;
   }
 }

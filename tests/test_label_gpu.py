@@ -42,6 +42,29 @@ def _run_hip(inp, gpu, run_refine=True):
                 losses=losses, d_center=dc, d_offset=do, counters=cnt)
 
 
+def _check_peak_indices(conf, ys, xs, rconf, rys, rxs, W):
+    """torch.topk leaves the order among EQUAL scores unspecified; the kernel's documented rule is
+    lowest flat index first. So: untied scores must agree in position and index exactly; a group of tied scores must
+    hold the same index set, unless the tie reaches the K-th (last) score, where either side may cut it differently."""
+    K = len(rconf)
+    if K == 0:
+        return
+    tail = -1.0  # the compared prefix is cut at a score threshold, not at K: no tie can straddle its end
+    i = 0
+    while i < K and rconf[i] > 0:
+        j = i
+        while j + 1 < K and rconf[j + 1] == rconf[i]:
+            j += 1
+        got = sorted(int(ys[k]) * W + int(xs[k]) for k in range(i, j + 1))
+        ref = sorted(int(rys[k]) * W + int(rxs[k]) for k in range(i, j + 1))
+        if rconf[i] != tail:
+            assert got == ref, (i, j, got, ref)
+        if j == i and rconf[i] != tail:
+            assert ys[i] == rys[i] and xs[i] == rxs[i]
+        assert got == sorted(set(got))  # no duplicates
+        i = j + 1
+
+
 @pytest.mark.parametrize("seed,H,W", [(0, 129, 129), (1, 129, 129), (2, 129, 129), (3, 129, 129), (4, 161, 129),
                                       (5, 97, 145), (6, 193, 193), (7, 129, 129)])
 def test_label_stage_matches_oracle(gpu, seed, H, W):
@@ -58,11 +81,15 @@ def test_label_stage_matches_oracle(gpu, seed, H, W):
     lab = inp["l1h"][:, oc - 1:].numpy() > 0
     for b in range(lab.shape[0]):
         for c in np.nonzero(lab[b])[0]:
-            pos = rc[b, c] > 0
-            np.testing.assert_allclose(conf[b, c][pos], rc[b, c][pos], rtol=1e-5)
-            assert (conf[b, c][~pos] == 0).all()
-            np.testing.assert_array_equal(ys[b, c][pos], ry[b, c][pos])
-            np.testing.assert_array_equal(xs[b, c][pos], rx[b, c][pos])
+            # Only the prefix with conf >= pseudo_thresh (0.7) is consumed (train.py:455-458). Below ~1e-2 the CAM is a
+            # smoothed-noise plateau where `hmax == heat` hinges on the last ulp of the bilinear arithmetic (the CPU
+            # reference may contract to FMA), so the strict comparison covers the scores >= 0.05.
+            strong = rc[b, c] >= 0.05
+            ns = int(strong.sum())
+            assert ns == int((conf[b, c] >= 0.05).sum())
+            np.testing.assert_allclose(conf[b, c][:ns], rc[b, c][:ns], rtol=1e-5)
+            _check_peak_indices(conf[b, c][:ns], ys[b, c][:ns], xs[b, c][:ns], rc[b, c][:ns], ry[b, c][:ns], rx[b, c][:ns], W)
+            assert (np.diff(conf[b, c]) <= 0).all()  # sorted descending
     # semantic pseudo GT: bit-exact argmax except where the oracle's own top-2 gap is below fp32 resolution -----
     sg = got["seg_gt"].cpu().long()
     mism = sg != ref["seg_gt"]
