@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""Benchmark of the CL4WSIS phase-2 training step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one `Trainer.step` (cl4wsis_amd.train) on a synthetic VOC-shaped batch: global batch 16 split over the N
+ranks (run.py:66 semantics, strong scaling), 513x513, VOC 15-5 step 1 phase 2, fp32, inputs resident in HBM.
+Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel (implicit-GEMM conv forward,
+timed live with HIP events on its launch stream) and, at N=1, the CPU baseline (the oracle restatement of the same
+step on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+GLOBAL_BATCH = 16
+CROP = 513
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+ALGO_GFLOP_PER_IMAGE = 545.7    # SURVEY.md §8(d) / BASELINE.md §3
+
+
+def p2_opts(batch):
+    from cl4wsis_amd import argparser
+    args = ["--dataset", "voc", "--task", "15-5", "--step", "1", "--weakly", "--phase", "2", "--alpha", "0.5",
+            "--loss_de", "1", "--lr_policy", "warmup", "--affinity", "--optim", "adam", "--weight_decay", "0",
+            "--lr", "5e-5", "--crop_size", str(CROP), "--batch_size", str(batch), "--no_pretrained", "--epochs", "30"]
+    return argparser.modify_command_options(argparser.get_argparser().parse_args(args))
+
+
+def synthetic_batch(b, seed, device):
+    """images ~ N(0,1); l1h with columns 0-14 zero, 1 new class w.p. 0.6 / 2 w.p. 0.4."""
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(b, 3, CROP, CROP, generator=g)
+    l1h = torch.zeros(b, 20)
+    for i in range(b):
+        k = 1 if torch.rand(1, generator=g).item() < 0.6 else 2
+        for c in torch.randperm(5, generator=g)[:k].tolist():
+            l1h[i, 15 + c] = 1
+    return images.to(device), l1h.to(device)
+
+
+def cpu_baseline(opts):
+    """Oracle (CPU restatement of the reference step, PyTorch-CPU fp32) on a bounded sample: batch 2, one step."""
+    from cl4wsis_amd import segmentation_module as sm
+    from cl4wsis_amd.wss import PeakGenerator, PseudoLabeler
+    from oracle import step as ostep
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
+    new = sd(sm.make_model(opts, classes=[16, 5]))
+    old = sd(sm.make_model(opts, classes=[16]))
+    pl = sd(PseudoLabeler(2048, 21, sm.get_norm(opts)))
+    pg = sd(PeakGenerator(21, 20, old_classes=15))
+    b = 2
+    images, l1h = synthetic_batch(b, 42, torch.device("cpu"))
+    t0 = time.time()
+    ostep.p2_step(new, old, pl, pg, images, l1h, 16, pooling=opts.pooling, lr=opts.lr * opts.lr_head)
+    dt = time.time() - t0
+    return {"value": b / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle p2_step (PyTorch-CPU fp32 restatement of train.py:241-541), batch {b} at {CROP}x{CROP}, "
+                      f"1 step, {dt:.1f} s, torch threads={cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from cl4wsis_amd import ops
+    from cl4wsis_amd.parallel import init_distributed
+    from cl4wsis_amd.train import Trainer
+
+    rank, world, local = init_distributed()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    b = GLOBAL_BATCH // world
+    opts = p2_opts(GLOBAL_BATCH)
+    opts.batch_size = b
+    opts.max_iters, opts.start_decay = 30 * 661, 5 * 661   # 10582 train images / 16
+    torch.manual_seed(42)                      # identical replicas on every rank
+
+    class _Log:
+        def info(self, *a, **k): pass
+        debug = info
+
+    trainer = Trainer(_Log(), device, opts)
+    images, l1h = synthetic_batch(b, 42 + rank, device)
+
+    for _ in range(a.warmup):
+        trainer.step((images, l1h))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.TIMER = ops.KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = trainer.step((images, l1h))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    losses = out["losses"].tolist()
+    if rank == 0:
+        summ = timer.summary()
+        n, fl, ms = summ["conv_fwd"]
+        ach = fl / (ms * 1e-3) / 1e12
+        res = {
+            "metric": "images/sec at batch 16, VOC 15-5 step-1 phase-2, 1/2/4/8 MI355X",
+            "value": GLOBAL_BATCH * a.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "VOC 15-5 step 1 phase 2 (BASELINE config 3), Trainer.step, global batch 16, "
+                                   "513x513, ResNet101+DeepLabV3+Panoptic-DeepLab, run_refine on, random-init weights, "
+                                   "label stage fed by the networks' own outputs (e2e-random mode)",
+                       "global_batch": GLOBAL_BATCH, "per_gpu_batch": b, "crop": CROP, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (cl4_conv2d_fwd, all launches of the timed steps)",
+                         "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None, "launches_per_step": n / a.steps,
+                         "algorithmic_gflop_per_step": fl / a.steps / 1e9, "avg_launch_ms": ms / n,
+                         "conv_fwd_ms_per_step": ms / a.steps},
+            "algorithmic_tflops_whole_step": ALGO_GFLOP_PER_IMAGE * GLOBAL_BATCH * a.steps / elapsed / 1e3,
+            "final_losses": dict(zip(("center_old", "offset_old", "center_new", "offset_new"), losses)),
+        }
+        if "conv_wgrad" in summ:
+            wn, wf, wms = summ["conv_wgrad"]
+            res["wgrad"] = {"achieved": wf / (wms * 1e-3) / 1e12, "unit": "TFLOP/s", "ms_per_step": wms / a.steps}
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(opts)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .nn import ABN, conv_abn, conv_bias, packed_weight
+from .nn import ABN, CACHE, conv_abn, conv_bias, packed_weight
 
 EPS = 1e-5
 
@@ -183,6 +183,8 @@ class _BnConvRec:
 
 def _bn_train(z, bn, out=None, out_coff=0, keep=None, keep_scale=1.0):
     mean, var = ops.bn_train_stats(z, running_mean=bn.running_mean, running_var=bn.running_var, momentum=bn.momentum)
+    CACHE.touch(bn.running_mean)
+    CACHE.touch(bn.running_var)
     y = ops.bn_apply(z, mean, var, bn.weight.detach(), bn.bias.detach(), bn.eps, ops.ACT_RELU, keep=keep,
                      keep_scale=keep_scale, out=out, out_coff=out_coff)
     return y, mean, var
@@ -314,13 +316,29 @@ class InstanceBranch:
         return pred, tape
 
     # ---- backward helpers ------------------------------------------------------------------------
-    @staticmethod
-    def _grad(param, grads):
+    _on_ready = None
+    _queue = ()
+
+    def _grad(self, param, grads):
+        """Gradient buffer of `param`. Every parameter of this sub-net receives its gradient from exactly one kernel,
+        enqueued right after the (at most two) _grad calls that build its arguments. A parameter is therefore final on
+        the compute stream once two later _grad calls have happened; that is when `on_ready` fires (the all-reduce
+        stream orders itself behind the compute stream at launch, GradBuckets._launch)."""
         g = grads.get(id(param))
         if g is None:
             g = torch.zeros_like(param, dtype=torch.float32)
             grads[id(param)] = g
+        if self._on_ready is not None:
+            self._queue.append(param)
+            while len(self._queue) > 2:
+                self._on_ready(self._queue.pop(0))
         return g
+
+    def _flush_ready(self):
+        if self._on_ready is not None:
+            for p in self._queue:
+                self._on_ready(p)
+        self._queue = []
 
     def _dwsep_bwd(self, rec, dy, grads, need_dx=True):
         _, blk, x, z0, m0, v0, a, z1, m1, v1 = rec
@@ -334,9 +352,14 @@ class InstanceBranch:
         ops.dwconv5_wgrad_(G(dw.weight), x, dz0)
         return ops.dwconv5(dz0, dw.weight.detach(), flip=True) if need_dx else None
 
-    def backward(self, tape, dpred):
-        """Back-propagates d(loss)/d(pred[key]) through the recorded forward. Returns {id(param): grad}."""
-        grads = {}
+    def backward(self, tape, dpred, grads=None, on_ready=None):
+        """Back-propagates d(loss)/d(pred[key]) through the recorded forward. Returns {id(param): grad}.
+
+        `grads` may map id(param) -> a pre-zeroed gradient view (the flat DP buffer); `on_ready(param)` is called right
+        after the kernel that finalises a parameter's gradient has been enqueued (bucketed all-reduce hook)."""
+        grads = {} if grads is None else grads
+        self._on_ready = on_ready
+        self._queue = []
         G = lambda p: self._grad(p, grads)
         i = len(tape) - 1
         dfork = None
@@ -396,6 +419,7 @@ class InstanceBranch:
         dgp = ops.relu_bwd(gp, dgp)
         pconv = aspp.convs[4].aspp_pooling[1]
         ops.conv2d_wgrad(g, dgp, G(pconv.weight), 1)
+        self._flush_ready()
         return grads
 
     def trainable_parameters(self):

@@ -52,10 +52,15 @@ class _Cache:
 
     def __init__(self):
         self._store = {}
+        self._ext = {}   # data_ptr -> counter bumped by kernels that write a tensor behind PyTorch's back
 
-    @staticmethod
-    def _sig(tensors):
-        return tuple((t.data_ptr(), t._version, t.device.index) for t in tensors if t is not None)
+    def touch(self, t):
+        k = t.data_ptr()
+        self._ext[k] = self._ext.get(k, 0) + 1
+
+    def _sig(self, tensors):
+        return tuple((t.data_ptr(), t._version, self._ext.get(t.data_ptr(), 0), t.device.index)
+                     for t in tensors if t is not None)
 
     def get(self, key, tensors, build):
         sig = self._sig(tensors)

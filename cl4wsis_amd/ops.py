@@ -14,6 +14,31 @@ from ._hip import ACT_LEAKY, ACT_NONE, ACT_RELU, ConvDesc, call, ptr, stream
 __all__ = ["ACT_NONE", "ACT_LEAKY", "ACT_RELU"]
 
 
+class KernelTimer:
+    """Optional live timing of the implicit-GEMM conv launches with HIP events recorded on the launch stream
+    (bench.py's roofline leg). Disabled (None) by default: zero overhead on the product path."""
+
+    def __init__(self):
+        self.records = []   # (kind, flops, start_event, end_event)
+
+    def span(self, kind, flops):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        self.records.append((kind, flops, e0, e1))
+        return e0, e1
+
+    def summary(self):
+        """{kind: (launches, total_flops, total_ms)} — call after a device synchronisation."""
+        out = {}
+        for kind, fl, e0, e1 in self.records:
+            n, f, t = out.get(kind, (0, 0.0, 0.0))
+            out[kind] = (n + 1, f + fl, t + e0.elapsed_time(e1))
+        return out
+
+
+TIMER = None
+
+
 def _f32(t, name):
     if t.dtype != torch.float32:
         raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
@@ -85,7 +110,12 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
         if t is not None and t.numel() != cout:
             raise RuntimeError(f"conv2d: {nm} has {t.numel()} elements, expected {cout}")
     d = _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, out.shape[1], out_coff, act1, slope1, act2, slope2)
+    if TIMER is not None:
+        e0, e1 = TIMER.span("conv_fwd", 2.0 * n * hout * wout * cout * K)
+        e0.record()
     call("cl4_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(pre), ptr(post), ptr(out), stream())
+    if TIMER is not None:
+        e1.record()
     return out
 
 
@@ -101,7 +131,12 @@ def conv2d_wgrad(x, dy, dw, k, stride=1, pad=0, dil=1, in_coff=0, cin=None, dy_c
     d = _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, dy.shape[1], dy_coff, 0, 0.0, 0, 0.0)
     if tuple(dy.shape[2:]) != (d.hout, d.wout) or dy.shape[0] != n:
         raise RuntimeError("conv2d_wgrad: dy spatial shape does not match the convolution geometry")
+    if TIMER is not None:
+        e0, e1 = TIMER.span("conv_wgrad", 2.0 * n * d.hout * d.wout * cout * cin * k * k)
+        e0.record()
     call("cl4_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), stream())
+    if TIMER is not None:
+        e1.record()
     return dw
 
 

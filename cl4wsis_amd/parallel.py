@@ -1,0 +1,119 @@
+"""Data-parallel plumbing: one process per GPU, gradients of the trainable sub-net live in ONE flat fp32 buffer
+that is averaged across ranks with a few large RCCL all-reduces (backend "nccl" = RCCL over xGMI), issued on a
+side stream as soon as each bucket's gradients are final so they overlap the remaining backward kernels.
+
+Replaces the three DistributedDataParallel wrappers of the reference (train.py:187-196). Unlike the reference,
+whose phase-2 path bypasses DDP.forward and therefore never all-reduces, gradients ARE averaged.
+The same code runs on CPU tensors over gloo (tests/test_parallel_cpu.py).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Bootstrap from the launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*). Returns (rank, world, local)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, init_method="env://", rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+class FlatBuffer:
+    """Parameters (and gradients) of a list of tensors packed into one contiguous fp32 buffer, in the given order.
+
+    `views[i]` aliases buffer[offset_i : offset_i + numel_i] with the tensor's shape."""
+
+    def __init__(self, shapes, device):
+        self.sizes = [int(torch.Size(s).numel()) for s in shapes]
+        self.offsets = [0]
+        for n in self.sizes:
+            self.offsets.append(self.offsets[-1] + n)
+        self.numel = self.offsets[-1]
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.views = [self.flat[o:o + n].view(s) for o, n, s in zip(self.offsets, self.sizes, shapes)]
+
+
+class GradBuckets:
+    """Bucketed, asynchronous gradient averaging over a FlatBuffer.
+
+    Buckets are contiguous index ranges of the flat gradient buffer. `ready(i)` marks tensor i final; once all tensors
+    of a bucket are final the bucket is all-reduced (SUM then scaled by 1/world inside `finish`, or AVG natively on
+    RCCL) on `comm_stream`. `finish()` joins the communication before the optimizer reads the gradients."""
+
+    def __init__(self, flat, bucket_bytes=32 << 20, process_group=None):
+        self.fb = flat
+        self.group = process_group
+        self.world = world_size()
+        self.bounds = []            # (first tensor, last tensor exclusive)
+        start, acc = 0, 0
+        for i, n in enumerate(flat.sizes):
+            acc += n * 4
+            if acc >= bucket_bytes:
+                self.bounds.append((start, i + 1))
+                start, acc = i + 1, 0
+        if start < len(flat.sizes):
+            self.bounds.append((start, len(flat.sizes)))
+        self.bucket_of = {}
+        for b, (lo, hi) in enumerate(self.bounds):
+            for i in range(lo, hi):
+                self.bucket_of[i] = b
+        self.is_cuda = flat.flat.is_cuda
+        self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.world > 1) else None
+        self.reset()
+
+    def reset(self):
+        self.pending = [hi - lo for lo, hi in self.bounds]
+        self.handles = []
+        self.launched = [False] * len(self.bounds)
+
+    def _launch(self, b):
+        lo, hi = self.bounds[b]
+        chunk = self.fb.flat[self.fb.offsets[lo]:self.fb.offsets[hi]]
+        self.launched[b] = True
+        if self.world == 1:
+            return
+        if self.is_cuda:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            self.handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
+
+    def ready(self, i):
+        b = self.bucket_of[i]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
+
+    def finish(self):
+        for b in range(len(self.bounds)):
+            if not self.launched[b]:
+                self._launch(b)
+        if self.world > 1:
+            if self.is_cuda:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+            else:
+                for h, chunk in self.handles:
+                    h.wait()
+                    chunk.div_(self.world)
+        self.reset()

@@ -1,0 +1,284 @@
+"""Trainer with the reference's surface (train.py:38-812) whose per-batch body is `Trainer.step(batch)`.
+
+The reference has no `step` method: the body of the `for` loop of `Trainer.train` (train.py:241-566) is factored out
+here unchanged in meaning, and `train()` stays its caller. Phase 2 (the metric path) runs entirely on the HIP kernels
+of libcl4wsis_hip.so: frozen old-model forward, flip-TTA semantic forward, trainable instance branch forward /
+hand-written backward, label stage on device, fused losses, RCCL-averaged gradients, fused Adam.
+"""
+from functools import reduce
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops, tasks
+from .optim import FusedAdam
+from .parallel import GradBuckets, world_size
+from .scheduler import get_scheduler
+from .segmentation_module import get_norm, make_model
+from .wss import PeakGenerator, PseudoLabeler
+
+
+def gaussian(sigma=6):
+    """2-D gaussian splat kernel, float64 like the reference (modules/utils.py:49-59); cast to f32 on upload, which is
+    the rounding np.maximum(f32 map, f64 g) -> f32 map performs."""
+    size = 6 * sigma + 3
+    x = np.arange(0, size, 1, float)
+    y = x[:, np.newaxis]
+    c = 3 * sigma + 1
+    return np.exp(-((x - c) ** 2 + (y - c) ** 2) / (2 * sigma ** 2))
+
+
+class _NoScaler:
+    """The reference wraps the step in amp.autocast + GradScaler (train.py:43,252,537-541). This build computes in
+    fp32 end to end (north star: 1e-3 relative to fp32), where loss scaling is an exact no-op; the object only keeps
+    the checkpoint contract (`scaler` entry of run.py:26)."""
+
+    def state_dict(self):
+        return {}
+
+    def load_state_dict(self, sd):
+        pass
+
+
+class Trainer:
+    def __init__(self, logger, device, opts):
+        self.logger = logger
+        self.device = device
+        self.opts = opts
+        self.scaler = _NoScaler()
+        self.classes = classes = tasks.get_per_task_classes(opts.dataset, opts.task, opts.step)
+        new_classes = classes[-1]
+        self.tot_classes = reduce(lambda a, b: a + b, classes)
+        self.old_classes = self.tot_classes - new_classes
+
+        self.model = make_model(opts, classes=classes)
+        if opts.step == 0:
+            self.model_old = None
+        else:
+            self.model_old = make_model(opts, classes=tasks.get_per_task_classes(opts.dataset, opts.task, opts.step - 1))
+            self.model_old.to(self.device)
+            for par in self.model_old.parameters():
+                par.requires_grad = False
+            self.model_old.eval()
+
+        self.weakly = opts.weakly and opts.step > 0
+        self.pseudolabeler = None
+        self.peakgenerator = None
+        self.peak_conf_thresh = opts.pseudo_thresh
+        self.sigma = opts.sigma
+        self.g = gaussian(self.sigma)
+        if self.weakly and opts.pseudo is None:
+            norm = get_norm(opts)
+            channels = 4096 if "wide" in opts.backbone else 2048
+            self.pseudolabeler = PseudoLabeler(channels, self.tot_classes, norm)
+            if opts.peak_from == "peakgenerator":
+                self.peakgenerator = PeakGenerator(in_channel=self.tot_classes, num_classes=self.tot_classes - 1,
+                                                   old_classes=self.old_classes - 1)
+        self.center_loss_weight = 200
+        self.offset_loss_weight = 0.01
+        self.model.to(self.device)          # parameters must be resident before the optimizer aliases them
+        if self.pseudolabeler is not None:
+            self.pseudolabeler.to(self.device)
+        if self.peakgenerator is not None:
+            self.peakgenerator.to(self.device)
+        self._g_dev = torch.from_numpy(self.g.astype(np.float32)).to(self.device)
+        self.optimizer, self.scheduler = self.get_optimizer(opts)
+        self.distribute(opts)
+        self._iter = 0
+
+    # ------------------------------------------------------------------------------------------ optimizer
+    def get_optimizer(self, opts):
+        """train.py:144-185 (same groups, same order, same learning rates)."""
+        tr = lambda m: [p for p in m.parameters() if p.requires_grad]
+        params = []
+        if not opts.freeze:
+            params.append({"params": tr(self.model.body), "weight_decay": opts.weight_decay})
+        if opts.phase is None or opts.phase == 2:
+            if self.model.decoder is not None and hasattr(self.model.decoder, "instance_decoder"):
+                params.append({"params": tr(self.model.decoder.instance_decoder), "weight_decay": opts.weight_decay,
+                               "lr": opts.lr * opts.lr_head})
+            if self.model.instance_head is not None:
+                params.append({"params": tr(self.model.instance_head), "weight_decay": opts.weight_decay,
+                               "lr": opts.lr * opts.lr_head})
+        if not opts.freeze_seg:
+            params.append({"params": tr(self.model.head), "weight_decay": opts.weight_decay, "lr": opts.lr * opts.lr_head})
+            params.append({"params": tr(self.model.cls), "weight_decay": opts.weight_decay, "lr": opts.lr * opts.lr_head})
+            if self.weakly and opts.pseudo is None:
+                params.append({"params": tr(self.pseudolabeler), "weight_decay": opts.weight_decay, "lr": opts.lr_pseudo})
+                if self.peakgenerator is not None:
+                    params.append({"params": tr(self.peakgenerator), "weight_decay": opts.weight_decay, "lr": opts.lr_pseudo})
+        if opts.optim != "adam":
+            raise NotImplementedError(f"--optim {opts.optim}: phase 2 uses adam (scripts/run.sh:39); sgd is the phase-1 row")
+        optimizer = FusedAdam(params, lr=opts.lr, weight_decay=opts.weight_decay)
+        if not hasattr(opts, "max_iters"):
+            opts.max_iters = getattr(opts, "epochs", 1) * 1000
+        if not hasattr(opts, "start_decay"):
+            opts.start_decay = opts.max_iters
+        return optimizer, get_scheduler(opts, optimizer)
+
+    def distribute(self, opts):
+        """Replaces the DDP wrappers of train.py:187-196: gradients of the flat buffer are averaged over RCCL."""
+        self.buckets = GradBuckets(self.optimizer.grads_fb, bucket_bytes=16 << 20)
+        self._branch = self.model.instance_branch()
+        self._grad_map = {id(p): self.optimizer.grad_view(p) for g in self.optimizer.param_groups for p in g["params"]}
+        self._bn_counters = [b for n, b in self.model.named_buffers()
+                             if n.endswith("num_batches_tracked") and n.startswith(("decoder.", "instance_head."))]
+
+    # ------------------------------------------------------------------------------------------ the hot path
+    def _set_phase2_modes(self):
+        self.model.train()
+        if self.opts.freeze:
+            self.model.body.eval()
+        if self.opts.freeze_seg:
+            self.model.head.eval()
+            self.model.cls.eval()
+
+    def step(self, batch, dropout_keep=None):
+        """One training iteration = the body of train.py:241-566 for phase 2. `batch` is the loader tuple
+        (images, seg_maps, center_maps, offset_maps, weights, l1h) or just (images, l1h): the weakly-supervised branch
+        only consumes images and l1h (the other four are uploaded but unused by the reference, train.py:243-248).
+        Returns a dict of device scalars (no host synchronisation)."""
+        opts = self.opts
+        if not (self.weakly and opts.phase == 2):
+            raise NotImplementedError("Trainer.step: only the phase-2 weakly-supervised step (BASELINE config 3) is built; "
+                                      "step 0 and phase 1 are later §8 rows")
+        images, l1h = (batch[0], batch[-1])
+        images = images.to(self.device, dtype=torch.float32).contiguous()
+        l1h = l1h.to(self.device, dtype=torch.float32).contiguous()
+        bs, _, H, W = images.shape
+        oc = self.old_classes
+        self._set_phase2_modes()
+
+        # train.py:253-255 — frozen old model, full forward, low resolution outputs
+        outputs_old, _ = self.model_old(images, interpolate=False)
+        self.optimizer.zero_grad()
+        # train.py:259-263 — semantic forward on [images ; flipped images]
+        x2 = torch.empty((2 * bs, 3, H, W), dtype=torch.float32, device=self.device)
+        x2[:bs].copy_(images)
+        ops.flip_w(images, out=x2[bs:])
+        outputs, features = self.model.forward_seg(x2, interpolate=False)
+        feats = {k: v[:bs] for k, v in features["features"].items()}   # first half = un-flipped images (contiguous views)
+        # train.py:265-272 — trainable instance decoder + heads on the detached features
+        seed = (opts.random_seed * 1000003 + self._iter * 7919 + dist.get_rank() * 104729 if dist.is_initialized()
+                else opts.random_seed * 1000003 + self._iter * 7919)
+        pred, tape = self._branch.forward_train(feats, dropout_keep=dropout_keep, seed=seed)
+        torch._foreach_add_(self._bn_counters, 1)
+        # train.py:421-436 — CAM of the new classes -> peaks
+        self.pseudolabeler.eval()
+        self.peakgenerator.eval()
+        int_masks = self.pseudolabeler(features["body"][:bs])
+        label_new = l1h[:, oc - 1:].contiguous()
+        cam = self.peakgenerator.cam(int_masks, label_new)
+        peaks = ops.peak_extract(cam, label_new, (H, W), kernel=15, K=25)
+        # train.py:438-449 — semantic pseudo ground truth
+        seg_gt, old_w, prob_win = ops.seg_pseudo_gt(outputs["seg"], l1h, oc, (H, W), no_mask=opts.no_mask)
+        # train.py:451-500 — pseudo labels + refined labels
+        pseudo, refined = ops.label_generation(
+            seg_gt, prob_win, label_new, peaks, pred["center"], pred["offset"], self._g_dev, oc, sigma=self.sigma,
+            pseudo_thresh=opts.pseudo_thresh, refine_thresh=opts.refine_thresh, nms_kernel=opts.kernel, beta=opts.beta,
+            run_refine=opts.run_refine)
+        # train.py:503-522 — blended targets + four weighted losses (+ gradient w.r.t. the low-resolution maps)
+        losses, dcen, doff = ops.p2_loss(pred["center"], pred["offset"], outputs_old["center"], outputs_old["offset"],
+                                         old_w, pseudo, refined, (H, W), self.center_loss_weight, self.offset_loss_weight)
+        # train.py:537-541 — backward, gradient averaging, optimizer, schedule
+        self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map, on_ready=self._ready)
+        self.buckets.finish()
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        self._iter += 1
+        return {"losses": losses, "seg_gt": seg_gt, "peaks": peaks, "pseudo": pseudo, "refined": refined,
+                "center": pred["center"], "offset": pred["offset"], "old_w": old_w}
+
+    def _ready(self, param):
+        self.buckets.ready(self.optimizer.index[id(param)])
+
+    # ------------------------------------------------------------------------------------------ epoch loop
+    def train(self, cur_epoch, train_loader, print_int=10):
+        """train.py:198-586 — epoch loop around `step`; returns (epoch_loss, reg_loss) like the reference."""
+        logger = self.logger
+        logger.info("Epoch %d, lr = %f" % (cur_epoch, self.optimizer.param_groups[0]["lr"]))
+        if hasattr(train_loader, "sampler") and hasattr(train_loader.sampler, "set_epoch"):
+            train_loader.sampler.set_epoch(cur_epoch)
+        total = torch.zeros((), dtype=torch.float32, device=self.device)
+        interval = torch.zeros_like(total)
+        n = 0
+        for cur_step, batch in enumerate(train_loader):
+            out = self.step(batch)
+            loss = out["losses"].sum()          # l_center + l_offset; the zeroed terms of train.py:524-529 vanish
+            total += loss
+            interval += loss
+            n += 1
+            if (cur_step + 1) % print_int == 0:
+                v = interval.item() / print_int  # the only host sync, every print_int iterations
+                assert np.isfinite(v), f"l_reg: {v}"   # train.py:535
+                logger.debug(f"Epoch {cur_epoch}, Batch {cur_step + 1}/{len(train_loader)}, Loss={v}")
+                if logger is not None and hasattr(logger, "add_scalar"):
+                    logger.add_scalar("Loss/tot", v, cur_epoch * len(train_loader) + cur_step + 1, intermediate=True)
+                interval.zero_()
+        reg = torch.zeros_like(total)
+        if dist.is_initialized():
+            dist.reduce(total, dst=0)
+            dist.reduce(reg, dst=0)
+        epoch_loss = total / world_size() / max(n, 1)
+        logger.info(f"Epoch {cur_epoch}, Class Loss={epoch_loss}, Reg Loss={reg}")
+        return (epoch_loss, reg)
+
+    def validate(self, valid_loader, opts):
+        raise NotImplementedError("Trainer.validate (VOC instance AP) is row 1 of SURVEY.md §8(f) — not built yet")
+
+    def validate_semseg(self, valid_loader, metrics, opts):
+        raise NotImplementedError("Trainer.validate_semseg is row 4 of SURVEY.md §8(f) — not built yet")
+
+    # ------------------------------------------------------------------------------------------ checkpoints
+    @staticmethod
+    def _strip(sd):
+        return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+    def load_step_ckpt(self, path):
+        """train.py:747-771 — weights of the previous step into the new model (non strict) and the old model."""
+        import os.path as osp
+        if self.opts.step_ckpt is not None:
+            path = self.opts.step_ckpt
+        if not osp.exists(path):
+            raise FileNotFoundError(path)
+        ck = torch.load(path, map_location="cpu")
+        state = self._strip(ck["model_state"])
+        self.model.load_state_dict(state, strict=False)
+        strict = self.opts.branch not in ("none", "seg")
+        self.model_old.load_state_dict(state, strict=strict)
+        self._realias()
+
+    def load_ckpt(self, path):
+        """train.py:773-795 — resume."""
+        import os.path as osp
+        assert osp.isfile(path), f"Error, ckpt not found in {path}"
+        ck = torch.load(path, map_location="cpu")
+        self.model.load_state_dict(self._strip(ck["model_state"]), strict=True)
+        self._realias()
+        self.optimizer.load_state_dict(ck["optimizer_state"])
+        self.scheduler.load_state_dict(ck["scheduler_state"])
+        if "pseudolabeler" in ck and self.pseudolabeler is not None:
+            self.pseudolabeler.load_state_dict(self._strip(ck["pseudolabeler"]))
+        if "peakgenerator" in ck and self.peakgenerator is not None:
+            self.peakgenerator.load_state_dict(self._strip(ck["peakgenerator"]))
+        return ck["epoch"] + 1, ck["best_score"]
+
+    def load_seg_ckpt(self, path):
+        """train.py:797-812 — phase-1 semantic weights (body / head / cls) + PseudoLabeler + PeakGenerator."""
+        import os.path as osp
+        assert osp.isfile(path), f"Error, ckpt not found in {path}"
+        ck = torch.load(path, map_location="cpu")
+        state = {k: v for k, v in self._strip(ck["model_state"]).items() if k.startswith(("body.", "head.", "cls."))}
+        self.model.load_state_dict(state, strict=False)
+        self._realias()
+        if "pseudolabeler" in ck and self.pseudolabeler is not None:
+            self.pseudolabeler.load_state_dict(self._strip(ck["pseudolabeler"]))
+        if "peakgenerator" in ck and self.peakgenerator is not None:
+            self.peakgenerator.load_state_dict(self._strip(ck["peakgenerator"]))
+
+    def _realias(self):
+        """load_state_dict copies in place, so the flat-buffer aliasing survives; only derived caches are stale."""
+        from .nn import CACHE
+        CACHE.clear()

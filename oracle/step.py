@@ -55,3 +55,54 @@ def label_and_loss(center_lo, offset_lo, old_center_lo, old_offset_lo, seg2b, l1
     out.update(L.blend_and_losses(center, offset, old_center, old_offset, old_w, pseudo, refined, old_classes))
     out["loss"] = out["l_center"] + out["l_offset"]
     return out
+
+
+TRAINABLE_PREFIXES = ("decoder.instance_decoder.", "instance_head.")
+
+
+def trainable_names(sd):
+    """Phase-2 trainable tensors (train.py:150-161 with --freeze --freeze_seg): instance decoder + instance head."""
+    return [k for k in sd if k.startswith(TRAINABLE_PREFIXES) and sd[k].is_floating_point()
+            and not k.endswith(("running_mean", "running_var"))]
+
+
+def p2_step(sd_new, sd_old, sd_pl, sd_pg, images, l1h, old_classes, pooling=32, dropout_mask=None, lr=5e-4,
+            adam_state=None, step=1, betas=(0.9, 0.999), eps=1e-8, **label_kw):
+    """One phase-2 iteration on the CPU (train.py:241-541): returns losses, intermediates, gradients and applies Adam
+    to `sd_new` in place (torch.optim.Adam arithmetic)."""
+    bs = images.shape[0]
+    size = tuple(images.shape[-2:])
+    with torch.no_grad():
+        out_old, _ = M.forward_full(images, sd_old, pooling=pooling, training=False)
+        out2, aux = M.forward_seg(torch.cat([images, images.flip(-1)], 0), sd_new, pooling=pooling, training=False)
+    feats = {k: v[:bs].detach().clone() for k, v in aux["features"].items()}
+    names = trainable_names(sd_new)
+    for k in names:
+        sd_new[k].requires_grad_(True)
+        sd_new[k].grad = None
+    ins = M.instance_decoder(feats, sd_new, training=True, dropout_mask=dropout_mask)
+    pred = M.instance_head(ins, sd_new, training=True)
+    with torch.no_grad():
+        int_masks = M.pseudolabeler(aux["body"][:bs], sd_pl)
+    out = label_and_loss(pred["center"], pred["offset"], out_old["center"], out_old["offset"], out2["seg"], l1h, int_masks,
+                         sd_pg, size, old_classes, **label_kw)
+    out["loss"].backward()
+    grads = {k: sd_new[k].grad.clone() for k in names}
+    if adam_state is None:
+        adam_state = {k: (torch.zeros_like(sd_new[k]), torch.zeros_like(sd_new[k])) for k in names}
+    b1, b2 = betas
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    with torch.no_grad():
+        for k in names:
+            m, v = adam_state[k]
+            g = grads[k]
+            m.lerp_(g, 1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+            sd_new[k].addcdiv_(m, denom, value=-lr / bc1)
+    for k in names:
+        sd_new[k].requires_grad_(False)
+    out.update(pred_center=pred["center"].detach(), pred_offset=pred["offset"].detach(), grads=grads,
+               adam_state=adam_state, seg2b=out2["seg"], int_masks=int_masks,
+               old_center=out_old["center"], old_offset=out_old["offset"])
+    return out
