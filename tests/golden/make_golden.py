@@ -1,0 +1,191 @@
+"""Golden-vector generator (runs in the BUILD CONTAINER only: it imports the upstream reference from
+/root/reference through tests/golden/ref_harness.py; the reference never travels to the GPU box).
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixtures (inputs are regenerated from seeds by the tests; only the reference's OUTPUTS are stored):
+  model_p2_c65.npz  — reference networks (make_model, PseudoLabeler, PeakGenerator) with name-keyed deterministic
+                      weights on a seeded 2x3x65x65 batch: old-model forward, forward_seg on the flip-TTA batch,
+                      train-mode instance decoder/head outputs under a recorded Dropout mask, gradient norms.
+  label_sXX.npz     — reference label stage on oracle.synth structured inputs: smoothing, peak_extract, the inline
+                      semantic pseudo-GT block of train.py:263,438-449 (driven with the reference's own tensors ops),
+                      pseudo_label_generation, refine_label_generation, Weighted_MSELoss / Weighted_L1_Loss blend.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import ref_harness  # noqa: E402
+
+from oracle import synth, weights  # noqa: E402
+
+CROP = 65
+MODEL_SEED = 1
+LABEL_CASES = [(0, 2, 129, 129), (3, 3, 129, 129), (5, 2, 97, 145), (6, 2, 193, 193)]
+
+
+def ref_opts(R, crop):
+    ap = R["argparser"]
+    args = ["--dataset", "voc", "--task", "15-5", "--step", "1", "--weakly", "--phase", "2", "--alpha", "0.5",
+            "--loss_de", "1", "--lr_policy", "warmup", "--affinity", "--optim", "adam", "--weight_decay", "0",
+            "--lr", "5e-5", "--crop_size", str(crop), "--batch_size", "16", "--no_pretrained"]
+    return ap.modify_command_options(ap.get_argparser().parse_args(args))
+
+
+def model_fixture(R):
+    opts = ref_opts(R, CROP)
+    sm, wm = R["segmentation_module"], R["wss_modules"]
+    torch.manual_seed(0)
+    new = sm.make_model(opts, classes=[16, 5])
+    old = sm.make_model(opts, classes=[16])
+    pl = wm.PseudoLabeler(2048, 21, sm.get_norm(opts))
+    pg = wm.PeakGenerator(in_channel=21, num_classes=20, old_classes=15)
+    for m, seed in ((new, MODEL_SEED), (old, MODEL_SEED + 1), (pl, MODEL_SEED + 2), (pg, MODEL_SEED + 3)):
+        m.load_state_dict(weights.fill_(m.state_dict(), seed=seed))
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, CROP, CROP, generator=g)
+    l1h = torch.zeros(2, 20)
+    l1h[0, 16] = 1
+    l1h[1, 15] = 1
+    l1h[1, 19] = 1
+    out = {}
+    old.eval()
+    with torch.no_grad():
+        o_old, _ = old(x, interpolate=False)
+    out.update({f"old_{k}": v.numpy() for k, v in o_old.items()})
+    # phase-2 mode switches of train.py:234-240
+    new.train()
+    new.body.eval(); new.head.eval(); new.cls.eval()
+    with torch.no_grad():
+        o2, f2 = new.forward_seg(torch.cat([x, x.flip(-1)], 0), interpolate=False)
+    out["seg2b"] = o2["seg"].numpy()
+    for k in ("res2", "res5"):
+        out[f"feat_{k}"] = f2["features"][k][:2].numpy()
+    feats = {k: v[:2].detach().clone() for k, v in f2["features"].items()}
+    drop = new.decoder.instance_decoder.aspp.project[3]
+    rec = {}
+    h = drop.register_forward_hook(lambda m, i, o: rec.update(inp=i[0].detach(), out=o.detach()))
+    torch.manual_seed(123)
+    _, ins = new.decoder(feats)
+    pred = new.instance_head(ins)
+    h.remove()
+    keep = (rec["out"] != 0) | (rec["inp"] == 0)      # where the input is 0 the mask is irrelevant
+    out["dropout_keep"] = np.packbits(keep.numpy().astype(np.uint8))
+    out["dropout_shape"] = np.array(keep.shape)
+    out["train_center"], out["train_offset"] = pred["center"].detach().numpy(), pred["offset"].detach().numpy()
+    gc = torch.randn(pred["center"].shape, generator=g)
+    go = torch.randn(pred["offset"].shape, generator=g)
+    ((pred["center"] * gc).sum() + (pred["offset"] * go).sum()).backward()
+    names, norms = [], []
+    for k, p in new.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            norms.append(p.grad.double().norm().item())
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms)
+    out["bn_running_mean_fuse2"] = new.decoder.instance_decoder.fuse[2][0][2].running_mean.numpy().copy()
+    # PseudoLabeler / PeakGenerator (eval) + smoothing, train.py:425-429
+    pl.eval(); pg.eval()
+    with torch.no_grad():
+        int_masks = pl(f2["body"][:2])
+        out["int_masks"] = int_masks.numpy().copy()   # PAM's in-place ReLU (wss/modules.py:349,356) mutates its input view
+        _, cam = pg(int_masks, l1h)
+        cam = R["wss_utils"].smoothing(cam)
+    out["cam_lo"] = cam.numpy()
+    out["l1h"] = l1h.numpy()
+    np.savez_compressed(os.path.join(HERE, "model_p2_c65.npz"), **out)
+    print("model_p2_c65.npz", {k: getattr(v, "shape", None) for k, v in out.items() if k != "grad_names"})
+
+
+def label_fixture(R, seed, b, H, W):
+    inp = synth.label_stage_inputs(seed, b=b, H=H, W=W)
+    oc, tot = inp["old_classes"], inp["tot_classes"]
+    wm, wu, bestie, loss = R["wss_modules"], R["wss_utils"], R["bestie"], R["loss"]
+    l1h = inp["l1h"]
+    pg = wm.PeakGenerator(in_channel=tot, num_classes=tot - 1, old_classes=oc - 1)
+    pg.load_state_dict({"extra_conv4.weight": inp["pg_w"], "extra_conv4.bias": inp["pg_b"]})
+    pg.eval()
+    size = (H, W)
+    out = {}
+    with torch.no_grad():
+        _, cam = pg(inp["int_masks"], l1h)
+        cam = wu.smoothing(cam)
+        out["cam_lo"] = cam.numpy()
+        cam = F.interpolate(cam, size=size, mode="bilinear", align_corners=False)
+    center = F.interpolate(inp["center_lo"], size=size, mode="bilinear", align_corners=False)
+    offset = F.interpolate(inp["offset_lo"], size=size, mode="bilinear", align_corners=False)
+    conf, py, px = wu.peak_extract(cam.detach(), kernel=15)
+    out.update(peak_conf=conf, peak_y=py, peak_x=px)
+    # --- the inline block train.py:263,438-449, driven on the reference's tensors -------------------------------
+    seg = inp["seg2b"]
+    seg_max = (seg[:b] + seg[b:].flip(-1)) / 2
+    seg_max = F.interpolate(seg_max, size=size, mode="bilinear", align_corners=False).detach()
+    soft = seg_max.softmax(dim=1).detach()
+    soft[:, oc:] *= l1h[:, oc - 1:, None, None]
+    seg_gt = torch.argmax(soft, 1)
+    old_w = ((seg_gt < oc) & (seg_gt != 0))[:, None, :, :].float()
+    seg_gt[seg_gt < oc] = 0
+    cls_label = l1h.cpu().detach().numpy()
+    cls_label[:, :oc - 1] = 0
+    out["seg_gt"] = seg_gt.numpy().astype(np.uint8)
+    out["old_w"] = np.packbits(old_w.numpy().astype(np.uint8))
+    top2 = soft.topk(2, dim=1).values
+    out["top2_gap_min"] = np.array((top2[:, 0] - top2[:, 1]).min().item())
+    g = bestie.gaussian(6)
+    pcs, pos, pws = [], [], []
+    for i in range(b):
+        points = []
+        for l in np.nonzero(cls_label[i])[0]:
+            for c, x, y in zip(conf[i, l], px[i, l], py[i, l]):
+                if c < 0.7:
+                    break
+                points.append([x, y, l, c])
+        cm, om, wt, _ = bestie.pseudo_label_generation(seg_gt[i].cpu().numpy(), points, cls_label[i], tot - 1, 6, g)
+        pcs.append(torch.from_numpy(cm)); pos.append(torch.from_numpy(om)); pws.append(torch.from_numpy(wt))
+    p_center, p_offset, p_weight = torch.stack(pcs), torch.stack(pos), torch.stack(pws)
+    # copies: the blend below (train.py:509-511) updates these tensors in place
+    out.update(p_center=p_center[:, oc - 1:].numpy().copy(), p_offset=p_offset.numpy().copy(),
+               p_weight=p_weight.numpy().astype(np.uint8))
+    assert (p_center[:, :oc - 1] == 0).all()
+
+    class A:  # the `args` the reference threads into refine_label_generation (argparser.py:219-222 defaults)
+        refine_thresh, kernel, beta, sigma = 0.3, 41, 3.0, 6
+
+    l1h_new = l1h.clone()
+    l1h_new[:, :oc - 1] = 0
+    refined = bestie.refine_label_generation(seg_max.clone(), center.clone(), offset.clone(), l1h_new.clone(),
+                                             seg_gt.clone(), None, A)
+    out.update(r_center=refined["center"][:, oc - 1:].numpy().copy(), r_offset=refined["offset"].numpy().copy(),
+               r_weight=refined["weight"].numpy().copy())
+    assert (refined["center"][:, :oc - 1] == 0).all()
+    # --- train.py:503-522 with the reference's criterion classes ------------------------------------------------
+    old_center = F.interpolate(inp["old_center_lo"], size=size, mode="bilinear", align_corners=False)
+    old_offset = F.interpolate(inp["old_offset_lo"], size=size, mode="bilinear", align_corners=False)
+    mse, l1 = loss.Weighted_MSELoss(), loss.Weighted_L1_Loss()
+    pw_sum = torch.maximum(old_w, p_weight)
+    p_center[:, oc - 1:] = p_weight * p_center[:, oc - 1:] + (1 - p_weight) * refined["center"][:, oc - 1:]
+    p_offset = pw_sum * p_offset + (1 - pw_sum) * refined["offset"]
+    p_weight = torch.maximum(p_weight, refined["weight"])
+    losses = [0.5 * mse(center[:, :oc - 1], old_center, old_w) * 200,
+              0.5 * l1(offset, old_offset, old_w) * 0.01,
+              0.5 * mse(center[:, oc - 1:], p_center[:, oc - 1:], p_weight) * 200,
+              0.5 * l1(offset, p_offset, p_weight) * 0.01]
+    out["losses"] = np.array([float(v) for v in losses], dtype=np.float64)
+    out["case"] = np.array([seed, b, H, W])
+    np.savez_compressed(os.path.join(HERE, f"label_s{seed:02d}.npz"), **out)
+    print(f"label_s{seed:02d}.npz", "peaks>=0.7:", int((conf >= 0.7).sum()), "pseudo px:", int(p_weight.gt(0).sum()),
+          "refined px:", int((refined['weight'] > 0).sum()), "losses:", out["losses"].round(4).tolist())
+
+
+if __name__ == "__main__":
+    R = ref_harness.load_reference()
+    torch.set_num_threads(8)
+    model_fixture(R)
+    for case in LABEL_CASES:
+        label_fixture(R, *case)

@@ -1,0 +1,157 @@
+"""GPU: the HIP path against the committed golden vectors of the upstream reference (tests/golden/*.npz) and an
+end-to-end `Trainer.step` against the oracle's `p2_step` on the same weights, batch and Dropout mask."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import p2_opts, rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _build(gpu, crop=65):
+    from cl4wsis_amd import segmentation_module as sm
+    from cl4wsis_amd.wss import PeakGenerator, PseudoLabeler
+    from oracle import weights
+    opts = p2_opts(crop)
+    torch.manual_seed(0)
+    mods = [sm.make_model(opts, classes=[16, 5]), sm.make_model(opts, classes=[16]),
+            PseudoLabeler(2048, 21, sm.get_norm(opts)), PeakGenerator(21, 20, old_classes=15)]
+    for i, m in enumerate(mods):
+        m.load_state_dict(weights.fill_(m.state_dict(), seed=1 + i))
+        m.to(gpu)
+    return opts, mods
+
+
+def test_networks_match_reference_golden(gpu):
+    gold = np.load(os.path.join(GOLD, "model_p2_c65.npz"))
+    opts, (new, old, pl, pg) = _build(gpu)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 65, 65, generator=g).to(gpu)
+    l1h = torch.from_numpy(gold["l1h"]).to(gpu)
+    old.eval()
+    o_old, _ = old(x, interpolate=False)
+    for k in ("seg", "center", "offset"):
+        assert rel_err(o_old[k].cpu(), torch.from_numpy(gold[f"old_{k}"])) < 1e-4, k
+    new.train(); new.body.eval(); new.head.eval(); new.cls.eval()
+    x2 = torch.cat([x, x.flip(-1)], 0).contiguous()
+    o2, f2 = new.forward_seg(x2, interpolate=False)
+    assert rel_err(o2["seg"].cpu(), torch.from_numpy(gold["seg2b"])) < 1e-4
+    for k in ("res2", "res5"):
+        assert rel_err(f2["features"][k][:2].cpu(), torch.from_numpy(gold[f"feat_{k}"])) < 1e-4
+    shape = tuple(gold["dropout_shape"])
+    keep = torch.from_numpy(np.unpackbits(gold["dropout_keep"])[:int(np.prod(shape))].reshape(shape)).to(gpu)
+    br = new.instance_branch()
+    feats = {k: v[:2] for k, v in f2["features"].items()}
+    pred, tape = br.forward_train(feats, dropout_keep=keep)
+    assert rel_err(pred["center"].cpu(), torch.from_numpy(gold["train_center"])) < 1e-4
+    assert rel_err(pred["offset"].cpu(), torch.from_numpy(gold["train_offset"])) < 1e-4
+    gc = torch.randn(pred["center"].shape, generator=g).to(gpu)
+    go = torch.randn(pred["offset"].shape, generator=g).to(gpu)
+    grads = br.backward(tape, {"center": gc, "offset": go})
+    params = dict(new.named_parameters())
+    norms = np.array([grads[id(params[str(n)])].double().norm().item() for n in gold["grad_names"]])
+    np.testing.assert_allclose(norms, gold["grad_norms"], rtol=5e-3)
+    pl.eval(); pg.eval()
+    im = pl(f2["body"][:2])
+    assert rel_err(im.cpu(), torch.from_numpy(gold["int_masks"])) < 1e-4
+    cam = pg.cam(im, l1h[:, 15:].contiguous())
+    assert rel_err(cam.cpu(), torch.from_numpy(gold["cam_lo"][:, 15:])) < 1e-4
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "label_s*.npz"))))
+def test_label_stage_matches_reference_golden(gpu, path):
+    """Bit-exact indices / labels against the reference's own outputs (not via the oracle)."""
+    from cl4wsis_amd import ops
+    from oracle import synth
+    from oracle.labels import gaussian
+    gold = np.load(path)
+    seed, b, H, W = (int(v) for v in gold["case"])
+    inp = synth.label_stage_inputs(seed, b=b, H=H, W=W)
+    d = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    oc = inp["old_classes"]
+    label_new = d["l1h"][:, oc - 1:].contiguous()
+    cam = ops.cam_smooth(d["int_masks"], d["pg_w"], d["pg_b"], label_new)
+    assert rel_err(cam.cpu(), torch.from_numpy(gold["cam_lo"][:, oc - 1:])) < 1e-5
+    peaks = ops.peak_extract(cam, label_new, (H, W))
+    conf, ys, xs = (t.cpu().numpy() for t in peaks)
+    gc, gy, gx = gold["peak_conf"][:, oc - 1:], gold["peak_y"][:, oc - 1:], gold["peak_x"][:, oc - 1:]
+    sel = gc >= 0.7                                   # the prefix the step consumes (train.py:455-458)
+    assert ((conf >= 0.7) == sel).all()
+    np.testing.assert_array_equal(ys[sel], gy[sel])
+    np.testing.assert_array_equal(xs[sel], gx[sel])
+    np.testing.assert_allclose(conf[sel], gc[sel], rtol=1e-5)
+    seg_gt, old_w, prob_win = ops.seg_pseudo_gt(d["seg2b"], d["l1h"], oc, (H, W))
+    assert float(gold["top2_gap_min"]) > 1e-6          # fixtures were chosen without fp32-level argmax ties
+    np.testing.assert_array_equal(seg_gt.cpu().numpy(), gold["seg_gt"])
+    ow = np.unpackbits(gold["old_w"])[:b * H * W].reshape(b, 1, H, W)
+    np.testing.assert_array_equal(old_w.cpu().numpy().astype(np.uint8), ow)
+    g = torch.from_numpy(gaussian(6).astype(np.float32)).to(gpu)
+    pseudo, refined = ops.label_generation(seg_gt, prob_win, label_new, peaks, d["center_lo"], d["offset_lo"], g, oc)
+    losses, _, _ = ops.p2_loss(d["center_lo"], d["offset_lo"], d["old_center_lo"], d["old_offset_lo"], old_w, pseudo,
+                               refined, (H, W), with_grad=False)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(pseudo["offset"].cpu().numpy(), gold["p_offset"])
+    np.testing.assert_array_equal(pseudo["weight"].cpu().numpy().astype(np.uint8), gold["p_weight"])
+    np.testing.assert_allclose(pseudo["center"].cpu().numpy(), gold["p_center"], atol=1e-7)
+    np.testing.assert_array_equal(refined["offset"].cpu().numpy(), gold["r_offset"])
+    np.testing.assert_allclose(refined["weight"].cpu().numpy(), gold["r_weight"], atol=1e-5)
+    np.testing.assert_allclose(refined["center"].cpu().numpy(), gold["r_center"], atol=1e-7)
+    np.testing.assert_allclose(losses.cpu().numpy().astype(np.float64), gold["losses"], rtol=1e-4)
+
+
+class _Log:
+    def info(self, *a, **k):
+        pass
+    debug = info
+
+
+def test_trainer_step_matches_oracle(gpu):
+    """Whole phase-2 iteration (train.py:241-541) at crop 97, batch 2: losses, the semantic pseudo GT, and the
+    parameter update of Adam against the CPU oracle on identical weights / inputs / Dropout mask."""
+    from cl4wsis_amd.train import Trainer
+    from oracle import step as ostep, weights
+    crop = 97
+    opts = p2_opts(crop)
+    opts.max_iters, opts.start_decay = 1000, 1000
+    torch.manual_seed(0)
+    tr = Trainer(_Log(), gpu, opts)
+    sds = []
+    for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
+        sd = weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=11 + i)
+        m.load_state_dict(sd)
+        sds.append({k: v.clone() for k, v in sd.items()})
+    tr._realias()
+    new, old, pl, pg = sds
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, crop, crop, generator=g)
+    l1h = torch.zeros(2, 20); l1h[0, 17] = 1; l1h[1, 15] = 1; l1h[1, 19] = 1
+    keep = torch.rand(2, 256, 7, 7, generator=g) >= 0.5
+    before = {k: v.clone() for k, v in new.items()}
+    ref = ostep.p2_step(new, old, pl, pg, x, l1h, 16, pooling=opts.pooling, dropout_mask=keep.float(),
+                        lr=opts.lr * opts.lr_head)
+    out = tr.step((x, l1h), dropout_keep=keep.to(torch.uint8).to(gpu))
+    torch.cuda.synchronize()
+    mism = out["seg_gt"].cpu().long() != ref["seg_gt"]
+    if mism.any():   # only admissible where the oracle's own top-2 softmax gap is at fp32 resolution
+        top2 = ref["soft"].topk(2, dim=1).values
+        assert (top2[:, 0] - top2[:, 1])[mism].max() < 1e-5
+    assert rel_err(out["center"].cpu(), ref["pred_center"]) < 1e-4
+    assert rel_err(out["offset"].cpu(), ref["pred_offset"]) < 1e-4
+    got = out["losses"].cpu().tolist()
+    for v, k in zip(got, ("center_old", "offset_old", "center_new", "offset_new")):
+        assert abs(v - float(ref[k])) <= 1e-3 * max(abs(float(ref[k])), 1e-3), (k, v, float(ref[k]))
+    # Adam's first step moves every weight by ~lr * sign(g): compare the updates where the gradient is not ~0
+    params = dict(tr.model.named_parameters())
+    agree, total = 0, 0
+    for k in ostep.trainable_names(new):
+        du = (params[k].detach().cpu() - before[k])
+        dr = (new[k] - before[k])
+        big = ref["grads"][k].abs() > 1e-3 * ref["grads"][k].abs().max()
+        agree += int(((du - dr).abs()[big] < 0.05 * opts.lr * opts.lr_head).sum())
+        total += int(big.sum())
+    assert agree / total > 0.995, (agree, total)
