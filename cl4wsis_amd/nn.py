@@ -47,32 +47,35 @@ InPlaceABNSync = ABN
 
 
 class _Cache:
-    """Device-side derived tensors (packed weights, folded BN) keyed by the source tensors'
-    (data_ptr, _version): an optimizer step or load_state_dict bumps _version and invalidates."""
+    """Derived device tensors (packed weights, folded BN) are cached ON the owning module (attribute `_cl4_cache`),
+    so they die with it, and are revalidated against the source tensors' (data_ptr, _version, external-write
+    counter): load_state_dict / in-place torch ops bump _version; kernels that write a tensor behind PyTorch's back
+    (fused Adam, BN running statistics) call `touch`."""
 
     def __init__(self):
-        self._store = {}
-        self._ext = {}   # data_ptr -> counter bumped by kernels that write a tensor behind PyTorch's back
+        self._ext = {}      # data_ptr -> counter of external writes
+        self._epoch = 0     # bumped by clear(): invalidates everything
 
     def touch(self, t):
         k = t.data_ptr()
         self._ext[k] = self._ext.get(k, 0) + 1
 
     def _sig(self, tensors):
-        return tuple((t.data_ptr(), t._version, self._ext.get(t.data_ptr(), 0), t.device.index)
-                     for t in tensors if t is not None)
+        return (self._epoch,) + tuple((t.data_ptr(), t._version, self._ext.get(t.data_ptr(), 0), t.device.index)
+                                      for t in tensors if t is not None)
 
-    def get(self, key, tensors, build):
+    def get(self, owner, key, tensors, build):
+        store = owner.__dict__.setdefault("_cl4_cache", {})
         sig = self._sig(tensors)
-        hit = self._store.get(key)
+        hit = store.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
         val = build()
-        self._store[key] = (sig, val)
+        store[key] = (sig, val)
         return val
 
     def clear(self):
-        self._store.clear()
+        self._epoch += 1
 
 
 CACHE = _Cache()
@@ -81,7 +84,7 @@ CACHE = _Cache()
 def packed_weight(conv):
     """[cout,cin,k,k] -> [cin*k*k, cout], cached until the weight changes."""
     w = conv.weight
-    return CACHE.get(("wp", id(conv)), (w,), lambda: ops.pack_conv_weight(w.detach()))
+    return CACHE.get(conv, "wp", (w,), lambda: ops.pack_conv_weight(w.detach()))
 
 
 def folded_bn(bn, lo=0, hi=None):
@@ -91,7 +94,7 @@ def folded_bn(bn, lo=0, hi=None):
     def build():
         return ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
 
-    scale, shift = CACHE.get(("bn", id(bn)), ts, build)
+    scale, shift = CACHE.get(bn, "bn", ts, build)
     if lo == 0 and hi is None:
         return scale, shift
     return scale[lo:hi], shift[lo:hi]

@@ -144,7 +144,7 @@ def test_trainer_step_matches_oracle(gpu):
     assert rel_err(out["offset"].cpu(), ref["pred_offset"]) < 1e-4
     got = out["losses"].cpu().tolist()
     for v, k in zip(got, ("center_old", "offset_old", "center_new", "offset_new")):
-        assert abs(v - float(ref[k])) <= 1e-3 * max(abs(float(ref[k])), 1e-3), (k, v, float(ref[k]))
+        assert abs(v - float(ref[k].detach())) <= 1e-3 * max(abs(float(ref[k].detach())), 1e-3), (k, v, float(ref[k].detach()))
     # Adam's first step moves every weight by ~lr * sign(g): compare the updates where the gradient is not ~0
     params = dict(tr.model.named_parameters())
     agree, total = 0, 0
