@@ -53,7 +53,12 @@ def cpu_baseline(opts):
     from cl4wsis_amd import segmentation_module as sm
     from cl4wsis_amd.wss import PeakGenerator, PseudoLabeler
     from oracle import step as ostep
-    cores = os.cpu_count() or 1
+    # host cores this process may actually use: a 1-GPU box shares a 256-thread host (16 threads per GPU)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -61,7 +66,7 @@ def cpu_baseline(opts):
     old = sd(sm.make_model(opts, classes=[16]))
     pl = sd(PseudoLabeler(2048, 21, sm.get_norm(opts)))
     pg = sd(PeakGenerator(21, 20, old_classes=15))
-    b = 2
+    b = 1
     images, l1h = synthetic_batch(b, 42, torch.device("cpu"))
     t0 = time.time()
     ostep.p2_step(new, old, pl, pg, images, l1h, 16, pooling=opts.pooling, lr=opts.lr * opts.lr_head)
