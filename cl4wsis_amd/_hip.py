@@ -70,7 +70,8 @@ def _decl(name, *argtypes):
 
 
 _decl("cl4_pack_conv_weight", _P, _P, _I, _I, _I, _I, _P)
-_decl("cl4_conv2d_fwd", C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P)
+_decl("cl4_conv2d_fwd", C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P)
+_decl("cl4_conv2d_fwd_set_plan", C.POINTER(ConvDesc), _I, _I, _I)
 _decl("cl4_conv2d_wgrad", C.POINTER(ConvDesc), _P, _P, _P, _P)
 _decl("cl4_bn_fold", _P, _P, _P, _P, _F, _P, _P, _I, _P)
 
@@ -120,6 +121,8 @@ def load():
     lib.cl4_last_error.restype = C.c_char_p
     lib.cl4_bn_workspace_bytes.restype = C.c_size_t
     lib.cl4_bn_workspace_bytes.argtypes = [C.c_int]
+    lib.cl4_conv2d_fwd_workspace_bytes.restype = C.c_size_t
+    lib.cl4_conv2d_fwd_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
     for nm, at in (("cl4_peak_workspace_bytes", [C.c_int, C.c_int]), ("cl4_label_workspace_bytes", [C.c_int] * 3),
                    ("cl4_p2_loss_workspace_bytes", [C.c_int] * 6)):
         getattr(lib, nm).restype = C.c_size_t

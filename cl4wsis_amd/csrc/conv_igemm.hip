@@ -14,6 +14,10 @@
 // Epilogue (fused; replaces the separate InPlaceABN / add / leaky-ReLU passes of the
 // reference, modules/residual.py:84-97, modules/deeplab.py:54-70):
 //   y = act2( act1( (acc + pre) * scale[co] + shift[co] ) + post )
+#include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include "common.h"
 
 namespace {
@@ -37,6 +41,8 @@ struct ConvArgs {
   float slope1, slope2;
   int K;        // cin*KS*KS
   int npix;     // n*hout*wout
+  float* ws;    // split-K partial slabs [splits][cout][npix] (v2 kernel only)
+  int kchunk;   // k range per split (multiple of 32)
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KS>
@@ -191,6 +197,233 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_f32(ConvArgs a) {
         a.y[ybase + (long)co * HWo] = v;
       }
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------
+// v2 forward kernel: same GEMM view and LDS image as above, but both operands are staged by LDS-DMA
+// (global_load_lds: global -> LDS with no VGPR round trip and no ds_write), BK = 32, two LDS buffers.
+//   * weights: one global_load_lds_dwordx4 moves two (BM=128) / four (BM=64) whole k-rows;
+//   * activations: global_load_lds_dword with a PER-LANE source address = the im2col gather; lanes that fall
+//     into the zero padding (or past K / past the last pixel) read from a small zero page instead, so EXEC
+//     stays full and the LDS image needs no separate clearing;
+//   * the DMA of tile t+1 is issued before the 64 MFMAs of tile t and retired by the single
+//     vmcnt(0)+barrier at the end of the iteration.
+// Requires cout % 4 == 0 (16-byte weight rows); other shapes use the register-staged kernel above.
+// ------------------------------------------------------------------------------------
+constexpr int BK2 = 32;
+
+#define CL4_GLDS(gptr, lptr, bytes)                                                            \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),      \
+                                   (__attribute__((address_space(3))) void*)(lptr), bytes, 0, 0)
+
+// Wave specialisation: a workgroup is 8 waves = 4 MFMA waves (one per SIMD, each owning a quarter of the output
+// tile) + 4 DMA waves (one per SIMD) that only issue the LDS-DMA of the next K-tile. An LDS-DMA wave-instruction
+// costs the issuing wave ~60-180 cycles (MI355X_MICROARCH.md), i.e. the 20 of them per K-tile rival the tile's MFMA
+// time when they sit in the MFMA wave's own in-order stream; in a partner wave they overlap it instead. The two
+// roles meet at one s_barrier per K-tile: DMA waves arrive after `vmcnt(0)` (tile t+1 landed), MFMA waves after
+// consuming tile t.
+constexpr int V2_THREADS = 512;
+
+template <int BM, int BN, int KS, bool SPLIT>
+__global__ __launch_bounds__(V2_THREADS, 2) void conv_igemm_f32_v2(ConvArgs a, const float* __restrict__ zero_page) {
+  constexpr int WAVES_M = 2, WAVES_N = 2;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int KHW = KS * KS;
+  constexpr int A_ROWS_PER_INSTR = 256 / BM;             // k-rows covered by one dwordx4 wave-instruction
+  constexpr int A_INSTR = BK2 / A_ROWS_PER_INSTR / 4;    // per wave
+  constexpr int B_ROWS = BK2 / 4;                        // k-rows per wave
+  constexpr int B_PER = BN / 64;                         // dword instructions per k-row
+
+  __shared__ __attribute__((aligned(16))) float lds[2][BK2 * (BM + BN)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool dma_role = wave8 >= 4;
+  const int wave = wave8 & 3;            // index within the role
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int HWo = a.hout * a.wout;
+  const int HWi = a.hin * a.win;
+  // split-K: this workgroup reduces k in [kbeg, kend) (kchunk is a multiple of BK2)
+  const int kbeg = SPLIT ? blockIdx.z * a.kchunk : 0;
+  const int kend = SPLIT ? min(a.K, kbeg + a.kchunk) : a.K;
+
+  const float* xptr[B_PER];
+  int iy0[B_PER], ix0[B_PER];
+  bool pvalid[B_PER];
+#pragma unroll
+  for (int q = 0; q < B_PER; ++q) {
+    int p = n0 + lane + 64 * q;
+    pvalid[q] = p < a.npix;
+    int pc = pvalid[q] ? p : 0;
+    int n = pc / HWo;
+    int hw = pc - n * HWo;
+    int oy = hw / a.wout;
+    int ox = hw - oy * a.wout;
+    iy0[q] = oy * a.stride - a.pad;
+    ix0[q] = ox * a.stride - a.pad;
+    xptr[q] = a.x + ((long)n * a.in_ctot + a.in_coff) * HWi + (long)iy0[q] * a.win + ix0[q];
+  }
+  // weight source: lane -> (row within the instruction, 4 consecutive output channels)
+  const int a_row = lane / (BM / 4);
+  const int a_m = (lane % (BM / 4)) * 4;
+  const bool a_mvalid = (m0 + a_m) < a.cout;
+  const float* wsrc = a.wp + m0 + a_m;
+
+  auto issue_tile = [&](int kt, int buf) {
+    float* As = lds[buf];
+    float* Bs = lds[buf] + BK2 * BM;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+      const int r0 = (wave * A_INSTR + i) * A_ROWS_PER_INSTR;   // wave-uniform first row of this instruction
+      const int k = kbeg + kt * BK2 + r0 + a_row;
+      const float* g = (a_mvalid && k < kend) ? wsrc + (long)k * a.cout : zero_page;
+      CL4_GLDS(g, As + r0 * BM, 16);
+    }
+#pragma unroll
+    for (int r = 0; r < B_ROWS; ++r) {
+      const int kr = wave * B_ROWS + r;
+      const int k = kbeg + kt * BK2 + kr;     // wave-uniform
+      const bool kval = k < kend;
+      const int kc = kval ? k : 0;
+      int ci, dy, dx;
+      if (KS == 1) {
+        ci = kc; dy = 0; dx = 0;
+      } else {
+        ci = kc / KHW;
+        int t = kc - ci * KHW;
+        int ky = t / KS;
+        dy = ky * a.dil;
+        dx = (t - ky * KS) * a.dil;
+      }
+      const long koff = (long)ci * HWi + (long)dy * a.win + dx;
+#pragma unroll
+      for (int q = 0; q < B_PER; ++q) {
+        bool ok = kval && pvalid[q];
+        if (KS != 1 || a.pad != 0) {
+          int iy = iy0[q] + dy, ix = ix0[q] + dx;
+          ok = ok && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+        }
+        const float* g = ok ? xptr[q] + koff : zero_page;
+        CL4_GLDS(g, Bs + kr * BN + 64 * q, 4);
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (kend - kbeg + BK2 - 1) / BK2;
+  const int lr = lane & 31, lh = lane >> 5;
+  if (dma_role) {
+    // ---- DMA waves: stream the K-tiles into the two LDS buffers, one tile ahead of the MFMA waves -------------
+    issue_tile(0, 0);
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): this wave's DMA has landed
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) issue_tile(kt + 1, (kt & 1) ^ 1);
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+  // ---- MFMA waves -------------------------------------------------------------------------------------------
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* As = lds[kt & 1] + wm * WTM + lr;
+    const float* Bs = lds[kt & 1] + BK2 * BM + wn * WTN + lr;
+    // operands of k-step kk+2 are fetched from LDS while the MFMAs of k-step kk run (two register sets)
+    float av[2][TM], bv[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[0][i] = As[lh * BM + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[0][j] = Bs[lh * BN + j * 32];
+#pragma unroll
+    for (int kk = 0; kk < BK2; kk += 2) {
+      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+      if (kk + 2 < BK2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[nxt][i] = As[(kk + 2 + lh) * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[nxt][j] = Bs[(kk + 2 + lh) * BN + j * 32];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int p = n0 + wn * WTN + j * 32 + lr;
+    if (p >= a.npix) continue;
+    if (SPLIT) {
+      // raw partial sums -> workspace [split][cout][npix]; the epilogue runs in conv_splitk_epilogue
+      float* wsp = a.ws + ((long)blockIdx.z * a.cout) * a.npix + p;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co < a.cout) wsp[(long)co * a.npix] = acc[i][j][r];
+        }
+      continue;
+    }
+    const int n = p / HWo;
+    const int hw = p - n * HWo;
+    const long ybase = ((long)n * a.out_ctot + a.out_coff) * HWo + hw;
+    const long rbase = (long)n * a.cout * HWo + hw;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co >= a.cout) continue;
+        float v = acc[i][j][r];
+        if (a.pre) v += a.pre[rbase + (long)co * HWo];
+        const float sc = a.scale ? a.scale[co] : 1.f;
+        const float sh = a.shift ? a.shift[co] : 0.f;
+        v = cl4::apply_act(v * sc + sh, a.act1, a.slope1);
+        if (a.post) v += a.post[rbase + (long)co * HWo];
+        v = cl4::apply_act(v, a.act2, a.slope2);
+        a.y[ybase + (long)co * HWo] = v;
+      }
+    }
+  }
+}
+
+// Split-K second pass: sum the partial slabs in a fixed order (bitwise reproducible) and apply the fused epilogue.
+__global__ void conv_splitk_epilogue(ConvArgs a, int splits) {
+  const long total = (long)a.cout * a.npix;
+  const int HWo = a.hout * a.wout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = i / a.npix;
+    const int p = i - (long)co * a.npix;
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += a.ws[(long)z * total + i];
+    const int n = p / HWo;
+    const int hw = p - n * HWo;
+    const long r = ((long)n * a.cout + co) * HWo + hw;
+    if (a.pre) v += a.pre[r];
+    const float sc = a.scale ? a.scale[co] : 1.f;
+    const float sh = a.shift ? a.shift[co] : 0.f;
+    v = cl4::apply_act(v * sc + sh, a.act1, a.slope1);
+    if (a.post) v += a.post[r];
+    v = cl4::apply_act(v, a.act2, a.slope2);
+    a.y[((long)n * a.out_ctot + a.out_coff + co) * HWo + hw] = v;
   }
 }
 
@@ -379,8 +612,112 @@ int check_desc(const cl4_conv_desc* d) {
   return CL4_OK;
 }
 
+// 16 zero floats the LDS-DMA lanes of the v2 kernel read instead of the convolution's zero padding.
+__device__ __attribute__((aligned(64))) float g_zero_page[16] = {0};
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// Tile / split-K plan of one forward launch. The fp32 MFMA pipe is slow enough (64 cycles per 32x32x2) that the
+// kernel is latency- rather than bandwidth-limited: what matters is having >= ~3 workgroups per CU in flight.
+// 128x128 tiles are used when the grid is large enough on its own; otherwise 64x64 tiles (4x the workgroups),
+// and if that is still short (the 33x33 maps at small batch) K is split across grid.z.
+struct FwdPlan {
+  int impl;    // 1: register-staged kernel, 2: LDS-DMA kernel
+  int tile;    // 128 or 64 (v2)
+  int splits;
+  int kchunk;
+};
+
+// Measured plans (cl4_conv2d_fwd_set_plan, filled by the host-side autotuner during warm-up) override the heuristic.
+struct PlanKey {
+  int cout, npix, K, ks, stride, dil, hin;
+  bool operator<(const PlanKey& o) const {
+    return std::tie(cout, npix, K, ks, stride, dil, hin) < std::tie(o.cout, o.npix, o.K, o.ks, o.stride, o.dil, o.hin);
+  }
+};
+std::map<PlanKey, FwdPlan>& plan_table() { static std::map<PlanKey, FwdPlan> t; return t; }
+std::mutex& plan_mutex() { static std::mutex m; return m; }
+
+FwdPlan make_plan(int impl, int tile, int splits, int cout, int K) {
+  FwdPlan p{1, 128, 1, 0};
+  if (impl != 2 || cout % 4 != 0 || cout < 64) return p;
+  p.impl = 2;
+  p.tile = (tile == 128 && cout >= 128) ? 128 : 64;
+  const int ktiles = cl4::cdiv(K, BK2);
+  int s = splits < 1 ? 1 : splits;
+  if (s > ktiles) s = ktiles;
+  const int per = cl4::cdiv(ktiles, s);
+  p.kchunk = per * BK2;
+  p.splits = cl4::cdiv(K, p.kchunk);
+  return p;
+}
+
+// Heuristic default. The fp32 MFMA pipe is slow (64 cycles per 32x32x2), so these kernels are limited by workgroup
+// quantisation, not bandwidth: W workgroups dealt over 256 CUs finish in ceil(W/256) rounds. Pick the tile (128 or 64)
+// and the K split that minimise  rounds * (k-tiles per workgroup + fixed cost) * tile area  + slab traffic.
+FwdPlan plan_fwd(const PlanKey& key) {
+  static const int impl = env_int("CL4_CONV_IMPL", 2);
+  static const int force_tile = env_int("CL4_CONV_TILE", 0);
+  static const int force_split = env_int("CL4_CONV_SPLIT", 0);
+  {
+    std::lock_guard<std::mutex> g(plan_mutex());
+    auto it = plan_table().find(key);
+    if (it != plan_table().end()) return it->second;
+  }
+  const int cout = key.cout, npix = key.npix, K = key.K;
+  if (impl != 2 || cout % 4 != 0 || cout < 64) return FwdPlan{1, 128, 1, 0};
+  if (force_tile || force_split) return make_plan(2, force_tile ? force_tile : 128, force_split ? force_split : 1, cout, K);
+  const int ktiles = cl4::cdiv(K, BK2);
+  double best = 1e30;
+  FwdPlan bestp = make_plan(2, 64, 1, cout, K);
+  for (int tile = 64; tile <= 128; tile += 64) {
+    if (tile == 128 && cout < 128) continue;
+    const long wgs = (long)cl4::cdiv(cout, tile) * cl4::cdiv(npix, tile);
+    const double t_tile = tile == 128 ? 2.4 : 0.65;   // us per K-tile of one workgroup at ~70 % MFMA issue
+    const double t_fixed = tile == 128 ? 5.0 : 2.5;   // prologue + epilogue
+    for (int s = 1; s <= 32 && s <= ktiles / 2 + (ktiles < 2); ++s) {
+      const FwdPlan p = make_plan(2, tile, s, cout, K);
+      if (p.splits != s && s != 1) continue;
+      const long rounds = (wgs * p.splits + 255) / 256;
+      double t = rounds * ((double)(p.kchunk / BK2) * t_tile + t_fixed);
+      if (p.splits > 1) t += (double)p.splits * cout * npix * 8.0 / 4.0e6 + 3.0;   // slab write+read at ~4 TB/s, + launch
+      if (t < best) { best = t; bestp = p; }
+    }
+  }
+  return bestp;
+}
+
 template <int KS>
-int launch_fwd(const ConvArgs& a, hipStream_t st) {
+int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes) {
+  const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin});
+  if (pl.impl == 2) {
+    static float* zp = nullptr;   // one device per process (one process per GPU): resolve the symbol once
+    if (!zp && hipGetSymbolAddress((void**)&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) return (int)hipGetLastError();
+    a.kchunk = pl.kchunk;
+    a.ws = nullptr;
+    if (pl.splits > 1) {
+      const size_t need = (size_t)pl.splits * a.cout * a.npix * sizeof(float);
+      if (!workspace || workspace_bytes < need) { cl4::set_error("conv2d_fwd: workspace too small for split-K"); return CL4_ENOSPC; }
+      a.ws = (float*)workspace;
+    }
+    const dim3 g(cl4::cdiv(a.cout, pl.tile), cl4::cdiv(a.npix, pl.tile), pl.splits);
+    const float* z = zp;
+    if (pl.tile == 128) {
+      if (pl.splits > 1) hipLaunchKernelGGL((conv_igemm_f32_v2<128, 128, KS, true>), g, dim3(V2_THREADS), 0, st, a, z);
+      else hipLaunchKernelGGL((conv_igemm_f32_v2<128, 128, KS, false>), g, dim3(V2_THREADS), 0, st, a, z);
+    } else {
+      if (pl.splits > 1) hipLaunchKernelGGL((conv_igemm_f32_v2<64, 64, KS, true>), g, dim3(V2_THREADS), 0, st, a, z);
+      else hipLaunchKernelGGL((conv_igemm_f32_v2<64, 64, KS, false>), g, dim3(V2_THREADS), 0, st, a, z);
+    }
+    if (pl.splits > 1) {
+      const long total = (long)a.cout * a.npix;
+      hipLaunchKernelGGL(conv_splitk_epilogue, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, a, pl.splits);
+    }
+    return cl4::launch_status();
+  }
   const int np = cl4::cdiv(a.npix, 128);
   if (a.cout > 64) {
     dim3 g(cl4::cdiv(a.cout, 128), np);
@@ -434,8 +771,32 @@ extern "C" int cl4_bn_fold(const float* gamma, const float* beta, const float* m
   return cl4::launch_status();
 }
 
+extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
+  if (!d || d->cout <= 0 || d->n <= 0) return 0;
+  const int K = d->cin * d->kh * d->kw;
+  const int npix = d->n * d->hout * d->wout;
+  const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin});
+  return pl.splits > 1 ? (size_t)pl.splits * d->cout * npix * sizeof(float) : 0;
+}
+
+// Pin the launch plan of one convolution shape (impl 1 = register-staged, 2 = LDS-DMA; tile 64|128; K splits).
+// impl = 0 removes the entry. Used by the host-side autotuner, which times the candidates during warm-up.
+extern "C" int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int tile, int splits) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  const int K = d->cin * d->kh * d->kw;
+  const PlanKey key{d->cout, d->n * d->hout * d->wout, K, d->kh, d->stride, d->dil, d->hin};
+  std::lock_guard<std::mutex> g(plan_mutex());
+  if (impl == 0) { plan_table().erase(key); return CL4_OK; }
+  CL4_REQUIRE(impl == 1 || impl == 2, "set_plan: impl must be 0, 1 or 2");
+  CL4_REQUIRE(tile == 64 || tile == 128, "set_plan: tile must be 64 or 128");
+  plan_table()[key] = make_plan(impl, tile, splits, d->cout, K);
+  return CL4_OK;
+}
+
 extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const float* wp, const float* scale,
-                              const float* shift, const float* pre, const float* post, float* y, void* stream) {
+                              const float* shift, const float* pre, const float* post, float* y, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   CL4_REQUIRE(x && wp && y, "conv2d_fwd: null tensor");
@@ -448,11 +809,12 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
   a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
   a.K = d->cin * d->kh * d->kw;
   a.npix = d->n * d->hout * d->wout;
+  a.ws = nullptr; a.kchunk = 0;
   hipStream_t st = cl4::as_stream(stream);
   switch (d->kh) {
-    case 1: return launch_fwd<1>(a, st);
-    case 3: return launch_fwd<3>(a, st);
-    default: return launch_fwd<7>(a, st);
+    case 1: return launch_fwd<1>(a, st, workspace, workspace_bytes);
+    case 3: return launch_fwd<3>(a, st, workspace, workspace_bytes);
+    default: return launch_fwd<7>(a, st, workspace, workspace_bytes);
   }
 }
 

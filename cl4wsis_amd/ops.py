@@ -66,6 +66,61 @@ def bn_fold(gamma, beta, mean, var, eps=1e-5):
     return scale, shift
 
 
+_conv_ws = {}
+
+
+def _conv_workspace(device, nbytes):
+    """Split-K scratch of the forward conv (its own buffer: it must not alias the BN / loss workspaces)."""
+    ws = _conv_ws.get(device.index)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _conv_ws[device.index] = ws
+    return ws
+
+
+AUTOTUNE = False      # set True during warm-up (Trainer / bench): time the launch plans of every new conv shape once
+_tuned = {}
+_CANDIDATES = [(1, 128, 1)] + [(2, t, s) for t in (128, 64) for s in (1, 2, 3, 4, 6, 8, 12, 16, 24)]
+
+
+def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=3):
+    """Measure-don't-guess: run each candidate plan of this shape a few times (HIP events on the launch stream) and pin
+    the fastest through cl4_conv2d_fwd_set_plan. The output is simply rewritten, so tuning is side-effect free."""
+    key = (d.n, d.cin, d.hin, d.win, d.cout, d.kh, d.stride, d.pad, d.dil, x.device.index)
+    if key in _tuned:
+        return
+    lib = _hip.load()
+    K = d.cin * d.kh * d.kw
+    best, best_ms = None, float("inf")
+    seen = set()
+    for impl, tile, splits in _CANDIDATES:
+        if impl == 2 and (d.cout % 4 or d.cout < 64):
+            continue
+        if impl == 2 and (tile == 128 and d.cout < 128 or splits > max(1, K // 64)):
+            continue
+        call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, tile, splits)
+        need = lib.cl4_conv2d_fwd_workspace_bytes(C.byref(d))
+        sig = (impl, tile, need)
+        if sig in seen or need > (1 << 30):
+            continue
+        seen.add(sig)
+        ws = _conv_workspace(x.device, need) if need else None
+        run = lambda: call("cl4_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(pre), ptr(post),
+                           ptr(out), ptr(ws), need, stream())
+        run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        if ms < best_ms:
+            best, best_ms = (impl, tile, splits), ms
+    call("cl4_conv2d_fwd_set_plan", C.byref(d), *best)
+    _tuned[key] = (best, best_ms)
+
+
 def _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, act1, slope1, act2, slope2):
     n, in_ctot, hin, win = x.shape
     d = ConvDesc()
@@ -113,7 +168,12 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     if TIMER is not None:
         e0, e1 = TIMER.span("conv_fwd", 2.0 * n * hout * wout * cout * K)
         e0.record()
-    call("cl4_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(pre), ptr(post), ptr(out), stream())
+    if AUTOTUNE:
+        _autotune_conv(d, x, wp, scale, shift, pre, post, out)
+    need = _hip.load().cl4_conv2d_fwd_workspace_bytes(C.byref(d))
+    ws = _conv_workspace(x.device, need) if need else None
+    call("cl4_conv2d_fwd", C.byref(d), ptr(x), ptr(wp), ptr(scale), ptr(shift), ptr(pre), ptr(post), ptr(out),
+         ptr(ws), need, stream())
     if TIMER is not None:
         e1.record()
     return out

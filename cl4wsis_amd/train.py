@@ -5,6 +5,7 @@ here unchanged in meaning, and `train()` stays its caller. Phase 2 (the metric p
 of libcl4wsis_hip.so: frozen old-model forward, flip-TTA semantic forward, trainable instance branch forward /
 hand-written backward, label stage on device, fused losses, RCCL-averaged gradients, fused Adam.
 """
+import os
 from functools import reduce
 
 import numpy as np
@@ -143,6 +144,15 @@ class Trainer:
         if not (self.weakly and opts.phase == 2):
             raise NotImplementedError("Trainer.step: only the phase-2 weakly-supervised step (BASELINE config 3) is built; "
                                       "step 0 and phase 1 are later §8 rows")
+        # first iteration: time the launch plans of every convolution shape of this step once (ops._autotune_conv)
+        ops.AUTOTUNE = self._iter == 0 and os.environ.get("CL4_AUTOTUNE", "1") != "0"
+        try:
+            return self._step_phase2(batch, dropout_keep)
+        finally:
+            ops.AUTOTUNE = False
+
+    def _step_phase2(self, batch, dropout_keep):
+        opts = self.opts
         images, l1h = (batch[0], batch[-1])
         images = images.to(self.device, dtype=torch.float32).contiguous()
         l1h = l1h.to(self.device, dtype=torch.float32).contiguous()

@@ -74,9 +74,17 @@ typedef struct cl4_conv_desc {
 /* w: [cout, cin, kh, kw] (PyTorch layout) -> wp: [cin*kh*kw, cout]. */
 int cl4_pack_conv_weight(const float* w, float* wp, int cout, int cin, int kh, int kw, void* stream);
 
+/* Bytes of scratch cl4_conv2d_fwd needs for this shape (0 unless the launch plan splits K: small grids on the 33x33
+ * maps are split across grid.z into partial slabs [splits][cout][npix] that a second pass reduces in a fixed order). */
+size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d);
+/* Pin the launch plan of this convolution shape: impl 1 = register-staged kernel, 2 = LDS-DMA kernel (tile 64|128,
+ * `splits` K-slices); impl 0 forgets it (back to the built-in heuristic). Results never depend on the plan beyond
+ * fp32 summation order. The host autotuner (cl4wsis_amd/ops.py) times the candidates once per shape in warm-up. */
+int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int tile, int splits);
 int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const float* wp,
                    const float* scale, const float* shift,
-                   const float* pre, const float* post, float* y, void* stream);
+                   const float* pre, const float* post, float* y,
+                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight gradient: dw[co,ci,ky,kx] += sum_{n,oy,ox} dy[n,co,oy,ox] * x[n,ci,iy,ix]
  * (autograd of nn.Conv2d, train.py:537). dw is in PyTorch layout [cout,cin,kh,kw]

@@ -28,7 +28,7 @@ def test_ctypes_prototypes_cover_header():
     from cl4wsis_amd import _hip
     lib = _hip.load()
     assert lib.cl4_abi_version() == 1
-    size_fns = {"cl4_bn_workspace_bytes", "cl4_peak_workspace_bytes", "cl4_label_workspace_bytes", "cl4_p2_loss_workspace_bytes",
+    size_fns = {"cl4_conv2d_fwd_workspace_bytes", "cl4_bn_workspace_bytes", "cl4_peak_workspace_bytes", "cl4_label_workspace_bytes", "cl4_p2_loss_workspace_bytes",
                 "cl4_abi_version", "cl4_last_error"}
     for n in _declared():
         assert n in _hip.PROTOTYPES or n in size_fns, f"{n} has no ctypes prototype"

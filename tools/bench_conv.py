@@ -9,7 +9,9 @@ def bench(n, cin, h, cout, k, s, p, d, iters=10, precision=0):
     x = torch.randn(n, cin, h, h, device=dev)
     w = torch.randn(cout, cin, k, k, device=dev) * 0.02
     wp = ops.pack_conv_weight(w)
+    ops.AUTOTUNE = os.environ.get("TUNE", "0") == "1"
     y = ops.conv2d(x, wp, k, stride=s, pad=p, dil=d)
+    ops.AUTOTUNE = False
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -36,4 +38,5 @@ if __name__ == "__main__":
     ]
     for name, cin, h, cout, k, s, p, d in shapes:
         ms, tf = bench(b, cin, h, cout, k, s, p, d)
-        print(f"{name:28s} b={b} {ms:8.3f} ms {tf:8.2f} TFLOP/s", flush=True)
+        plan = [v for kk, v in ops._tuned.items() if kk[1] == cin and kk[4] == cout and kk[5] == k]
+        print(f"{name:28s} b={b} {ms:8.3f} ms {tf:8.2f} TFLOP/s {plan[-1][0] if plan else ''}", flush=True)
