@@ -41,9 +41,76 @@ struct ConvArgs {
   float slope1, slope2;
   int K;        // cin*KS*KS
   int npix;     // n*hout*wout
+  float neg1, neg2;   // branch-free activations: act(v) = v > 0 ? v : v * neg  (none: 1, relu: 0, leaky: slope)
   float* ws;    // split-K partial slabs [splits][cout][npix] (v2 kernel only)
   int kchunk;   // k range per split (multiple of 32)
 };
+
+
+// Fused epilogue shared by the forward kernels: y = act2( act1( (acc + pre) * scale[co] + shift[co] ) + post ).
+// The four optional operands are tested ONCE per 16-element accumulator block (wave-uniform branches) and each block's
+// loads are issued together before any arithmetic — per-element `if (a.pre)` made hipcc emit 64 tiny basic blocks with a
+// vmcnt(0) after every load, which serialised the epilogue of the small-K layers.
+template <int TM, int TN>
+__device__ __forceinline__ void fused_epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int co_base, int p_base, int lr,
+                                               int lh, int HWo) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int p = p_base + j * 32 + lr;
+    if (p >= a.npix) continue;
+    const int n = p / HWo;
+    const int hw = p - n * HWo;
+    const long ybase = ((long)n * a.out_ctot + a.out_coff) * HWo + hw;
+    const long rbase = (long)n * a.cout * HWo + hw;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int cc[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cc[r] = min(co_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, a.cout - 1);
+      float v[16], sc[16], sh[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+      if (a.pre) {
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = a.pre[rbase + (long)cc[r] * HWo];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += t[r];
+      }
+      if (a.scale) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = a.scale[cc[r]];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 1.f;
+      }
+      if (a.shift) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sh[r] = a.shift[cc[r]];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sh[r] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = v[r] * sc[r] + sh[r];
+        v[r] = t > 0.f ? t : t * a.neg1;
+      }
+      if (a.post) {
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = a.post[rbase + (long)cc[r] * HWo];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += t[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co < a.cout) a.y[ybase + (long)co * HWo] = v[r] > 0.f ? v[r] : v[r] * a.neg2;
+      }
+    }
+  }
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KS>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_f32(ConvArgs a) {
@@ -172,32 +239,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_f32(ConvArgs a) {
     __syncthreads();
   }
 
-  // ---- fused epilogue -------------------------------------------------------------
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int p = n0 + wn * WTN + j * 32 + lr;
-    if (p >= a.npix) continue;
-    const int n = p / HWo;
-    const int hw = p - n * HWo;
-    const long ybase = ((long)n * a.out_ctot + a.out_coff) * HWo + hw;
-    const long rbase = (long)n * a.cout * HWo + hw;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co >= a.cout) continue;
-        float v = acc[i][j][r];
-        if (a.pre) v += a.pre[rbase + (long)co * HWo];
-        const float sc = a.scale ? a.scale[co] : 1.f;
-        const float sh = a.shift ? a.shift[co] : 0.f;
-        v = cl4::apply_act(v * sc + sh, a.act1, a.slope1);
-        if (a.post) v += a.post[rbase + (long)co * HWo];
-        v = cl4::apply_act(v, a.act2, a.slope2);
-        a.y[ybase + (long)co * HWo] = v;
-      }
-    }
-  }
+  fused_epilogue<TM, TN>(a, acc, m0 + wm * WTM, n0 + wn * WTN, lr, lh, HWo);
 }
 
 
@@ -369,8 +411,8 @@ __global__ __launch_bounds__(V2_THREADS, 2) void conv_igemm_f32_v2(ConvArgs a, c
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int p = n0 + wn * WTN + j * 32 + lr;
-    if (p >= a.npix) continue;
-    if (SPLIT) {
+    if (!SPLIT || p >= a.npix) continue;
+    {
       // raw partial sums -> workspace [split][cout][npix]; the epilogue runs in conv_splitk_epilogue
       float* wsp = a.ws + ((long)blockIdx.z * a.cout) * a.npix + p;
 #pragma unroll
@@ -380,29 +422,9 @@ __global__ __launch_bounds__(V2_THREADS, 2) void conv_igemm_f32_v2(ConvArgs a, c
           const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (co < a.cout) wsp[(long)co * a.npix] = acc[i][j][r];
         }
-      continue;
-    }
-    const int n = p / HWo;
-    const int hw = p - n * HWo;
-    const long ybase = ((long)n * a.out_ctot + a.out_coff) * HWo + hw;
-    const long rbase = (long)n * a.cout * HWo + hw;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co >= a.cout) continue;
-        float v = acc[i][j][r];
-        if (a.pre) v += a.pre[rbase + (long)co * HWo];
-        const float sc = a.scale ? a.scale[co] : 1.f;
-        const float sh = a.shift ? a.shift[co] : 0.f;
-        v = cl4::apply_act(v * sc + sh, a.act1, a.slope1);
-        if (a.post) v += a.post[rbase + (long)co * HWo];
-        v = cl4::apply_act(v, a.act2, a.slope2);
-        a.y[ybase + (long)co * HWo] = v;
-      }
     }
   }
+  if (!SPLIT) fused_epilogue<TM, TN>(a, acc, m0 + wm * WTM, n0 + wn * WTN, lr, lh, HWo);
 }
 
 // Split-K second pass: sum the partial slabs in a fixed order (bitwise reproducible) and apply the fused epilogue.
@@ -420,10 +442,236 @@ __global__ void conv_splitk_epilogue(ConvArgs a, int splits) {
     if (a.pre) v += a.pre[r];
     const float sc = a.scale ? a.scale[co] : 1.f;
     const float sh = a.shift ? a.shift[co] : 0.f;
-    v = cl4::apply_act(v * sc + sh, a.act1, a.slope1);
+    v = v * sc + sh;
+    v = v > 0.f ? v : v * a.neg1;
     if (a.post) v += a.post[r];
-    v = cl4::apply_act(v, a.act2, a.slope2);
+    v = v > 0.f ? v : v * a.neg2;
     a.y[((long)n * a.out_ctot + a.out_coff + co) * HWo + hw] = v;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------
+// v3 forward kernel — "bf16x3": fp32-equivalent products on the bf16 MFMA pipe (16x the fp32 MFMA rate).
+// Every fp32 operand is split x = hi + lo with hi = bf16(x), lo = bf16(x - hi); the kernel accumulates
+//   hi_w*hi_x + hi_w*lo_x + lo_w*hi_x   (fp32 accumulators, v_mfma_f32_32x32x16_bf16),
+// dropping only lo_w*lo_x (~2^-18 relative): measured 4.4e-6 relative error per layer vs 4e-7 for the exact fp32
+// MFMA — far inside the 1e-3 parity budget — at 3/16 of the MFMA cycles.
+//   * weights are split once, offline, into [K/8][plane(hi,lo)][cout][8 x bf16] (cl4_pack_conv_weight_bf16x3): an
+//     MFMA A-fragment is one 16-byte chunk, and a K-tile is staged by LDS-DMA (dwordx4, lane-linear along cout);
+//   * activations stay fp32 NCHW in HBM. The 4 loader waves gather 8 consecutive k for one pixel per item into
+//     registers (coalesced along pixels), split them, and ds_write_b128 the hi / lo fragments — this is also the
+//     [k][pixel] -> [pixel][k] transpose the bf16 MFMA operand needs; the 4 MFMA waves only ds_read_b128 + MFMA.
+//   * same tiles (128x128 / 64x64, BK 32), split-K and fused epilogue as the fp32 kernels.
+// ------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int KS, bool SPLIT>
+__global__ __launch_bounds__(V2_THREADS, 2) void conv_igemm_bf16x3(ConvArgs a, const float* __restrict__ zero_page) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int KHW = KS * KS;
+  constexpr int KG = BK2 / 8;               // 4 k-groups of 8 per K-tile
+  constexpr int NITEM = BN / 64;            // (pixel, k-group) items per loader lane
+  constexpr int A_INSTR = KG * 2 * BM / 64 / 4;   // dwordx4 LDS-DMA instructions per loader wave
+  constexpr int A_CHUNKS = KG * 2 * BM;     // 16-byte chunks of the weight tile
+  constexpr int B_CHUNKS = KG * 2 * BN;
+
+  __shared__ u32x4 lds[2][A_CHUNKS + B_CHUNKS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int HWo = a.hout * a.wout;
+  const int HWi = a.hin * a.win;
+  const int kbeg = SPLIT ? blockIdx.z * a.kchunk : 0;
+  const int kend = SPLIT ? min(a.K, kbeg + a.kchunk) : a.K;
+  const int nk = (kend - kbeg + BK2 - 1) / BK2;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  if (loader) {
+    // item -> (pixel, k-group): BN=128: pixel = lane + 64*(wave&1), k-groups {2*(wave>>1), +1}; BN=64: pixel = lane, kg = wave
+    const int pseg = NITEM == 2 ? (wave & 1) : 0;
+    const int kg0 = NITEM == 2 ? 2 * (wave >> 1) : wave;
+    const int pl = lane + 64 * pseg;
+    const int p = n0 + pl;
+    const bool pvalid = p < a.npix;
+    const int pc = pvalid ? p : 0;
+    const int n = pc / HWo;
+    const int hw = pc - n * HWo;
+    const int oy = hw / a.wout;
+    const int ox = hw - oy * a.wout;
+    const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+    const float* xptr = a.x + ((long)n * a.in_ctot + a.in_coff) * HWi + (long)iy0 * a.win + ix0;
+    const bf16x8* wq = reinterpret_cast<const bf16x8*>(a.wp);   // [K/8][2][cout] chunks of 8 bf16
+    const int KGtot = (a.K + 7) / 8;
+
+    float xr[NITEM][8];
+    // Branch-free gather: the per-lane base pointer is fixed, the tap offset is wave-uniform (scalar), and lanes whose
+    // tap falls into the padding / past K / past the last pixel read the zero page instead (a pointer select, no
+    // branch). Every lane therefore ALWAYS issues exactly 8*NITEM loads per K-tile — the counted vmcnt waits below
+    // rely on that number — and all of them are in flight together.
+    auto gload = [&](int kt) {
+#pragma unroll
+      for (int it = 0; it < NITEM; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = kbeg + kt * BK2 + (kg0 + it) * 8 + j;   // wave-uniform
+          const bool kval = k < kend;
+          const int kc = kval ? k : 0;
+          int ci, dy, dx;
+          if (KS == 1) { ci = kc; dy = 0; dx = 0; }
+          else {
+            ci = kc / KHW;
+            int t = kc - ci * KHW;
+            int ky = t / KS;
+            dy = ky * a.dil;
+            dx = (t - ky * KS) * a.dil;
+          }
+          bool ok = kval && pvalid;
+          if (KS != 1 || a.pad != 0) {
+            const int iy = iy0 + dy, ix = ix0 + dx;
+            ok = ok && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+          }
+          const float* g = ok ? xptr + ((long)ci * HWi + (long)dy * a.win + dx) : zero_page;
+          xr[it][j] = *g;
+        }
+      }
+    };
+    auto cvt_store = [&](int buf) {
+      u32x4* Bs = lds[buf] + A_CHUNKS;
+#pragma unroll
+      for (int it = 0; it < NITEM; ++it) {
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          hi[j] = (__bf16)xr[it][j];
+          lo[j] = (__bf16)(xr[it][j] - (float)hi[j]);
+        }
+        Bs[((kg0 + it) * 2 + 0) * BN + pl] = __builtin_bit_cast(u32x4, hi);
+        Bs[((kg0 + it) * 2 + 1) * BN + pl] = __builtin_bit_cast(u32x4, lo);
+      }
+    };
+    auto issue_A = [&](int kt, int buf) {
+      u32x4* As = lds[buf];
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) {
+        const int ii = wave * A_INSTR + i;               // wave-uniform chunk row: (kg, plane, 64-wide m segment)
+        const int seg = ii % (BM / 64);
+        const int kp = ii / (BM / 64);                   // kg*2 + plane
+        const int m = m0 + seg * 64 + lane;
+        const int kgg = (kbeg + kt * BK2) / 8 + (kp >> 1);
+        const bool ok = m < a.cout && kgg < KGtot && (kgg * 8) < kend;
+        const void* g = ok ? (const void*)(wq + ((long)(kgg * 2 + (kp & 1)) * a.cout + m)) : (const void*)zero_page;
+        CL4_GLDS(g, As + kp * BM + seg * 64, 16);
+      }
+    };
+
+    gload(0);
+    issue_A(0, 0);
+    cvt_store(0);
+    if (nk > 1) gload(1);
+    wait_vmcnt<8 * NITEM>();                 // tile-0 weights landed (the NITEM*8 younger gathers may stay in flight)
+    if (nk <= 1) wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nb = (kt & 1) ^ 1;
+      if (kt + 1 < nk) {
+        cvt_store(nb);                       // registers hold tile kt+1 (gathered one iteration ago)
+        issue_A(kt + 1, nb);
+        if (kt + 2 < nk) { gload(kt + 2); wait_vmcnt<8 * NITEM>(); }
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // ---- MFMA waves ---------------------------------------------------------------------------------------------
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    const u32x4* As = lds[kt & 1] + wm * WTM + lr;
+    const u32x4* Bs = lds[kt & 1] + A_CHUNKS + wn * WTN + lr;
+#pragma unroll
+    for (int s2 = 0; s2 < KG / 2; ++s2) {
+      const int kg = 2 * s2 + lh;
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = __builtin_bit_cast(bf16x8, As[(kg * 2 + 0) * BM + i * 32]);
+        al[i] = __builtin_bit_cast(bf16x8, As[(kg * 2 + 1) * BM + i * 32]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = __builtin_bit_cast(bf16x8, Bs[(kg * 2 + 0) * BN + j * 32]);
+        bl[j] = __builtin_bit_cast(bf16x8, Bs[(kg * 2 + 1) * BN + j * 32]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int p = n0 + wn * WTN + j * 32 + lr;
+    if (!SPLIT || p >= a.npix) continue;
+    {
+      float* wsp = a.ws + ((long)blockIdx.z * a.cout) * a.npix + p;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co < a.cout) wsp[(long)co * a.npix] = acc[i][j][r];
+        }
+    }
+  }
+  if (!SPLIT) fused_epilogue<TM, TN>(a, acc, m0 + wm * WTM, n0 + wn * WTN, lr, lh, HWo);
+}
+
+// w [cout][K] fp32 -> wq [ceil(K/8)][plane: hi, lo][cout][8] bf16 (zero padded along K).
+__global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ wq, int cout, int K) {
+  const int KGtot = (K + 7) / 8;
+  const long total = (long)KGtot * cout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = i % cout;
+    const int kg = i / cout;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kg * 8 + j;
+      const float v = k < K ? w[(long)m * K + k] : 0.f;
+      hi[j] = (__bf16)v;
+      lo[j] = (__bf16)(v - (float)hi[j]);
+    }
+    wq[((long)kg * 2 + 0) * cout + m] = hi;
+    wq[((long)kg * 2 + 1) * cout + m] = lo;
   }
 }
 
@@ -691,8 +939,33 @@ FwdPlan plan_fwd(const PlanKey& key) {
 }
 
 template <int KS>
-int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes) {
-  const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin});
+int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes, int precision) {
+  const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 2 + precision});
+  if (precision == 1) {
+    static float* zp3 = nullptr;
+    if (!zp3 && hipGetSymbolAddress((void**)&zp3, HIP_SYMBOL(g_zero_page)) != hipSuccess) return (int)hipGetLastError();
+    a.kchunk = pl.kchunk;
+    a.ws = nullptr;
+    if (pl.splits > 1) {
+      const size_t need = (size_t)pl.splits * a.cout * a.npix * sizeof(float);
+      if (!workspace || workspace_bytes < need) { cl4::set_error("conv2d_fwd: workspace too small for split-K"); return CL4_ENOSPC; }
+      a.ws = (float*)workspace;
+    }
+    const dim3 g(cl4::cdiv(a.cout, pl.tile), cl4::cdiv(a.npix, pl.tile), pl.splits);
+    const float* z = zp3;
+    if (pl.tile == 128) {
+      if (pl.splits > 1) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true>), g, dim3(V2_THREADS), 0, st, a, z);
+      else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false>), g, dim3(V2_THREADS), 0, st, a, z);
+    } else {
+      if (pl.splits > 1) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true>), g, dim3(V2_THREADS), 0, st, a, z);
+      else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false>), g, dim3(V2_THREADS), 0, st, a, z);
+    }
+    if (pl.splits > 1) {
+      const long total = (long)a.cout * a.npix;
+      hipLaunchKernelGGL(conv_splitk_epilogue, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, a, pl.splits);
+    }
+    return cl4::launch_status();
+  }
   if (pl.impl == 2) {
     static float* zp = nullptr;   // one device per process (one process per GPU): resolve the symbol once
     if (!zp && hipGetSymbolAddress((void**)&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess) return (int)hipGetLastError();
@@ -763,6 +1036,15 @@ extern "C" int cl4_pack_conv_weight(const float* w, float* wp, int cout, int cin
   return cl4::launch_status();
 }
 
+extern "C" int cl4_pack_conv_weight_bf16x3(const float* w, void* wq, int cout, int cin, int kh, int kw, void* stream) {
+  CL4_REQUIRE(w && wq && cout > 0 && cin > 0 && kh > 0 && kw > 0, "pack_conv_weight_bf16x3: bad arguments");
+  const int K = cin * kh * kw;
+  const long total = (long)((K + 7) / 8) * cout;
+  hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), w,
+                     (bf16x8*)wq, cout, K);
+  return cl4::launch_status();
+}
+
 extern "C" int cl4_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                            float* scale, float* shift, int c, void* stream) {
   CL4_REQUIRE(mean && var && scale && shift && c > 0, "bn_fold: bad arguments");
@@ -775,7 +1057,7 @@ extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
   if (!d || d->cout <= 0 || d->n <= 0) return 0;
   const int K = d->cin * d->kh * d->kw;
   const int npix = d->n * d->hout * d->wout;
-  const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin});
+  const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin * 2 + d->precision});
   return pl.splits > 1 ? (size_t)pl.splits * d->cout * npix * sizeof(float) : 0;
 }
 
@@ -785,7 +1067,7 @@ extern "C" int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int til
   int rc = check_desc(d);
   if (rc) return rc;
   const int K = d->cin * d->kh * d->kw;
-  const PlanKey key{d->cout, d->n * d->hout * d->wout, K, d->kh, d->stride, d->dil, d->hin};
+  const PlanKey key{d->cout, d->n * d->hout * d->wout, K, d->kh, d->stride, d->dil, d->hin * 2 + d->precision};
   std::lock_guard<std::mutex> g(plan_mutex());
   if (impl == 0) { plan_table().erase(key); return CL4_OK; }
   CL4_REQUIRE(impl == 1 || impl == 2, "set_plan: impl must be 0, 1 or 2");
@@ -800,7 +1082,8 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
   int rc = check_desc(d);
   if (rc) return rc;
   CL4_REQUIRE(x && wp && y, "conv2d_fwd: null tensor");
-  CL4_REQUIRE(d->precision == 0, "conv2d_fwd: precision %d not built", d->precision);
+  CL4_REQUIRE(d->precision == 0 || d->precision == 1, "conv2d_fwd: precision %d unknown (0 fp32, 1 bf16x3)", d->precision);
+  CL4_REQUIRE(d->precision == 0 || (d->cout % 4 == 0 && d->cout >= 64), "conv2d_fwd: bf16x3 needs cout %% 4 == 0 and cout >= 64");
   ConvArgs a;
   a.x = x; a.wp = wp; a.scale = scale; a.shift = shift; a.pre = pre; a.post = post; a.y = y;
   a.n = d->n; a.cin = d->cin; a.hin = d->hin; a.win = d->win; a.cout = d->cout;
@@ -810,11 +1093,13 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
   a.K = d->cin * d->kh * d->kw;
   a.npix = d->n * d->hout * d->wout;
   a.ws = nullptr; a.kchunk = 0;
+  a.neg1 = d->act1 == CL4_ACT_NONE ? 1.f : (d->act1 == CL4_ACT_RELU ? 0.f : d->slope1);
+  a.neg2 = d->act2 == CL4_ACT_NONE ? 1.f : (d->act2 == CL4_ACT_RELU ? 0.f : d->slope2);
   hipStream_t st = cl4::as_stream(stream);
   switch (d->kh) {
-    case 1: return launch_fwd<1>(a, st, workspace, workspace_bytes);
-    case 3: return launch_fwd<3>(a, st, workspace, workspace_bytes);
-    default: return launch_fwd<7>(a, st, workspace, workspace_bytes);
+    case 1: return launch_fwd<1>(a, st, workspace, workspace_bytes, d->precision);
+    case 3: return launch_fwd<3>(a, st, workspace, workspace_bytes, d->precision);
+    default: return launch_fwd<7>(a, st, workspace, workspace_bytes, d->precision);
   }
 }
 

