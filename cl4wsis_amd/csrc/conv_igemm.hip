@@ -470,8 +470,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int KS, bool SPLIT>
-__global__ __launch_bounds__(V2_THREADS, 2) void conv_igemm_bf16x3(ConvArgs a, const float* __restrict__ zero_page) {
+// TAP = true (cin % 32 == 0): K is ordered tap-major (k = tap*cin + ci, the weights are packed in the same order), so a
+// 32-deep K-tile holds ONE filter tap and 32 consecutive input channels: padding validity and the pixel address are
+// computed once per tile and lane, and each gather is a buffer_load with the lane's byte offset in a VGPR and the
+// channel offset in an SGPR (out-of-image lanes carry an out-of-range offset and read 0 through the descriptor's
+// bounds check). TAP = false keeps the generic ci-major decode (stem 7x7 with cin = 3).
+template <int BM, int BN, int KS, bool SPLIT, bool TAP>
+__global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, const float* __restrict__ zero_page) {
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KHW = KS * KS;
@@ -515,12 +520,36 @@ __global__ __launch_bounds__(V2_THREADS, 2) void conv_igemm_bf16x3(ConvArgs a, c
     const bf16x8* wq = reinterpret_cast<const bf16x8*>(a.wp);   // [K/8][2][cout] chunks of 8 bf16
     const int KGtot = (a.K + 7) / 8;
 
-    float xr[NITEM][8];
+    // Two static register sets (tile t lives in set t & 1): the gathers of tile t+3 are issued right after tile t+1 has
+    // been converted, i.e. a whole K-tile of MFMA time before they are needed — with a single set the loader was a
+    // serial load -> wait(full memory latency) -> convert chain.
+    float xr0[NITEM][8], xr1[NITEM][8];
     // Branch-free gather: the per-lane base pointer is fixed, the tap offset is wave-uniform (scalar), and lanes whose
     // tap falls into the padding / past K / past the last pixel read the zero page instead (a pointer select, no
     // branch). Every lane therefore ALWAYS issues exactly 8*NITEM loads per K-tile — the counted vmcnt waits below
     // rely on that number — and all of them are in flight together.
-    auto gload = [&](int kt) {
+    const unsigned x_bytes = (unsigned)((long)a.n * a.in_ctot * HWi * 4);   // < 2^31, checked on the host for TAP
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, TAP ? x_bytes : 0u, 0x00020000);
+    const int lane_base = (int)((((long)n * a.in_ctot + a.in_coff) * HWi + (long)iy0 * a.win + ix0) * 4);
+    auto gload = [&](float (&xr)[NITEM][8], int kt) {
+      if constexpr (TAP) {
+        const int k0 = kbeg + kt * BK2;                     // wave-uniform, multiple of 32
+        const int tap = KS == 1 ? 0 : k0 / a.cin;
+        const int ci0 = k0 - tap * a.cin;
+        const int ky = tap / KS;
+        const int dy = ky * a.dil, dx = (tap - ky * KS) * a.dil;
+        const int iy = iy0 + dy, ix = ix0 + dx;
+        const bool ok = pvalid && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+        const unsigned voff = ok ? (unsigned)(lane_base + (dy * a.win + dx) * 4) : 0x80000000u;
+#pragma unroll
+        for (int it = 0; it < NITEM; ++it)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int soff = (ci0 + (kg0 + it) * 8 + j) * HWi * 4;   // scalar
+            xr[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+          }
+        return;
+      }
 #pragma unroll
       for (int it = 0; it < NITEM; ++it) {
 #pragma unroll
@@ -547,7 +576,7 @@ __global__ __launch_bounds__(V2_THREADS, 2) void conv_igemm_bf16x3(ConvArgs a, c
         }
       }
     };
-    auto cvt_store = [&](int buf) {
+    auto cvt_store = [&](const float (&xr)[NITEM][8], int buf) {
       u32x4* Bs = lds[buf] + A_CHUNKS;
 #pragma unroll
       for (int it = 0; it < NITEM; ++it) {
@@ -575,25 +604,31 @@ __global__ __launch_bounds__(V2_THREADS, 2) void conv_igemm_bf16x3(ConvArgs a, c
         CL4_GLDS(g, As + kp * BM + seg * 64, 16);
       }
     };
-
-    gload(0);
-    issue_A(0, 0);
-    cvt_store(0);
-    if (nk > 1) gload(1);
-    wait_vmcnt<8 * NITEM>();                 // tile-0 weights landed (the NITEM*8 younger gathers may stay in flight)
-    if (nk <= 1) wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int nb = (kt & 1) ^ 1;
-      if (kt + 1 < nk) {
-        cvt_store(nb);                       // registers hold tile kt+1 (gathered one iteration ago)
-        issue_A(kt + 1, nb);
-        if (kt + 2 < nk) { gload(kt + 2); wait_vmcnt<8 * NITEM>(); }
+    // One loader iteration while the MFMA waves consume tile t: convert tile t+1 (set `cur`), DMA its weights, refill the
+    // set with tile t+3, retire the DMA (vmcnt leaves only the 8*NITEM youngest gathers in flight), meet at the barrier.
+    auto body = [&](float (&cur)[NITEM][8], int t) {
+      if (t + 1 < nk) {
+        const int nb = (t + 1) & 1;
+        cvt_store(cur, nb);
+        issue_A(t + 1, nb);
+        if (t + 3 < nk) { gload(cur, t + 3); wait_vmcnt<8 * NITEM>(); }
         else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
+    };
+
+    gload(xr0, 0);
+    issue_A(0, 0);
+    cvt_store(xr0, 0);
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (nk > 1) gload(xr1, 1);
+    if (nk > 2) gload(xr0, 2);
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nk; t += 2) {
+      body(xr1, t);                         // tile t+1 (odd) lives in xr1
+      if (t + 1 < nk) body(xr0, t + 1);     // tile t+2 (even) lives in xr0
     }
     return;
   }
@@ -656,7 +691,8 @@ __global__ __launch_bounds__(V2_THREADS, 2) void conv_igemm_bf16x3(ConvArgs a, c
 }
 
 // w [cout][K] fp32 -> wq [ceil(K/8)][plane: hi, lo][cout][8] bf16 (zero padded along K).
-__global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ wq, int cout, int K) {
+__global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ wq, int cout, int K, int cin,
+                                          int khw, int tap_major) {
   const int KGtot = (K + 7) / 8;
   const long total = (long)KGtot * cout;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -665,8 +701,10 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, bf16x8* _
     bf16x8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int k = kg * 8 + j;
-      const float v = k < K ? w[(long)m * K + k] : 0.f;
+      const int k = kg * 8 + j;                      // position in the kernel's K order
+      int ksrc = k;                                  // position in PyTorch's [cin][kh*kw] order
+      if (tap_major && k < K) { const int tap = k / cin; ksrc = (k - tap * cin) * khw + tap; }
+      const float v = k < K ? w[(long)m * K + ksrc] : 0.f;
       hi[j] = (__bf16)v;
       lo[j] = (__bf16)(v - (float)hi[j]);
     }
@@ -953,12 +991,17 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
     }
     const dim3 g(cl4::cdiv(a.cout, pl.tile), cl4::cdiv(a.npix, pl.tile), pl.splits);
     const float* z = zp3;
+    const bool tapmaj = a.cin % 32 == 0;   // must match cl4_pack_conv_weight_bf16x3
+    if (tapmaj && (long)a.n * a.in_ctot * a.hin * a.win * 4 >= 0x7FFFFFFFL) {
+      cl4::set_error("conv2d_fwd(bf16x3): input tensor >= 2 GiB is not addressable by the 32-bit buffer offsets");
+      return CL4_EINVAL;
+    }
     if (pl.tile == 128) {
-      if (pl.splits > 1) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true>), g, dim3(V2_THREADS), 0, st, a, z);
-      else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false>), g, dim3(V2_THREADS), 0, st, a, z);
+      if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false>), g, dim3(V2_THREADS), 0, st, a, z); }
+      else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false>), g, dim3(V2_THREADS), 0, st, a, z); }
     } else {
-      if (pl.splits > 1) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true>), g, dim3(V2_THREADS), 0, st, a, z);
-      else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false>), g, dim3(V2_THREADS), 0, st, a, z);
+      if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false>), g, dim3(V2_THREADS), 0, st, a, z); }
+      else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false>), g, dim3(V2_THREADS), 0, st, a, z); }
     }
     if (pl.splits > 1) {
       const long total = (long)a.cout * a.npix;
@@ -1041,7 +1084,7 @@ extern "C" int cl4_pack_conv_weight_bf16x3(const float* w, void* wq, int cout, i
   const int K = cin * kh * kw;
   const long total = (long)((K + 7) / 8) * cout;
   hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), w,
-                     (bf16x8*)wq, cout, K);
+                     (bf16x8*)wq, cout, K, cin, kh * kw, (cin % 32 == 0) ? 1 : 0);
   return cl4::launch_status();
 }
 
