@@ -25,7 +25,7 @@ EPS = 1e-5
 # noise (measured on a 75-sample batch: median gradient error 5e-4 with fp32 products vs 1e-2 with the bf16x3 split), and
 # it is only 6 % of the step's FLOPs. The frozen, no-grad networks (old model, flip-TTA semantic forward, PseudoLabeler)
 # run at ops.CONV_PRECISION (bf16x3 by default).
-TRAIN_PRECISION = 0
+TRAIN_PRECISION = int(__import__("os").environ.get("CL4_TRAIN_PRECISION", "0"))
 
 
 class DeeplabV3(nn.Module):

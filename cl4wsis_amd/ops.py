@@ -99,11 +99,13 @@ _conv_ws = {}
 
 
 def _conv_workspace(device, nbytes):
-    """Split-K scratch of the forward conv (its own buffer: it must not alias the BN / loss workspaces)."""
-    ws = _conv_ws.get(device.index)
+    """Split-K scratch of the forward conv — one buffer PER STREAM (kernels of different streams run concurrently and
+    must not share scratch); it never aliases the BN / loss workspaces."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _conv_ws.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _conv_ws[device.index] = ws
+        _conv_ws[key] = ws
     return ws
 
 
@@ -323,7 +325,7 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes):
-    key = (device.type, device.index)
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

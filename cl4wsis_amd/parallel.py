@@ -21,7 +21,7 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CL4_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
@@ -78,6 +78,7 @@ class GradBuckets:
             for i in range(lo, hi):
                 self.bucket_of[i] = b
         self.is_cuda = flat.flat.is_cuda
+        self.native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.world > 1) else None
         self.reset()
 
@@ -95,7 +96,11 @@ class GradBuckets:
         if self.is_cuda:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)
+                if self.native_avg:
+                    dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)      # RCCL
+                else:                                                                   # gloo rehearsal on a GPU
+                    dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+                    chunk.div_(self.world)
         else:
             self.handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
 

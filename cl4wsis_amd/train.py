@@ -87,6 +87,7 @@ class Trainer:
         self.optimizer, self.scheduler = self.get_optimizer(opts)
         self.distribute(opts)
         self._iter = 0
+        self._side_stream = torch.cuda.Stream(device=self.device) if os.environ.get("CL4_OVERLAP", "1") != "0" else None
 
     # ------------------------------------------------------------------------------------------ optimizer
     def get_optimizer(self, opts):
@@ -160,8 +161,18 @@ class Trainer:
         oc = self.old_classes
         self._set_phase2_modes()
 
-        # train.py:253-255 — frozen old model, full forward, low resolution outputs
-        outputs_old, _ = self.model_old(images, interpolate=False)
+        # train.py:253-255 — frozen old model, full forward, low resolution outputs. It is independent of the new model's
+        # forward below, so it runs on a side stream: the two kernel sequences interleave on the device and fill each
+        # other's workgroup-quantisation tails (33x33 layers at b=16 are only ~1 workgroup per CU).
+        main = torch.cuda.current_stream()
+        if self._side_stream is not None:
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                outputs_old, _ = self.model_old(images, interpolate=False)
+                for t in outputs_old.values():
+                    t.record_stream(main)
+        else:
+            outputs_old, _ = self.model_old(images, interpolate=False)
         self.optimizer.zero_grad()
         # train.py:259-263 — semantic forward on [images ; flipped images]
         x2 = torch.empty((2 * bs, 3, H, W), dtype=torch.float32, device=self.device)
@@ -188,6 +199,8 @@ class Trainer:
             seg_gt, prob_win, label_new, peaks, pred["center"], pred["offset"], self._g_dev, oc, sigma=self.sigma,
             pseudo_thresh=opts.pseudo_thresh, refine_thresh=opts.refine_thresh, nms_kernel=opts.kernel, beta=opts.beta,
             run_refine=opts.run_refine)
+        if self._side_stream is not None:
+            main.wait_stream(self._side_stream)      # the old model's centre / offset maps are consumed from here on
         # train.py:503-522 — blended targets + four weighted losses (+ gradient w.r.t. the low-resolution maps)
         losses, dcen, doff = ops.p2_loss(pred["center"], pred["offset"], outputs_old["center"], outputs_old["offset"],
                                          old_w, pseudo, refined, (H, W), self.center_loss_weight, self.offset_loss_weight)
