@@ -203,7 +203,7 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
                    wp.precision)
     wp = wp.data
     if TIMER is not None:
-        e0, e1 = TIMER.span("conv_fwd", 2.0 * n * hout * wout * cout * K)
+        e0, e1 = TIMER.span("conv_fwd_bf16x3" if d.precision == 1 else "conv_fwd_f32", 2.0 * n * hout * wout * cout * K)
         e0.record()
     if AUTOTUNE:
         _autotune_conv(d, x, wp, scale, shift, pre, post, out)

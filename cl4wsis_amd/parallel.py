@@ -26,6 +26,8 @@ def init_distributed(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)
+        elif torch.cuda.is_available():
+            local = local % torch.cuda.device_count()
         dist.init_process_group(backend, init_method="env://", rank=rank, world_size=world, **kw)
     return rank, world, local
 
