@@ -119,7 +119,6 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = trainer.step((images, l1h))
@@ -128,10 +127,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer, ops.TIMER = ops.TIMER, None
-    # Roofline leg: the timed steps overlap the old-model and new-model forwards on two streams, so event durations of
-    # individual launches include time shared with the other stream. Two more steps are run right here with the overlap
-    # switched off (same process, same tuned plans, same inputs) to time each launch exclusively.
+    losses = out["losses"].tolist()
+    # Roofline leg: the timed steps are HIP-graph replays that overlap the old-model and new-model forwards on two
+    # streams, so a launch cannot be bracketed by events there (and would share the device anyway). Two more steps are run
+    # right here eagerly with the overlap switched off (same process, same tuned plans, same inputs) and every
+    # cl4_conv2d_fwd launch is timed with HIP events on its launch stream.
     side, trainer._side_stream = trainer._side_stream, None
     ops.TIMER = ops.KernelTimer()
     for _ in range(2):
@@ -143,13 +143,10 @@ def main():
         t = torch.tensor([elapsed], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    losses = out["losses"].tolist()
     if rank == 0:
-        summ_ov = timer.summary()
         summ = timer_excl.summary()
         n, fl, ms = summ["conv_fwd_bf16x3"]
         ach = fl / (ms * 1e-3) / 1e12
-        n_ov, fl_ov, ms_ov = summ_ov["conv_fwd_bf16x3"]
         # The dominant kernel multiplies fp32 operands as three bf16 MFMA products (hi*hi + hi*lo + lo*hi), so one
         # algorithmic (fp32-equivalent) FLOP costs three bf16 MFMA FLOPs: its ceiling is the dense bf16 peak / 3.
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0
@@ -164,17 +161,13 @@ def main():
                                    "label stage fed by the networks' own outputs (e2e-random mode)",
                        "global_batch": GLOBAL_BATCH, "per_gpu_batch": b, "crop": CROP, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_bf16x3 (cl4_conv2d_fwd precision 1): all its launches of 2 "
-                                                    "steps run right after the timed region with the two-stream overlap off, "
-                                                    "HIP events on the launch stream around every launch",
+                                                    "eager steps run right after the timed region (graph replay and two-stream "
+                                                    "overlap off), HIP events on the launch stream around every launch",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                          "peak_note": "2500 TFLOP/s dense bf16 MFMA / 3 MFMA products per fp32-equivalent MAC",
                          "mfma_issued_tflops": 3 * ach, "launches_per_step": n / 2,
                          "algorithmic_gflop_per_step": fl / 2 / 1e9, "avg_launch_ms": ms / n,
-                         "kernel_ms_per_step": ms / 2,
-                         "timed_region_overlapped": {"achieved": fl_ov / (ms_ov * 1e-3) / 1e12,
-                                                     "kernel_ms_per_step": ms_ov / a.steps,
-                                                     "note": "same launches inside the timed steps; durations include "
-                                                             "sharing the device with the other stream"}},
+                         "kernel_ms_per_step": ms / 2},
             "algorithmic_tflops_whole_step": ALGO_GFLOP_PER_IMAGE * GLOBAL_BATCH * a.steps / elapsed / 1e3,
             "final_losses": dict(zip(("center_old", "offset_old", "center_new", "offset_new"), losses)),
         }

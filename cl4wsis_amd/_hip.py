@@ -91,6 +91,7 @@ _decl("cl4_bn_train_bwd", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P
 _decl("cl4_relu_bwd", _P, _P, _P, _L, _P)
 _decl("cl4_bias_grad", _P, _P, _I, _I, _I, _I, _I, _P)
 _decl("cl4_dropout_mask", _P, _L, C.c_uint64, _F, _P)
+_decl("cl4_dropout_mask_dev", _P, _L, _P, C.c_uint64, _F, _P)
 _decl("cl4_dwconv5_fwd", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_dwconv5_wgrad", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 
@@ -103,6 +104,7 @@ _decl("cl4_label_generation", C.POINTER(LabelIO), _P, C.c_size_t, _P)
 _decl("cl4_label_counters", _P, _I, _I, _I, _P, _P)
 _decl("cl4_p2_loss", C.POINTER(P2LossIO), _P, C.c_size_t, _P)
 _decl("cl4_adam_step", _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P)
+_decl("cl4_adam_step_dev", _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _I, _P)
 _decl("cl4_fill_zero", _P, C.c_size_t, _P)
 
 _lib = None

@@ -212,6 +212,41 @@ extern "C" int cl4_adam_step(float* p, const float* g, float* m, float* v, long 
   return cl4::launch_status();
 }
 
+// Graph-friendly Adam: learning rate and step count live in device memory, bias corrections are computed on the device,
+// and the step counter is advanced by the launch itself — nothing in the kernel arguments changes between replays.
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                long n, const float* __restrict__ lr_dev, float beta1, float beta2, float eps, float wd,
+                                const int* __restrict__ step_dev) {
+  const int step = *step_dev + 1;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)*lr_dev / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    float pi = p[i];
+    if (wd != 0.f) gi = gi + wd * pi;
+    float mi = m[i];
+    mi = mi + (gi - mi) * (1.f - beta1);
+    float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+__global__ void int_add_kernel(int* c, int inc) { *c += inc; }
+
+extern "C" int cl4_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float beta1,
+                                 float beta2, float eps, float weight_decay, int* step_dev, int advance, void* stream) {
+  CL4_REQUIRE(p && g && m && v && lr_dev && step_dev && n > 0, "adam_step_dev: bad arguments");
+  hipStream_t st = cl4::as_stream(stream);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, st, p, g, m, v, n, lr_dev, beta1, beta2, eps,
+                     weight_decay, (const int*)step_dev);
+  if (advance) hipLaunchKernelGGL(int_add_kernel, dim3(1), dim3(1), 0, st, step_dev, advance);
+  return cl4::launch_status();
+}
+
 extern "C" int cl4_fill_zero(void* p, size_t bytes, void* stream) {
   CL4_REQUIRE(p && bytes > 0, "fill_zero: bad arguments");
   hipError_t e = hipMemsetAsync(p, 0, bytes, cl4::as_stream(stream));

@@ -176,7 +176,8 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict
 }
 
 // Counter-based keep mask for nn.Dropout(p): splitmix64 of (seed, element index).
-__global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, uint64_t seed, float p) {
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, uint64_t seed, const uint64_t* seed_dev, float p) {
+  if (seed_dev) seed = *seed_dev;   // device-resident seed: lets a captured HIP graph draw a new mask on every replay
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -264,6 +265,18 @@ extern "C" int cl4_bias_grad(const float* dy, float* db, int n, int c, int hw, i
 
 extern "C" int cl4_dropout_mask(uint8_t* keep, long n, uint64_t seed, float p, void* stream) {
   CL4_REQUIRE(keep && n > 0 && p >= 0.f && p < 1.f, "dropout_mask: bad arguments");
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), keep, n, seed, p);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), keep, n, seed,
+                     (const uint64_t*)nullptr, p);
+  return cl4::launch_status();
+}
+
+__global__ void counter_add_kernel(uint64_t* c, uint64_t inc) { *c += inc; }
+
+extern "C" int cl4_dropout_mask_dev(uint8_t* keep, long n, uint64_t* seed_dev, uint64_t advance, float p, void* stream) {
+  CL4_REQUIRE(keep && seed_dev && n > 0 && p >= 0.f && p < 1.f, "dropout_mask_dev: bad arguments");
+  hipStream_t st = cl4::as_stream(stream);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, st, keep, n, (uint64_t)0,
+                     (const uint64_t*)seed_dev, p);
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, st, seed_dev, advance);
   return cl4::launch_status();
 }

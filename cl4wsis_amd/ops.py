@@ -396,6 +396,13 @@ def dropout_mask(shape, p, seed, device):
     return keep
 
 
+def dropout_mask_dev(shape, p, seed_dev, advance, device):
+    """Keep mask from a device-resident seed (uint64 tensor [1]) that the launch advances: graph-replay safe."""
+    keep = torch.empty(shape, dtype=torch.uint8, device=device)
+    call("cl4_dropout_mask_dev", ptr(keep), keep.numel(), ptr(seed_dev), C.c_uint64(advance), C.c_float(p), stream())
+    return keep
+
+
 def dwconv5(x, w, flip=False, c=None, x_coff=0, out=None, out_coff=0):
     n, x_ctot, h, wd = x.shape
     if c is None:
@@ -551,6 +558,11 @@ def adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
         raise RuntimeError("adam_step_: size mismatch")
     call("cl4_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), n, C.c_float(lr), C.c_float(beta1), C.c_float(beta2),
          C.c_float(eps), C.c_float(weight_decay), int(step), stream())
+
+
+def adam_step_dev_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step_dev, advance):
+    call("cl4_adam_step_dev", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(lr_dev), C.c_float(beta1), C.c_float(beta2),
+         C.c_float(eps), C.c_float(weight_decay), ptr(step_dev), int(advance), stream())
 
 
 def zero_(t):

@@ -37,6 +37,11 @@ class FusedAdam(torch.optim.Optimizer):
             self._ranges.append((self.params_fb.offsets[k], self.params_fb.offsets[k + n]))
             k += n
         self._step = 0
+        # learning rates and the step counter also live on the device: the update kernels read them there, so a captured
+        # HIP graph of the step stays valid while the schedule changes the learning rate
+        self.lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._lr_host = None
 
     def grad_view(self, p):
         return self.grads_fb.views[self.index[id(p)]]
@@ -44,18 +49,40 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         ops.zero_(self.grads_fb.flat)
 
+    def upload_lr(self):
+        """Push the groups' current learning rates to the device (no-op when unchanged). Call outside graph capture."""
+        lrs = [float(g["lr"]) for g in self.param_groups]
+        if lrs != self._lr_host:
+            self.lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=False)
+            self._lr_host = lrs
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, upload=True):
+        if upload:
+            self.upload_lr()
         self._step += 1
-        for g, (lo, hi) in zip(self.param_groups, self._ranges):
+        last = max(i for i, (lo, hi) in enumerate(self._ranges) if hi > lo)
+        for gi, (g, (lo, hi)) in enumerate(zip(self.param_groups, self._ranges)):
             if hi == lo:
                 continue
             b1, b2 = g["betas"]
-            ops.adam_step_(self.params_fb.flat[lo:hi], self.grads_fb.flat[lo:hi], self.m_fb.flat[lo:hi],
-                           self.v_fb.flat[lo:hi], g["lr"], b1, b2, g["eps"], g["weight_decay"], self._step)
+            ops.adam_step_dev_(self.params_fb.flat[lo:hi], self.grads_fb.flat[lo:hi], self.m_fb.flat[lo:hi],
+                               self.v_fb.flat[lo:hi], self.lr_dev[gi:gi + 1], b1, b2, g["eps"], g["weight_decay"],
+                               self.step_dev, 1 if gi == last else 0)
             for p in g["params"]:
-                self.state[p]["step"] += 1
                 CACHE.touch(p)   # the kernel wrote the weights behind PyTorch's back: invalidate packed copies
+
+    def note_replayed_step(self):
+        """Bookkeeping after a graph replay that contained the update kernels."""
+        self._step += 1
+        self._opt_called = True                      # what lr_scheduler's "step() before optimizer.step()" check reads
+        self._step_count = getattr(self, "_step_count", 0) + 1
+
+    def state_dict(self):
+        for g in self.param_groups:
+            for p in g["params"]:
+                self.state[p]["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -65,3 +92,5 @@ class FusedAdam(torch.optim.Optimizer):
                 self.m_fb.views[i].copy_(st["exp_avg"]); st["exp_avg"] = self.m_fb.views[i]
                 self.v_fb.views[i].copy_(st["exp_avg_sq"]); st["exp_avg_sq"] = self.v_fb.views[i]
                 self._step = max(self._step, int(st["step"]))
+            self.step_dev.fill_(self._step)
+            self._lr_host = None

@@ -88,6 +88,10 @@ class Trainer:
         self.distribute(opts)
         self._iter = 0
         self._side_stream = torch.cuda.Stream(device=self.device) if os.environ.get("CL4_OVERLAP", "1") != "0" else None
+        self._use_graph = os.environ.get("CL4_GRAPH", "1") != "0"
+        self._graph, self._static, self._graph_active = None, None, False
+        self._seed_dev = torch.tensor([opts.random_seed * 1000003 + 7919 * (dist.get_rank() if dist.is_initialized() else 0)],
+                                      dtype=torch.int64, device=self.device)
 
     # ------------------------------------------------------------------------------------------ optimizer
     def get_optimizer(self, opts):
@@ -145,21 +149,67 @@ class Trainer:
         if not (self.weakly and opts.phase == 2):
             raise NotImplementedError("Trainer.step: only the phase-2 weakly-supervised step (BASELINE config 3) is built; "
                                       "step 0 and phase 1 are later §8 rows")
-        # first iteration: time the launch plans of every convolution shape of this step once (ops._autotune_conv)
-        ops.AUTOTUNE = self._iter == 0 and os.environ.get("CL4_AUTOTUNE", "1") != "0"
-        try:
-            return self._step_phase2(batch, dropout_keep)
-        finally:
-            ops.AUTOTUNE = False
-
-    def _step_phase2(self, batch, dropout_keep):
-        opts = self.opts
         images, l1h = (batch[0], batch[-1])
         images = images.to(self.device, dtype=torch.float32).contiguous()
         l1h = l1h.to(self.device, dtype=torch.float32).contiguous()
+        self._set_phase2_modes()
+        use_graph = (self._use_graph and dropout_keep is None and self._iter >= 1 and ops.TIMER is None
+                     and (self._static is None or tuple(images.shape) == tuple(self._static["images"].shape)))
+        if not use_graph:
+            if self._graph_active:
+                from .nn import CACHE
+                CACHE.clear()            # packed weights cached by the captured run are one step stale for eager code
+                self._graph_active = False
+            # first iteration: time the launch plans of every convolution shape of this step once (ops._autotune_conv)
+            ops.AUTOTUNE = self._iter == 0 and os.environ.get("CL4_AUTOTUNE", "1") != "0"
+            try:
+                out = self._forward_backward(images, l1h, dropout_keep)
+            finally:
+                ops.AUTOTUNE = False
+            self.buckets.finish()
+            self.optimizer.step()
+        else:
+            out = self._replay(images, l1h)
+        if self.scheduler is not None:
+            self.scheduler.step()
+        self._iter += 1
+        return out
+
+    # HIP-graph path: iteration 0 runs eagerly (autotuning), iteration 1 captures the whole step — both streams, ~600
+    # kernel launches — into one graph, and every later iteration is a copy of the batch into static buffers plus one
+    # graph launch. Everything that changes between iterations lives in device memory (Dropout seed, Adam step count,
+    # learning rates), so the captured kernel arguments stay valid.
+    def _replay(self, images, l1h):
+        opt = self.optimizer
+        if self._static is None:
+            self._static = {"images": images.clone(), "l1h": l1h.clone()}
+            opt.upload_lr()
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                out = self._forward_backward(self._static["images"], self._static["l1h"], None)
+                if self.buckets.world == 1:
+                    opt.step(upload=False)
+            self._static["out"] = out
+            opt._step -= 1 if self.buckets.world == 1 else 0   # capture only recorded the kernels
+        self._static["images"].copy_(images)
+        self._static["l1h"].copy_(l1h)
+        opt.upload_lr()
+        self._graph.replay()
+        self._graph_active = True
+        if self.buckets.world == 1:
+            opt.note_replayed_step()
+        else:                                   # gradients are averaged eagerly between the graph and the update
+            for i in range(len(self.buckets.fb.sizes)):
+                self.buckets.ready(i)
+            self.buckets.finish()
+            opt.step()
+        return self._static["out"]
+
+    def _forward_backward(self, images, l1h, dropout_keep):
+        opts = self.opts
         bs, _, H, W = images.shape
         oc = self.old_classes
-        self._set_phase2_modes()
 
         # train.py:253-255 — frozen old model, full forward, low resolution outputs. It is independent of the new model's
         # forward below, so it runs on a side stream: the two kernel sequences interleave on the device and fill each
@@ -181,9 +231,12 @@ class Trainer:
         outputs, features = self.model.forward_seg(x2, interpolate=False)
         feats = {k: v[:bs] for k, v in features["features"].items()}   # first half = un-flipped images (contiguous views)
         # train.py:265-272 — trainable instance decoder + heads on the detached features
-        seed = (opts.random_seed * 1000003 + self._iter * 7919 + dist.get_rank() * 104729 if dist.is_initialized()
-                else opts.random_seed * 1000003 + self._iter * 7919)
-        pred, tape = self._branch.forward_train(feats, dropout_keep=dropout_keep, seed=seed)
+        if dropout_keep is None:
+            n5, _, h5, w5 = feats["res5"].shape
+            drop = self.model.decoder.instance_decoder.aspp.project
+            dropout_keep = ops.dropout_mask_dev((n5, drop[0].out_channels, h5, w5), drop[3].p, self._seed_dev,
+                                                0x9E3779B97F4A7C15, self.device)
+        pred, tape = self._branch.forward_train(feats, dropout_keep=dropout_keep)
         torch._foreach_add_(self._bn_counters, 1)
         # train.py:421-436 — CAM of the new classes -> peaks
         self.pseudolabeler.eval()
@@ -204,13 +257,9 @@ class Trainer:
         # train.py:503-522 — blended targets + four weighted losses (+ gradient w.r.t. the low-resolution maps)
         losses, dcen, doff = ops.p2_loss(pred["center"], pred["offset"], outputs_old["center"], outputs_old["offset"],
                                          old_w, pseudo, refined, (H, W), self.center_loss_weight, self.offset_loss_weight)
-        # train.py:537-541 — backward, gradient averaging, optimizer, schedule
-        self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map, on_ready=self._ready)
-        self.buckets.finish()
-        self.optimizer.step()
-        if self.scheduler is not None:
-            self.scheduler.step()
-        self._iter += 1
+        # train.py:537 — backward of the trainable sub-net; gradient buckets are all-reduced as they complete
+        self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map,
+                              on_ready=self._ready if (self.buckets.world > 1 and not torch.cuda.is_current_stream_capturing()) else None)
         return {"losses": losses, "seg_gt": seg_gt, "peaks": peaks, "pseudo": pseudo, "refined": refined,
                 "center": pred["center"], "offset": pred["offset"], "old_w": old_w}
 

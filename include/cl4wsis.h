@@ -151,6 +151,9 @@ int cl4_relu_bwd(const float* y, const float* dy, float* dx, long n, void* strea
 int cl4_bias_grad(const float* dy, float* db, int n, int c, int hw, int ctot, int coff, void* stream);
 /* Counter-based keep mask for nn.Dropout(p) — modules/panoptic_deeplab.py:123. */
 int cl4_dropout_mask(uint8_t* keep, long n, uint64_t seed, float p, void* stream);
+/* Same, with the seed read from device memory and advanced by `advance` afterwards: a captured HIP graph of the step
+ * then draws a fresh mask on every replay. */
+int cl4_dropout_mask_dev(uint8_t* keep, long n, uint64_t* seed_dev, uint64_t advance, float p, void* stream);
 
 /* ------------------------------------------------------------------------
  * 5x5 depthwise conv, stride 1, pad 2 — modules/panoptic_deeplab.py:39-40. w: [c,1,5,5].
@@ -235,6 +238,10 @@ int cl4_p2_loss(const cl4_p2_loss_io* d, void* workspace, size_t workspace_bytes
 /* torch.optim.Adam step (train.py:181-182,538) over flat buffers; `step` is the 1-based step count. */
 int cl4_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, void* stream);
+/* Graph-replayable form: learning rate and 0-based step counter in device memory (bias corrections computed on the
+ * device); the counter is advanced by `advance` after the update. */
+int cl4_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float beta1, float beta2,
+                      float eps, float weight_decay, int* step_dev, int advance, void* stream);
 int cl4_fill_zero(void* p, size_t bytes, void* stream);
 
 #ifdef __cplusplus
