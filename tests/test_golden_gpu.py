@@ -162,3 +162,37 @@ def test_trainer_step_matches_oracle(gpu):
         agree += int(((du - dr).abs()[big] < 0.05 * opts.lr * opts.lr_head).sum())
         total += int(big.sum())
     assert agree / total > 0.995, (agree, total)
+
+
+def test_graph_replay_matches_eager(gpu, monkeypatch):
+    """Three iterations through the captured HIP graph (device-resident Dropout seed / Adam step / learning rate) give the
+    same losses and weights as three eager iterations from the same state (differences: fp32 atomics order only)."""
+    from cl4wsis_amd.train import Trainer
+    from oracle import weights
+    crop = 97
+    g = torch.Generator().manual_seed(8)
+    batches = [(torch.randn(2, 3, crop, crop, generator=g), torch.eye(20)[[16 + i % 4, 15]].clone()) for i in range(3)]
+
+    def run(graph):
+        monkeypatch.setenv("CL4_GRAPH", "1" if graph else "0")
+        opts = p2_opts(crop)
+        opts.max_iters, opts.start_decay = 50, 1     # the schedule changes the learning rate every iteration
+        torch.manual_seed(0)
+        tr = Trainer(_Log(), gpu, opts)
+        for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
+            m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=31 + i))
+        tr._realias()
+        losses = []
+        for x, l in batches:
+            losses.append(tr.step((x, l))["losses"].clone())
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == graph
+        w = torch.cat([p.detach().flatten() for p in tr._branch.trainable_parameters()]).cpu()
+        return torch.stack(losses).cpu(), w, tr.optimizer.param_groups[0]["lr"]
+
+    le, we, lre = run(False)
+    lg, wg, lrg = run(True)
+    assert lre == lrg and lre < 5e-4
+    assert torch.allclose(le, lg, rtol=2e-3, atol=1e-6), (le, lg)
+    assert (we - wg).abs().max() < 2e-4          # three Adam steps of lr 5e-4: identical directions
+    assert (we - wg).abs().mean() < 1e-5
