@@ -41,6 +41,7 @@ struct ConvArgs {
   float slope1, slope2;
   int K;        // cin*KS*KS
   int npix;     // n*hout*wout
+  int xcd_remap;      // 1: XCD-aware logical tile order (bf16x3 kernel)
   float neg1, neg2;   // branch-free activations: act(v) = v > 0 ? v : v * neg  (none: 1, relu: 0, leaky: slope)
   float* ws;    // split-K partial slabs [splits][cout][npix] (v2 kernel only)
   int kchunk;   // k range per split (multiple of 32)
@@ -494,11 +495,20 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
   const bool loader = wave8 >= 4;
   const int wave = wave8 & 3;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs in dispatch order, so ids that
+  // are congruent mod 8 share an L2. Remap so that each XCD walks a CONTIGUOUS range of logical tiles with the M index
+  // fastest: the M tiles that re-read one pixel tile (and neighbouring pixel tiles that share halo rows) meet in one L2.
+  const unsigned gx = gridDim.x, gxy = gridDim.x * gridDim.y, total = gxy * gridDim.z;
+  const unsigned id = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
+  const unsigned q8 = total >> 3, r8 = total & 7, xcd = id & 7;
+  const unsigned lid = a.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3) : id;
+  const unsigned bz = lid / gxy, rem2 = lid - bz * gxy;
+  const unsigned by_ = rem2 / gx, bx_ = rem2 - by_ * gx;
+  const int m0 = bx_ * BM;
+  const int n0 = by_ * BN;
   const int HWo = a.hout * a.wout;
   const int HWi = a.hin * a.win;
-  const int kbeg = SPLIT ? blockIdx.z * a.kchunk : 0;
+  const int kbeg = SPLIT ? bz * a.kchunk : 0;
   const int kend = SPLIT ? min(a.K, kbeg + a.kchunk) : a.K;
   const int nk = (kend - kbeg + BK2 - 1) / BK2;
   const int lr = lane & 31, lh = lane >> 5;
@@ -533,9 +543,13 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
     const int lane_base = (int)((((long)n * a.in_ctot + a.in_coff) * HWi + (long)iy0 * a.win + ix0) * 4);
     auto gload = [&](float (&xr)[NITEM][8], int kt) {
       if constexpr (TAP) {
-        const int k0 = kbeg + kt * BK2;                     // wave-uniform, multiple of 32
-        const int tap = KS == 1 ? 0 : k0 / a.cin;
-        const int ci0 = k0 - tap * a.cin;
+        // K order (shared with cl4_pack_conv_weight_bf16x3): k = (cb*KHW + tap)*32 + cil — all KHW taps of a 32-channel
+        // block are adjacent K-tiles, so the (shifted) re-reads of those channels hit L1/L2 instead of streaming the whole
+        // input once per tap (FETCH_SIZE showed ~4x the algorithmic bytes with the plain tap-major order).
+        const int T = (kbeg >> 5) + kt;                     // wave-uniform K-tile index
+        const int cb = T / KHW;
+        const int tap = T - cb * KHW;
+        const int ci0 = cb * 32;
         const int ky = tap / KS;
         const int dy = ky * a.dil, dx = (tap - ky * KS) * a.dil;
         const int iy = iy0 + dy, ix = ix0 + dx;
@@ -677,7 +691,7 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
     const int p = n0 + wn * WTN + j * 32 + lr;
     if (!SPLIT || p >= a.npix) continue;
     {
-      float* wsp = a.ws + ((long)blockIdx.z * a.cout) * a.npix + p;
+      float* wsp = a.ws + ((long)bz * a.cout) * a.npix + p;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -703,7 +717,11 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, bf16x8* _
     for (int j = 0; j < 8; ++j) {
       const int k = kg * 8 + j;                      // position in the kernel's K order
       int ksrc = k;                                  // position in PyTorch's [cin][kh*kw] order
-      if (tap_major && k < K) { const int tap = k / cin; ksrc = (k - tap * cin) * khw + tap; }
+      if (tap_major && k < K) {                      // k = (cb*khw + tap)*32 + cil  ->  ci = cb*32 + cil
+        const int t32 = k >> 5, cil = k & 31;
+        const int cb = t32 / khw, tap = t32 - cb * khw;
+        ksrc = (cb * 32 + cil) * khw + tap;
+      }
       const float v = k < K ? w[(long)m * K + ksrc] : 0.f;
       hi[j] = (__bf16)v;
       lo[j] = (__bf16)(v - (float)hi[j]);
@@ -1136,6 +1154,8 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
   a.K = d->cin * d->kh * d->kw;
   a.npix = d->n * d->hout * d->wout;
   a.ws = nullptr; a.kchunk = 0;
+  static const int xcd_default = env_int("CL4_XCD_REMAP", 1);
+  a.xcd_remap = xcd_default;
   a.neg1 = d->act1 == CL4_ACT_NONE ? 1.f : (d->act1 == CL4_ACT_RELU ? 0.f : d->slope1);
   a.neg2 = d->act2 == CL4_ACT_NONE ? 1.f : (d->act2 == CL4_ACT_RELU ? 0.f : d->slope2);
   hipStream_t st = cl4::as_stream(stream);

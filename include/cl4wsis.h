@@ -74,7 +74,8 @@ typedef struct cl4_conv_desc {
 /* w: [cout, cin, kh, kw] (PyTorch layout) -> wp: [cin*kh*kw, cout]. */
 int cl4_pack_conv_weight(const float* w, float* wp, int cout, int cin, int kh, int kw, void* stream);
 /* precision 1 ("bf16x3"): w -> wq [ceil(K/8)][2 planes: hi, lo][cout][8 x bf16], i.e. ceil(K/8)*2*cout*16 bytes, where
- * hi = bf16(w), lo = bf16(w - hi); K runs tap-major (k = (ky*kw+kx)*cin + ci) when cin % 32 == 0 and in PyTorch's
+ * hi = bf16(w), lo = bf16(w - hi); when cin % 32 == 0, K runs k = ((ci/32)*kh*kw + ky*kw+kx)*32 + ci%32 (32-channel
+ * blocks, all taps of a block adjacent), otherwise in PyTorch's
  * order (k = ci*kh*kw + ky*kw + kx) otherwise. cl4_conv2d_fwd with desc.precision = 1 takes this buffer as `wp` and accumulates
  * hi*hi + hi*lo + lo*hi on the bf16 MFMA pipe in fp32 (~4e-6 relative error per layer; needs cout % 4 == 0, cout >= 64). */
 int cl4_pack_conv_weight_bf16x3(const float* w, void* wq, int cout, int cin, int kh, int kw, void* stream);

@@ -5,7 +5,7 @@ d = sys.argv[1]
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 f = glob.glob(d + '/*/*_kernel_trace.csv')[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+adam = [i for i, r in enumerate(rows) if 'adam' in r['Kernel_Name']]
 start, end = adam[-2 * nsteps - 1] + 1, adam[-1] + 1
 sel = rows[start:end]
 wall = (int(sel[-1]['End_Timestamp']) - int(sel[0]['Start_Timestamp'])) / 1e6
