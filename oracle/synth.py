@@ -70,3 +70,22 @@ def label_stage_inputs(seed, b=2, H=129, W=129, stride=16, tot_classes=21, old_c
         "old_offset_lo": t(rng.randn(b, 2, hc, wc).astype(np.float32)),
         "H": H, "W": W, "old_classes": old_classes, "tot_classes": C, "K": K,
     }
+
+
+def wss_inputs(seed, b, c, h, w):
+    """Seeded inputs of the phase-1 loss-stack fixtures (regenerated identically by the tests)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    img = torch.rand(b, 3, h, w, generator=g)                                   # denormalised image in [0, 1]
+    img[:, :, h // 3:2 * h // 3, w // 4:w // 2] += 0.5                        # an edge for the affinity to respect
+    logits = torch.randn(b, c, h, w, generator=g) * 2.0
+    logits[:, 0] += 1.0
+    labels = (torch.rand(b, c - 1, generator=g) < 0.3).float()
+    labels[:, -1] = 1.0
+    for i in range(b):                                                          # make labelled classes win somewhere
+        for k in torch.nonzero(labels[i]).flatten().tolist():
+            y0, x0 = int(torch.randint(0, h - 6, (1,), generator=g)), int(torch.randint(0, w - 6, (1,), generator=g))
+            logits[i, k + 1, y0:y0 + 6, x0:x0 + 6] += 6.0
+    seg_lab = torch.randint(0, c, (b, 2 * h + 1, 2 * w + 1), generator=g)
+    seg_lab[torch.rand(seg_lab.shape, generator=g) < 0.1] = 255
+    big = torch.randn(b, c, 2 * h + 1, 2 * w + 1, generator=g)
+    return dict(img=img, logits=logits, labels=labels, seg_lab=seg_lab, big=big)

@@ -7,6 +7,8 @@ Fixtures (inputs are regenerated from seeds by the tests; only the reference's O
   model_p2_c65.npz  — reference networks (make_model, PseudoLabeler, PeakGenerator) with name-keyed deterministic
                       weights on a seeded 2x3x65x65 batch: old-model forward, forward_seg on the flip-TTA batch,
                       train-mode instance decoder/head outputs under a recorded Dropout mask, gradient norms.
+  wss_sXX.npz       — reference phase-1 / step-0 loss stack on oracle.synth.wss_inputs: PAMR, nGWP+focal bce_loss (+grad),
+                      pseudo_gtmask, binarize, balanced_mask_loss_ce (+grad), BCEWithLogitsLossWithIgnoreIndex (+grad).
   label_sXX.npz     — reference label stage on oracle.synth structured inputs: smoothing, peak_extract, the inline
                       semantic pseudo-GT block of train.py:263,438-449 (driven with the reference's own tensors ops),
                       pseudo_label_generation, refine_label_generation, Weighted_MSELoss / Weighted_L1_Loss blend.
@@ -183,9 +185,51 @@ def label_fixture(R, seed, b, H, W):
           "refined px:", int((refined['weight'] > 0).sum()), "losses:", out["losses"].round(4).tolist())
 
 
+WSS_CASES = [(0, 2, 21, 33, 33), (1, 3, 21, 17, 25), (2, 2, 11, 33, 33)]
+
+
+def wss_fixture(R, seed, b, c, h, w):
+    wm, wl, loss = R["wss_modules"], R["wss_loss"], R["loss"]
+    from wss import single_stage as ss                                          # reference package, on sys.path after load
+    d = synth.wss_inputs(seed, b, c, h, w)
+    out = {"case": np.array([seed, b, c, h, w])}
+    soft = d["logits"].softmax(1)
+    pamr = wm.PAMR(num_iter=10, dilations=[1, 2, 4, 8, 12])
+    with torch.no_grad():
+        out["pamr"] = pamr(d["img"], soft.clone()).numpy()
+    nl = d["labels"].shape[1] // 2 + 1                                         # "new classes" = last nl channels
+    for red in ("mean", "sum"):
+        x = d["logits"].clone().requires_grad_(True)
+        l = wl.bce_loss(x, d["labels"][:, -nl:], mode="ngwp", reduction=red)
+        l.backward()
+        out[f"bce_{red}"] = np.array(l.item())
+        out[f"bce_{red}_grad"] = x.grad.numpy()
+    out["ngwp"] = wl.ngwp_focal(d["logits"]).numpy()
+    masked = soft.clone()
+    masked[:, 1:] *= d["labels"][:, :, None, None]
+    pg = ss.pseudo_gtmask(masked, ambiguous=True, cutoff_top=0.6, cutoff_bkg=0.7, cutoff_low=0.2)
+    out["pseudo_gt"] = pg.numpy().astype(np.uint8)
+    out["binarize"] = wl.binarize(masked).numpy().astype(np.uint8)
+    x = d["logits"].clone().requires_grad_(True)
+    l = ss.balanced_mask_loss_ce(x, pg, d["labels"])
+    l.backward()
+    out["bal_ce"] = np.array(l.item())
+    out["bal_ce_grad"] = x.grad.numpy()
+    x = d["big"].clone().requires_grad_(True)
+    l = loss.BCEWithLogitsLossWithIgnoreIndex(reduction="none")(x, d["seg_lab"]).mean()
+    l.backward()
+    out["bce_ignore"] = np.array(l.item())
+    out["bce_ignore_grad_sum"] = np.array([x.grad.double().abs().sum().item(), x.grad.double().pow(2).sum().item()])
+    out["bce_ignore_grad_slice"] = x.grad[:, :, ::7, ::5].numpy()
+    np.savez_compressed(os.path.join(HERE, f"wss_s{seed:02d}.npz"), **out)
+    print(f"wss_s{seed:02d}.npz", {k: (v.shape if v.ndim else float(v)) for k, v in out.items() if k != "case"})
+
+
 if __name__ == "__main__":
     R = ref_harness.load_reference()
     torch.set_num_threads(8)
     model_fixture(R)
     for case in LABEL_CASES:
         label_fixture(R, *case)
+    for case in WSS_CASES:
+        wss_fixture(R, *case)
