@@ -568,3 +568,106 @@ def adam_step_dev_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step_dev
 def zero_(t):
     call("cl4_fill_zero", ptr(t), t.numel() * t.element_size(), stream())
     return t
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Phase-1 / step-0 weakly-supervised loss stack — csrc/wss.hip
+# ---------------------------------------------------------------------------------------------------------------------
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError(f"{name}: contiguous float32 tensor expected")
+    return t
+
+
+def pamr(img, mask, num_iter=10, dilations=(1, 2, 4, 8, 12)):
+    """PAMR.forward (wss/modules.py:133-152). img [b,3,H,W]; mask [b,c,h,w] is first resized to the image size
+    (bilinear, align_corners=True) like the reference does; returns the refined mask [b,c,H,W]."""
+    _f32c(img, "pamr img"), _f32c(mask, "pamr mask")
+    b, _, h, w = img.shape
+    if img.shape[1] != 3 or mask.shape[0] != b:
+        raise RuntimeError("pamr: img [b,3,h,w] and mask [b,c,*,*] expected")
+    if tuple(mask.shape[-2:]) != (h, w):
+        mask = resize_bilinear(mask, (h, w), align_corners=True)
+    c = mask.shape[1]
+    out = torch.empty_like(mask)
+    dil = (C.c_int * len(dilations))(*[int(d) for d in dilations])
+    nbytes = _hip.load().cl4_pamr_workspace_bytes(b, c, h, w, len(dilations))
+    ws = _workspace(img.device, nbytes)
+    call("cl4_pamr", ptr(img), ptr(mask), ptr(out), b, c, h, w, int(num_iter), dil, len(dilations), ptr(ws), ws.numel(),
+         stream())
+    return out
+
+
+def ngwp_focal_bce(x, labels, reduction="mean", lam=1e-2, with_grad=True):
+    """bce_loss(x, labels, mode='ngwp', reduction) of utils/wss_loss.py:36-53. Returns (loss [1], ngwp [b,c], dx or None)."""
+    _f32c(x, "ngwp x"), _f32c(labels, "ngwp labels")
+    b, c, h, w = x.shape
+    nl = labels.shape[1]
+    if labels.shape[0] != b or nl > c or reduction not in ("mean", "sum"):
+        raise RuntimeError("ngwp_focal_bce: labels [b, nl <= c] and reduction 'mean' | 'sum' expected")
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    ngwp = torch.empty(b, c, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if with_grad else None
+    nbytes = _hip.load().cl4_ngwp_workspace_bytes(b, c)
+    ws = _workspace(x.device, nbytes)
+    call("cl4_ngwp_focal_bce", ptr(x), ptr(labels), b, c, h, w, nl, int(reduction == "sum"), C.c_float(lam), ptr(ngwp),
+         ptr(loss), ptr(dx) if with_grad else None, ptr(ws), ws.numel(), stream())
+    return loss, ngwp, dx
+
+
+def pseudo_gtmask(mask, labels=None, cutoff_top=0.6, cutoff_bkg=0.7, cutoff_low=0.2):
+    """pseudo_gtmask(mask * labels, ambiguous=True, ...) of wss/single_stage.py:18-40 (label masking of train.py:381-382
+    fused when `labels` [b,c-1] is given)."""
+    _f32c(mask, "pseudo_gtmask mask")
+    b, c, h, w = mask.shape
+    if labels is not None and tuple(_f32c(labels, "pseudo_gtmask labels").shape) != (b, c - 1):
+        raise RuntimeError("pseudo_gtmask: labels [b, c-1] expected")
+    out = torch.empty_like(mask)
+    thr = torch.empty(b, c, dtype=torch.float32, device=mask.device)
+    call("cl4_pseudo_gtmask", ptr(mask), ptr(labels) if labels is not None else None, ptr(out), b, c, h, w,
+         C.c_float(cutoff_top), C.c_float(cutoff_bkg), C.c_float(cutoff_low), ptr(thr), stream())
+    return out
+
+
+def binarize(x, labels=None):
+    """binarize(x * labels) of utils/wss_loss.py:188-190."""
+    _f32c(x, "binarize x")
+    b, c, h, w = x.shape
+    if labels is not None and tuple(_f32c(labels, "binarize labels").shape) != (b, c - 1):
+        raise RuntimeError("binarize: labels [b, c-1] expected")
+    out = torch.empty_like(x)
+    call("cl4_binarize", ptr(x), ptr(labels) if labels is not None else None, ptr(out), b, c, h, w, stream())
+    return out
+
+
+def balanced_mask_loss_ce(mask, pseudo_gt, labels, with_grad=True):
+    """balanced_mask_loss_ce of wss/single_stage.py:43-80. Returns (loss [1], dmask or None)."""
+    _f32c(mask, "balanced_ce mask"), _f32c(pseudo_gt, "balanced_ce pseudo_gt"), _f32c(labels, "balanced_ce labels")
+    if tuple(mask.shape[-2:]) != tuple(pseudo_gt.shape[-2:]):
+        mask = resize_bilinear(mask, tuple(pseudo_gt.shape[-2:]), align_corners=True)
+        if with_grad:
+            raise RuntimeError("balanced_mask_loss_ce: gradient needs mask and pseudo_gt at the same size")
+    b, c, h, w = pseudo_gt.shape
+    if tuple(mask.shape) != (b, c, h, w) or tuple(labels.shape) != (b, c - 1):
+        raise RuntimeError("balanced_mask_loss_ce: mask/pseudo_gt [b,c,h,w], labels [b,c-1] expected")
+    loss = torch.empty(1, dtype=torch.float32, device=mask.device)
+    dmask = torch.empty_like(mask) if with_grad else None
+    nbytes = _hip.load().cl4_balanced_ce_workspace_bytes(b, c, h, w)
+    ws = _workspace(mask.device, nbytes)
+    call("cl4_balanced_mask_loss_ce", ptr(mask), ptr(pseudo_gt), ptr(labels), b, c, h, w, ptr(loss),
+         ptr(dmask) if with_grad else None, ptr(ws), ws.numel(), stream())
+    return loss, dmask
+
+
+def bce_ignore_mean(x, target, ignore_index=255, with_grad=True):
+    """BCEWithLogitsLossWithIgnoreIndex(reduction='none')(x, target).mean() — utils/loss.py:62-85, train.py:285-288."""
+    _f32c(x, "bce_ignore x")
+    b, c, h, w = x.shape
+    if target.dtype != torch.int64 or not target.is_contiguous() or tuple(target.shape) != (b, h, w):
+        raise RuntimeError("bce_ignore_mean: contiguous int64 target [b,h,w] expected")
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if with_grad else None
+    ws = _workspace(x.device, _hip.load().cl4_bce_ignore_workspace_bytes())
+    call("cl4_bce_ignore_mean", ptr(x), ptr(target), b, c, h, w, int(ignore_index), ptr(loss), ptr(dx) if with_grad else None,
+         ptr(ws), ws.numel(), stream())
+    return loss, dx

@@ -245,6 +245,41 @@ int cl4_adam_step_dev(float* p, const float* g, float* m, float* v, long n, cons
                       float eps, float weight_decay, int* step_dev, int advance, void* stream);
 int cl4_fill_zero(void* p, size_t bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Weakly-supervised loss stack of phase 1 / step 0. Class maps are [b,c,h,w] fp32 at the
+ * network stride (33x33 at crop 513); `labels` are the image-level one-hot labels [b,c-1] (l1h, no background).
+ * ------------------------------------------------------------------------ */
+/* PAMR.forward — wss/modules.py:133-152 with LocalAffinityAbs / LocalStDev / LocalAffinityCopy :47-119 (call site
+ * train.py:378-381, num_iter=10, dilations [1,2,4,8,12]). img [b,3,h,w] is the denormalised image already resized to
+ * the mask size (cl4_resize_bilinear_fwd, align_corners=1); mask/out [b,c,h,w], out != mask. */
+size_t cl4_pamr_workspace_bytes(int b, int c, int h, int w, int ndil);
+int cl4_pamr(const float* img, const float* mask, float* out, int b, int c, int h, int w, int num_iter,
+             const int* dilations /* host */, int ndil, void* workspace, size_t workspace_bytes, void* stream);
+/* bce_loss(outputs, labels, mode='ngwp', reduction) = BCE-with-logits(ngwp_focal(outputs)[:, -nl:], labels) —
+ * utils/wss_loss.py:7-22,36-53 (train.py:340-342). labels [b,nl]; reduction_sum=0: 'mean', 1: 'sum' (sum over
+ * classes, mean over b). Writes the scalar loss, optionally the nGWP logits [b,c] and d(loss)/d(x) [b,c,h,w]. */
+size_t cl4_ngwp_workspace_bytes(int b, int c);
+int cl4_ngwp_focal_bce(const float* x, const float* labels, int b, int c, int h, int w, int nl, int reduction_sum, float lam,
+                       float* ngwp /* or NULL */, float* loss, float* dx /* or NULL */, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* pseudo_gtmask(mask * labels, ambiguous=True, cutoffs) — wss/single_stage.py:18-40 with the label masking of
+ * train.py:381-382 fused (labels NULL = no masking). out [b,c,h,w] of 0/1; thresholds [b,c] scratch/out. */
+int cl4_pseudo_gtmask(const float* mask, const float* labels, float* out, int b, int c, int h, int w, float cutoff_top,
+                      float cutoff_bkg, float cutoff_low, float* thresholds, void* stream);
+/* binarize(x * labels) — utils/wss_loss.py:188-190 (train.py:387). */
+int cl4_binarize(const float* x, const float* labels, float* out, int b, int c, int h, int w, void* stream);
+/* balanced_mask_loss_ce(mask, pseudo_gt, gt_labels) — wss/single_stage.py:43-80 (train.py:411); mask and pseudo_gt
+ * have the same spatial size. Scalar loss and optionally d(loss)/d(mask). */
+size_t cl4_balanced_ce_workspace_bytes(int b, int c, int h, int w);
+int cl4_balanced_mask_loss_ce(const float* mask, const float* pseudo_gt, const float* labels, int b, int c, int h, int w,
+                              float* loss, float* dmask /* or NULL */, void* workspace, size_t workspace_bytes, void* stream);
+/* BCEWithLogitsLossWithIgnoreIndex(reduction='none')(x, target).mean() — utils/loss.py:62-85 with train.py:285-288.
+ * x [b,c,h,w], target int64 [b,h,w]; labels equal to ignore_index (or outside [0,c), where the reference raises)
+ * contribute nothing. Scalar loss and optionally d(loss)/d(x). */
+size_t cl4_bce_ignore_workspace_bytes(void);
+int cl4_bce_ignore_mean(const float* x, const long long* target, int b, int c, int h, int w, int ignore_index, float* loss,
+                        float* dx /* or NULL */, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
