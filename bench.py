@@ -143,6 +143,14 @@ def main():
         t = torch.tensor([elapsed], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    if rank == 0 and os.environ.get("CL4_BENCH_LAYER_TABLE"):
+        # per-shape table of the conv launches (experiments / profiles): ms per step, TFLOP/s, share of conv time
+        rows = sorted(timer_excl.by_shape().items(), key=lambda kv: -kv[1][2])
+        tot = sum(v[2] for _, v in rows)
+        with open(os.environ["CL4_BENCH_LAYER_TABLE"], "w") as f:
+            f.write("kind (n,cin,hin,cout,k,stride,dil) launches/step ms/step TFLOP/s share\n")
+            for (kind, shp), (n_, fl_, ms_) in rows:
+                f.write(f"{kind:16s} {str(shp):34s} {n_ / 2:6.1f} {ms_ / 2:8.3f} {fl_ / ms_ / 1e9:8.1f} {100 * ms_ / tot:5.1f}%\n")
     if rank == 0:
         summ = timer_excl.summary()
         n, fl, ms = summ["conv_fwd_bf16x3"]

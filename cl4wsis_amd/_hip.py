@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcl4wsis_hip.so")
+LIB_PATH = os.environ.get("CL4_LIB") or os.path.join(_HERE, "libcl4wsis_hip.so")   # CL4_LIB: kernel experiments only
 
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 

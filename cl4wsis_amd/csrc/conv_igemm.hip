@@ -465,6 +465,9 @@ __global__ void conv_splitk_epilogue(ConvArgs a, int splits) {
 //     [k][pixel] -> [pixel][k] transpose the bf16 MFMA operand needs; the 4 MFMA waves only ds_read_b128 + MFMA.
 //   * same tiles (128x128 / 64x64, BK 32), split-K and fused epilogue as the fp32 kernels.
 // ------------------------------------------------------------------------------------
+#ifndef CL4_DBG
+#define CL4_DBG 0   // experiments only: 1 = loader issues no loads in the loop, 2 = no convert/LDS stores, 4 = no MFMA
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -553,13 +556,15 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
         const int ky = tap / KS;
         const int dy = ky * a.dil, dx = (tap - ky * KS) * a.dil;
         const int iy = iy0 + dy, ix = ix0 + dx;
-        const bool ok = pvalid && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
+        const bool ok = pvalid && kt < nk && (unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win;
         const unsigned voff = ok ? (unsigned)(lane_base + (dy * a.win + dx) * 4) : 0x80000000u;
 #pragma unroll
         for (int it = 0; it < NITEM; ++it)
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const int soff = (ci0 + (kg0 + it) * 8 + j) * HWi * 4;   // scalar
+            // readfirstlane: the value is wave-uniform by construction, but unless the compiler can prove it, it keeps
+            // the offset in a VGPR and wraps every load in a waterfall loop (~14 instructions per load)
+            const int soff = __builtin_amdgcn_readfirstlane((ci0 + (kg0 + it) * 8 + j) * HWi * 4);
             xr[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
           }
         return;
@@ -604,45 +609,71 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
         Bs[((kg0 + it) * 2 + 1) * BN + pl] = __builtin_bit_cast(u32x4, lo);
       }
     };
-    auto issue_A = [&](int kt, int buf) {
-      u32x4* As = lds[buf];
+    // Weight tile through registers as well (buffer_load_dwordx4, A_PER_LANE 16-byte chunks per lane and K-tile): with
+    // LDS-DMA the tile had to be issued and awaited inside the same iteration (its landing zone is the LDS stage itself),
+    // which exposed one full L2 round trip per K-tile; two register sets keep two tiles of BOTH operands in flight.
+    constexpr int A_PER_LANE = A_INSTR;
+    const unsigned w_bytes = (unsigned)((long)KGtot * 2 * a.cout * 16);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, w_bytes, 0x00020000);
+    u32x4 ar0[A_PER_LANE], ar1[A_PER_LANE];
+    auto loadA = [&](u32x4 (&ar)[A_PER_LANE], int kt) {
 #pragma unroll
-      for (int i = 0; i < A_INSTR; ++i) {
-        const int ii = wave * A_INSTR + i;               // wave-uniform chunk row: (kg, plane, 64-wide m segment)
+      for (int i = 0; i < A_PER_LANE; ++i) {
+        const int ii = wave * A_PER_LANE + i;            // wave-uniform chunk row: (kg, plane, 64-wide m segment)
         const int seg = ii % (BM / 64);
         const int kp = ii / (BM / 64);                   // kg*2 + plane
         const int m = m0 + seg * 64 + lane;
         const int kgg = (kbeg + kt * BK2) / 8 + (kp >> 1);
-        const bool ok = m < a.cout && kgg < KGtot && (kgg * 8) < kend;
-        const void* g = ok ? (const void*)(wq + ((long)(kgg * 2 + (kp & 1)) * a.cout + m)) : (const void*)zero_page;
-        CL4_GLDS(g, As + kp * BM + seg * 64, 16);
+        const bool kok = kgg < KGtot && (kgg * 8) < kend;             // scalar
+        const unsigned voff = (kok && m < a.cout) ? (unsigned)m * 16u : 0x80000000u;
+        const int soff = __builtin_amdgcn_readfirstlane(kok ? (kgg * 2 + (kp & 1)) * a.cout * 16 : 0);
+        ar[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, soff, 0);
       }
     };
-    // One loader iteration while the MFMA waves consume tile t: convert tile t+1 (set `cur`), DMA its weights, refill the
-    // set with tile t+3, retire the DMA (vmcnt leaves only the 8*NITEM youngest gathers in flight), meet at the barrier.
-    auto body = [&](float (&cur)[NITEM][8], int t) {
-      if (t + 1 < nk) {
-        const int nb = (t + 1) & 1;
-        cvt_store(cur, nb);
-        issue_A(t + 1, nb);
-        if (t + 3 < nk) { gload(cur, t + 3); wait_vmcnt<8 * NITEM>(); }
-        else wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto storeA = [&](const u32x4 (&ar)[A_PER_LANE], int buf) {
+      u32x4* As = lds[buf];
+#pragma unroll
+      for (int i = 0; i < A_PER_LANE; ++i) {
+        const int ii = wave * A_PER_LANE + i;
+        As[(ii / (BM / 64)) * BM + (ii % (BM / 64)) * 64 + lane] = ar[i];
       }
+    };
+    constexpr int TILE_LOADS = 8 * NITEM + A_PER_LANE;   // vector-memory instructions per lane and K-tile
+    // One loader half-iteration while the MFMA waves consume tile t: retire the loads of tile t+1 (issued two
+    // half-iterations ago; only tile t+2's stay in flight), split / store it into the other LDS stage, refill the register
+    // set with tile t+3. The sequence is deliberately free of conditionals: tiles past the end of K are "loaded" through
+    // out-of-range buffer offsets (no memory traffic, zeros) and stored into the idle LDS stage. With any data-dependent
+    // skip in the loop the compiler's own s_waitcnt insertion must assume the shortest path at every join and drains
+    // the queue to vmcnt(0) before each conversion — which serialised the loader on one memory round trip per K-tile.
+    auto half = [&](float (&cur)[NITEM][8], u32x4 (&acur)[A_PER_LANE], int t) {
+      const int nb = (t + 1) & 1;
+      wait_vmcnt<TILE_LOADS>();
+#if !(CL4_DBG & 2)
+      cvt_store(cur, nb);
+      storeA(acur, nb);
+#endif
+#if !(CL4_DBG & 1)
+      gload(cur, t + 3);
+      loadA(acur, t + 3);
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
 
     gload(xr0, 0);
-    issue_A(0, 0);
+    loadA(ar0, 0);
+    gload(xr1, 1);
+    loadA(ar1, 1);
+    wait_vmcnt<TILE_LOADS>();
     cvt_store(xr0, 0);
-    wait_vmcnt<0>();
+    storeA(ar0, 0);
+    gload(xr0, 2);
+    loadA(ar0, 2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (nk > 1) gload(xr1, 1);
-    if (nk > 2) gload(xr0, 2);
     __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nk; t += 2) {
-      body(xr1, t);                         // tile t+1 (odd) lives in xr1
-      if (t + 1 < nk) body(xr0, t + 1);     // tile t+2 (even) lives in xr0
+    for (int t = 0; t < nk; t += 2) {       // 1 + 2*ceil(nk/2) barriers; the MFMA waves add one when nk is odd
+      half(xr1, ar1, t);                    // tile t+1 (odd) lives in set 1
+      half(xr0, ar0, t + 1);                // tile t+2 (even) lives in set 0
     }
     return;
   }
@@ -678,13 +709,20 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+#if CL4_DBG & 4
+          acc[i][j][0] += (float)al[i][0] * (float)bh[j][0] + (float)ah[i][1] * (float)bl[j][1];
+#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#endif
         }
     }
+    // all of this wave's LDS reads of the stage have returned before the loaders are told it may be overwritten
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+  if (nk & 1) __builtin_amdgcn_s_barrier();   // pairs with the loaders' padded half-iteration
 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {

@@ -21,12 +21,22 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []   # (kind, flops, start_event, end_event)
+        self.shapes = []    # per record: (n, cin, hin, cout, k, stride, dil) of the launch
 
-    def span(self, kind, flops):
+    def span(self, kind, flops, shape=None):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         self.records.append((kind, flops, e0, e1))
+        self.shapes.append(shape)
         return e0, e1
+
+    def by_shape(self):
+        """{(kind, shape): (launches, total_flops, total_ms)} — call after a device synchronisation."""
+        out = {}
+        for (kind, fl, e0, e1), shp in zip(self.records, self.shapes):
+            n, f, t = out.get((kind, shp), (0, 0.0, 0.0))
+            out[(kind, shp)] = (n + 1, f + fl, t + e0.elapsed_time(e1))
+        return out
 
     def summary(self):
         """{kind: (launches, total_flops, total_ms)} — call after a device synchronisation."""
@@ -203,7 +213,8 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
                    wp.precision)
     wp = wp.data
     if TIMER is not None:
-        e0, e1 = TIMER.span("conv_fwd_bf16x3" if d.precision == 1 else "conv_fwd_f32", 2.0 * n * hout * wout * cout * K)
+        e0, e1 = TIMER.span("conv_fwd_bf16x3" if d.precision == 1 else "conv_fwd_f32", 2.0 * n * hout * wout * cout * K,
+                            (n, cin, hin, cout, k, stride, dil))
         e0.record()
     if AUTOTUNE:
         _autotune_conv(d, x, wp, scale, shift, pre, post, out)
