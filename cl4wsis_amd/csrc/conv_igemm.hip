@@ -639,6 +639,7 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
       }
     };
     constexpr int TILE_LOADS = 8 * NITEM + A_PER_LANE;   // vector-memory instructions per lane and K-tile
+    constexpr int PF_PER_LANE = (BM * (BN / 32) + 255) / 256;     // residual-prefetch touches per loader lane
     // One loader half-iteration while the MFMA waves consume tile t: retire the loads of tile t+1 (issued two
     // half-iterations ago; only tile t+2's stay in flight), split / store it into the other LDS stage, refill the register
     // set with tile t+3. The sequence is deliberately free of conditionals: tiles past the end of K are "loaded" through
@@ -669,11 +670,34 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
     storeA(ar0, 0);
     gload(xr0, 2);
     loadA(ar0, 2);
+    // Pull the residual tile of the fused epilogue towards L2 now: the MFMA waves read it in four dependent batches after
+    // the K loop, and with the lines still in HBM each batch paid a full memory round trip (the epilogue of a K = 256
+    // layer took as long as its K loop). One dword per 32-pixel row segment touches every line of the tile but the last
+    // partial one. The loads are younger than tile 2's, so the counted waits below only become (harmlessly) stricter; the
+    // destination registers stay live until the loop is over.
+    float pf[PF_PER_LANE];
+    if (!SPLIT && (a.post || a.pre)) {
+      const float* r = a.post ? a.post : a.pre;
+#pragma unroll
+      for (int i = 0; i < PF_PER_LANE; ++i) {
+        const int item = (wave * 64 + lane) * PF_PER_LANE + i;   // (row, segment)
+        const int co = min(m0 + min(item / (BN / 32), BM - 1), a.cout - 1);
+        const int pp = min(n0 + (item % (BN / 32)) * 32, a.npix - 1);
+        const int pn = pp / HWo;
+        const float* g = r + ((long)pn * a.cout + co) * HWo + (pp - pn * HWo);
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pf[i]) : "v"(g) : "memory");
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nk; t += 2) {       // 1 + 2*ceil(nk/2) barriers; the MFMA waves add one when nk is odd
       half(xr1, ar1, t);                    // tile t+1 (odd) lives in set 1
       half(xr0, ar0, t + 1);                // tile t+2 (even) lives in set 0
+    }
+    if (!SPLIT && (a.post || a.pre)) {
+      wait_vmcnt<0>();
+#pragma unroll
+      for (int i = 0; i < PF_PER_LANE; ++i) asm volatile("" ::"v"(pf[i]));
     }
     return;
   }
@@ -1104,6 +1128,177 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
   return cl4::launch_status();
 }
 
+// bf16x3 weight gradient: same staging as conv_wgrad_f32 (lane = pixel along K, rows fixed per thread), but the tiles are
+// split into bf16 hi / lo planes on their way into LDS and multiplied with three v_mfma_f32_32x32x16_bf16 per fragment
+// pair (1/5 of the MFMA cycles of the fp32 kernel; ~4e-6 relative error, like the forward kernel). LDS image per plane:
+// [row][4 k-groups of 8 bf16], 64-byte rows, the 16-byte k-group slots XOR-swizzled with (row >> 2) & 3 so that the
+// ds_read_b128 fragment reads (32 rows x one k-group) are bank-conflict free without padding (4 planes x 2 stages of
+// a 128-row tile = 64 KB).
+template <int BM, int BN, int KS>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16x3(WgradArgs a) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int KHW = KS * KS;
+  constexpr int RA = BM * BKP / NTHREADS;
+  constexpr int RB = BN * BKP / NTHREADS;
+  static_assert(BKP == 32, "one K tile = 4 k-groups of 8 pixels");
+
+  __shared__ __attribute__((aligned(16))) unsigned short Ash[2][2][BM * BKP];   // [stage][plane][row*32 + swizzled k]
+  __shared__ __attribute__((aligned(16))) unsigned short Bsh[2][2][BN * BKP];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM;
+  const int j0 = blockIdx.y * BN;
+  const int pbeg = blockIdx.z * a.chunk;
+  const int pend = min(a.npix, pbeg + a.chunk);
+  if (pbeg >= pend) return;
+
+  const int HWo = a.hout * a.wout;
+  const int HWi = a.hin * a.win;
+  const int pl = lane & 31;      // pixel within the K tile
+  const int rsub = lane >> 5;    // which of the two rows this half-wave stages
+
+  // Per staged B row (ci, tap): element offset relative to the pixel's (iy0, ix0) corner and the tap's bit in the
+  // per-pixel validity mask (computed once per K tile and lane for all KS*KS taps).
+  int b_off[RB];
+  unsigned b_bit[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    int row = wave * (BN / 4) + 2 * r + rsub;
+    int j = j0 + row;
+    const bool ok = j < a.Nj;
+    int jc = ok ? j : 0;
+    int ci = jc / KHW;
+    int t = jc - ci * KHW;
+    int ky = t / KS;
+    b_off[r] = (a.in_coff + ci) * HWi + ky * a.dil * a.win + (t - ky * KS) * a.dil;
+    b_bit[r] = ok ? 1u << t : 0u;
+  }
+  // 32-bit buffer addressing (host guarantees < 2 GiB tensors): masked elements read 0 through an out-of-range offset
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)((long)a.n * a.in_ctot * HWi * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (unsigned)((long)a.n * a.out_ctot * HWo * 4), 0x00020000);
+  const bool m_interior = m0 + BM <= a.cout;   // uniform
+
+  float ra[RA], rb[RB];
+  auto load_tile = [&](int kt) {
+    int p = pbeg + kt * BKP + pl;
+    bool pv = p < pend;
+    int pc = pv ? p : 0;
+    int n = pc / HWo;
+    int hw = pc - n * HWo;
+    int oy = hw / a.wout;
+    int ox = hw - oy * a.wout;
+    int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+    const int dybase = (n * a.out_ctot + a.out_coff) * HWo + hw;
+    const int xbase = n * a.in_ctot * HWi + iy0 * a.win + ix0;
+    unsigned vmask = 0;                       // bit t: tap t of this pixel reads inside the image
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const bool in = (unsigned)(iy0 + ky * a.dil) < (unsigned)a.hin && (unsigned)(ix0 + kx * a.dil) < (unsigned)a.win;
+        vmask |= in ? 1u << (ky * KS + kx) : 0u;
+      }
+    vmask = pv ? vmask : 0u;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      int co = m0 + wave * (BM / 4) + 2 * r + rsub;
+      const unsigned off = (pv && (m_interior || co < a.cout)) ? (unsigned)(dybase + co * HWo) * 4u : OOB;
+      ra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, off, 0, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const unsigned off = (vmask & b_bit[r]) ? (unsigned)(xbase + b_off[r]) * 4u : OOB;
+      rb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+    }
+  };
+  // element (row, k = pl) -> bf16 index row*32 + ((k>>3) ^ ((row>>2)&3))*8 + (k&7). Neighbouring lanes hold neighbouring
+  // k of the same row: even lanes fetch the odd neighbour's hi half (DPP row_shl:1) and store the hi pair, odd lanes fetch
+  // the even neighbour's lo half (row_shr:1) and store the lo pair — one ds_write_b32 per element instead of two b16.
+  const bool odd = pl & 1;
+  auto store_pair = [&](unsigned short* base_hi, unsigned short* base_lo, int row, float v) {
+    const __bf16 hb = (__bf16)v;
+    const unsigned hi = __builtin_bit_cast(unsigned short, hb);
+    const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hb));
+    const unsigned nb_hi = __builtin_amdgcn_update_dpp(0u, hi, 0x101, 0xf, 0xf, true);   // lane+1
+    const unsigned nb_lo = __builtin_amdgcn_update_dpp(0u, lo, 0x111, 0xf, 0xf, true);   // lane-1
+    const unsigned word = odd ? (nb_lo | (lo << 16)) : (hi | (nb_hi << 16));
+    const int idx = row * BKP + (((pl >> 3) ^ ((row >> 2) & 3)) << 3) + (pl & 6);
+    *reinterpret_cast<unsigned*>((odd ? base_lo : base_hi) + idx) = word;
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) store_pair(Ash[buf][0], Ash[buf][1], wave * (BM / 4) + 2 * r + rsub, ra[r]);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) store_pair(Bsh[buf][0], Bsh[buf][1], wave * (BN / 4) + 2 * r + rsub, rb[r]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (pend - pbeg + BKP - 1) / BKP;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int lr = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int kg = 2 * s2 + lh;
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + lr;
+        const int o = row * BKP + ((kg ^ ((row >> 2) & 3)) << 3);
+        ah[i] = *reinterpret_cast<const bf16x8*>(&Ash[buf][0][o]);
+        al[i] = *reinterpret_cast<const bf16x8*>(&Ash[buf][1][o]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WTN + j * 32 + lr;
+        const int o = row * BKP + ((kg ^ ((row >> 2) & 3)) << 3);
+        bh[j] = *reinterpret_cast<const bf16x8*>(&Bsh[buf][0][o]);
+        bl[j] = *reinterpret_cast<const bf16x8*>(&Bsh[buf][1][o]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int jj = j0 + wn * WTN + j * 32 + lr;
+    if (jj >= a.Nj) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co >= a.cout) continue;
+        atomicAdd(&a.dw[(long)co * a.Nj + jj], acc[i][j][r]);
+      }
+  }
+}
+
 template <int KS>
 int launch_wgrad(WgradArgs& a, hipStream_t st) {
   const bool small_m = a.cout <= 64;
@@ -1118,7 +1313,15 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   a.chunk = tiles_per * BKP;
   int gz = cl4::cdiv(a.npix, a.chunk);
   dim3 g(gm, gn, gz);
-  if (small_m)
+  // bf16x3 MFMA path: 32-bit buffer offsets, so both tensors must stay below 2 GiB (always true on the phase-2 path)
+  static const int wg_prec = env_int("CL4_WGRAD_PRECISION", 1);
+  const long lim = (1L << 31) - 4096;
+  const bool split3 = wg_prec == 1 && (long)a.n * a.in_ctot * a.hin * a.win * 4 < lim && (long)a.n * a.out_ctot * a.hout * a.wout * 4 < lim;
+  if (split3 && small_m)
+    hipLaunchKernelGGL((conv_wgrad_bf16x3<64, 128, KS>), g, dim3(NTHREADS), 0, st, a);
+  else if (split3)
+    hipLaunchKernelGGL((conv_wgrad_bf16x3<128, 128, KS>), g, dim3(NTHREADS), 0, st, a);
+  else if (small_m)
     hipLaunchKernelGGL((conv_wgrad_f32<64, 128, KS>), g, dim3(NTHREADS), 0, st, a);
   else
     hipLaunchKernelGGL((conv_wgrad_f32<128, 128, KS>), g, dim3(NTHREADS), 0, st, a);

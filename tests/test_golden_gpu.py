@@ -194,5 +194,10 @@ def test_graph_replay_matches_eager(gpu, monkeypatch):
     lg, wg, lrg = run(True)
     assert lre == lrg and lre < 5e-4
     assert torch.allclose(le, lg, rtol=2e-3, atol=1e-6), (le, lg)
-    assert (we - wg).abs().max() < 2e-4          # three Adam steps of lr 5e-4: identical directions
+    # Adam turns a gradient of ~1e-8 into a step of +-lr, so a weight whose gradient is numerically zero can move by up to
+    # 3 * lr differently in two runs that differ only in the order of the fp32 atomics of the split-K weight gradient
+    # (two EAGER runs show the same: tools/dbg_graph_eager.py). Such weights are a handful out of 15.7 M.
+    d = (we - wg).abs()
+    assert d.max() < 3.2 * 5e-4
+    assert (d > 2e-4).float().mean() < 1e-5
     assert (we - wg).abs().mean() < 1e-5
