@@ -52,32 +52,37 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
   }
 }
 
-// dw[c][ky][kx] += sum_{n,y,x} dy[n,c,y,x] * x[n,c,y+ky-2,x+kx-2]. One workgroup per (tile, c, n):
-// 25 per-lane partial sums -> wave reduction -> one atomic per tap per workgroup.
+// dw[c][ky][kx] += sum_{n,y,x} dy[n,c,y,x] * x[n,c,y+ky-2,x+kx-2]. grid (tile groups, c, n): a workgroup walks its tiles
+// of one (n, c) plane with 25 per-lane partial sums and pays the 25 wave reductions + atomics once at the end (one
+// reduction per tile made the reductions, not the 25 FMAs per pixel, the cost of this kernel).
 __global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ dw, DwArgs a) {
   __shared__ float tile[TS][LDT];
   __shared__ float red[4][25];
   const int tiles_x = (a.w + T - 1) / T;
-  const int ty0 = (blockIdx.x / tiles_x) * T, tx0 = (blockIdx.x % tiles_x) * T;
+  const int ntiles = tiles_x * ((a.h + T - 1) / T);
   const int c = blockIdx.y, n = blockIdx.z;
   const float* xp = x + ((long)n * a.x_ctot + a.x_coff + c) * a.h * a.w;
   const float* dp = dy + ((long)n * a.y_ctot + a.y_coff + c) * a.h * a.w;
-  stage_tile(tile, xp, a.h, a.w, ty0, tx0);
-  __syncthreads();
   const int lx = threadIdx.x & 31, ly0 = threadIdx.x >> 5;
   float acc[25];
 #pragma unroll
   for (int t = 0; t < 25; ++t) acc[t] = 0.f;
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const int ty0 = (tl / tiles_x) * T, tx0 = (tl % tiles_x) * T;
+    __syncthreads();                       // the previous tile has been consumed
+    stage_tile(tile, xp, a.h, a.w, ty0, tx0);
+    __syncthreads();
 #pragma unroll
-  for (int pass = 0; pass < T / 8; ++pass) {
-    int ly = ly0 + pass * 8;
-    int oy = ty0 + ly, ox = tx0 + lx;
-    float g = (oy < a.h && ox < a.w) ? dp[(long)oy * a.w + ox] : 0.f;
+    for (int pass = 0; pass < T / 8; ++pass) {
+      int ly = ly0 + pass * 8;
+      int oy = ty0 + ly, ox = tx0 + lx;
+      float g = (oy < a.h && ox < a.w) ? dp[(long)oy * a.w + ox] : 0.f;
 #pragma unroll
-    for (int ky = 0; ky < 5; ++ky)
+      for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 5; ++kx) acc[ky * 5 + kx] = fmaf(g, tile[ly + ky][lx + kx], acc[ky * 5 + kx]);
+        for (int kx = 0; kx < 5; ++kx) acc[ky * 5 + kx] = fmaf(g, tile[ly + ky][lx + kx], acc[ky * 5 + kx]);
+    }
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -119,7 +124,11 @@ extern "C" int cl4_dwconv5_wgrad(const float* x, const float* dy, float* dw, int
   int rc = check(a);
   if (rc) return rc;
   CL4_REQUIRE(x && dy && dw, "dwconv5_wgrad: null pointer");
-  dim3 g(cl4::cdiv(h, T) * cl4::cdiv(wd, T), c, n);
+  const int ntiles = cl4::cdiv(h, T) * cl4::cdiv(wd, T);
+  int groups = cl4::cdiv(2048, (long)c * n);           // ~8 workgroups per CU in total
+  if (groups > ntiles) groups = ntiles;
+  if (groups < 1) groups = 1;
+  dim3 g(groups, c, n);
   hipLaunchKernelGGL(dwconv5_wgrad_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, dy, dw, a);
   return cl4::launch_status();
 }

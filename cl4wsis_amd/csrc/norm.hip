@@ -158,13 +158,15 @@ __global__ void relu_bwd_kernel(const float* __restrict__ y, const float* __rest
     dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
-// Per-channel sum over (n, hw) of dy -> bias gradient (accumulated). One workgroup per channel.
+// Per-channel sum over (n, hw) of dy -> bias gradient (accumulated). grid (c, slices): the heads have 2-15 channels, so
+// one workgroup per channel left 240 CUs idle on a 4 M element reduction; every slice sums in double and adds its part
+// with one fp32 atomic (like the split-K weight gradients).
 __global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int n, int c, int hw, int ctot, int coff) {
   __shared__ double part[4];
   const int ch = blockIdx.x;
   double a = 0.0;
   const long per_c = (long)n * hw;
-  for (long i = threadIdx.x; i < per_c; i += blockDim.x) {
+  for (long i = blockIdx.y * (long)blockDim.x + threadIdx.x; i < per_c; i += (long)gridDim.y * blockDim.x) {
     int nn = i / hw;
     int p = i - (long)nn * hw;
     a += (double)dy[((long)nn * ctot + coff + ch) * hw + p];
@@ -172,7 +174,7 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict
   a = cl4::wave_sum_d(a);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) db[ch] += (float)(part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) atomicAdd(&db[ch], (float)(part[0] + part[1] + part[2] + part[3]));
 }
 
 // Counter-based keep mask for nn.Dropout(p): splitmix64 of (seed, element index).
@@ -259,7 +261,12 @@ extern "C" int cl4_relu_bwd(const float* y, const float* dy, float* dx, long n, 
 
 extern "C" int cl4_bias_grad(const float* dy, float* db, int n, int c, int hw, int ctot, int coff, void* stream) {
   CL4_REQUIRE(dy && db && n > 0 && c > 0 && hw > 0 && coff >= 0 && coff + c <= ctot, "bias_grad: bad arguments");
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(c), dim3(256), 0, cl4::as_stream(stream), dy, db, n, c, hw, ctot, coff);
+  const long per_c = (long)n * hw;
+  int slices = (int)((per_c + 4095) / 4096);          // >= 16 elements per thread
+  const int want = (1024 + c - 1) / c;                // ~4 workgroups per CU over all channels
+  if (slices > want) slices = want;
+  if (slices < 1) slices = 1;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(c, slices), dim3(256), 0, cl4::as_stream(stream), dy, db, n, c, hw, ctot, coff);
   return cl4::launch_status();
 }
 
