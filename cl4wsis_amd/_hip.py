@@ -106,6 +106,7 @@ _decl("cl4_p2_loss", C.POINTER(P2LossIO), _P, C.c_size_t, _P)
 _decl("cl4_adam_step", _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P)
 _decl("cl4_adam_step_dev", _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _I, _P)
 _decl("cl4_fill_zero", _P, C.c_size_t, _P)
+_decl("cl4_sgd_step", _P, _P, _P, _L, _F, _P, _F, _F, _I, _P)
 _decl("cl4_pamr", _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, C.c_size_t, _P)
 _decl("cl4_ngwp_focal_bce", _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_pseudo_gtmask", _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P)

@@ -247,6 +247,34 @@ extern "C" int cl4_adam_step_dev(float* p, const float* g, float* m, float* v, l
   return cl4::launch_status();
 }
 
+// torch.optim.SGD(momentum, nesterov, dampening 0) over a flat segment — train.py:180 (phase 1 / step 0 with --optim sgd):
+//   g += wd * p;  buf = momentum * buf + g  (buf starts at 0, which equals torch's "buf = g" first step);
+//   p -= lr * (nesterov ? g + momentum * buf : buf).  lr_dev != NULL reads the learning rate from device memory.
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n, float lr,
+                           const float* __restrict__ lr_dev, float momentum, float wd, int nesterov) {
+  if (lr_dev) lr = *lr_dev;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (wd != 0.f) gi = gi + wd * pi;
+    float step = gi;
+    if (momentum != 0.f) {
+      const float b = buf[i] * momentum + gi;
+      buf[i] = b;
+      step = nesterov ? gi + momentum * b : b;
+    }
+    p[i] = pi - lr * step;
+  }
+}
+
+extern "C" int cl4_sgd_step(float* p, const float* g, float* buf, long n, float lr, const float* lr_dev, float momentum,
+                            float weight_decay, int nesterov, void* stream) {
+  CL4_REQUIRE(p && g && n > 0 && (buf || momentum == 0.f), "sgd_step: bad arguments");
+  hipLaunchKernelGGL(sgd_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), p, g, buf, n, lr, lr_dev,
+                     momentum, weight_decay, nesterov);
+  return cl4::launch_status();
+}
+
 extern "C" int cl4_fill_zero(void* p, size_t bytes, void* stream) {
   CL4_REQUIRE(p && bytes > 0, "fill_zero: bad arguments");
   hipError_t e = hipMemsetAsync(p, 0, bytes, cl4::as_stream(stream));

@@ -576,6 +576,15 @@ def adam_step_dev_(p, g, m, v, lr_dev, beta1, beta2, eps, weight_decay, step_dev
          C.c_float(eps), C.c_float(weight_decay), ptr(step_dev), int(advance), stream())
 
 
+def sgd_step_(p, g, buf, lr, momentum=0.9, weight_decay=0.0, nesterov=True, lr_dev=None):
+    """torch.optim.SGD step on flat fp32 segments (momentum buffer `buf` starts at zero)."""
+    n = p.numel()
+    if g.numel() != n or (buf is not None and buf.numel() != n):
+        raise RuntimeError("sgd_step_: size mismatch")
+    call("cl4_sgd_step", ptr(p), ptr(g), ptr(buf), n, C.c_float(lr), ptr(lr_dev), C.c_float(momentum),
+         C.c_float(weight_decay), int(bool(nesterov)), stream())
+
+
 def zero_(t):
     call("cl4_fill_zero", ptr(t), t.numel() * t.element_size(), stream())
     return t

@@ -94,3 +94,69 @@ class FusedAdam(torch.optim.Optimizer):
                 self._step = max(self._step, int(st["step"]))
             self.step_dev.fill_(self._step)
             self._lr_host = None
+
+
+class FusedSGD(torch.optim.Optimizer):
+    """torch.optim.SGD(momentum=0.9, nesterov=True) on flat buffers (train.py:179-180: phase 1 / step 0 with --optim sgd),
+    one launch per parameter group (each group keeps its own lr / weight_decay, train.py:145-177). Same flat-buffer and
+    device-resident-lr design as FusedAdam; `state_dict()` exposes `momentum_buffer` per parameter like torch."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.9, weight_decay=0.0, nesterov=True):
+        defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, dampening=0)
+        super().__init__(params, defaults)
+        plist = [p for g in self.param_groups for p in g["params"]]
+        if not plist:
+            raise ValueError("FusedSGD: no parameters")
+        dev = plist[0].device
+        shapes = [p.shape for p in plist]
+        self.params_fb = FlatBuffer(shapes, dev)
+        self.grads_fb = FlatBuffer(shapes, dev)
+        self.buf_fb = FlatBuffer(shapes, dev)
+        self.index = {}
+        with torch.no_grad():
+            for i, p in enumerate(plist):
+                self.params_fb.views[i].copy_(p.data)
+                p.data = self.params_fb.views[i]
+                self.index[id(p)] = i
+                self.state[p] = {"momentum_buffer": self.buf_fb.views[i]}
+        self._ranges, k = [], 0
+        for g in self.param_groups:
+            n = len(g["params"])
+            self._ranges.append((self.params_fb.offsets[k], self.params_fb.offsets[k + n]))
+            k += n
+        self.lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
+        self._lr_host = None
+
+    def grad_view(self, p):
+        return self.grads_fb.views[self.index[id(p)]]
+
+    def zero_grad(self, set_to_none=False):
+        ops.zero_(self.grads_fb.flat)
+
+    def upload_lr(self):
+        lrs = [float(g["lr"]) for g in self.param_groups]
+        if lrs != self._lr_host:
+            self.lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=False)
+            self._lr_host = lrs
+
+    @torch.no_grad()
+    def step(self, closure=None, upload=True):
+        if upload:
+            self.upload_lr()
+        for gi, (g, (lo, hi)) in enumerate(zip(self.param_groups, self._ranges)):
+            if hi == lo:
+                continue
+            ops.sgd_step_(self.params_fb.flat[lo:hi], self.grads_fb.flat[lo:hi], self.buf_fb.flat[lo:hi], g["lr"],
+                          g["momentum"], g["weight_decay"], g["nesterov"], lr_dev=self.lr_dev[gi:gi + 1])
+            for p in g["params"]:
+                CACHE.touch(p)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        with torch.no_grad():
+            for p, i in ((p, self.index[id(p)]) for g in self.param_groups for p in g["params"]):
+                st = self.state[p]
+                if st.get("momentum_buffer") is not None:
+                    self.buf_fb.views[i].copy_(st["momentum_buffer"])
+                st["momentum_buffer"] = self.buf_fb.views[i]
+            self._lr_host = None

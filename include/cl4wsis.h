@@ -243,6 +243,10 @@ int cl4_adam_step(float* p, const float* g, float* m, float* v, long n, float lr
  * device); the counter is advanced by `advance` after the update. */
 int cl4_adam_step_dev(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float beta1, float beta2,
                       float eps, float weight_decay, int* step_dev, int advance, void* stream);
+/* torch.optim.SGD(momentum=0.9, nesterov=True) step over a flat segment (train.py:179-180, phase 1 / step 0). `buf` is the
+ * momentum buffer (zero-initialised); lr_dev (device float, or NULL to use `lr`) makes the launch graph-replayable. */
+int cl4_sgd_step(float* p, const float* g, float* buf, long n, float lr, const float* lr_dev, float momentum,
+                 float weight_decay, int nesterov, void* stream);
 int cl4_fill_zero(void* p, size_t bytes, void* stream);
 
 /* ------------------------------------------------------------------------

@@ -95,3 +95,77 @@ def bce_ignore_mean(inputs, targets, ignore_index=255):
     t = F.one_hot(lab, n_cl + 1).float().permute(0, 3, 1, 2)[:, :n_cl]
     loss = F.binary_cross_entropy_with_logits(inputs, t, reduction="none").sum(dim=1)
     return (loss * t.sum(dim=1)).mean()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Phase-1 training-path pieces
+# ---------------------------------------------------------------------------------------------------------------------
+def pam(x, alpha=0.7):
+    """PAM.forward — wss/modules.py:354-368 (out of place)."""
+    x = F.relu(x)
+    peak = F.adaptive_max_pool2d(x, 1)
+    return torch.where(x < peak * alpha, torch.zeros_like(x), x)
+
+
+def peakgen_train_loss(int_masks_raw, weight, bias, labels_new, alpha=0.7):
+    """PeakGenerator.forward (training) + the phase-1 peak loss: wss/modules.py:390-423 with train.py:334-336,344-345.
+    int_masks_raw [b,C,h,w]; the generator sees the last `nc` channels; weight [nc,nc,1,1], bias [nc]; labels_new [b,nc].
+    Returns (loss, logits [b,nc])."""
+    nc = weight.shape[0]
+    x = pam(int_masks_raw[:, -nc:], alpha)
+    x = F.conv2d(x, weight, bias)
+    m = F.softmax(x, dim=1).flatten(2)
+    logit = (x.flatten(2) * m).sum(-1) / (1.0 + m.sum(-1))
+    return F.binary_cross_entropy_with_logits(logit, labels_new), logit
+
+
+def rot90k(t, angle):
+    """torchvision.transforms.functional.rotate for multiples of 90 degrees on square maps = torch.rot90."""
+    return torch.rot90(t, int(round(angle / 90)) % 4, dims=(-2, -1))
+
+
+def flac_loss(A, bs, old_classes, angle):
+    """FLAC consistency loss — train.py:320-331. A [3*bs, C, h, h]: PseudoLabeler logits on [x, flip(x), rot(x, angle)]."""
+    a_rot = torch.sigmoid(torch.mean(A[bs * 2: bs * 3, old_classes:], dim=1))
+    a_rot_back = rot90k(a_rot.detach().clone(), -angle)
+    a_flip = torch.sigmoid(torch.mean(A[bs: bs * 2, old_classes:].flip(-1), dim=1))
+    a_ori = torch.sigmoid(torch.mean(A[:bs, old_classes:], dim=1))
+    tgt = torch.maximum(torch.maximum(a_ori, a_flip).detach(), a_rot_back).detach()
+    tgt_rot = rot90k(tgt.clone(), angle).detach()
+    mse = torch.nn.MSELoss()
+    return (mse(a_ori, tgt) + mse(a_flip, tgt) + mse(a_rot, tgt_rot)) / 3
+
+
+def l_loc(int_masks_raw, old_seg, old_classes, labels=None):
+    """Localisation prior — train.py:346-354: BCE(int_masks_raw[:, :old], sigmoid(old seg)), optional --no_mask masking."""
+    target = torch.sigmoid(old_seg.detach())
+    if labels is not None:
+        target = target.clone()
+        target[:, 1:] *= labels[:, :old_classes - 1, None, None]
+    return F.binary_cross_entropy_with_logits(int_masks_raw[:, :old_classes], target, reduction="mean")
+
+
+def lde(feat, feat_old):
+    """Feature distillation — train.py:362-363 (nn.MSELoss on res5)."""
+    return F.mse_loss(feat, feat_old)
+
+
+def l_seg(outputs_seg, old_seg, int_masks, labels, old_classes, alpha=0.5, icarl_bkg=-1.0, weight=1.0):
+    """Segmentation loss against the blended pseudo map — train.py:374-409 (without the PAMR branch, which only feeds
+    `pseudo_gt_seg` / l_cls). outputs_seg [b,tot,h,w], old_seg [b,old,h,w], int_masks [b,tot,h,w] (detached logits)."""
+    bs, tot = outputs_seg.shape[:2]
+    orig = int_masks.softmax(dim=1)
+    orig[:, 1:] *= labels[:, :, None, None]
+    lx = alpha * binarize(orig) + (1 - alpha) * orig
+    px = lx.view(bs, tot, -1).sum(dim=-1)
+    bw = torch.eq(px[:, old_classes:] > 0, labels[:, old_classes - 1:].bool())
+    bw = (bw.sum(dim=1) == (tot - old_classes)).float()
+    target_old = torch.sigmoid(old_seg.detach())
+    pseudo = torch.cat((target_old, lx[:, old_classes:]), dim=1)
+    if icarl_bkg == -1:
+        pseudo[:, 0] = torch.min(pseudo[:, 0], lx[:, 0])
+    else:
+        pseudo[:, 0] = (1 - icarl_bkg) * pseudo[:, 0] + icarl_bkg * lx[:, 0]
+    l = F.binary_cross_entropy_with_logits(outputs_seg, pseudo, reduction="none").sum(dim=1)
+    l = l.view(bs, -1).mean(dim=-1)
+    return weight * (bw * l).sum() / (bw.sum() + 1e-5)

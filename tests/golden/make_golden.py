@@ -221,6 +221,25 @@ def wss_fixture(R, seed, b, c, h, w):
     out["bce_ignore"] = np.array(l.item())
     out["bce_ignore_grad_sum"] = np.array([x.grad.double().abs().sum().item(), x.grad.double().pow(2).sum().item()])
     out["bce_ignore_grad_slice"] = x.grad[:, :, ::7, ::5].numpy()
+    # PeakGenerator in training mode (wss/modules.py:390-423) + the phase-1 peak loss of train.py:334-336,344-345
+    if c == 21:
+        gpk = torch.Generator().manual_seed(2000 + seed)
+        pg = wm.PeakGenerator(21, 20, old_classes=15)
+        with torch.no_grad():
+            pg.extra_conv4.weight.copy_(torch.randn(5, 5, 1, 1, generator=gpk) * 0.5)
+            pg.extra_conv4.bias.copy_(torch.randn(5, generator=gpk) * 0.1)
+        pg.train()
+        x = d["logits"].clone().requires_grad_(True)
+        logit, _ = pg(x * 1.0)          # non-leaf input, as in training (PAM applies an in-place ReLU to a view)
+        l = F.binary_cross_entropy_with_logits(logit[:, 15:], d["labels"][:, 15:])
+        l.backward()
+        out["pg_weight"] = pg.extra_conv4.weight.detach().numpy().copy()
+        out["pg_bias"] = pg.extra_conv4.bias.detach().numpy().copy()
+        out["pg_logit"] = logit[:, 15:].detach().numpy().copy()
+        out["pg_loss"] = np.array(l.item())
+        out["pg_dx"] = x.grad.numpy().copy()
+        out["pg_dw"] = pg.extra_conv4.weight.grad.numpy().copy()
+        out["pg_db"] = pg.extra_conv4.bias.grad.numpy().copy()
     np.savez_compressed(os.path.join(HERE, f"wss_s{seed:02d}.npz"), **out)
     print(f"wss_s{seed:02d}.npz", {k: (v.shape if v.ndim else float(v)) for k, v in out.items() if k != "case"})
 
