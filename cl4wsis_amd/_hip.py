@@ -106,6 +106,11 @@ _decl("cl4_p2_loss", C.POINTER(P2LossIO), _P, C.c_size_t, _P)
 _decl("cl4_adam_step", _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P)
 _decl("cl4_adam_step_dev", _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _I, _P)
 _decl("cl4_fill_zero", _P, C.c_size_t, _P)
+_decl("cl4_peakgen_train_loss", _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, C.c_size_t, _P)
+_decl("cl4_flac_loss", _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)
+_decl("cl4_lloc_loss", _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)
+_decl("cl4_mse_loss", _P, _P, _L, _F, _P, _P, _P, C.c_size_t, _P)
+_decl("cl4_p1_seg_loss", _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_sgd_step", _P, _P, _P, _L, _F, _P, _F, _F, _I, _P)
 _decl("cl4_pamr", _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, C.c_size_t, _P)
 _decl("cl4_ngwp_focal_bce", _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, C.c_size_t, _P)
@@ -136,7 +141,7 @@ def load():
     for nm, at in (("cl4_peak_workspace_bytes", [C.c_int, C.c_int]), ("cl4_label_workspace_bytes", [C.c_int] * 3),
                    ("cl4_p2_loss_workspace_bytes", [C.c_int] * 6), ("cl4_pamr_workspace_bytes", [C.c_int] * 5),
                    ("cl4_ngwp_workspace_bytes", [C.c_int] * 2), ("cl4_balanced_ce_workspace_bytes", [C.c_int] * 4),
-                   ("cl4_bce_ignore_workspace_bytes", [])):
+                   ("cl4_bce_ignore_workspace_bytes", []), ("cl4_p1loss_workspace_bytes", [C.c_int] * 4)):
         getattr(lib, nm).restype = C.c_size_t
         getattr(lib, nm).argtypes = at
     for name, args in PROTOTYPES.items():

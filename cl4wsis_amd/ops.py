@@ -691,3 +691,84 @@ def bce_ignore_mean(x, target, ignore_index=255, with_grad=True):
     call("cl4_bce_ignore_mean", ptr(x), ptr(target), b, c, h, w, int(ignore_index), ptr(loss), ptr(dx) if with_grad else None,
          ptr(ws), ws.numel(), stream())
     return loss, dx
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Phase-1 training-path losses — csrc/p1loss.hip
+# ---------------------------------------------------------------------------------------------------------------------
+def _p1_ws(t, b, tot, h, w):
+    return _workspace(t.device, _hip.load().cl4_p1loss_workspace_bytes(b, tot, h, w))
+
+
+def peakgen_train_loss(x, weight, bias, labels_new, alpha=0.7, dweight=None, dbias=None, with_grad=True):
+    """PeakGenerator (training) + peak loss. Returns (loss [1], logit [b,nc], dx or None); the weight / bias gradients are
+    ACCUMULATED into `dweight` / `dbias` (allocated zeroed when None) and returned as a 5-tuple's last two items."""
+    _f32c(x, "peakgen x"), _f32c(labels_new, "peakgen labels")
+    b, ctot, h, w = x.shape
+    nc = labels_new.shape[1]
+    wt = _f32c(weight.reshape(nc, nc), "peakgen weight")
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    logit = torch.empty(b, nc, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if with_grad else None
+    if with_grad:
+        dweight = torch.zeros(nc, nc, dtype=torch.float32, device=x.device) if dweight is None else dweight
+        dbias = torch.zeros(nc, dtype=torch.float32, device=x.device) if dbias is None else dbias
+    ws = _p1_ws(x, b, ctot, h, w)
+    call("cl4_peakgen_train_loss", ptr(x), ptr(wt), ptr(bias), ptr(labels_new), b, ctot, h, w, nc, C.c_float(alpha), ptr(logit),
+         ptr(loss), ptr(dx), ptr(dweight) if with_grad else None, ptr(dbias) if with_grad else None, ptr(ws), ws.numel(), stream())
+    return loss, logit, dx, dweight, dbias
+
+
+def flac_loss(A, bs, old_classes, angle, with_grad=True):
+    """FLAC consistency loss of train.py:314-333. Returns (loss [1], dA or None)."""
+    _f32c(A, "flac A")
+    n3, c, h, w = A.shape
+    if n3 != 3 * bs:
+        raise RuntimeError("flac_loss: A must hold 3*bs images")
+    loss = torch.empty(1, dtype=torch.float32, device=A.device)
+    dA = torch.empty_like(A) if with_grad else None
+    ws = _p1_ws(A, bs, c, h, w)
+    call("cl4_flac_loss", ptr(A), bs, c, int(old_classes), h, w, int(angle), ptr(loss), ptr(dA), ptr(ws), ws.numel(), stream())
+    return loss, dA
+
+
+def lloc_loss(x, old_seg, labels=None, with_grad=True):
+    """l_loc of train.py:346-354. Returns (loss [1], dx or None; channels >= cold of dx are zero)."""
+    _f32c(x, "lloc x"), _f32c(old_seg, "lloc old_seg")
+    b, ctot, h, w = x.shape
+    cold = old_seg.shape[1]
+    if tuple(old_seg.shape) != (b, cold, h, w):
+        raise RuntimeError("lloc_loss: old_seg must be [b, cold, h, w] at the size of x")
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.zeros_like(x) if with_grad else None
+    ws = _p1_ws(x, b, ctot, h, w)
+    call("cl4_lloc_loss", ptr(x), ptr(old_seg), ptr(labels) if labels is not None else None, b, ctot, cold, h, w, ptr(loss),
+         ptr(dx), ptr(ws), ws.numel(), stream())
+    return loss, dx
+
+
+def mse_loss(x, y, grad_scale=1.0, with_grad=True):
+    """nn.MSELoss()(x, y) and grad_scale * d/dx. Returns (loss [1], dx or None)."""
+    _f32c(x, "mse x"), _f32c(y, "mse y")
+    if x.shape != y.shape:
+        raise RuntimeError("mse_loss: shape mismatch")
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if with_grad else None
+    ws = _workspace(x.device, _hip.load().cl4_p1loss_workspace_bytes(1, 1, 1, 1))
+    call("cl4_mse_loss", ptr(x), ptr(y), x.numel(), C.c_float(grad_scale), ptr(loss), ptr(dx), ptr(ws), ws.numel(), stream())
+    return loss, dx
+
+
+def p1_seg_loss(seg, old_seg, masks, labels, alpha=0.5, icarl_bkg=-1.0, weight=1.0, with_grad=True):
+    """l_seg of train.py:374-409. Returns (loss [1], dseg or None)."""
+    _f32c(seg, "l_seg seg"), _f32c(old_seg, "l_seg old_seg"), _f32c(masks, "l_seg masks"), _f32c(labels, "l_seg labels")
+    b, tot, h, w = seg.shape
+    cold = old_seg.shape[1]
+    if tuple(masks.shape) != (b, tot, h, w) or tuple(old_seg.shape) != (b, cold, h, w) or tuple(labels.shape) != (b, tot - 1):
+        raise RuntimeError("p1_seg_loss: seg/masks [b,tot,h,w], old_seg [b,cold,h,w], labels [b,tot-1] expected")
+    loss = torch.empty(1, dtype=torch.float32, device=seg.device)
+    dseg = torch.empty_like(seg) if with_grad else None
+    ws = _p1_ws(seg, b, tot, h, w)
+    call("cl4_p1_seg_loss", ptr(seg), ptr(old_seg), ptr(masks), ptr(labels), b, tot, cold, h, w, C.c_float(alpha),
+         C.c_float(icarl_bkg), C.c_float(weight), ptr(loss), ptr(dseg), ptr(ws), ws.numel(), stream())
+    return loss, dseg

@@ -284,6 +284,37 @@ size_t cl4_bce_ignore_workspace_bytes(void);
 int cl4_bce_ignore_mean(const float* x, const long long* target, int b, int c, int h, int w, int ignore_index, float* loss,
                         float* dx /* or NULL */, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Phase-1 training-path losses: value + gradient on the stride-16 class maps.
+ * One workspace size serves all five entry points.
+ * ------------------------------------------------------------------------ */
+size_t cl4_p1loss_workspace_bytes(int b, int tot, int h, int w);
+/* PeakGenerator.forward (training: PAM -> 1x1 conv nc->nc -> nGWP logit, wss/modules.py:354-423) + the peak loss
+ * BCE-with-logits(logit, labels) of train.py:334-336,344-345. x [b,ctot,h,w] (the generator reads the last nc channels),
+ * weight [nc,nc], bias [nc], labels [b,nc]; writes logit [b,nc], loss [1] and, when dx != NULL, dx [b,ctot,h,w]
+ * (old-class channels zero) and ACCUMULATES into dweight [nc,nc] / dbias [nc]. 1 <= nc <= 8. */
+int cl4_peakgen_train_loss(const float* x, const float* weight, const float* bias, const float* labels, int b, int ctot, int h,
+                           int w, int nc, float alpha, float* logit, float* loss, float* dx, float* dweight, float* dbias,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* FLAC consistency loss — train.py:314-333. A [3*bs,c,h,h] = PseudoLabeler logits on [x, flip_w(x), rot90(x, angle/90)];
+ * angle in {90,180,270}; dA [3*bs,c,h,h] or NULL. */
+int cl4_flac_loss(const float* A, int bs, int c, int old_classes, int h, int w, int angle, float* loss, float* dA, void* workspace,
+                  size_t workspace_bytes, void* stream);
+/* l_loc — train.py:346-354: mean BCE-with-logits(x[:, :cold], sigmoid(old_seg) [* labels with --no_mask]); x [b,ctot,h,w],
+ * old_seg [b,cold,h,w], labels [b,ctot-1] or NULL; dx [b,ctot,h,w] (only the first cold channels are written) or NULL. */
+int cl4_lloc_loss(const float* x, const float* old_seg, const float* labels, int b, int ctot, int cold, int h, int w, float* loss,
+                  float* dx, void* workspace, size_t workspace_bytes, void* stream);
+/* nn.MSELoss (lde, train.py:362-363; also the FLAC / distillation building block): loss = mean((x-y)^2),
+ * dx = grad_scale * 2 (x - y) / n or NULL. */
+int cl4_mse_loss(const float* x, const float* y, long n, float grad_scale, float* loss, float* dx, void* workspace,
+                 size_t workspace_bytes, void* stream);
+/* l_seg — train.py:374-409: BCE of the new model's seg logits against [sigmoid(old seg) | alpha*binarize + (1-alpha)*soft]
+ * with the background rule (icarl_bkg == -1: min), gated per image by the label-set match and normalised by the number of
+ * gated images. seg/masks [b,tot,h,w], old_seg [b,cold,h,w], labels [b,tot-1]; dseg [b,tot,h,w] or NULL. */
+int cl4_p1_seg_loss(const float* seg, const float* old_seg, const float* masks, const float* labels, int b, int tot, int cold,
+                    int h, int w, float alpha, float icarl_bkg, float weight, float* loss, float* dseg, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
