@@ -64,6 +64,44 @@ __global__ void bn_stats_final_kernel(const double* __restrict__ partial, float*
   }
 }
 
+// Cross-rank (InPlaceABNSync) form: the SPLIT partials are folded to sums[c][2] doubles, which the host all-reduces over the
+// ranks before the statistics are finalised with the global element count.
+__global__ void bn_fold_partials_kernel(const double* __restrict__ partial, double* __restrict__ sums, int c) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < SPLIT; ++s) {
+    a += partial[((long)i * SPLIT + s) * 2 + 0];
+    b += partial[((long)i * SPLIT + s) * 2 + 1];
+  }
+  sums[2 * i] = a;
+  sums[2 * i + 1] = b;
+}
+
+__global__ void bn_stats_from_sums_kernel(const double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ var,
+                                          float* running_mean, float* running_var, float momentum, double count, int c) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  double m = sums[2 * i] / count;
+  double v = sums[2 * i + 1] / count - m * m;
+  if (v < 0.0) v = 0.0;
+  mean[i] = (float)m;
+  var[i] = (float)v;
+  if (running_mean) {
+    double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+    running_mean[i] = (1.f - momentum) * running_mean[i] + momentum * (float)m;
+    running_var[i] = (1.f - momentum) * running_var[i] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_bwd_sums_to_float_kernel(const double* __restrict__ sums, float* __restrict__ sum_dz, float* __restrict__ sum_dz_xh,
+                                            int c) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  sum_dz[i] = (float)sums[2 * i];
+  sum_dz_xh[i] = (float)sums[2 * i + 1];
+}
+
 // y = act((x - mean) * rstd * gamma + beta); optional inverted-dropout mask (uint8 keep flags, scale 1/(1-p)).
 __global__ void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
                                 const float* __restrict__ var, const float* __restrict__ gamma,
@@ -84,12 +122,19 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, float* __restrict__
   }
 }
 
-// Backward reductions. dz = dy * keepscale * [z > 0] with z recomputed from x.
+// Derivative of the fused activation at pre-activation z (ReLU: [z > 0]; leaky: slope where z <= 0).
+__device__ __forceinline__ float act_grad(float d, float z, int act, float slope) {
+  if (act == CL4_ACT_RELU) return z > 0.f ? d : 0.f;
+  if (act == CL4_ACT_LEAKY) return z > 0.f ? d : d * slope;
+  return d;
+}
+
+// Backward reductions. dz = dy * keepscale * act'(z) with z recomputed from x.
 //   partial = {sum dz, sum dz * xhat}
 __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, double* __restrict__ partial,
                                       const float* __restrict__ mean, const float* __restrict__ var,
                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
-                                      BnShape s, int dy_ctot, int dy_coff, const uint8_t* __restrict__ keep,
+                                      float slope, BnShape s, int dy_ctot, int dy_coff, const uint8_t* __restrict__ keep,
                                       float keep_scale) {
   const int c = blockIdx.x, sp = blockIdx.y;
   const long per_c = (long)s.n * s.hw;
@@ -102,7 +147,7 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
     float xh = (x[((long)n * s.ctot + s.coff + c) * s.hw + p] - mu) * rstd;
     float d = dy[((long)n * dy_ctot + dy_coff + c) * s.hw + p];
     if (keep) d = keep[((long)n * s.c + c) * s.hw + p] ? d * keep_scale : 0.f;
-    if (act == CL4_ACT_RELU && !(xh * g + bb > 0.f)) d = 0.f;
+    d = act_grad(d, xh * g + bb, act, slope);
     a += (double)d;
     b += (double)d * (double)xh;
   }
@@ -133,9 +178,9 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ mean, const float* __restrict__ var,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ sum_dz, const float* __restrict__ sum_dz_xh, float eps, int act,
-                                    BnShape s, int dy_ctot, int dy_coff, const uint8_t* __restrict__ keep, float keep_scale) {
+                                    float slope, float invn, BnShape s, int dy_ctot, int dy_coff,
+                                    const uint8_t* __restrict__ keep, float keep_scale) {
   long total = (long)s.n * s.c * s.hw;
-  const float invn = 1.f / (float)((long)s.n * s.hw);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int p = i % s.hw;
     long t = i / s.hw;
@@ -147,7 +192,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     float xh = (x[xi] - mean[c]) * rstd;
     float d = dy[((long)n * dy_ctot + dy_coff + c) * s.hw + p];
     if (keep) d = keep[i] ? d * keep_scale : 0.f;
-    if (act == CL4_ACT_RELU && !(xh * g + bb > 0.f)) d = 0.f;
+    d = act_grad(d, xh * g + bb, act, slope);
     dx[xi] = g * rstd * (d - sum_dz[c] * invn - xh * sum_dz_xh[c] * invn);
   }
 }
@@ -244,12 +289,76 @@ extern "C" int cl4_bn_train_bwd(const float* x, const float* dy, float* dx, int 
   float* sums = (float*)((char*)workspace + cl4_bn_workspace_bytes(c));
   hipStream_t st = cl4::as_stream(stream);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
-                     s, dy_ctot, dy_coff, keep, keep_scale);
+                     0.f, s, dy_ctot, dy_coff, keep, keep_scale);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, sums + c,
                      dgamma, dbeta, c);
   long total = (long)n * c * hw;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, x, dy, dx, mean, var, gamma,
-                     beta, sums, sums + c, eps, act, s, dy_ctot, dy_coff, keep, keep_scale);
+                     beta, sums, sums + c, eps, act, 0.f, 1.f / (float)((long)n * hw), s, dy_ctot, dy_coff, keep, keep_scale);
+  return cl4::launch_status();
+}
+
+// ---- two-phase (cross-rank) forms: InPlaceABNSync in training mode (segmentation_module.py:17-29) ----------------------
+extern "C" int cl4_bn_sync_stats_local(const float* x, int n, int c, int hw, int ctot, int coff, double* sums, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  BnShape s{n, c, hw, ctot, coff};
+  int rc = check_shape(s);
+  if (rc) return rc;
+  CL4_REQUIRE(x && sums && workspace, "bn_sync_stats_local: null pointer");
+  if (workspace_bytes < cl4_bn_workspace_bytes(c)) { cl4::set_error("bn_sync_stats_local: workspace too small"); return CL4_ENOSPC; }
+  hipStream_t st = cl4::as_stream(stream);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, (double*)workspace, s);
+  hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)workspace, sums, c);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_bn_sync_stats_final(const double* sums, double count, float* mean, float* var, float* running_mean,
+                                       float* running_var, float momentum, int c, void* stream) {
+  CL4_REQUIRE(sums && mean && var && c > 0 && count > 0.0, "bn_sync_stats_final: bad arguments");
+  hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, cl4::as_stream(stream), sums, mean, var,
+                     running_mean, running_var, momentum, count, c);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_bn_sync_bwd_local(const float* x, const float* dy, int n, int c, int hw, int x_ctot, int x_coff, int dy_ctot,
+                                     int dy_coff, const float* mean, const float* var, const float* gamma, const float* beta,
+                                     float eps, int act, float slope, const uint8_t* keep, float keep_scale, double* sums,
+                                     float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+  BnShape s{n, c, hw, x_ctot, x_coff};
+  int rc = check_shape(s);
+  if (rc) return rc;
+  CL4_REQUIRE(x && dy && mean && var && sums && workspace, "bn_sync_bwd_local: null pointer");
+  CL4_REQUIRE(dy_coff >= 0 && dy_coff + c <= dy_ctot, "bn_sync_bwd_local: dy slice out of range");
+  size_t need = cl4_bn_workspace_bytes(c) + (size_t)2 * c * sizeof(float);
+  if (workspace_bytes < need) { cl4::set_error("bn_sync_bwd_local: workspace too small"); return CL4_ENOSPC; }
+  double* partial = (double*)workspace;
+  float* fsum = (float*)((char*)workspace + cl4_bn_workspace_bytes(c));
+  hipStream_t st = cl4::as_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
+                     slope, s, dy_ctot, dy_coff, keep, keep_scale);
+  hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, c);
+  // the affine gradients are this rank's share (the gradient all-reduce averages them with everything else)
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, fsum, fsum + c, dgamma,
+                     dbeta, c);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_bn_sync_bwd_apply(const float* x, const float* dy, float* dx, int n, int c, int hw, int x_ctot, int x_coff,
+                                     int dy_ctot, int dy_coff, const float* mean, const float* var, const float* gamma,
+                                     const float* beta, float eps, int act, float slope, const uint8_t* keep, float keep_scale,
+                                     const double* sums, double count, void* workspace, size_t workspace_bytes, void* stream) {
+  BnShape s{n, c, hw, x_ctot, x_coff};
+  int rc = check_shape(s);
+  if (rc) return rc;
+  CL4_REQUIRE(x && dy && dx && mean && var && sums && workspace && count > 0.0, "bn_sync_bwd_apply: bad arguments");
+  CL4_REQUIRE(dy_coff >= 0 && dy_coff + c <= dy_ctot, "bn_sync_bwd_apply: dy slice out of range");
+  if (workspace_bytes < (size_t)2 * c * sizeof(float)) { cl4::set_error("bn_sync_bwd_apply: workspace too small"); return CL4_ENOSPC; }
+  float* fsum = (float*)workspace;
+  hipStream_t st = cl4::as_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_sums_to_float_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, sums, fsum, fsum + c, c);
+  long total = (long)n * c * hw;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, x, dy, dx, mean, var, gamma,
+                     beta, fsum, fsum + c, eps, act, slope, (float)(1.0 / count), s, dy_ctot, dy_coff, keep, keep_scale);
   return cl4::launch_status();
 }
 

@@ -387,6 +387,55 @@ def bn_train_bwd(x, dy, mean, var, gamma, beta, dgamma, dbeta, eps=1e-5, act=ACT
     return dx
 
 
+def _allreduce_sum(t, group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=ACT_LEAKY, slope=0.01,
+                      group=None, extra_sums=None):
+    """InPlaceABNSync in training mode (segmentation_module.py:17-29): batch statistics over every rank of
+    `group`, then BN + leaky-ReLU / identity. Returns (y, mean, var, count). `extra_sums` ([c*2] doubles, count) adds the
+    statistics of shards held elsewhere — used by the tests to emulate a second rank on one GPU."""
+    n, c, h, w = x.shape
+    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
+    ws = _workspace(x.device, bn_workspace_bytes(c))
+    call("cl4_bn_sync_stats_local", ptr(x), n, c, h * w, c, 0, ptr(sums), ptr(ws), ws.numel(), stream())
+    sums[2 * c] = float(n * h * w)
+    if extra_sums is not None:
+        sums += extra_sums
+    _allreduce_sum(sums, group)
+    count = float(sums[2 * c].item()) if (extra_sums is not None or group is not None) else float(n * h * w)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    var = torch.empty(c, dtype=torch.float32, device=x.device)
+    call("cl4_bn_sync_stats_final", ptr(sums), C.c_double(count), ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+         C.c_float(momentum), c, stream())
+    y = bn_apply(x, mean, var, gamma, beta, eps=eps, act=act, slope=slope)
+    return y, mean, var, count
+
+
+def abn_train_backward(x, dy, mean, var, gamma, beta, dgamma, dbeta, count, eps=1e-5, act=ACT_LEAKY, slope=0.01, group=None,
+                       extra_sums=None, return_sums=False):
+    """Backward of abn_train_forward: dx; this rank's share of the affine gradients is accumulated into dgamma / dbeta."""
+    n, c, h, w = x.shape
+    sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+    ws = _workspace(x.device, bn_workspace_bytes(c))
+    call("cl4_bn_sync_bwd_local", ptr(x), ptr(dy), n, c, h * w, c, 0, dy.shape[1], 0, ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+         C.c_float(eps), act, C.c_float(slope), None, C.c_float(1.0), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(),
+         stream())
+    local = sums.clone() if return_sums else None
+    if extra_sums is not None:
+        sums += extra_sums
+    _allreduce_sum(sums, group)
+    dx = torch.empty_like(x)
+    call("cl4_bn_sync_bwd_apply", ptr(x), ptr(dy), ptr(dx), n, c, h * w, c, 0, dy.shape[1], 0, ptr(mean), ptr(var), ptr(gamma),
+         ptr(beta), C.c_float(eps), act, C.c_float(slope), None, C.c_float(1.0), ptr(sums), C.c_double(count), ptr(ws),
+         ws.numel(), stream())
+    return (dx, local) if return_sums else dx
+
+
 def relu_bwd(y, dy):
     dx = torch.empty_like(dy)
     call("cl4_relu_bwd", ptr(y), ptr(dy), ptr(dx), y.numel(), stream())

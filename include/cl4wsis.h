@@ -148,6 +148,25 @@ int cl4_bn_train_bwd(const float* x, const float* dy, float* dx, int n, int c, i
                      const float* beta, float eps, int act, const uint8_t* keep, float keep_scale,
                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 int cl4_relu_bwd(const float* y, const float* dy, float* dx, long n, void* stream);
+/* Two-phase forms for cross-rank batch statistics — InPlaceABNSync in training mode (segmentation_module.py:17-29;
+ * SURVEY.md §8 A2): BN (eps 1e-5, momentum 0.1) + leaky-ReLU(slope) / identity, statistics over ALL ranks.
+ *   forward : cl4_bn_sync_stats_local -> host all-reduce(SUM) of sums[c*2] doubles and of the element count ->
+ *             cl4_bn_sync_stats_final -> cl4_bn_apply;
+ *   backward: cl4_bn_sync_bwd_local (local {sum dz, sum dz*xhat}; accumulates this rank's dgamma / dbeta) ->
+ *             all-reduce(SUM) -> cl4_bn_sync_bwd_apply with the global count.
+ * With one rank the pair reproduces cl4_bn_train_stats / cl4_bn_train_bwd (and adds the leaky-ReLU derivative). */
+int cl4_bn_sync_stats_local(const float* x, int n, int c, int hw, int ctot, int coff, double* sums, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int cl4_bn_sync_stats_final(const double* sums, double count, float* mean, float* var, float* running_mean, float* running_var,
+                            float momentum, int c, void* stream);
+int cl4_bn_sync_bwd_local(const float* x, const float* dy, int n, int c, int hw, int x_ctot, int x_coff, int dy_ctot, int dy_coff,
+                          const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act,
+                          float slope, const uint8_t* keep, float keep_scale, double* sums, float* dgamma, float* dbeta,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int cl4_bn_sync_bwd_apply(const float* x, const float* dy, float* dx, int n, int c, int hw, int x_ctot, int x_coff, int dy_ctot,
+                          int dy_coff, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                          int act, float slope, const uint8_t* keep, float keep_scale, const double* sums, double count,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* db[c] += sum_{n,hw} dy — bias gradient of the classifier convs. */
 int cl4_bias_grad(const float* dy, float* db, int n, int c, int hw, int ctot, int coff, void* stream);
 /* Counter-based keep mask for nn.Dropout(p) — modules/panoptic_deeplab.py:123. */

@@ -1,0 +1,77 @@
+"""GPU parity of the train-mode InPlaceABNSync path (cl4_bn_sync_*: SURVEY §8 A2) against PyTorch-CPU autograd of
+F.batch_norm(training=True) + leaky-ReLU: one rank, and two shards whose statistics are combined the way the all-reduce
+does (the second shard's sums are computed with the same kernels and added) — the result must equal full-batch BN."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _reference(x, gamma, beta, dy, slope):
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(x.shape[1]), torch.ones(x.shape[1])
+    y = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5)
+    y = F.leaky_relu(y, slope) if slope is not None else y
+    y.backward(dy)
+    return y.detach(), xr.grad, gr.grad, br.grad, rm, rv
+
+
+@pytest.mark.parametrize("slope", [0.01, None])
+def test_abn_train_single_rank(gpu, slope):
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 37, 17, 13, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(37, generator=g) + 0.5, torch.randn(37, generator=g)
+    dy = torch.randn(x.shape, generator=g)
+    y_ref, dx_ref, dg_ref, db_ref, rm_ref, rv_ref = _reference(x, gamma, beta, dy, slope)
+    act = ops.ACT_LEAKY if slope is not None else ops.ACT_NONE
+    rm, rv = torch.zeros(37, device=gpu), torch.ones(37, device=gpu)
+    xd, gd, bd = x.to(gpu), gamma.to(gpu), beta.to(gpu)
+    y, mean, var, count = ops.abn_train_forward(xd, gd, bd, rm, rv, act=act, slope=slope or 0.0)
+    dgamma, dbeta = torch.zeros(37, device=gpu), torch.zeros(37, device=gpu)
+    dx = ops.abn_train_backward(xd, dy.to(gpu), mean, var, gd, bd, dgamma, dbeta, count, act=act, slope=slope or 0.0)
+    assert _rel(y, y_ref) < 1e-5 and _rel(rm, rm_ref) < 1e-6 and _rel(rv, rv_ref) < 1e-6
+    assert _rel(dx, dx_ref) < 2e-5 and _rel(dgamma, dg_ref) < 2e-5 and _rel(dbeta, db_ref) < 2e-5
+
+
+def test_abn_train_two_shards_equal_full_batch(gpu):
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(6, 24, 9, 11, generator=g) + torch.arange(6).float()[:, None, None, None] * 0.3   # shards differ in mean
+    gamma, beta = torch.rand(24, generator=g) + 0.5, torch.randn(24, generator=g)
+    dy = torch.randn(x.shape, generator=g)
+    y_ref, dx_ref, dg_ref, db_ref, _, _ = _reference(x, gamma, beta, dy, 0.01)
+    gd, bd = gamma.to(gpu), beta.to(gpu)
+    shards = [x[:2].contiguous().to(gpu), x[2:].contiguous().to(gpu)]       # unequal shard sizes
+    dys = [dy[:2].contiguous().to(gpu), dy[2:].contiguous().to(gpu)]
+    c = 24
+    # "rank" r's local statistics, as the all-reduce would deliver them to the other rank
+    stat = []
+    for xs in shards:
+        s = torch.empty(2 * c + 1, dtype=torch.float64, device=gpu)
+        ws = ops._workspace(gpu, ops.bn_workspace_bytes(c))
+        ops.call("cl4_bn_sync_stats_local", ops.ptr(xs), xs.shape[0], c, 99, c, 0, ops.ptr(s), ops.ptr(ws), ws.numel(), ops.stream())
+        s[2 * c] = float(xs.shape[0] * 99)
+        stat.append(s)
+    fwd = [ops.abn_train_forward(xs, gd, bd, extra_sums=stat[1 - r]) for r, xs in enumerate(shards)]
+    assert _rel(torch.cat([f[0] for f in fwd]), y_ref) < 1e-5
+    dgamma, dbeta = torch.zeros(c, device=gpu), torch.zeros(c, device=gpu)
+    # first pass collects each shard's local backward sums, second pass applies with the combined sums
+    local = []
+    for r, xs in enumerate(shards):
+        _, mean, var, count = fwd[r]
+        _, ls = ops.abn_train_backward(xs, dys[r], mean, var, gd, bd, torch.zeros(c, device=gpu), torch.zeros(c, device=gpu), count,
+                                       return_sums=True)
+        local.append(ls)
+    dxs = []
+    for r, xs in enumerate(shards):
+        _, mean, var, count = fwd[r]
+        dxs.append(ops.abn_train_backward(xs, dys[r], mean, var, gd, bd, dgamma, dbeta, count, extra_sums=local[1 - r]))
+    assert _rel(torch.cat(dxs), dx_ref) < 2e-5
+    assert _rel(dgamma, dg_ref) < 2e-5 and _rel(dbeta, db_ref) < 2e-5       # sum over shards = full-batch gradient
