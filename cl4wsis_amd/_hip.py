@@ -116,6 +116,11 @@ _decl("cl4_bn_sync_stats_local", _P, _I, _I, _I, _I, _I, _P, _P, C.c_size_t, _P)
 _decl("cl4_bn_sync_stats_final", _P, _D, _P, _P, _P, _P, _F, _I, _P)
 _decl("cl4_bn_sync_bwd_local", _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _F, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_bn_sync_bwd_apply", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _F, _P, _D, _P, C.c_size_t, _P)
+_decl("cl4_zero_insert", _P, _P, _L, _I, _I, _I, _I, _I, _P)
+_decl("cl4_maxpool3x3s2_bwd", _P, _P, _P, _L, _I, _I, _I, _I, _P)
+_decl("cl4_add_act", _P, _P, _P, _L, _I, _F, _P)
+_decl("cl4_act_bwd", _P, _P, _P, _L, _I, _F, _P)
+_decl("cl4_transpose_flip_weight", _P, _P, _I, _I, _I, _P)
 _decl("cl4_sgd_step", _P, _P, _P, _L, _F, _P, _F, _F, _I, _P)
 _decl("cl4_pamr", _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, C.c_size_t, _P)
 _decl("cl4_ngwp_focal_bce", _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, C.c_size_t, _P)

@@ -1,0 +1,140 @@
+// Building blocks of the train-mode forward / backward of the ResNet body, DeepLabV3 head and PseudoLabeler (phase 1 /
+// step 0; SURVEY.md §8 A1-A4, A8 with gradients). All HBM-bound streaming kernels:
+//   * zero_insert        : dy of a strided conv spread onto the stride-1 grid, so that the input gradient is the ordinary
+//                          forward kernel run with transposed / flipped weights (models/resnet.py strided 3x3 / 1x1);
+//   * maxpool3x3s2_bwd   : nn.MaxPool2d(3, 2, 1) backward as a deterministic gather (first maximum wins, like ATen);
+//   * add_act / act_bwd  : residual add + in-place leaky-ReLU of modules/residual.py:91-93 and its derivative;
+//   * transpose_flip     : w[co][ci][ky][kx] -> wt[ci][co][k-1-ky][k-1-kx], the weight of the input-gradient conv.
+#include "common.h"
+
+namespace {
+
+__global__ void zero_insert_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int h, int w, int stride, int H,
+                                   int W) {
+  const long total = planes * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int X = i % W;
+    const long t = i / W;
+    const int Y = t % H;
+    const long pl = t / H;
+    float v = 0.f;
+    if (Y % stride == 0 && X % stride == 0) {
+      const int yy = Y / stride, xx = X / stride;
+      if (yy < h && xx < w) v = x[(pl * h + yy) * w + xx];
+    }
+    y[i] = v;
+  }
+}
+
+// argmax of the 3x3 stride-2 pad-1 window (oy, ox): first maximum in row-major order (ATen: `val > maxval`).
+__device__ __forceinline__ int window_argmax(const float* __restrict__ xp, int oy, int ox, int hin, int win) {
+  float m = -INFINITY;
+  int arg = -1;
+  const int iy0 = oy * 2 - 1, ix0 = ox * 2 - 1;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = iy0 + dy;
+    if ((unsigned)iy >= (unsigned)hin) continue;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ix0 + dx;
+      if ((unsigned)ix >= (unsigned)win) continue;
+      const float v = xp[iy * win + ix];
+      if (v > m || arg < 0) { m = v; arg = iy * win + ix; }
+    }
+  }
+  return arg;
+}
+
+__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long planes,
+                                        int hin, int win, int hout, int wout) {
+  const long total = planes * hin * win;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ix = i % win;
+    const long t = i / win;
+    const int iy = t % hin;
+    const long pl = t / hin;
+    const float* xp = x + pl * hin * win;
+    const float* dp = dy + pl * hout * wout;
+    // windows containing (iy, ix): 2*o - 1 <= i <= 2*o + 1  ->  o in [ceil((i-1)/2), floor((i+1)/2)]
+    const int oy_lo = iy / 2, oy_hi = min(hout - 1, (iy + 1) / 2);
+    const int ox_lo = ix / 2, ox_hi = min(wout - 1, (ix + 1) / 2);
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+      for (int ox = ox_lo; ox <= ox_hi; ++ox)
+        if (window_argmax(xp, oy, ox, hin, win) == iy * win + ix) acc += dp[oy * wout + ox];
+    dx[i] = acc;
+  }
+}
+
+__global__ void add_act_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n, int act,
+                               float slope) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = cl4::apply_act(a[i] + b[i], act, slope);
+}
+
+// dx = dy * act'(pre-activation); for ReLU / leaky-ReLU the sign of the output y equals the sign of the pre-activation.
+__global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, long n, int act,
+                               float slope) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = dy[i];
+    float r = d;
+    if (act == CL4_ACT_RELU) r = y[i] > 0.f ? d : 0.f;
+    else if (act == CL4_ACT_LEAKY) r = y[i] > 0.f ? d : d * slope;
+    dx[i] = r;
+  }
+}
+
+__global__ void transpose_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int cin, int k) {
+  const long total = (long)cout * cin * k * k;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int kx = i % k;
+    long t = i / k;
+    const int ky = t % k;
+    t /= k;
+    const int ci = t % cin;
+    const int co = t / cin;
+    wt[(((long)ci * cout + co) * k + (k - 1 - ky)) * k + (k - 1 - kx)] = w[i];
+  }
+}
+
+}  // namespace
+
+extern "C" int cl4_zero_insert(const float* x, float* y, long planes, int h, int w, int stride, int H, int W, void* stream) {
+  CL4_REQUIRE(x && y && planes > 0 && h > 0 && w > 0 && stride >= 1, "zero_insert: bad arguments");
+  CL4_REQUIRE(H >= (h - 1) * stride + 1 && W >= (w - 1) * stride + 1, "zero_insert: output %dx%d too small", H, W);
+  const long total = planes * H * W;
+  hipLaunchKernelGGL(zero_insert_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, planes, h,
+                     w, stride, H, W);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, long planes, int hin, int win, int hout, int wout,
+                                    void* stream) {
+  CL4_REQUIRE(x && dy && dx && planes > 0, "maxpool_bwd: bad arguments");
+  CL4_REQUIRE(hout == (hin + 2 - 3) / 2 + 1 && wout == (win + 2 - 3) / 2 + 1, "maxpool_bwd: output size mismatch");
+  const long total = planes * hin * win;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, dy, dx,
+                     planes, hin, win, hout, wout);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_add_act(const float* a, const float* b, float* y, long n, int act, float slope, void* stream) {
+  CL4_REQUIRE(a && b && y && n > 0, "add_act: bad arguments");
+  hipLaunchKernelGGL(add_act_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), a, b, y, n, act, slope);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_act_bwd(const float* y, const float* dy, float* dx, long n, int act, float slope, void* stream) {
+  CL4_REQUIRE(y && dy && dx && n > 0, "act_bwd: bad arguments");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), y, dy, dx, n, act, slope);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_transpose_flip_weight(const float* w, float* wt, int cout, int cin, int k, void* stream) {
+  CL4_REQUIRE(w && wt && w != wt && cout > 0 && cin > 0 && k > 0, "transpose_flip_weight: bad arguments");
+  const long total = (long)cout * cin * k * k;
+  hipLaunchKernelGGL(transpose_flip_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), w, wt, cout,
+                     cin, k);
+  return cl4::launch_status();
+}

@@ -821,3 +821,53 @@ def p1_seg_loss(seg, old_seg, masks, labels, alpha=0.5, icarl_bkg=-1.0, weight=1
     call("cl4_p1_seg_loss", ptr(seg), ptr(old_seg), ptr(masks), ptr(labels), b, tot, cold, h, w, C.c_float(alpha),
          C.c_float(icarl_bkg), C.c_float(weight), ptr(loss), ptr(dseg), ptr(ws), ws.numel(), stream())
     return loss, dseg
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Backward building blocks of the body / heads (phase 1 / step 0) — csrc/backward.hip
+# ---------------------------------------------------------------------------------------------------------------------
+def zero_insert(x, stride, size):
+    n, c, h, w = x.shape
+    H, W = size
+    y = torch.empty((n, c, H, W), dtype=torch.float32, device=x.device)
+    call("cl4_zero_insert", ptr(x), ptr(y), n * c, h, w, int(stride), H, W, stream())
+    return y
+
+
+def maxpool3x3s2_bwd(x, dy):
+    n, c, h, w = x.shape
+    dx = torch.empty_like(x)
+    call("cl4_maxpool3x3s2_bwd", ptr(x), ptr(dy), ptr(dx), n * c, h, w, dy.shape[2], dy.shape[3], stream())
+    return dx
+
+
+def add_act(a, b, act=ACT_LEAKY, slope=0.01):
+    if a.shape != b.shape:
+        raise RuntimeError("add_act: shape mismatch")
+    y = torch.empty_like(a)
+    call("cl4_add_act", ptr(a), ptr(b), ptr(y), a.numel(), act, C.c_float(slope), stream())
+    return y
+
+
+def act_bwd(y, dy, act=ACT_LEAKY, slope=0.01):
+    dx = torch.empty_like(dy)
+    call("cl4_act_bwd", ptr(y), ptr(dy), ptr(dx), y.numel(), act, C.c_float(slope), stream())
+    return dx
+
+
+def dgrad_weight(w):
+    """[cout,cin,k,k] -> packed operand of the input-gradient convolution (a stride-1 conv over dy with cin' = cout)."""
+    cout, cin, k, _ = w.shape
+    wt = torch.empty((cin, cout, k, k), dtype=torch.float32, device=w.device)
+    call("cl4_transpose_flip_weight", ptr(w), ptr(wt), cout, cin, k, stream())
+    return pack_conv_weight(wt, 0)
+
+
+def conv2d_dgrad(dy, wd, in_size, k, stride=1, pad=0, dil=1):
+    """Input gradient of conv2d(x, w, stride, pad, dil): `wd` = dgrad_weight(w); in_size = (hin, win) of x."""
+    hin, win = in_size
+    if k == 1 and pad == 0:
+        dx = conv2d(dy, wd, 1)
+        return dx if stride == 1 else zero_insert(dx, stride, (hin, win))
+    up = dy if stride == 1 else zero_insert(dy, stride, (hin + 2 * pad - dil * (k - 1), win + 2 * pad - dil * (k - 1)))
+    return conv2d(up, wd, k, stride=1, pad=dil * (k - 1) - pad, dil=dil)

@@ -334,6 +334,20 @@ int cl4_p1_seg_loss(const float* seg, const float* old_seg, const float* masks, 
                     int h, int w, float alpha, float icarl_bkg, float weight, float* loss, float* dseg, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Building blocks of the train-mode backward of the body / heads (phase 1 / step 0).
+ * ------------------------------------------------------------------------ */
+/* y[.., s*i, s*j] = x[.., i, j], zero elsewhere: spreads the output gradient of a strided conv onto the stride-1 grid so
+ * that its input gradient is cl4_conv2d_fwd with the cl4_transpose_flip_weight weights (models/resnet.py strided convs). */
+int cl4_zero_insert(const float* x, float* y, long planes, int h, int w, int stride, int H, int W, void* stream);
+/* nn.MaxPool2d(3, stride=2, padding=1) backward (models/resnet.py:63): deterministic gather, first maximum wins. */
+int cl4_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, long planes, int hin, int win, int hout, int wout, void* stream);
+/* y = act(a + b) — the residual add + in-place activation of modules/residual.py:91-93; dx = dy * act'(.) from the output. */
+int cl4_add_act(const float* a, const float* b, float* y, long n, int act, float slope, void* stream);
+int cl4_act_bwd(const float* y, const float* dy, float* dx, long n, int act, float slope, void* stream);
+/* w [cout,cin,k,k] -> wt [cin,cout,k,k] with both spatial axes reversed (the weight of the input-gradient convolution). */
+int cl4_transpose_flip_weight(const float* w, float* wt, int cout, int cin, int k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,69 @@
+"""GPU parity of the backward building blocks (csrc/backward.hip + the conv kernels run as input-gradient convolutions)
+against PyTorch-CPU autograd: conv input gradients for the stride / padding / dilation combinations of ResNet101 +
+DeepLabV3 + PseudoLabeler, max-pool backward including ties, residual add + leaky-ReLU and its derivative."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("case", [
+    (2, 24, 17, 17, 40, 1, 1, 0, 1),     # 1x1
+    (2, 24, 17, 17, 40, 1, 2, 0, 1),     # 1x1 stride 2 (proj_conv of the first block of res3 / res4)
+    (2, 16, 18, 18, 32, 1, 2, 0, 1),     # even input size
+    (2, 24, 17, 19, 24, 3, 1, 1, 1),     # 3x3
+    (2, 24, 17, 17, 24, 3, 2, 1, 1),     # 3x3 stride 2
+    (1, 16, 18, 20, 24, 3, 2, 1, 1),     # 3x3 stride 2, even sizes
+    (1, 16, 21, 21, 24, 3, 1, 2, 2),     # res5 dilation 2
+    (1, 32, 33, 33, 16, 3, 1, 12, 12),   # ASPP dilation 12
+    (1, 32, 33, 33, 16, 3, 1, 18, 18),   # dilation 18: most taps fall outside
+])
+def test_conv_input_gradient(gpu, case):
+    from cl4wsis_amd import ops
+    n, cin, h, w, cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn(cout, cin, k, k, generator=g, dtype=torch.float64) / (cin * k * k) ** 0.5
+    y = F.conv2d(x, wt, stride=s, padding=p, dilation=d)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    wd = ops.dgrad_weight(wt.float().to(gpu))
+    dx = ops.conv2d_dgrad(dy.float().to(gpu), wd, (h, w), k, stride=s, pad=p, dil=d)
+    torch.cuda.synchronize()
+    assert dx.shape == x.shape
+    assert _rel(dx, x.grad.float()) < 1e-5
+
+
+def test_maxpool_backward_with_ties(gpu):
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for shape in [(2, 5, 17, 17), (1, 3, 18, 20), (1, 2, 5, 4)]:
+        x = torch.randint(0, 4, shape, generator=g).float()     # many equal values inside every window
+        x[0, 0, :2] = float("-inf")
+        xr = x.clone().requires_grad_(True)
+        y = F.max_pool2d(xr, 3, 2, 1)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        dx = ops.maxpool3x3s2_bwd(x.to(gpu), dy.to(gpu))
+        assert torch.equal(dx.cpu(), xr.grad)
+
+
+def test_add_act_and_derivative(gpu):
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(3, 7, 9, 5, generator=g), torch.randn(3, 7, 9, 5, generator=g)
+    dy = torch.randn(a.shape, generator=g)
+    for act, slope, fn in ((ops.ACT_LEAKY, 0.01, lambda t: F.leaky_relu(t, 0.01)), (ops.ACT_RELU, 0.0, F.relu),
+                           (ops.ACT_NONE, 0.0, lambda t: t)):
+        ar = a.clone().requires_grad_(True)
+        y = fn(ar + b)
+        y.backward(dy)
+        yd = ops.add_act(a.to(gpu), b.to(gpu), act, slope)
+        assert torch.equal(yd.cpu(), y.detach())
+        assert torch.equal(ops.act_bwd(yd, dy.to(gpu), act, slope).cpu(), ar.grad)
