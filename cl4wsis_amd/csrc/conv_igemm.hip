@@ -1164,7 +1164,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16x3(WgradArgs a) {
   // Per staged B row (ci, tap): element offset relative to the pixel's (iy0, ix0) corner and the tap's bit in the
   // per-pixel validity mask (computed once per K tile and lane for all KS*KS taps).
   int b_off[RB];
-  unsigned b_bit[RB];
+  typedef unsigned long long mask_t;       // one bit per filter tap (49 taps for the 7x7 stem)
+  mask_t b_bit[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
     int row = wave * (BN / 4) + 2 * r + rsub;
@@ -1175,7 +1176,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16x3(WgradArgs a) {
     int t = jc - ci * KHW;
     int ky = t / KS;
     b_off[r] = (a.in_coff + ci) * HWi + ky * a.dil * a.win + (t - ky * KS) * a.dil;
-    b_bit[r] = ok ? 1u << t : 0u;
+    b_bit[r] = ok ? (mask_t)1 << t : (mask_t)0;
   }
   // 32-bit buffer addressing (host guarantees < 2 GiB tensors): masked elements read 0 through an out-of-range offset
   constexpr unsigned OOB = 0x80000000u;
@@ -1195,15 +1196,15 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16x3(WgradArgs a) {
     int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
     const int dybase = (n * a.out_ctot + a.out_coff) * HWo + hw;
     const int xbase = n * a.in_ctot * HWi + iy0 * a.win + ix0;
-    unsigned vmask = 0;                       // bit t: tap t of this pixel reads inside the image
+    mask_t vmask = 0;                         // bit t: tap t of this pixel reads inside the image
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
       for (int kx = 0; kx < KS; ++kx) {
         const bool in = (unsigned)(iy0 + ky * a.dil) < (unsigned)a.hin && (unsigned)(ix0 + kx * a.dil) < (unsigned)a.win;
-        vmask |= in ? 1u << (ky * KS + kx) : 0u;
+        vmask |= in ? (mask_t)1 << (ky * KS + kx) : (mask_t)0;
       }
-    vmask = pv ? vmask : 0u;
+    vmask = pv ? vmask : (mask_t)0;
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       int co = m0 + wave * (BM / 4) + 2 * r + rsub;

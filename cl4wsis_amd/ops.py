@@ -387,6 +387,11 @@ def bn_train_bwd(x, dy, mean, var, gamma, beta, dgamma, dbeta, eps=1e-5, act=ACT
     return dx
 
 
+def _world(group=None):
+    import torch.distributed as dist
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
 def _allreduce_sum(t, group):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -407,7 +412,7 @@ def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momen
     if extra_sums is not None:
         sums += extra_sums
     _allreduce_sum(sums, group)
-    count = float(sums[2 * c].item()) if (extra_sums is not None or group is not None) else float(n * h * w)
+    count = float(sums[2 * c].item()) if (extra_sums is not None or _world(group) > 1) else float(n * h * w)
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     var = torch.empty(c, dtype=torch.float32, device=x.device)
     call("cl4_bn_sync_stats_final", ptr(sums), C.c_double(count), ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),

@@ -41,31 +41,33 @@ def _bn_relu(x, sd, p, training, relu=True):
     return F.relu(y) if relu else y
 
 
-def bottleneck(x, sd, p, stride, dil):
+def bottleneck(x, sd, p, stride, dil, training=False):
     """ResidualBlock.forward — modules/residual.py:84-97 (bottleneck variant, :66-76)."""
     if (p + ".proj_conv.weight") in sd:
         r = F.conv2d(x, sd[p + ".proj_conv.weight"], stride=stride)
-        r = _abn(r, sd, p + ".proj_bn", act=False)
+        r = _abn(r, sd, p + ".proj_bn", act=False, training=training)
     else:
         r = x
-    y = _abn(F.conv2d(x, sd[p + ".convs.conv1.weight"]), sd, p + ".convs.bn1")
-    y = _abn(F.conv2d(y, sd[p + ".convs.conv2.weight"], stride=stride, padding=dil, dilation=dil), sd, p + ".convs.bn2")
-    y = _abn(F.conv2d(y, sd[p + ".convs.conv3.weight"]), sd, p + ".convs.bn3", act=False)
+    y = _abn(F.conv2d(x, sd[p + ".convs.conv1.weight"]), sd, p + ".convs.bn1", training=training)
+    y = _abn(F.conv2d(y, sd[p + ".convs.conv2.weight"], stride=stride, padding=dil, dilation=dil), sd, p + ".convs.bn2",
+             training=training)
+    y = _abn(F.conv2d(y, sd[p + ".convs.conv3.weight"]), sd, p + ".convs.bn3", act=False, training=training)
     return F.leaky_relu(y + r, SLOPE)
 
 
-def resnet_body(x, sd, p="body", structure=RESNET101, output_stride=16):
-    """ResNet.forward with keep_outputs — models/resnet.py:106-123; strides/dilations :49-55,101-104."""
+def resnet_body(x, sd, p="body", structure=RESNET101, output_stride=16, training=False):
+    """ResNet.forward with keep_outputs — models/resnet.py:106-123; strides/dilations :49-55,101-104. training=True uses
+    batch statistics (InPlaceABNSync in train mode: step 0 / phase 1) and updates the running statistics in `sd`."""
     dilation = [1, 1, 1, 2] if output_stride == 16 else [1, 1, 2, 4]
     y = F.conv2d(x, sd[p + ".mod1.conv1.weight"], stride=2, padding=3)
-    y = _abn(y, sd, p + ".mod1.bn1")
+    y = _abn(y, sd, p + ".mod1.bn1", training=training)
     y = F.max_pool2d(y, 3, stride=2, padding=1)
     outs = [y]
     for mod_id, num in enumerate(structure):
         d = dilation[mod_id]
         for b in range(num):
             s = 2 if (d == 1 and b == 0 and mod_id > 0) else 1
-            y = bottleneck(y, sd, f"{p}.mod{mod_id + 2}.block{b + 1}", s, d)
+            y = bottleneck(y, sd, f"{p}.mod{mod_id + 2}.block{b + 1}", s, d, training=training)
         outs.append(y)
     return outs
 

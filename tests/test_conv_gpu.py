@@ -112,6 +112,9 @@ def test_conv_channel_slices(gpu):
     (2, 96, 33, 33, 160, 3, 1, 3, 3),
     (3, 40, 21, 19, 50, 3, 1, 1, 1),
     (2, 128, 33, 33, 2, 1, 1, 0, 1),
+    (2, 3, 65, 65, 64, 7, 2, 3, 1),        # stem: 49 taps, stride 2
+    (2, 32, 33, 33, 48, 3, 2, 1, 1),       # strided 3x3
+    (1, 24, 33, 33, 40, 3, 1, 12, 12),     # ASPP dilation
 ])
 def test_conv_wgrad(gpu, case):
     from cl4wsis_amd import ops
