@@ -120,6 +120,7 @@ _decl("cl4_zero_insert", _P, _P, _L, _I, _I, _I, _I, _I, _P)
 _decl("cl4_maxpool3x3s2_bwd", _P, _P, _P, _L, _I, _I, _I, _I, _P)
 _decl("cl4_add_act", _P, _P, _P, _L, _I, _F, _P)
 _decl("cl4_act_bwd", _P, _P, _P, _L, _I, _F, _P)
+_decl("cl4_add_per_plane", _P, _P, _L, _I, _F, _P)
 _decl("cl4_transpose_flip_weight", _P, _P, _I, _I, _I, _P)
 _decl("cl4_sgd_step", _P, _P, _P, _L, _F, _P, _F, _F, _I, _P)
 _decl("cl4_pamr", _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, C.c_size_t, _P)

@@ -85,6 +85,14 @@ __global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restr
   }
 }
 
+// y[pl][:] += scale * v[pl]: the broadcast add of the image-pooling branch (modules/deeplab.py:64-67) and, with
+// scale = 1/hw, the backward of the global mean.
+__global__ void add_per_plane_kernel(float* __restrict__ y, const float* __restrict__ v, long planes, int hw, float scale) {
+  const long total = planes * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    y[i] += scale * v[i / hw];
+}
+
 __global__ void transpose_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int cin, int k) {
   const long total = (long)cout * cin * k * k;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -128,6 +136,13 @@ extern "C" int cl4_add_act(const float* a, const float* b, float* y, long n, int
 extern "C" int cl4_act_bwd(const float* y, const float* dy, float* dx, long n, int act, float slope, void* stream) {
   CL4_REQUIRE(y && dy && dx && n > 0, "act_bwd: bad arguments");
   hipLaunchKernelGGL(act_bwd_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), y, dy, dx, n, act, slope);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_add_per_plane(float* y, const float* v, long planes, int hw, float scale, void* stream) {
+  CL4_REQUIRE(y && v && planes > 0 && hw > 0, "add_per_plane: bad arguments");
+  hipLaunchKernelGGL(add_per_plane_kernel, dim3(cl4::stream_grid(planes * hw, 256)), dim3(256), 0, cl4::as_stream(stream), y, v,
+                     planes, hw, scale);
   return cl4::launch_status();
 }
 

@@ -322,6 +322,11 @@ def axpy_(y, x, alpha=1.0):
     return y
 
 
+def scale_(y, alpha):
+    """y *= alpha (cl4_axpy with x aliased to y: y += (alpha - 1) * y)."""
+    return axpy_(y, y, float(alpha) - 1.0)
+
+
 def copy_channels(x, out, c, in_coff=0, out_coff=0):
     n, in_ctot = x.shape[:2]
     hw = x.shape[2] * x.shape[3]
@@ -858,6 +863,15 @@ def act_bwd(y, dy, act=ACT_LEAKY, slope=0.01):
     dx = torch.empty_like(dy)
     call("cl4_act_bwd", ptr(y), ptr(dy), ptr(dx), y.numel(), act, C.c_float(slope), stream())
     return dx
+
+
+def add_per_plane_(y, v, scale=1.0):
+    """y [n,c,h,w] += scale * v [n,c] (broadcast over the plane)."""
+    n, c, h, w = y.shape
+    if v.numel() != n * c:
+        raise RuntimeError("add_per_plane_: v must hold one value per (n, c) plane")
+    call("cl4_add_per_plane", ptr(y), ptr(v), n * c, h * w, C.c_float(scale), stream())
+    return y
 
 
 def dgrad_weight(w):

@@ -345,6 +345,9 @@ int cl4_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, long planes
 /* y = act(a + b) — the residual add + in-place activation of modules/residual.py:91-93; dx = dy * act'(.) from the output. */
 int cl4_add_act(const float* a, const float* b, float* y, long n, int act, float slope, void* stream);
 int cl4_act_bwd(const float* y, const float* dy, float* dx, long n, int act, float slope, void* stream);
+/* y[plane][:] += scale * v[plane] — broadcast add of DeepLabV3's image-pooling branch in training mode
+ * (modules/deeplab.py:64-67) and, with scale = 1/hw, the backward of the global mean. */
+int cl4_add_per_plane(float* y, const float* v, long planes, int hw, float scale, void* stream);
 /* w [cout,cin,k,k] -> wt [cin,cout,k,k] with both spatial axes reversed (the weight of the input-gradient convolution). */
 int cl4_transpose_flip_weight(const float* w, float* wt, int cout, int cin, int k, void* stream);
 

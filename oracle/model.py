@@ -169,10 +169,10 @@ def forward_full(x, sd, pooling=32, training=False, dropout_mask=None):
     return pred, aux
 
 
-def pseudolabeler(x, sd, p=""):
-    """PseudoLabeler.forward (eval) — wss/modules.py:335-343."""
-    y = _abn(F.conv2d(x, sd[p + "conv1.weight"], padding=1), sd, p + "norm1")
-    y = _abn(F.conv2d(y, sd[p + "conv2.weight"], padding=1), sd, p + "norm2")
+def pseudolabeler(x, sd, p="", training=False):
+    """PseudoLabeler.forward — wss/modules.py:335-343 (training=True: batch statistics, phase 1)."""
+    y = _abn(F.conv2d(x, sd[p + "conv1.weight"], padding=1), sd, p + "norm1", training=training)
+    y = _abn(F.conv2d(y, sd[p + "conv2.weight"], padding=1), sd, p + "norm2", training=training)
     return F.conv2d(y, sd[p + "cls.weight"], sd[p + "cls.bias"])
 
 
