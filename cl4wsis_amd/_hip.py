@@ -121,11 +121,16 @@ _decl("cl4_maxpool3x3s2_bwd", _P, _P, _P, _L, _I, _I, _I, _I, _P)
 _decl("cl4_add_act", _P, _P, _P, _L, _I, _F, _P)
 _decl("cl4_act_bwd", _P, _P, _P, _L, _I, _F, _P)
 _decl("cl4_add_per_plane", _P, _P, _L, _I, _F, _P)
+_decl("cl4_rot90", _P, _P, _L, _I, _I, _I, _P)
+_decl("cl4_channel_affine", _P, _P, _I, _I, _I, _P, _P, _P)
+_decl("cl4_randrop_loss", _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_transpose_flip_weight", _P, _P, _I, _I, _I, _P)
+_decl("cl4_random_labels", _P, _L, C.c_uint64, _I, _P)
 _decl("cl4_sgd_step", _P, _P, _P, _L, _F, _P, _F, _F, _I, _P)
 _decl("cl4_pamr", _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, C.c_size_t, _P)
 _decl("cl4_ngwp_focal_bce", _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_pseudo_gtmask", _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P, _P)
+_decl("cl4_softmax_channels", _P, _P, _I, _I, _I, _I, _P)
 _decl("cl4_binarize", _P, _P, _P, _I, _I, _I, _I, _P)
 _decl("cl4_balanced_mask_loss_ce", _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_bce_ignore_mean", _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)

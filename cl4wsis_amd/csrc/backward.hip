@@ -93,6 +93,31 @@ __global__ void add_per_plane_kernel(float* __restrict__ y, const float* __restr
     y[i] += scale * v[i / hw];
 }
 
+// torch.rot90(x, k, dims=(-2,-1)) on square planes: out[i][j] = x[j][h-1-i] (k=1), x[h-1-i][h-1-j] (k=2), x[h-1-j][i] (k=3).
+__global__ void rot90_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int h, int k) {
+  const long hw = (long)h * h, total = planes * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pl = i / hw;
+    const int q = (int)(i - pl * hw), r = q / h, c = q % h;
+    int sr = r, sc = c;
+    if (k == 1) { sr = c; sc = h - 1 - r; }
+    else if (k == 2) { sr = h - 1 - r; sc = h - 1 - c; }
+    else if (k == 3) { sr = h - 1 - c; sc = r; }
+    y[i] = x[pl * hw + (long)sr * h + sc];
+  }
+}
+
+// y[n][c][:] = x[n][c][:] * scale[c] + shift[c] (utils/utils.py:23-40 `denorm`: t.mul_(s).add_(m), no contraction).
+__global__ void channel_affine_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int c, int hw,
+                                      const float* __restrict__ scale, const float* __restrict__ shift) {
+  const long total = planes * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)((i / hw) % c);
+    const float t = x[i] * scale[ch];
+    y[i] = t + shift[ch];
+  }
+}
+
 __global__ void transpose_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int cin, int k) {
   const long total = (long)cout * cin * k * k;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -143,6 +168,21 @@ extern "C" int cl4_add_per_plane(float* y, const float* v, long planes, int hw, 
   CL4_REQUIRE(y && v && planes > 0 && hw > 0, "add_per_plane: bad arguments");
   hipLaunchKernelGGL(add_per_plane_kernel, dim3(cl4::stream_grid(planes * hw, 256)), dim3(256), 0, cl4::as_stream(stream), y, v,
                      planes, hw, scale);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_rot90(const float* x, float* y, long planes, int h, int w, int k, void* stream) {
+  CL4_REQUIRE(x && y && x != y && planes > 0 && h > 0 && h == w, "rot90: square planes expected");
+  k = ((k % 4) + 4) % 4;
+  hipLaunchKernelGGL(rot90_kernel, dim3(cl4::stream_grid(planes * h * h, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, planes, h, k);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_channel_affine(const float* x, float* y, int n, int c, int hw, const float* scale, const float* shift, void* stream) {
+  CL4_REQUIRE(x && y && scale && shift && n > 0 && c > 0 && hw > 0, "channel_affine: bad arguments");
+  const long planes = (long)n * c;
+  hipLaunchKernelGGL(channel_affine_kernel, dim3(cl4::stream_grid(planes * hw, 256)), dim3(256), 0, cl4::as_stream(stream), x, y,
+                     planes, c, hw, scale, shift);
   return cl4::launch_status();
 }
 

@@ -235,6 +235,17 @@ __global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, uint64_t
   }
 }
 
+// Uniform integer draws in [0, modulus): splitmix64 of (seed, element index) — RandropLoss' random old classes.
+__global__ void random_labels_kernel(int* __restrict__ out, long n, uint64_t seed, int modulus) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    out[i] = (int)((z >> 33) % (uint64_t)modulus);
+  }
+}
+
 int check_shape(const BnShape& s) {
   CL4_REQUIRE(s.n > 0 && s.c > 0 && s.hw > 0, "bn: non-positive dims");
   CL4_REQUIRE(s.coff >= 0 && s.coff + s.c <= s.ctot, "bn: channel slice out of range");
@@ -383,6 +394,12 @@ extern "C" int cl4_dropout_mask(uint8_t* keep, long n, uint64_t seed, float p, v
   CL4_REQUIRE(keep && n > 0 && p >= 0.f && p < 1.f, "dropout_mask: bad arguments");
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), keep, n, seed,
                      (const uint64_t*)nullptr, p);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_random_labels(int* out, long n, uint64_t seed, int modulus, void* stream) {
+  CL4_REQUIRE(out && n > 0 && modulus > 0, "random_labels: bad arguments");
+  hipLaunchKernelGGL(random_labels_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), out, n, seed, modulus);
   return cl4::launch_status();
 }
 

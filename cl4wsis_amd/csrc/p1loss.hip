@@ -349,6 +349,54 @@ __global__ __launch_bounds__(256) void seg_grad_kernel(SegArgs a) {   // grid (n
   for (int k = 0; k < a.tot; ++k) db[(long)k * a.hw] = gs * (sigmoidf(sb[(long)k * a.hw]) - tgt[k]);
 }
 
+// RandropLoss.forward — utils/wss_loss.py:227-248: at pixels where the largest new-class reference probability
+// (sigmoid(masks) * labels) exceeds 0.5, a randomly drawn OLD class (drawn by the caller; the reference draws with the CPU
+// generator) is pushed as a positive: -log sigmoid(x[neg]) averaged over those pixels. partial[2*blk] = loss sum,
+// partial[2*blk+1] = pixel count; the gradient is written unscaled and normalised by randrop_scale_kernel.
+__global__ __launch_bounds__(256) void randrop_kernel(const float* __restrict__ x, const float* __restrict__ masks,
+                                                      const float* __restrict__ labels, const int* __restrict__ neg,
+                                                      const float* __restrict__ mask_labels, float* __restrict__ dx,
+                                                      double* __restrict__ partial, int b, int tot, int cold, int hw) {
+  const long N = (long)b * hw;
+  double v = 0.0, cnt = 0.0;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < N; p += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(p / hw), q = (int)(p % hw);
+    const float* mb = masks + (long)n * tot * hw + q;
+    float mx = -INFINITY;
+    for (int k = cold; k < tot; ++k) mx = fmaxf(mx, sigmoidf(mb[(long)k * hw]) * labels[(long)n * (tot - 1) + k - 1]);
+    int t = neg[p];
+    bool live = mx > 0.5f && t >= 0 && t < tot;
+    // --no_mask: a drawn class whose image-level label is 0 is ignored (class 0 = background is always kept)
+    if (live && mask_labels && t > 0 && mask_labels[(long)n * (tot - 1) + t - 1] == 0.f) live = false;
+    const float* xb = x + (long)n * tot * hw + q;
+    if (dx) {
+      float* db = dx + (long)n * tot * hw + q;
+      for (int k = 0; k < tot; ++k) db[(long)k * hw] = (live && k == t) ? sigmoidf(xb[(long)k * hw]) - 1.f : 0.f;
+    }
+    if (live) { v += (double)bce_logits(xb[(long)t * hw], 1.f); cnt += 1.0; }
+  }
+  v = block_sum_d(v);
+  cnt = block_sum_d(cnt);
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = v; partial[2 * blockIdx.x + 1] = cnt; }
+}
+
+__global__ __launch_bounds__(256) void randrop_final_kernel(const double* __restrict__ partial, int n, float* __restrict__ loss,
+                                                            float* __restrict__ inv_count) {
+  double s = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { s += partial[2 * i]; c += partial[2 * i + 1]; }
+  s = block_sum_d(s);
+  c = block_sum_d(c);
+  if (threadIdx.x == 0) {
+    loss[0] = c > 0.0 ? (float)(s / c) : 0.f;
+    inv_count[0] = c > 0.0 ? (float)(1.0 / c) : 0.f;
+  }
+}
+
+__global__ void scale_by_dev_kernel(float* __restrict__ x, long n, const float* __restrict__ s) {
+  const float f = *s;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= f;
+}
+
 constexpr int RED_GRID = 1024;
 
 }  // namespace
@@ -358,7 +406,7 @@ extern "C" size_t cl4_p1loss_workspace_bytes(int b, int tot, int h, int w) {
   const size_t nchunk = (size_t)cl4::cdiv((long)h * w, 256);
   size_t seg = (size_t)b * nchunk * (1 + tot) * sizeof(double) + ((size_t)b + 1) * sizeof(float);
   size_t pg = (size_t)b * NC_MAX * (2 * sizeof(double) + 3 * sizeof(float));
-  size_t red = (size_t)RED_GRID * sizeof(double);
+  size_t red = (size_t)RED_GRID * 2 * sizeof(double) + 64;
   size_t m = seg > pg ? seg : pg;
   return (m > red ? m : red) + 256;
 }
@@ -458,5 +506,28 @@ extern "C" int cl4_p1_seg_loss(const float* seg, const float* old_seg, const flo
   hipLaunchKernelGGL(seg_sums_kernel, dim3(a.nchunk, b), dim3(256), 0, st, a);
   hipLaunchKernelGGL(seg_final_kernel, dim3(1), dim3(256), 0, st, a);
   if (dseg) hipLaunchKernelGGL(seg_grad_kernel, dim3(a.nchunk, b), dim3(256), 0, st, a);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_randrop_loss(const float* x, const float* masks, const float* labels, const int* neg_labels,
+                                const float* mask_labels, int b, int tot, int cold, int h, int w, float* loss, float* dx,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  CL4_REQUIRE(x && masks && labels && neg_labels && loss && workspace, "randrop_loss: null pointer");
+  CL4_REQUIRE(b > 0 && cold > 0 && cold < tot && h > 0 && w > 0, "randrop_loss: bad dims");
+  if (workspace_bytes < (size_t)RED_GRID * 2 * sizeof(double) + 64) {
+    cl4::set_error("randrop_loss: workspace too small");
+    return CL4_ENOSPC;
+  }
+  hipStream_t st = cl4::as_stream(stream);
+  const long N = (long)b * h * w;
+  int grid = cl4::stream_grid(N, 256);
+  if (grid > RED_GRID) grid = RED_GRID;
+  double* partial = (double*)workspace;
+  float* inv = (float*)(partial + (size_t)RED_GRID * 2);
+  hipLaunchKernelGGL(randrop_kernel, dim3(grid), dim3(256), 0, st, x, masks, labels, neg_labels, mask_labels, dx, partial, b, tot, cold,
+                     h * w);
+  hipLaunchKernelGGL(randrop_final_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, grid, loss, inv);
+  if (dx) hipLaunchKernelGGL(scale_by_dev_kernel, dim3(cl4::stream_grid((long)b * tot * h * w, 256)), dim3(256), 0, st, dx,
+                             (long)b * tot * h * w, (const float*)inv);
   return cl4::launch_status();
 }

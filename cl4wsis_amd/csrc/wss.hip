@@ -441,6 +441,20 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
   if (threadIdx.x == 0) out[0] = (float)(s * scale);
 }
 
+// softmax over the channel axis of [b, c, hw] (train.py:372-373 `int_masks.softmax(dim=1)`).
+__global__ __launch_bounds__(256) void softmax_channels_kernel(const float* __restrict__ x, float* __restrict__ y, int b, int c, int hw) {
+  const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (p >= (long)b * hw) return;
+  const int n = (int)(p / hw), q = (int)(p % hw);
+  const float* xb = x + (long)n * c * hw + q;
+  float* yb = y + (long)n * c * hw + q;
+  float mx = -INFINITY;
+  for (int k = 0; k < c; ++k) mx = fmaxf(mx, xb[(long)k * hw]);
+  float den = 0.f;
+  for (int k = 0; k < c; ++k) den += expf(xb[(long)k * hw] - mx);
+  for (int k = 0; k < c; ++k) yb[(long)k * hw] = expf(xb[(long)k * hw] - mx) / den;
+}
+
 bool make_dil(const int* dilations, int ndil, Dil* out) {
   if (!dilations || ndil < 1 || ndil > MAX_DIL) return false;
   out->n = ndil;
@@ -593,5 +607,12 @@ extern "C" int cl4_bce_ignore_mean(const float* x, const long long* target, int 
   const int grid = cl4::stream_grid(N, 256);
   hipLaunchKernelGGL(bce_ignore_kernel, dim3(grid), dim3(256), 0, st, x, target, dx, (double*)workspace, b, c, hw, ignore_index);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, grid, 1.0 / (double)N, loss);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_softmax_channels(const float* x, float* y, int b, int c, int h, int w, void* stream) {
+  CL4_REQUIRE(x && y && b > 0 && c > 0 && h > 0 && w > 0, "softmax_channels: bad arguments");
+  hipLaunchKernelGGL(softmax_channels_kernel, dim3(cl4::cdiv((long)b * h * w, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, b, c,
+                     h * w);
   return cl4::launch_status();
 }

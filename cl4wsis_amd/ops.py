@@ -417,7 +417,8 @@ def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momen
     if extra_sums is not None:
         sums += extra_sums
     _allreduce_sum(sums, group)
-    count = float(sums[2 * c].item()) if (extra_sums is not None or _world(group) > 1) else float(n * h * w)
+    # equal shards on every rank (run.py:66 splits the batch evenly): the global count needs no host round trip
+    count = float(sums[2 * c].item()) if extra_sums is not None else float(n * h * w) * _world(group)
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     var = torch.empty(c, dtype=torch.float32, device=x.device)
     call("cl4_bn_sync_stats_final", ptr(sums), C.c_double(count), ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
@@ -890,3 +891,47 @@ def conv2d_dgrad(dy, wd, in_size, k, stride=1, pad=0, dil=1):
         return dx if stride == 1 else zero_insert(dx, stride, (hin, win))
     up = dy if stride == 1 else zero_insert(dy, stride, (hin + 2 * pad - dil * (k - 1), win + 2 * pad - dil * (k - 1)))
     return conv2d(up, wd, k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
+
+
+def rot90(x, k, out=None):
+    """torch.rot90(x, k, dims=(-2, -1)) for square maps."""
+    n, c, h, w = x.shape
+    y = torch.empty_like(x) if out is None else out
+    call("cl4_rot90", ptr(x), ptr(y), n * c, h, w, int(k), stream())
+    return y
+
+
+def softmax_channels(x):
+    _f32c(x, "softmax_channels")
+    b, c, h, w = x.shape
+    y = torch.empty_like(x)
+    call("cl4_softmax_channels", ptr(x), ptr(y), b, c, h, w, stream())
+    return y
+
+
+def channel_affine(x, scale, shift):
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    call("cl4_channel_affine", ptr(x), ptr(y), n, c, h * w, ptr(scale), ptr(shift), stream())
+    return y
+
+
+def randrop_loss(x, masks, labels, neg_labels, cold, mask_labels=None, with_grad=True):
+    """RandropLoss of utils/wss_loss.py:227-248 with caller-drawn random old classes (int32 [b,h,w])."""
+    _f32c(x, "randrop x"), _f32c(masks, "randrop masks"), _f32c(labels, "randrop labels")
+    b, tot, h, w = x.shape
+    if neg_labels.dtype != torch.int32 or tuple(neg_labels.shape) != (b, h, w) or not neg_labels.is_contiguous():
+        raise RuntimeError("randrop_loss: contiguous int32 neg_labels [b,h,w] expected")
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if with_grad else None
+    ws = _p1_ws(x, b, tot, h, w)
+    call("cl4_randrop_loss", ptr(x), ptr(masks), ptr(labels), ptr(neg_labels), ptr(mask_labels) if mask_labels is not None else None,
+         b, tot, int(cold), h, w, ptr(loss), ptr(dx), ptr(ws), ws.numel(), stream())
+    return loss, dx
+
+
+def random_labels(shape, modulus, seed, device):
+    """int32 tensor of uniform draws in [0, modulus) from the counter-based generator of the Dropout masks."""
+    out = torch.empty(shape, dtype=torch.int32, device=device)
+    call("cl4_random_labels", ptr(out), out.numel(), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), int(modulus), stream())
+    return out

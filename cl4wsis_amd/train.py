@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops, tasks
-from .optim import FusedAdam
+from .optim import FusedAdam, FusedSGD
 from .parallel import GradBuckets, world_size
 from .scheduler import get_scheduler
 from .segmentation_module import get_norm, make_model
@@ -76,6 +76,9 @@ class Trainer:
             if opts.peak_from == "peakgenerator":
                 self.peakgenerator = PeakGenerator(in_channel=self.tot_classes, num_classes=self.tot_classes - 1,
                                                    old_classes=self.old_classes - 1)
+        self.use_aff = opts.affinity                      # train.py:68
+        self.pseudo_epoch = opts.pseudo_ep                # train.py:70
+        self.lde = opts.loss_de                           # train.py:120-121
         self.center_loss_weight = 200
         self.offset_loss_weight = 0.01
         self.model.to(self.device)          # parameters must be resident before the optimizer aliases them
@@ -114,9 +117,13 @@ class Trainer:
                 params.append({"params": tr(self.pseudolabeler), "weight_decay": opts.weight_decay, "lr": opts.lr_pseudo})
                 if self.peakgenerator is not None:
                     params.append({"params": tr(self.peakgenerator), "weight_decay": opts.weight_decay, "lr": opts.lr_pseudo})
-        if opts.optim != "adam":
-            raise NotImplementedError(f"--optim {opts.optim}: phase 2 uses adam (scripts/run.sh:39); sgd is the phase-1 row")
-        optimizer = FusedAdam(params, lr=opts.lr, weight_decay=opts.weight_decay)
+        params = [g for g in params if g["params"]]
+        if opts.optim == "sgd":       # train.py:179-180 (phase 1, scripts/run.sh:33)
+            optimizer = FusedSGD(params, lr=opts.lr, momentum=0.9, nesterov=True)
+        elif opts.optim == "adam":
+            optimizer = FusedAdam(params, lr=opts.lr, weight_decay=opts.weight_decay)
+        else:
+            raise NotImplementedError(f"--optim {opts.optim}")
         if not hasattr(opts, "max_iters"):
             opts.max_iters = getattr(opts, "epochs", 1) * 1000
         if not hasattr(opts, "start_decay"):
@@ -127,6 +134,8 @@ class Trainer:
         """Replaces the DDP wrappers of train.py:187-196: gradients of the flat buffer are averaged over RCCL."""
         self.buckets = GradBuckets(self.optimizer.grads_fb, bucket_bytes=16 << 20)
         self._branch = self.model.instance_branch()
+        self._p1 = None
+        self._cur_epoch = 0
         self._grad_map = {id(p): self.optimizer.grad_view(p) for g in self.optimizer.param_groups for p in g["params"]}
         self._bn_counters = [b for n, b in self.model.named_buffers()
                              if n.endswith("num_batches_tracked") and n.startswith(("decoder.", "instance_head."))]
@@ -146,9 +155,11 @@ class Trainer:
         only consumes images and l1h (the other four are uploaded but unused by the reference, train.py:243-248).
         Returns a dict of device scalars (no host synchronisation)."""
         opts = self.opts
+        if self.weakly and opts.phase == 1:
+            return self._step_phase1(batch)
         if not (self.weakly and opts.phase == 2):
-            raise NotImplementedError("Trainer.step: only the phase-2 weakly-supervised step (BASELINE config 3) is built; "
-                                      "step 0 and phase 1 are later §8 rows")
+            raise NotImplementedError("Trainer.step: the weakly-supervised phase-1 and phase-2 steps (BASELINE configs 2, 3) are "
+                                      "built; step 0 (supervised) is a later §8 row")
         images, l1h = (batch[0], batch[-1])
         images = images.to(self.device, dtype=torch.float32).contiguous()
         l1h = l1h.to(self.device, dtype=torch.float32).contiguous()
@@ -174,6 +185,29 @@ class Trainer:
             self.scheduler.step()
         self._iter += 1
         return out
+
+    def _step_phase1(self, batch, cur_epoch=None, flac_angle=None, randrop_neg=None):
+        """One phase-1 iteration (train.py:241-566 with --phase 1) — see cl4wsis_amd/phase1.py."""
+        from .phase1 import Phase1Step
+        if self._p1 is None:
+            self._p1 = Phase1Step(self)
+        images, l1h = (batch[0], batch[-1])
+        images = images.to(self.device, dtype=torch.float32).contiguous()
+        l1h = l1h.to(self.device, dtype=torch.float32).contiguous()
+        self.model.train()
+        ops.AUTOTUNE = self._iter == 0 and os.environ.get("CL4_AUTOTUNE", "1") != "0"
+        try:
+            losses = self._p1.run(images, l1h, self._cur_epoch if cur_epoch is None else cur_epoch, flac_angle, randrop_neg)
+        finally:
+            ops.AUTOTUNE = False
+        for i in range(len(self.buckets.fb.sizes)):
+            self.buckets.ready(i)
+        self.buckets.finish()
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        self._iter += 1
+        return {"losses": losses}
 
     # HIP-graph path: iteration 0 runs eagerly (autotuning), iteration 1 captures the whole step — both streams, ~600
     # kernel launches — into one graph, and every later iteration is a copy of the batch into static buffers plus one
@@ -276,9 +310,11 @@ class Trainer:
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         interval = torch.zeros_like(total)
         n = 0
+        self._cur_epoch = cur_epoch
         for cur_step, batch in enumerate(train_loader):
             out = self.step(batch)
-            loss = out["losses"].sum()          # l_center + l_offset; the zeroed terms of train.py:524-529 vanish
+            l = out["losses"]                   # phase 2: l_center + l_offset (the zeroed terms of train.py:524-529 vanish)
+            loss = torch.stack([v.reshape(()) for v in l.values()]).sum() if isinstance(l, dict) else l.sum()
             total += loss
             interval += loss
             n += 1

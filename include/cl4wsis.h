@@ -148,6 +148,9 @@ int cl4_bn_train_bwd(const float* x, const float* dy, float* dx, int n, int c, i
                      const float* beta, float eps, int act, const uint8_t* keep, float keep_scale,
                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 int cl4_relu_bwd(const float* y, const float* dy, float* dx, long n, void* stream);
+/* int32 uniform draws in [0, modulus) (counter-based, like the Dropout masks): the random old classes of RandropLoss
+ * (utils/wss_loss.py:237; the reference draws them with the CPU generator, so the stream itself cannot be matched). */
+int cl4_random_labels(int* out, long n, uint64_t seed, int modulus, void* stream);
 /* Two-phase forms for cross-rank batch statistics — InPlaceABNSync in training mode (segmentation_module.py:17-29;
  * SURVEY.md §8 A2): BN (eps 1e-5, momentum 0.1) + leaky-ReLU(slope) / identity, statistics over ALL ranks.
  *   forward : cl4_bn_sync_stats_local -> host all-reduce(SUM) of sums[c*2] doubles and of the element count ->
@@ -289,6 +292,8 @@ int cl4_ngwp_focal_bce(const float* x, const float* labels, int b, int c, int h,
  * train.py:381-382 fused (labels NULL = no masking). out [b,c,h,w] of 0/1; thresholds [b,c] scratch/out. */
 int cl4_pseudo_gtmask(const float* mask, const float* labels, float* out, int b, int c, int h, int w, float cutoff_top,
                       float cutoff_bkg, float cutoff_low, float* thresholds, void* stream);
+/* softmax over the channel axis (train.py:372-373). */
+int cl4_softmax_channels(const float* x, float* y, int b, int c, int h, int w, void* stream);
 /* binarize(x * labels) — utils/wss_loss.py:188-190 (train.py:387). */
 int cl4_binarize(const float* x, const float* labels, float* out, int b, int c, int h, int w, void* stream);
 /* balanced_mask_loss_ce(mask, pseudo_gt, gt_labels) — wss/single_stage.py:43-80 (train.py:411); mask and pseudo_gt
@@ -330,6 +335,13 @@ int cl4_mse_loss(const float* x, const float* y, long n, float grad_scale, float
 /* l_seg — train.py:374-409: BCE of the new model's seg logits against [sigmoid(old seg) | alpha*binarize + (1-alpha)*soft]
  * with the background rule (icarl_bkg == -1: min), gated per image by the label-set match and normalised by the number of
  * gated images. seg/masks [b,tot,h,w], old_seg [b,cold,h,w], labels [b,tot-1]; dseg [b,tot,h,w] or NULL. */
+/* RandropLoss.forward — utils/wss_loss.py:227-248 (train.py:413-416). x [b,tot,h,w] logits, masks [b,tot,h,w] the detached
+ * PseudoLabeler logits (reference = sigmoid(masks) * labels), labels [b,tot-1], neg_labels int32 [b,h,w] the randomly
+ * drawn old classes in [0,cold) (the caller draws them; the reference uses the CPU generator), mask_labels = labels with
+ * --no_mask else NULL. loss = mean over the selected pixels of -log sigmoid(x[neg]) (0 when none); dx or NULL. */
+int cl4_randrop_loss(const float* x, const float* masks, const float* labels, const int* neg_labels, const float* mask_labels,
+                     int b, int tot, int cold, int h, int w, float* loss, float* dx, void* workspace, size_t workspace_bytes,
+                     void* stream);
 int cl4_p1_seg_loss(const float* seg, const float* old_seg, const float* masks, const float* labels, int b, int tot, int cold,
                     int h, int w, float alpha, float icarl_bkg, float weight, float* loss, float* dseg, void* workspace,
                     size_t workspace_bytes, void* stream);
@@ -348,6 +360,10 @@ int cl4_act_bwd(const float* y, const float* dy, float* dx, long n, int act, flo
 /* y[plane][:] += scale * v[plane] — broadcast add of DeepLabV3's image-pooling branch in training mode
  * (modules/deeplab.py:64-67) and, with scale = 1/hw, the backward of the global mean. */
 int cl4_add_per_plane(float* y, const float* v, long planes, int hw, float scale, void* stream);
+/* torch.rot90(x, k, dims=(-2,-1)) on square planes = torchvision `rotate` by k*90 degrees (train.py:317,324,330; FLAC). */
+int cl4_rot90(const float* x, float* y, long planes, int h, int w, int k, void* stream);
+/* y[n,c,:] = x[n,c,:] * scale[c] + shift[c] — `denorm` (utils/utils.py:23-40, train.py:376). */
+int cl4_channel_affine(const float* x, float* y, int n, int c, int hw, const float* scale, const float* shift, void* stream);
 /* w [cout,cin,k,k] -> wt [cin,cout,k,k] with both spatial axes reversed (the weight of the input-gradient convolution). */
 int cl4_transpose_flip_weight(const float* w, float* wt, int cout, int cin, int k, void* stream);
 

@@ -106,3 +106,107 @@ def p2_step(sd_new, sd_old, sd_pl, sd_pg, images, l1h, old_classes, pooling=32, 
                adam_state=adam_state, seg2b=out2["seg"], int_masks=int_masks,
                old_center=out_old["center"], old_offset=out_old["offset"])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Phase 1 (train.py:241-566 with --phase 1: body / head / classifier / PseudoLabeler / PeakGenerator train with SGD)
+# ---------------------------------------------------------------------------------------------------------------------
+DENORM_MEAN = (0.485, 0.456, 0.4069)      # utils/utils.py:23 (sic)
+DENORM_STD = (0.229, 0.224, 0.225)
+
+
+def _leaf(sd, keys):
+    for k in keys:
+        sd[k].requires_grad_(True)
+        sd[k].grad = None
+
+
+def p1_param_groups(sd_new, sd_pl, sd_pg, lr, lr_head, lr_pseudo, weight_decay):
+    """The parameter groups of train.py:144-177 for --phase 1 (branch 'none'): body, head, cls, PseudoLabeler,
+    PeakGenerator — (dict, key, lr, weight_decay) per trainable tensor."""
+    is_par = lambda k: k.endswith(".weight") or k.endswith(".bias")
+    out = []
+    for k in sd_new:
+        if not is_par(k):
+            continue
+        if k.startswith("body."):
+            out.append((sd_new, k, lr, weight_decay))
+        elif k.startswith("head.") or k.startswith("cls."):
+            out.append((sd_new, k, lr * lr_head, weight_decay))
+    out += [(sd_pl, k, lr_pseudo, weight_decay) for k in sd_pl if is_par(k)]
+    out += [(sd_pg, k, lr_pseudo, weight_decay) for k in sd_pg if is_par(k)]
+    return out
+
+
+def p1_step(sd_new, sd_old, sd_pl, sd_pg, images, l1h, old_classes, cur_epoch=0, pseudo_epoch=5, flac_angle=90,
+            randrop_neg=None, lr=1e-3, lr_head=10.0, lr_pseudo=0.01, weight_decay=1e-4, loss_de=1.0, alpha=0.5,
+            l_seg_weight=1.0, icarl_bkg=-1.0, momentum_state=None, pooling=32, structure=M.RESNET101):
+    """One phase-1 iteration on the CPU. Applies torch.optim.SGD(momentum 0.9, nesterov) arithmetic in place to the three
+    state dicts and returns the loss terms, the gradients and the momentum buffers."""
+    from . import wss as W
+    bs = images.shape[0]
+    tot = sd_pl["cls.weight"].shape[0]
+    groups = p1_param_groups(sd_new, sd_pl, sd_pg, lr, lr_head, lr_pseudo, weight_decay)
+    for d, k, _, _ in groups:
+        d[k].requires_grad_(True)
+        d[k].grad = None
+    with torch.no_grad():
+        outs_old = M.resnet_body(images, sd_old, structure=structure)
+        old_seg = M.incremental_classifier(M.deeplab_head(outs_old[-1], sd_old, pooling=pooling), sd_old)
+        res5_old = outs_old[-1]
+    outs = M.resnet_body(images, sd_new, structure=structure, training=True)
+    res5 = outs[-1]
+    seg = M.incremental_classifier(M.deeplab_head(res5, sd_new, pooling=pooling, training=True), sd_new)
+    with torch.no_grad():
+        int_masks = M.pseudolabeler(res5, sd_pl)                              # eval mode, detached (train.py:304-311)
+    feat3 = torch.cat([res5, res5.flip(-1), W.rot90k(res5, flac_angle)], 0)   # train.py:314-317
+    A = M.pseudolabeler(feat3, sd_pl, training=True)
+    flac = W.flac_loss(A, bs, old_classes, flac_angle)
+    raw = A[:bs]
+    lab_new = l1h[:, old_classes - 1:]
+    l_peak, _ = W.peakgen_train_loss(raw, sd_pg["extra_conv4.weight"], sd_pg["extra_conv4.bias"], lab_new)
+    l_cam_new = W.bce_loss(raw, lab_new, reduction="mean")
+    l_loc = W.l_loc(raw, old_seg, old_classes)
+    l_cam_int = l_cam_new + l_loc + flac + l_peak
+    lde = loss_de * W.lde(res5, res5_old)
+    l_seg = torch.zeros((), dtype=images.dtype)
+    l_cls = torch.zeros((), dtype=images.dtype)
+    l_rand = torch.zeros((), dtype=images.dtype)
+    if cur_epoch >= pseudo_epoch:
+        soft = int_masks.softmax(dim=1)
+        img_raw = images * torch.tensor(DENORM_STD, dtype=images.dtype)[None, :, None, None] + \
+            torch.tensor(DENORM_MEAN, dtype=images.dtype)[None, :, None, None]
+        im = F.interpolate(img_raw, int_masks.shape[-2:], mode="bilinear", align_corners=True)
+        soft = W.pamr(im, soft.detach())
+        soft[:, 1:] *= l1h[:, :, None, None]
+        pseudo_gt = W.pseudo_gtmask(soft).detach()
+        l_seg = W.l_seg(seg, old_seg, int_masks.clone(), l1h, old_classes, alpha=alpha, icarl_bkg=icarl_bkg, weight=l_seg_weight)
+        l_cls = W.balanced_mask_loss_ce(raw, pseudo_gt, l1h)
+        if randrop_neg is not None:
+            ref = torch.sigmoid(int_masks).clone()
+            ref[:, 1:] *= l1h[:, :, None, None]
+            live = ref[:, old_classes:].max(dim=1)[0] > 0.5
+            if live.sum() > 0:
+                t = randrop_neg.long().clone()
+                t[~live] = 255
+                l_rand = W.bce_ignore_mean_selected(raw, t)
+    loss = l_seg + l_cls + l_cam_int + l_rand + lde
+    loss.backward()
+    if momentum_state is None:
+        momentum_state = {}
+    grads = {}
+    with torch.no_grad():
+        for d, k, g_lr, wd in groups:
+            gr = d[k].grad if d[k].grad is not None else torch.zeros_like(d[k])   # `0 * outputs['seg']...` (train.py:365)
+            g = gr + wd * d[k]
+            key = (id(d), k)
+            buf = momentum_state.get(key)
+            buf = g.clone() if buf is None else buf.mul_(0.9).add_(g)
+            momentum_state[key] = buf
+            grads[key] = gr.clone()
+            d[k].sub_(g_lr * (g + 0.9 * buf))
+    for d, k, _, _ in groups:
+        d[k].requires_grad_(False)
+    return dict(loss=loss.detach(), l_cam_new=l_cam_new.detach(), l_loc=l_loc.detach(), flac=flac.detach(), l_peak=l_peak.detach(),
+                lde=lde.detach(), l_seg=l_seg.detach(), l_cls=l_cls.detach(), l_rand=l_rand.detach(), grads=grads,
+                momentum_state=momentum_state, seg=seg.detach(), int_masks=int_masks, A=A.detach(), res5=res5.detach())

@@ -63,7 +63,7 @@ def pseudo_gtmask(mask, cutoff_top=0.6, cutoff_bkg=0.7, cutoff_low=0.2):
     mx = m.max(-1, keepdim=True)[0].clone()
     mx[:, :1] *= cutoff_bkg
     mx[:, 1:] *= cutoff_top
-    mx = mx.max(torch.tensor([cutoff_low]).type_as(mx))
+    mx = mx.max(torch.tensor([cutoff_low]).type_as(mx))   # float32 constant widened like the reference does
     gt = (m > mx).type_as(m)
     amb = (gt.sum(1, keepdim=True) > 1).type_as(m)
     return ((1 - amb) * gt).reshape(bs, c, h, w)
@@ -169,3 +169,13 @@ def l_seg(outputs_seg, old_seg, int_masks, labels, old_classes, alpha=0.5, icarl
     l = F.binary_cross_entropy_with_logits(outputs_seg, pseudo, reduction="none").sum(dim=1)
     l = l.view(bs, -1).mean(dim=-1)
     return weight * (bw * l).sum() / (bw.sum() + 1e-5)
+
+
+def bce_ignore_mean_selected(inputs, targets, ignore_index=255):
+    """BCEWithLogitsLossWithIgnoreIndex(reduction='mean') — utils/wss_loss.py:250-271 as used by RandropLoss :246-248: the
+    one-hot weighted BCE (only the target class contributes), averaged over the non-ignored pixels."""
+    n_cl = inputs.shape[1]
+    lab = torch.where(targets != ignore_index, targets, torch.tensor(n_cl))
+    t = F.one_hot(lab, n_cl + 1).float().permute(0, 3, 1, 2)[:, :n_cl]
+    loss = (F.binary_cross_entropy_with_logits(inputs, t, reduction="none") * (t == 1).float()).sum(dim=1)
+    return torch.masked_select(loss, t.sum(dim=1) != 0).mean()
