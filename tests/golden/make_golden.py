@@ -105,6 +105,43 @@ def model_fixture(R):
     print("model_p2_c65.npz", {k: getattr(v, "shape", None) for k, v in out.items() if k != "grad_names"})
 
 
+def model_p1_fixture(R):
+    """Reference network of phase 1 (branch 'none': body + DeepLabV3 + classifiers, argparser.py:21-24) and the
+    PseudoLabeler in TRAINING mode: outputs, updated running statistics and the gradient norm of every parameter."""
+    ap = R["argparser"]
+    args = ["--dataset", "voc", "--task", "15-5", "--step", "1", "--weakly", "--phase", "1", "--alpha", "0.5", "--loss_de", "1",
+            "--lr_policy", "warmup", "--affinity", "--optim", "sgd", "--lr", "0.001", "--crop_size", str(CROP), "--batch_size", "16",
+            "--no_pretrained"]
+    opts = ap.modify_command_options(ap.get_argparser().parse_args(args))
+    sm, wm = R["segmentation_module"], R["wss_modules"]
+    torch.manual_seed(0)
+    new = sm.make_model(opts, classes=[16, 5])
+    pl = wm.PseudoLabeler(2048, 21, sm.get_norm(opts))
+    new.load_state_dict(weights.fill_(new.state_dict(), seed=MODEL_SEED + 10))
+    pl.load_state_dict(weights.fill_(pl.state_dict(), seed=MODEL_SEED + 11))
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(3, 3, CROP, CROP, generator=g)
+    new.train(); pl.train()
+    o, f = new(x, interpolate=False)
+    res5 = f["body"]
+    A = pl(res5)
+    gs = torch.randn(o["seg"].shape, generator=g)
+    ga = torch.randn(A.shape, generator=g)
+    ((o["seg"] * gs).sum() + (A * ga).sum()).backward()
+    out = {"seg": o["seg"].detach().numpy(), "res5": res5.detach().numpy(), "pl_out": A.detach().numpy()}
+    names, norms = [], []
+    for prefix, m in (("", new), ("pl.", pl)):
+        for k, p in m.named_parameters():
+            names.append(prefix + k)
+            norms.append(p.grad.double().norm().item())
+    out["grad_names"], out["grad_norms"] = np.array(names), np.array(norms)
+    out["rm_mod5"] = new.body.mod5.block3.convs.bn3.running_mean.numpy().copy()
+    out["rv_head"] = new.head.red_bn.running_var.numpy().copy()
+    out["rm_pl"] = pl.norm2.running_mean.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "model_p1_c65.npz"), **out)
+    print("model_p1_c65.npz", {k: getattr(v, "shape", None) for k, v in out.items() if k != "grad_names"})
+
+
 def label_fixture(R, seed, b, H, W):
     inp = synth.label_stage_inputs(seed, b=b, H=H, W=W)
     oc, tot = inp["old_classes"], inp["tot_classes"]
@@ -248,6 +285,7 @@ if __name__ == "__main__":
     R = ref_harness.load_reference()
     torch.set_num_threads(8)
     model_fixture(R)
+    model_p1_fixture(R)
     for case in LABEL_CASES:
         label_fixture(R, *case)
     for case in WSS_CASES:

@@ -64,6 +64,39 @@ def test_model_restatement_matches_reference():
     assert rel_err(cam, torch.from_numpy(gold["cam_lo"])) < 1e-5
 
 
+def test_phase1_train_mode_restatement_matches_reference():
+    """Train-mode body + DeepLabV3 + classifiers (phase-1 model, branch 'none') and PseudoLabeler: outputs, running
+    statistics and the gradient norm of all 337 parameters against the reference's own modules under autograd."""
+    from cl4wsis_amd import segmentation_module as sm
+    from cl4wsis_amd.wss import PseudoLabeler
+    from oracle import model as M, weights
+    from util import p1_opts
+    gold = np.load(os.path.join(GOLD, "model_p1_c65.npz"))
+    opts = p1_opts(65)
+    torch.manual_seed(0)
+    new = weights.fill_(sm.make_model(opts, classes=[16, 5]).state_dict(), seed=11)
+    pl = weights.fill_(PseudoLabeler(2048, 21, sm.get_norm(opts)).state_dict(), seed=12)
+    names = [str(n) for n in gold["grad_names"]]
+    for k in names:
+        (pl[k[3:]] if k.startswith("pl.") else new[k]).requires_grad_(True)
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(3, 3, 65, 65, generator=g)
+    res5 = M.resnet_body(x, new, training=True)[-1]
+    seg = M.incremental_classifier(M.deeplab_head(res5, new, pooling=opts.pooling, training=True), new)
+    A = M.pseudolabeler(res5, pl, training=True)
+    assert rel_err(seg.detach(), torch.from_numpy(gold["seg"])) < 1e-5
+    assert rel_err(res5.detach(), torch.from_numpy(gold["res5"])) < 1e-5
+    assert rel_err(A.detach(), torch.from_numpy(gold["pl_out"])) < 1e-5
+    gs = torch.randn(seg.shape, generator=g)
+    ga = torch.randn(A.shape, generator=g)
+    ((seg * gs).sum() + (A * ga).sum()).backward()
+    norms = np.array([(pl[k[3:]] if k.startswith("pl.") else new[k]).grad.double().norm().item() for k in names])
+    np.testing.assert_allclose(norms, gold["grad_norms"], rtol=2e-3)
+    assert rel_err(new["body.mod5.block3.convs.bn3.running_mean"], torch.from_numpy(gold["rm_mod5"])) < 1e-5
+    assert rel_err(new["head.red_bn.running_var"], torch.from_numpy(gold["rv_head"])) < 1e-5
+    assert rel_err(pl["norm2.running_mean"], torch.from_numpy(gold["rm_pl"])) < 1e-5
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "label_s*.npz"))))
 def test_label_stage_restatement_matches_reference(path):
     """cam, peaks, seg pseudo-GT, pseudo / refined labels, losses: the oracle equals the reference exactly
