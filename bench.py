@@ -158,6 +158,26 @@ def main():
         # The dominant kernel multiplies fp32 operands as three bf16 MFMA products (hi*hi + hi*lo + lo*hi), so one
         # algorithmic (fp32-equivalent) FLOP costs three bf16 MFMA FLOPs: its ceiling is the dense bf16 peak / 3.
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+        # HBM-side bytes per launch of the same kernel: PMC counters cannot be read from inside the process, so this is the
+        # committed result of the two separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 correction,
+        # WRITE_SIZE exact) over the last eager step of this same command (tools/pmc_traffic.py); null when absent.
+        traffic, traffic_note = None, "no PMC file"
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01g_pmc_traffic.json")
+        if os.path.exists(pmc) and b == GLOBAL_BATCH:
+            with open(pmc) as f:
+                t = json.load(f)["conv_igemm_bf16x3"]
+            traffic = t["hbm_bytes_per_launch"]
+            traffic_note = ("bytes per launch, average over the %d conv_igemm_bf16x3 launches of one step; rocprofv3 --pmc FETCH_SIZE "
+                            "(x2) + WRITE_SIZE in separate passes, profiles/r01g_pmc_traffic.json" % t["launches_per_step"])
+        # algorithmic operand bytes of the same launches: input + output activations (fp32) + split weights (4 B / weight);
+        # epilogue operands (residual, scale / shift) not counted
+        alg_bytes, alg_n = 0.0, 0
+        for (kind, shp), (cnt, _, _) in timer_excl.by_shape().items():
+            if kind == "conv_fwd_bf16x3" and shp is not None:
+                n_, cin_, hin_, cout_, k_, st_, _ = shp
+                ho = -(-hin_ // st_)
+                alg_bytes += cnt * 4.0 * (n_ * cin_ * hin_ * hin_ + n_ * cout_ * ho * ho + cin_ * cout_ * k_ * k_)
+                alg_n += cnt
         res = {
             "metric": "images/sec at batch 16, VOC 15-5 step-1 phase-2, 1/2/4/8 MI355X",
             "value": GLOBAL_BATCH * a.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": a.steps,
@@ -171,7 +191,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_bf16x3 (cl4_conv2d_fwd precision 1): all its launches of 2 "
                                                     "eager steps run right after the timed region (graph replay and two-stream "
                                                     "overlap off), HIP events on the launch stream around every launch",
-                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                         "traffic_note": traffic_note,
+                         "algorithmic_bytes_per_launch": alg_bytes / max(alg_n, 1),
                          "peak_note": "2500 TFLOP/s dense bf16 MFMA / 3 MFMA products per fp32-equivalent MAC",
                          "mfma_issued_tflops": 3 * ach, "launches_per_step": n / 2,
                          "algorithmic_gflop_per_step": fl / 2 / 1e9, "avg_launch_ms": ms / n,
