@@ -40,7 +40,7 @@ def conv_abn_backward(r, conv, bn, dy, grad_of, need_dx=True, group=None):
     dz = ops.abn_train_backward(r.z, dy, r.mean, r.var, bn.weight.detach(), bn.bias.detach(), grad_of(bn.weight), grad_of(bn.bias),
                                 r.count, bn.eps, act, slope, group)
     k = conv.kernel_size[0]
-    ops.conv2d_wgrad(r.x, dz, grad_of(conv.weight), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0])
+    ops.conv2d_wgrad(r.x, dz, grad_of(conv.weight), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], precision=0)
     if not need_dx:
         return None
     return ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(r.x.shape[2:]), k, stride=conv.stride[0], pad=conv.padding[0],

@@ -811,6 +811,7 @@ struct WgradArgs {
   int Nj;       // cin*KS*KS
   int npix;     // n*hout*wout
   int chunk;    // pixels per grid.z slice (multiple of BKP)
+  int precision;  // 0: exact fp32 MFMA, 1: bf16x3 split products
 };
 
 template <int BM, int BN, int KS>
@@ -1315,9 +1316,8 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   int gz = cl4::cdiv(a.npix, a.chunk);
   dim3 g(gm, gn, gz);
   // bf16x3 MFMA path: 32-bit buffer offsets, so both tensors must stay below 2 GiB (always true on the phase-2 path)
-  static const int wg_prec = env_int("CL4_WGRAD_PRECISION", 1);
   const long lim = (1L << 31) - 4096;
-  const bool split3 = wg_prec == 1 && (long)a.n * a.in_ctot * a.hin * a.win * 4 < lim && (long)a.n * a.out_ctot * a.hout * a.wout * 4 < lim;
+  const bool split3 = a.precision == 1 && (long)a.n * a.in_ctot * a.hin * a.win * 4 < lim && (long)a.n * a.out_ctot * a.hout * a.wout * 4 < lim;
   if (split3 && small_m)
     hipLaunchKernelGGL((conv_wgrad_bf16x3<64, 128, KS>), g, dim3(NTHREADS), 0, st, a);
   else if (split3)
@@ -1417,6 +1417,8 @@ extern "C" int cl4_conv2d_wgrad(const cl4_conv_desc* d, const float* x, const fl
   a.n = d->n; a.cin = d->cin; a.hin = d->hin; a.win = d->win; a.cout = d->cout;
   a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.hout = d->hout; a.wout = d->wout;
   a.in_ctot = d->in_ctot; a.in_coff = d->in_coff; a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
+  CL4_REQUIRE(d->precision == 0 || d->precision == 1, "conv2d_wgrad: precision %d unknown (0 fp32, 1 bf16x3)", d->precision);
+  a.precision = d->precision;
   a.Nj = d->cin * d->kh * d->kw;
   a.npix = d->n * d->hout * d->wout;
   a.chunk = 0;

@@ -147,9 +147,16 @@ __global__ void resize_bwd_kernel(const float* __restrict__ dy, float* __restric
     t /= a.hin;
     int c = t % a.c;
     int n = t / a.c;
-    // outputs with src in (iy-1, iy+1): dst in ((iy-1)/s - 1, (iy+1)/s + 1) (covers both align modes)
-    int oy_lo = max(0, (int)floorf(((float)iy - 1.f) * ry) - 1), oy_hi = min(a.hout - 1, (int)ceilf(((float)iy + 1.f) * ry) + 1);
-    int ox_lo = max(0, (int)floorf(((float)ix - 1.f) * rx) - 1), ox_hi = min(a.wout - 1, (int)ceilf(((float)ix + 1.f) * rx) + 1);
+    // outputs whose source coordinate falls in (iy-1, iy+1). align_corners: src = dst*s -> dst in ((iy-1)/s, (iy+1)/s);
+    // half-pixel: src = (dst+0.5)*s - 0.5 -> dst in ((iy-0.5)/s - 0.5, (iy+1.5)/s - 0.5). One conservative range covers both
+    // (the +1.5 matters for large upsampling factors: 33 -> 513 spans 15.5 outputs per input); the clamped borders take
+    // everything beyond them. Every candidate re-derives the forward's own (i0, i1, l1), so extra candidates contribute 0.
+    int oy_lo = max(0, (int)floorf(((float)iy - 1.f) * ry) - 1), oy_hi = min(a.hout - 1, (int)ceilf(((float)iy + 1.5f) * ry) + 1);
+    int ox_lo = max(0, (int)floorf(((float)ix - 1.f) * rx) - 1), ox_hi = min(a.wout - 1, (int)ceilf(((float)ix + 1.5f) * rx) + 1);
+    if (iy == a.hin - 1) oy_hi = a.hout - 1;
+    if (ix == a.win - 1) ox_hi = a.wout - 1;
+    if (iy == 0) oy_lo = 0;
+    if (ix == 0) ox_lo = 0;
     if (a.sy == 0.f) { oy_lo = 0; oy_hi = a.hout - 1; }
     if (a.sx == 0.f) { ox_lo = 0; ox_hi = a.wout - 1; }
     const float* dyp = dy + ((long)n * a.out_ctot + a.out_coff + c) * a.hout * a.wout;

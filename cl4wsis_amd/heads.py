@@ -358,8 +358,10 @@ class InstanceBranch:
         ops.dwconv5_wgrad_(G(dw.weight), x, dz0)
         return ops.dwconv5(dz0, dw.weight.detach(), flip=True) if need_dx else None
 
-    def backward(self, tape, dpred, grads=None, on_ready=None):
+    def backward(self, tape, dpred, grads=None, on_ready=None, feature_grads=None):
         """Back-propagates d(loss)/d(pred[key]) through the recorded forward. Returns {id(param): grad}.
+        `feature_grads` (a dict) additionally receives d(loss)/d(feature) for the backbone features the decoder read —
+        step 0 trains the body through the instance branch; phases 1 / 2 detach them (modules/panoptic_deeplab.py:422-426).
 
         `grads` may map id(param) -> a pre-zeroed gradient view (the flat DP buffer); `on_ready(param)` is called right
         after the kernel that finalises a parameter's gradient has been enqueued (bucketed all-reduce hook)."""
@@ -402,6 +404,8 @@ class InstanceBranch:
             dlz = ops.bn_train_bwd(lz, dcat, lm, lv, bn.weight.detach(), bn.bias.detach(), G(bn.weight), G(bn.bias), bn.eps,
                                    dy_coff=cy)
             ops.conv2d_wgrad(l, dlz, G(conv.weight), 1)
+            if feature_grads is not None:
+                feature_grads[d.low_level_key[si]] = ops.conv2d(dlz, conv.weight.detach().reshape(conv.out_channels, conv.in_channels), 1)
             dy = ops.resize_bilinear_bwd(dcat, tuple(prev_hw), True, dy_coff=0, c=cy)
             i -= 2
         # ASPP ------------------------------------------------------------------------------------------
@@ -414,17 +418,26 @@ class InstanceBranch:
         ops.conv2d_wgrad(cat5, dpz, G(pconv0.weight), 1)
         dcat5 = ops.conv2d(dpz, pconv0.weight.detach().reshape(pconv0.out_channels, pconv0.in_channels), 1)
         cout = aspp.convs[0][0].out_channels
+        dx = None
         for j in range(4):
             conv, bn = aspp.convs[j][0], aspp.convs[j][1]
             z, m, v = recs[j]
             dz = ops.bn_train_bwd(z, dcat5, m, v, bn.weight.detach(), bn.bias.detach(), G(bn.weight), G(bn.bias), bn.eps,
                                   dy_coff=j * cout)
-            ops.conv2d_wgrad(x, dz, G(conv.weight), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0])
+            k, pad, dil = conv.kernel_size[0], conv.padding[0], conv.dilation[0]
+            ops.conv2d_wgrad(x, dz, G(conv.weight), k, pad=pad, dil=dil)
+            if feature_grads is not None:
+                from .body_train import _dgrad_weight
+                part = ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(x.shape[2:]), k, pad=pad, dil=dil)
+                dx = part if dx is None else ops.axpy_(dx, part)
         h, w = x.shape[2:]
         dgp = ops.resize_bilinear_bwd(dcat5, (1, 1), True, dy_coff=4 * cout, c=cout)
         dgp = ops.relu_bwd(gp, dgp)
         pconv = aspp.convs[4].aspp_pooling[1]
         ops.conv2d_wgrad(g, dgp, G(pconv.weight), 1)
+        if feature_grads is not None:
+            dg = ops.conv2d(dgp, pconv.weight.detach().reshape(pconv.out_channels, pconv.in_channels), 1)
+            feature_grads[d.feature_key] = ops.add_per_plane_(dx, dg, 1.0 / (h * w))
         self._flush_ready()
         return grads
 

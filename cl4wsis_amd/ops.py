@@ -227,7 +227,12 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     return out
 
 
-def conv2d_wgrad(x, dy, dw, k, stride=1, pad=0, dil=1, in_coff=0, cin=None, dy_coff=0, cout=None):
+# Arithmetic of the weight gradients: 1 = bf16x3 split products (phase 2's trainable branch: ~4e-6 relative, 1.4x faster),
+# 0 = exact fp32 MFMA (step 0 / phase 1, where the whole network trains and heavily cancelling sums need fp32 products).
+WGRAD_PRECISION = int(os.environ.get("CL4_WGRAD_PRECISION", "1"))
+
+
+def conv2d_wgrad(x, dy, dw, k, stride=1, pad=0, dil=1, in_coff=0, cin=None, dy_coff=0, cout=None, precision=None):
     """dw[cout,cin,k,k] += conv weight gradient. dw is accumulated into (zero it first)."""
     n, in_ctot, hin, win = x.shape
     if cin is None:
@@ -236,7 +241,8 @@ def conv2d_wgrad(x, dy, dw, k, stride=1, pad=0, dil=1, in_coff=0, cin=None, dy_c
         cout = dy.shape[1] - dy_coff
     if tuple(dw.shape) != (cout, cin, k, k):
         raise RuntimeError(f"conv2d_wgrad: dw shape {tuple(dw.shape)} != {(cout, cin, k, k)}")
-    d = _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, dy.shape[1], dy_coff, 0, 0.0, 0, 0.0)
+    d = _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, dy.shape[1], dy_coff, 0, 0.0, 0, 0.0,
+                   WGRAD_PRECISION if precision is None else precision)
     if tuple(dy.shape[2:]) != (d.hout, d.wout) or dy.shape[0] != n:
         raise RuntimeError("conv2d_wgrad: dy spatial shape does not match the convolution geometry")
     if TIMER is not None:

@@ -25,7 +25,7 @@ class Phase1Step:
         self._dn_shift = torch.tensor(DENORM_MEAN, dtype=torch.float32, device=dev)
         self._draws = 0
 
-    def run(self, images, l1h, cur_epoch, flac_angle=None, randrop_neg=None):
+    def run(self, images, l1h, cur_epoch, flac_angle=None, randrop_neg=None, debug=None):
         tr, opts = self.tr, self.tr.opts
         bs = images.shape[0]
         old, tot = tr.old_classes, tr.tot_classes
@@ -92,6 +92,9 @@ class Phase1Step:
                 losses["l_rand"], g = ops.randrop_loss(raw, int_masks, l1h, randrop_neg, old, mask_labels=l1h if opts.no_mask else None)
                 ops.axpy_(draw, g)
 
+        if debug is not None:
+            debug.update(A=A.clone(), dA=dA.clone(), res5=res5.clone(), res5_old=res5_old.clone(), old_seg=old_seg.clone(),
+                         seg=seg.clone(), dres5_lde=dres5.clone())
         # backward ------------------------------------------------------------------------------------------------
         dfeat3 = heads_train.pseudolabeler_backward(pl, ptape, dA, G)
         ops.axpy_(dres5, dfeat3[:bs])

@@ -157,9 +157,11 @@ class Trainer:
         opts = self.opts
         if self.weakly and opts.phase == 1:
             return self._step_phase1(batch)
+        if not self.weakly and opts.step == 0 and opts.phase is None:
+            return self._step0_supervised(batch, dropout_keep)
         if not (self.weakly and opts.phase == 2):
-            raise NotImplementedError("Trainer.step: the weakly-supervised phase-1 and phase-2 steps (BASELINE configs 2, 3) are "
-                                      "built; step 0 (supervised) is a later §8 row")
+            raise NotImplementedError("Trainer.step: built for step 0 (supervised, --bce) and for the weakly-supervised phase-1 / "
+                                      "phase-2 steps (BASELINE configs 1-3); other option combinations are not on the CL4WSIS path")
         images, l1h = (batch[0], batch[-1])
         images = images.to(self.device, dtype=torch.float32).contiguous()
         l1h = l1h.to(self.device, dtype=torch.float32).contiguous()
@@ -185,6 +187,31 @@ class Trainer:
             self.scheduler.step()
         self._iter += 1
         return out
+
+    def _step0_supervised(self, batch, dropout_keep=None):
+        """One supervised step-0 iteration (train.py:241-300, BASELINE config 1) — see cl4wsis_amd/step0.py."""
+        from .step0 import Step0
+        if not self.opts.bce:
+            raise NotImplementedError("step 0 is built for --bce (scripts/run.sh:24); plain BCE / DeepLabCE are not on the path")
+        if getattr(self, "_s0", None) is None:
+            self._s0 = Step0(self)
+        images, seg_maps, center_maps, offset_maps, weights = batch[:5]
+        f32 = lambda t: t.to(self.device, dtype=torch.float32).contiguous()
+        self.model.train()
+        ops.AUTOTUNE = self._iter == 0 and os.environ.get("CL4_AUTOTUNE", "1") != "0"
+        try:
+            losses = self._s0.run(f32(images), seg_maps.to(self.device, dtype=torch.long).contiguous(), f32(center_maps),
+                                  f32(offset_maps), f32(weights), dropout_keep)
+        finally:
+            ops.AUTOTUNE = False
+        for i in range(len(self.buckets.fb.sizes)):
+            self.buckets.ready(i)
+        self.buckets.finish()
+        self.optimizer.step()
+        if self.scheduler is not None:
+            self.scheduler.step()
+        self._iter += 1
+        return {"losses": losses}
 
     def _step_phase1(self, batch, cur_epoch=None, flac_angle=None, randrop_neg=None):
         """One phase-1 iteration (train.py:241-566 with --phase 1) — see cl4wsis_amd/phase1.py."""

