@@ -126,6 +126,7 @@ _decl("cl4_channel_affine", _P, _P, _I, _I, _I, _P, _P, _P)
 _decl("cl4_randrop_loss", _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_transpose_flip_weight", _P, _P, _I, _I, _I, _P)
 _decl("cl4_random_labels", _P, _L, C.c_uint64, _I, _P)
+_decl("cl4_semseg_hist", _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_sgd_step", _P, _P, _P, _L, _F, _P, _F, _F, _I, _P)
 _decl("cl4_pamr", _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, C.c_size_t, _P)
 _decl("cl4_ngwp_focal_bce", _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, C.c_size_t, _P)

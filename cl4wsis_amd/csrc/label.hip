@@ -328,6 +328,61 @@ __global__ void cc_stats_kernel(const int* __restrict__ L, int H, int W, long to
   }
 }
 
+
+// Validation (train.py:695-745): softmax over the (optionally flip-averaged) full-resolution logits, arg-max (first maximum,
+// like torch.max), and the confusion-matrix update of metrics/stream_metrics.py:72-79 — hist[true * n + pred] += 1 for
+// labels in [0, n). grid-stride over pixels; per-workgroup LDS histogram when n*n fits, else global atomics.
+__global__ __launch_bounds__(256) void semseg_hist_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                          unsigned long long* __restrict__ hist, unsigned char* __restrict__ pred,
+                                                          int nb, int c, int H, int W, int flip, int n_classes, int zero_below) {
+  extern __shared__ unsigned int lh[];
+  const int nn = n_classes * n_classes;
+  const bool use_lds = nn <= 4096;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < nn; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+  }
+  const long HW = (long)H * W;
+  const int nimg = flip ? 1 : nb;
+  const long N = (long)nimg * HW;
+  for (long p = blockIdx.x * (long)blockDim.x + threadIdx.x; p < N; p += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(p / HW);
+    const long q = p - (long)n * HW;
+    const int y = (int)(q / W), x = (int)(q - (long)y * W);
+    const float* a = logits + (long)n * c * HW + q;
+    const float* b = flip ? logits + (long)c * HW + (long)y * W + (W - 1 - x) : nullptr;
+    float mx = -INFINITY;
+    for (int k = 0; k < c; ++k) {
+      const float v = flip ? (a[(long)k * HW] + b[(long)k * HW]) / 2.f : a[(long)k * HW];
+      mx = fmaxf(mx, v);
+    }
+    float den = 0.f;
+    for (int k = 0; k < c; ++k) {
+      const float v = flip ? (a[(long)k * HW] + b[(long)k * HW]) / 2.f : a[(long)k * HW];
+      den += expf(v - mx);
+    }
+    float best = -1.f;
+    int arg = 0;
+    for (int k = 0; k < c; ++k) {
+      const float v = flip ? (a[(long)k * HW] + b[(long)k * HW]) / 2.f : a[(long)k * HW];
+      const float pr = expf(v - mx) / den;
+      if (pr > best) { best = pr; arg = k; }
+    }
+    if (pred) pred[p] = (unsigned char)arg;
+    long long t = labels[p];
+    if (t >= 0 && t < zero_below) t = 0;            // eval_pseudolabeler: labels[labels < old_classes] = 0
+    if (t >= 0 && t < n_classes) {
+      if (use_lds) atomicAdd(&lh[(int)t * n_classes + arg], 1u);
+      else atomicAdd(&hist[(long)t * n_classes + arg], 1ull);
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nn; i += blockDim.x)
+      if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+  }
+}
+
 }  // namespace
 
 extern "C" int cl4_cam_smooth(const float* int_masks, int b, int ctot, int h, int w, const float* pg_w, const float* pg_b,
@@ -403,5 +458,17 @@ extern "C" int cl4_cc_stats(const int* labels, int b, int H, int W, unsigned* ar
   int rpr = cl4::cdiv(W, RUN);
   long runs = (long)b * H * rpr;
   hipLaunchKernelGGL(cc_stats_kernel, dim3(cl4::stream_grid(runs, 256)), dim3(256), 0, st, labels, H, W, runs, rpr, area, sumx, sumy);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_semseg_hist(const float* logits, const long long* labels, unsigned long long* hist, unsigned char* pred, int nb, int c,
+                               int H, int W, int flip, int n_classes, int zero_below, void* stream) {
+  CL4_REQUIRE(logits && labels && hist, "semseg_hist: null pointer");
+  CL4_REQUIRE(nb > 0 && c > 0 && H > 0 && W > 0 && n_classes > 0 && c <= n_classes, "semseg_hist: bad dims");
+  CL4_REQUIRE(!flip || nb == 2, "semseg_hist: flip averaging expects the batch [image, flipped image]");
+  const long N = (long)(flip ? 1 : nb) * H * W;
+  const int nn = n_classes * n_classes;
+  hipLaunchKernelGGL(semseg_hist_kernel, dim3(cl4::stream_grid(N, 256)), dim3(256), nn <= 4096 ? (size_t)nn * 4 : 0, cl4::as_stream(stream),
+                     logits, labels, hist, pred, nb, c, H, W, flip, n_classes, zero_below);
   return cl4::launch_status();
 }

@@ -941,3 +941,18 @@ def random_labels(shape, modulus, seed, device):
     out = torch.empty(shape, dtype=torch.int32, device=device)
     call("cl4_random_labels", ptr(out), out.numel(), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), int(modulus), stream())
     return out
+
+
+def semseg_hist_(hist, logits, labels, n_classes, flip=False, zero_below=0, want_pred=False):
+    """Confusion-matrix update of validation (train.py:695-745): hist (int64 [n,n] device tensor) += counts."""
+    _f32c(logits, "semseg_hist logits")
+    nb, c, H, W = logits.shape
+    nimg = 1 if flip else nb
+    if labels.dtype != torch.int64 or tuple(labels.shape) != (nimg, H, W) or not labels.is_contiguous():
+        raise RuntimeError("semseg_hist_: contiguous int64 labels [nimg,H,W] expected")
+    if hist.dtype != torch.int64 or hist.numel() != n_classes * n_classes:
+        raise RuntimeError("semseg_hist_: int64 hist [n,n] expected")
+    pred = torch.empty((nimg, H, W), dtype=torch.uint8, device=logits.device) if want_pred else None
+    call("cl4_semseg_hist", ptr(logits), ptr(labels), ptr(hist), ptr(pred), nb, c, H, W, int(bool(flip)), int(n_classes),
+         int(zero_below), stream())
+    return pred

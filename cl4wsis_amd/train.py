@@ -363,8 +363,37 @@ class Trainer:
     def validate(self, valid_loader, opts):
         raise NotImplementedError("Trainer.validate (VOC instance AP) is row 1 of SURVEY.md §8(f) — not built yet")
 
-    def validate_semseg(self, valid_loader, metrics, opts):
-        raise NotImplementedError("Trainer.validate_semseg is row 4 of SURVEY.md §8(f) — not built yet")
+    def validate_semseg(self, loader, metrics, opts, eval_pseudolabeler=False):
+        """train.py:695-745 — semantic validation: eval forward (optionally [image, flipped image]), logits to image size,
+        flip average, softmax, arg-max, confusion matrix. The matrix is accumulated on the device (cl4_semseg_hist) and
+        read back once; `metrics` is a cl4wsis_amd.metrics.StreamSegMetrics (same results dict as the reference's)."""
+        metrics.reset()
+        model, device = self.model, self.device
+        model.eval()
+        if eval_pseudolabeler:
+            self.pseudolabeler.eval()
+        hist = metrics.device_hist(device)
+        n = 0
+        for batch in loader:
+            img, seg = batch[0], batch[1]
+            images = img.to(device, dtype=torch.float32).contiguous()
+            labels = seg.to(device, dtype=torch.long).contiguous()
+            if opts.val_flip:
+                if images.shape[0] != 1:
+                    raise RuntimeError("validate_semseg: --val_flip expects batch size 1 (train.py:709-711)")
+                images = torch.cat([images, ops.flip_w(images)], dim=0)   # batch assembly only
+            size = tuple(images.shape[-2:])
+            if eval_pseudolabeler:
+                lo = self.pseudolabeler(model(images, as_feature_extractor=True)["body"])
+                masks = ops.resize_bilinear(lo, size, False)
+            else:
+                masks = model(images)[0]["seg"]       # interpolate=True: align_corners=True upsampling of the reference
+            ops.semseg_hist_(hist, masks, labels, metrics.n_classes, flip=opts.val_flip,
+                             zero_below=self.old_classes if eval_pseudolabeler else 0)
+            n += labels.shape[0]
+        metrics.flush_device(n)
+        metrics.synch(device)
+        return metrics.get_results()
 
     # ------------------------------------------------------------------------------------------ checkpoints
     @staticmethod

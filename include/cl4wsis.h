@@ -368,6 +368,16 @@ int cl4_channel_affine(const float* x, float* y, int n, int c, int hw, const flo
 /* w [cout,cin,k,k] -> wt [cin,cout,k,k] with both spatial axes reversed (the weight of the input-gradient convolution). */
 int cl4_transpose_flip_weight(const float* w, float* wt, int cout, int cin, int k, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Validation: softmax + arg-max of the full-resolution semantic logits ([nb,c,H,W]; flip != 0: nb == 2 =
+ * [image, flipped image], averaged like train.py:709-711) and the confusion-matrix update of
+ * metrics/stream_metrics.py:72-79 into hist [n_classes*n_classes] uint64 (accumulated). labels int64 [nimg,H,W]; labels
+ * outside [0,n_classes) are ignored; labels in [0,zero_below) count as 0 (eval_pseudolabeler, train.py:737-738). pred (u8
+ * [nimg,H,W]) or NULL receives the prediction.
+ * ------------------------------------------------------------------------ */
+int cl4_semseg_hist(const float* logits, const long long* labels, unsigned long long* hist, unsigned char* pred, int nb, int c, int H,
+                    int W, int flip, int n_classes, int zero_below, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

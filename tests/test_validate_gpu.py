@@ -1,0 +1,76 @@
+"""GPU: Trainer.validate_semseg (train.py:695-745) and the device-side confusion matrix (cl4_semseg_hist) against the
+reference's formulae on the CPU: oracle forward in eval mode -> align_corners=True upsampling -> flip average -> softmax ->
+arg-max -> np.bincount confusion matrix (metrics/stream_metrics.py:72-79) -> mIoU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import p2_opts
+
+pytestmark = pytest.mark.gpu
+
+
+class _Log:
+    def info(self, *a, **k):
+        pass
+    debug = info
+
+
+def _np_hist(lt, lp, n):
+    mask = (lt >= 0) & (lt < n)
+    return np.bincount(n * lt[mask].astype(int) + lp[mask], minlength=n * n).reshape(n, n)
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_semseg_hist_kernel(gpu, flip):
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(2)
+    n, c, H, W = (2, 21, 37, 41)
+    logits = torch.randn(2 if flip else n, c, H, W, generator=g) * 3
+    nimg = 1 if flip else n
+    labels = torch.randint(0, 21, (nimg, H, W), generator=g)
+    labels[torch.rand(nimg, H, W, generator=g) < 0.1] = 255
+    m = (logits[:1] + logits[1:].flip(-1)) / 2 if flip else logits
+    pred = m.softmax(1).max(1)[1]
+    ref = sum(_np_hist(labels[i].numpy().flatten(), pred[i].numpy().flatten(), 21) for i in range(nimg))
+    hist = torch.zeros(21, 21, dtype=torch.int64, device=gpu)
+    got_pred = ops.semseg_hist_(hist, logits.to(gpu), labels.to(gpu), 21, flip=flip, want_pred=True)
+    assert torch.equal(got_pred.cpu().long(), pred)
+    assert np.array_equal(hist.cpu().numpy(), ref)
+    ops.semseg_hist_(hist, logits.to(gpu), labels.to(gpu), 21, flip=flip)      # accumulates
+    assert np.array_equal(hist.cpu().numpy(), 2 * ref)
+
+
+def test_validate_semseg_matches_reference_pipeline(gpu):
+    from cl4wsis_amd.metrics import StreamSegMetrics
+    from cl4wsis_amd.train import Trainer
+    from oracle import model as M, weights
+    crop = 65
+    opts = p2_opts(crop, extra=["--val_flip"]) if False else p2_opts(crop)
+    opts.val_flip = True
+    torch.manual_seed(0)
+    tr = Trainer(_Log(), gpu, opts)
+    sd = weights.fill_({k: v.cpu().clone() for k, v in tr.model.state_dict().items()}, seed=7)
+    tr.model.load_state_dict(sd)
+    tr._realias()
+    g = torch.Generator().manual_seed(4)
+    loader = [(torch.randn(1, 3, crop, crop, generator=g), torch.randint(0, 21, (1, crop, crop), generator=g)) for _ in range(3)]
+    metrics = StreamSegMetrics(21)
+    res = tr.validate_semseg(loader, metrics, opts)
+    ref = np.zeros((21, 21))
+    mism = 0
+    for img, seg in loader:
+        x = torch.cat([img, img.flip(-1)], 0)
+        with torch.no_grad():
+            lo, _ = M.forward_seg(x, sd, pooling=opts.pooling)
+            up = F.interpolate(lo["seg"], size=(crop, crop), mode="bilinear", align_corners=True)
+            m = ((up[:1] + up[1:].flip(-1)) / 2).softmax(1)
+        pred = m.max(1)[1]
+        ref += _np_hist(seg[0].numpy().flatten(), pred[0].numpy().flatten(), 21)
+    # arg-max may differ from the fp32 CPU evaluation only where the top-2 gap is at rounding level
+    diff = np.abs(res["Confusion Matrix"] - ref).sum() / 2
+    assert diff <= 3 * 1e-3 * crop * crop, diff
+    assert res["Total samples"] == 3 and abs(res["Overall Acc"] - np.diag(ref).sum() / ref.sum()) < 2e-3
+    iu = np.diag(ref) / (ref.sum(1) + ref.sum(0) - np.diag(ref) + 1e-6)
+    assert abs(res["Mean IoU"] - iu[ref.sum(1) != 0].mean()) < 2e-3
