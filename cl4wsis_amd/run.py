@@ -22,10 +22,13 @@ from .train import Trainer
 
 
 class SyntheticVOC(data.Dataset):
-    """Loader-contract stand-in (dataset/dataset.py:245): (images, seg, center, offset, weight, l1h)."""
+    """Loader-contract stand-in (dataset/dataset.py:245): (images, seg, center, offset, weight, l1h). The weakly-supervised
+    phases only read images and l1h (train.py:243-248); `supervised=True` (step 0) also synthesises the dense targets:
+    a semantic map of rectangles over the 15 base classes (+255 borders), a gaussian centre bump per rectangle in its class
+    channel, offsets to the rectangle centre and unit weights inside the rectangles."""
 
-    def __init__(self, n, crop, seed):
-        self.n, self.crop, self.seed = n, crop, seed
+    def __init__(self, n, crop, seed, supervised=False, n_classes=16):
+        self.n, self.crop, self.seed, self.supervised, self.n_classes = n, crop, seed, supervised, n_classes
 
     def __len__(self):
         return self.n
@@ -33,12 +36,34 @@ class SyntheticVOC(data.Dataset):
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 100003 + i)
         c = self.crop
-        l1h = torch.zeros(20)
-        k = 1 if torch.rand(1, generator=g).item() < 0.6 else 2
-        for cls in torch.randperm(5, generator=g)[:k].tolist():
-            l1h[15 + cls] = 1
-        z = torch.zeros(1)
-        return torch.randn(3, c, c, generator=g), z, z, z, z, l1h
+        img = torch.randn(3, c, c, generator=g)
+        if not self.supervised:
+            l1h = torch.zeros(20)
+            k = 1 if torch.rand(1, generator=g).item() < 0.6 else 2
+            for cls in torch.randperm(5, generator=g)[:k].tolist():
+                l1h[15 + cls] = 1
+            z = torch.zeros(1)
+            return img, z, z, z, z, l1h
+        nc = self.n_classes - 1
+        seg = torch.zeros(c, c, dtype=torch.long)
+        center = torch.zeros(nc, c, c)
+        offset = torch.zeros(2, c, c)
+        weight = torch.zeros(1, c, c)
+        l1h = torch.zeros(nc)
+        ys, xs = torch.meshgrid(torch.arange(c, dtype=torch.float32), torch.arange(c, dtype=torch.float32), indexing="ij")
+        for _ in range(int(torch.randint(1, 4, (1,), generator=g))):
+            cls = int(torch.randint(1, self.n_classes, (1,), generator=g))
+            h, w = (int(v) for v in torch.randint(max(c // 8, 2), max(c // 3, 3), (2,), generator=g))
+            y0, x0 = int(torch.randint(0, c - h, (1,), generator=g)), int(torch.randint(0, c - w, (1,), generator=g))
+            seg[y0:y0 + h, x0:x0 + w] = cls
+            cy, cx = y0 + h // 2, x0 + w // 2
+            center[cls - 1] = torch.maximum(center[cls - 1], torch.exp(-((ys - cy) ** 2 + (xs - cx) ** 2) / 72.0))
+            offset[0, y0:y0 + h, x0:x0 + w] = (cy - ys)[y0:y0 + h, x0:x0 + w]
+            offset[1, y0:y0 + h, x0:x0 + w] = (cx - xs)[y0:y0 + h, x0:x0 + w]
+            weight[0, y0:y0 + h, x0:x0 + w] = 1.0
+            l1h[cls - 1] = 1
+        seg[:2] = 255
+        return img, seg, center, offset, weight, l1h
 
 
 class _Logger:
@@ -93,7 +118,8 @@ def main(opts):
         from dataset import get_dataset                              # the reference's pipeline, if present
         train_dst, val_dst, test_dst, labels, n_classes = get_dataset(opts)
     except ImportError:
-        train_dst = SyntheticVOC(10582, opts.crop_size, opts.random_seed)
+        n_img = int(os.environ.get("CL4_SYNTH_LEN", "10582"))        # VOC 2012 aug train size
+        train_dst = SyntheticVOC(n_img, opts.crop_size, opts.random_seed, supervised=opts.step == 0 and not opts.weakly)
     sampler = DistributedSampler(train_dst, num_replicas=world, rank=rank) if world > 1 else None
     loader = data.DataLoader(train_dst, batch_size=opts.batch_size, sampler=sampler, shuffle=sampler is None,
                              num_workers=opts.num_workers, drop_last=True)
