@@ -166,8 +166,8 @@ def group_pixels(ctr, offsets):
     return torch.argmin(dist, dim=0).reshape(H, W) + 1
 
 
-def get_instance_segmentation(fg, c_center_map, offsets, threshold, nms_kernel, beta):
-    """modules/utils.py:545-606 (ignore=True, top_k=None). fg [H,W] bool; c_center_map [H,W] is modified in place
+def get_instance_segmentation(fg, c_center_map, offsets, threshold, nms_kernel, beta, ignore=True):
+    """modules/utils.py:545-606 (top_k=None; ignore=True in training, --val_ignore (False) in validation). fg [H,W] bool; c_center_map [H,W] is modified in place
     (cluster centres are marked with 1.0, :583,592). Returns [H,W] long instance ids."""
     ctr = find_instance_center(c_center_map, threshold, nms_kernel)
     new_ctr = ctr
@@ -187,7 +187,7 @@ def get_instance_segmentation(fg, c_center_map, offsets, threshold, nms_kernel, 
                         new_ctr = torch.cat([new_ctr, c.unsqueeze(0)], 0)
                         c_center_map[c[0], c[1]] = 1.0
     if new_ctr.size(0) == 0:
-        return torch.zeros_like(fg).long()
+        return torch.zeros_like(fg).long() if ignore else fg.long()
     return (fg * group_pixels(new_ctr, offsets)).long()
 
 
@@ -269,3 +269,80 @@ def blend_and_losses(center, offset, old_center, old_offset, old_w, pseudo, refi
     return {"center_old": c1, "offset_old": o1, "center_new": c2, "offset_new": o2,
             "l_center": c1 + c2, "l_offset": o1 + o2,
             "target_center": p_center, "target_offset": p_offset, "target_weight": pw}
+
+
+VAL_MINIMUM_MASK_SIZE = 50     # dataset/utils.py:147 (the validation copy; training uses 20, modules/utils.py:14)
+
+
+def get_ins_map(seg, center, offset, target_size=None, val_flip=False, val_thresh=0.1, val_kernel=41, beta=3.0, val_ignore=False,
+                cls_label=None):
+    """dataset/utils.py:795-892 — network outputs (already at `target_size`) -> semantic map and instance predictions.
+    seg [B,C+1,H,W] logits, center [B,C,H,W], offset [B,2,H,W] with B = 2 (image, flipped image) when val_flip else 1.
+    Returns (seg_map [H,W] long, pred_label [R] int, pred_mask [R,H,W] bool, pred_score [R] float); one all-zero prediction
+    when nothing is found (:882-885)."""
+    seg_prob = torch.softmax(seg, 1)
+    offset_map = offset[0].clone()
+    if val_flip:
+        seg_prob = (seg_prob[0] + seg_prob[1].flip(-1)) / 2.
+        center_map = (center[0] + center[1].flip(-1)) / 2.
+    else:
+        seg_prob, center_map = seg_prob[0], center[0].clone()
+    if cls_label is not None:                                   # --val_clean
+        seg_prob = seg_prob.clone()
+        seg_prob[1:] *= cls_label[0, :, None, None]
+    seg_map = torch.argmax(seg_prob, 0)
+    labels, masks, scores = [], [], []
+    for cls in (torch.unique(seg_map).numpy() - 1):
+        if cls < 0:
+            continue
+        n, contours, area, _ = connected_components((seg_map == cls + 1).numpy().astype(np.uint8), 8)
+        for k in range(1, n):
+            if area[k] < VAL_MINIMUM_MASK_SIZE:
+                continue
+            cmask = torch.from_numpy(contours == k)
+            roi = center_map[cls] * cmask
+            ins = get_instance_segmentation(cmask, roi, offset_map, val_thresh, val_kernel, beta, ignore=val_ignore)
+            for i in range(1, int(ins.max()) + 1):
+                m = ins == i
+                if m.sum() > 0:
+                    idx = torch.where(m)
+                    seg_score = seg_prob[cls + 1][idx].mean().item()
+                    center_score = roi[idx].max().item()
+                    if center_score >= 1:
+                        center_score = seg_score
+                    labels.append(int(cls))
+                    masks.append(m.numpy())
+                    scores.append(center_score * seg_score)
+    if not labels:
+        H, W = seg_map.shape
+        return seg_map, np.zeros(1, dtype=np.int64), np.zeros((1, H, W), dtype=bool), np.zeros(1)
+    return seg_map, np.array(labels), np.stack(masks, 0), np.array(scores)
+
+
+def mask_iou(a, b):
+    """chainercv.utils.mask.mask_iou (absent third-party, restated): pairwise IoU of bool masks [N,H,W] x [K,H,W]."""
+    a, b = a.reshape(len(a), -1).astype(np.float64), b.reshape(len(b), -1).astype(np.float64)
+    inter = a @ b.T
+    union = a.sum(1)[:, None] + b.sum(1)[None, :] - inter
+    return inter / np.maximum(union, 1e-12) * (union > 0)
+
+
+def calc_detection_voc_ap(prec, rec, use_07_metric=False):
+    """chainercv.evaluations.calc_detection_voc_ap (absent third-party, restated from its documented algorithm)."""
+    ap = np.empty(len(prec))
+    for l in range(len(prec)):
+        if prec[l] is None or rec[l] is None:
+            ap[l] = np.nan
+            continue
+        if use_07_metric:
+            ap[l] = 0
+            for t in np.arange(0., 1.1, 0.1):
+                p = 0 if np.sum(rec[l] >= t) == 0 else np.max(np.nan_to_num(prec[l])[rec[l] >= t])
+                ap[l] += p / 11
+        else:
+            mpre = np.concatenate(([0], np.nan_to_num(prec[l]), [0]))
+            mrec = np.concatenate(([0], rec[l], [1]))
+            mpre = np.maximum.accumulate(mpre[::-1])[::-1]
+            i = np.where(mrec[1:] != mrec[:-1])[0]
+            ap[l] = np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
+    return ap

@@ -7,6 +7,7 @@ Used by tests/, the golden generator and bench.py (label-stage inputs of the syn
 """
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 
 def label_stage_inputs(seed, b=2, H=129, W=129, stride=16, tot_classes=21, old_classes=16, K=25, noise=0.3,
@@ -89,3 +90,18 @@ def wss_inputs(seed, b, c, h, w):
     seg_lab[torch.rand(seg_lab.shape, generator=g) < 0.1] = 255
     big = torch.randn(b, c, 2 * h + 1, 2 * w + 1, generator=g)
     return dict(img=img, logits=logits, labels=labels, seg_lab=seg_lab, big=big)
+
+
+def insmap_inputs(seed, H, W, flip):
+    """Full-resolution network outputs for the validation post-processing fixtures (get_ins_map): the structured
+    low-resolution maps of label_stage_inputs upsampled to (H, W); batch 2 = (image, flipped image) when flip."""
+    inp = label_stage_inputs(seed, b=2 if flip else 1, H=H, W=W)
+    tot, old = inp["tot_classes"], inp["old_classes"]
+    nb = 2 if flip else 1
+    up = lambda t: F.interpolate(t, size=(H, W), mode="bilinear", align_corners=False)
+    seg = up(inp["seg2b"][:nb]) * 3
+    center = torch.zeros(nb, tot - 1, H, W)
+    center[:, old - 1:] = up(inp["center_lo"][:nb, old - 1:])
+    center = center.clamp(0, 0.95)
+    offset = up(inp["offset_lo"][:nb])
+    return seg, center, offset

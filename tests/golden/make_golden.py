@@ -29,6 +29,7 @@ from oracle import synth, weights  # noqa: E402
 
 CROP = 65
 MODEL_SEED = 1
+INSMAP_CASES = [(0, 129, 129, False), (3, 129, 129, True), (6, 161, 145, True)]
 LABEL_CASES = [(0, 2, 129, 129), (3, 3, 129, 129), (5, 2, 97, 145), (6, 2, 193, 193)]
 
 
@@ -140,6 +141,21 @@ def model_p1_fixture(R):
     out["rm_pl"] = pl.norm2.running_mean.numpy().copy()
     np.savez_compressed(os.path.join(HERE, "model_p1_c65.npz"), **out)
     print("model_p1_c65.npz", {k: getattr(v, "shape", None) for k, v in out.items() if k != "grad_names"})
+
+
+def insmap_fixture(R, seed, H, W, flip):
+    """Reference get_ins_map (dataset/utils.py:795-892) on structured outputs: semantic blobs, centre bumps, offsets."""
+    import types
+    du = R["dataset_utils"]
+    seg, center, offset = synth.insmap_inputs(seed, H, W, flip)
+    args = types.SimpleNamespace(val_flip=flip, val_clean=False, val_thresh=0.1, val_kernel=41, beta=3.0, val_ignore=False)
+    out = {"seg": seg.clone(), "center": center.clone(), "offset": offset.clone()}
+    seg_map, lab, msk, sc = du.get_ins_map(out, False, (H, W), torch.device("cpu"), args)
+    order = np.lexsort((msk.reshape(len(msk), -1).argmax(1), lab))
+    np.savez_compressed(os.path.join(HERE, f"insmap_s{seed:02d}.npz"), case=np.array([seed, H, W, int(flip)]),
+                        seg_map=seg_map.astype(np.uint8), labels=lab[order],
+                        masks=np.packbits(msk[order].astype(np.uint8)), n=len(lab), scores=sc[order])
+    print(f"insmap_s{seed:02d}.npz", len(lab), "instances, classes", np.unique(lab))
 
 
 def label_fixture(R, seed, b, H, W):
@@ -286,6 +302,8 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     model_fixture(R)
     model_p1_fixture(R)
+    for case in INSMAP_CASES:
+        insmap_fixture(R, *case)
     for case in LABEL_CASES:
         label_fixture(R, *case)
     for case in WSS_CASES:

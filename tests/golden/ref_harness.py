@@ -109,5 +109,6 @@ def load_reference():
     _loaded.update(dict(segmentation_module=segmentation_module, argparser=argparser, tasks=tasks, bestie=bestie,
                         wss_modules=wss_modules, wss_utils=wss_utils,
                         loss=by_path("ref_utils_loss", "utils/loss.py"),
-                        wss_loss=by_path("ref_utils_wss_loss", "utils/wss_loss.py")))
+                        wss_loss=by_path("ref_utils_wss_loss", "utils/wss_loss.py"),
+                        dataset_utils=by_path("ref_dataset_utils", "dataset/utils.py")))
     return _loaded
