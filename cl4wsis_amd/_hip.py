@@ -56,6 +56,16 @@ class P2LossIO(C.Structure):
     ]
 
 
+class InsmapIO(C.Structure):
+    _fields_ = [
+        ("H", C.c_int32), ("W", C.c_int32), ("classes", C.c_int32), ("nms_kernel", C.c_int32), ("min_mask", C.c_int32),
+        ("ignore", C.c_int32), ("cap", C.c_int32),
+        ("thresh", C.c_float), ("beta", C.c_float),
+        ("seg_map", C.c_void_p), ("prob_win", C.c_void_p), ("center", C.c_void_p), ("offset", C.c_void_p),
+        ("ins_map", C.c_void_p), ("table", C.c_void_p), ("count", C.c_void_p),
+    ]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -126,6 +136,8 @@ _decl("cl4_channel_affine", _P, _P, _I, _I, _I, _P, _P, _P)
 _decl("cl4_randrop_loss", _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_transpose_flip_weight", _P, _P, _I, _I, _I, _P)
 _decl("cl4_random_labels", _P, _L, C.c_uint64, _I, _P)
+_decl("cl4_val_seg", _P, _P, _P, _P, _I, _I, _I, _I, _I, _P)
+_decl("cl4_instance_map", C.POINTER(InsmapIO), _P, C.c_size_t, _P)
 _decl("cl4_semseg_hist", _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_sgd_step", _P, _P, _P, _L, _F, _P, _F, _F, _I, _P)
 _decl("cl4_pamr", _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, C.c_size_t, _P)

@@ -383,6 +383,34 @@ __global__ __launch_bounds__(256) void semseg_hist_kernel(const float* __restric
   }
 }
 
+
+// get_ins_map's semantic part (dataset/utils.py:817-836): per-sample softmax, flip average of the PROBABILITIES,
+// optional image-level label mask (--val_clean), arg-max (first maximum) and the winning probability.
+__global__ __launch_bounds__(256) void val_seg_kernel(const float* __restrict__ logits, const float* __restrict__ cls_label,
+                                                      unsigned char* __restrict__ seg_map, float* __restrict__ prob_win, int c, int H,
+                                                      int W, int flip) {
+  const long HW = (long)H * W;
+  for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < HW; q += (long)gridDim.x * blockDim.x) {
+    const int y = (int)(q / W), x = (int)(q - (long)y * W);
+    const float* a = logits + q;
+    const float* b = logits + (long)c * HW + (long)y * W + (W - 1 - x);
+    float ma = -INFINITY, mb = -INFINITY;
+    for (int k = 0; k < c; ++k) { ma = fmaxf(ma, a[(long)k * HW]); if (flip) mb = fmaxf(mb, b[(long)k * HW]); }
+    float da = 0.f, db = 0.f;
+    for (int k = 0; k < c; ++k) { da += expf(a[(long)k * HW] - ma); if (flip) db += expf(b[(long)k * HW] - mb); }
+    float best = -1.f;
+    int arg = 0;
+    for (int k = 0; k < c; ++k) {
+      float pr = expf(a[(long)k * HW] - ma) / da;
+      if (flip) pr = (pr + expf(b[(long)k * HW] - mb) / db) / 2.f;
+      if (cls_label && k > 0) pr *= cls_label[k - 1];
+      if (pr > best) { best = pr; arg = k; }
+    }
+    seg_map[q] = (unsigned char)arg;
+    prob_win[q] = best;
+  }
+}
+
 }  // namespace
 
 extern "C" int cl4_cam_smooth(const float* int_masks, int b, int ctot, int h, int w, const float* pg_w, const float* pg_b,
@@ -470,5 +498,14 @@ extern "C" int cl4_semseg_hist(const float* logits, const long long* labels, uns
   const int nn = n_classes * n_classes;
   hipLaunchKernelGGL(semseg_hist_kernel, dim3(cl4::stream_grid(N, 256)), dim3(256), nn <= 4096 ? (size_t)nn * 4 : 0, cl4::as_stream(stream),
                      logits, labels, hist, pred, nb, c, H, W, flip, n_classes, zero_below);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_val_seg(const float* logits, const float* cls_label, unsigned char* seg_map, float* prob_win, int nb, int c, int H,
+                           int W, int flip, void* stream) {
+  CL4_REQUIRE(logits && seg_map && prob_win && c > 0 && c < 256 && H > 0 && W > 0, "val_seg: bad arguments");
+  CL4_REQUIRE(nb == (flip ? 2 : 1), "val_seg: batch must be 1, or 2 = [image, flipped image] with flip");
+  hipLaunchKernelGGL(val_seg_kernel, dim3(cl4::stream_grid((long)H * W, 256)), dim3(256), 0, cl4::as_stream(stream), logits, cls_label,
+                     seg_map, prob_win, c, H, W, flip);
   return cl4::launch_status();
 }

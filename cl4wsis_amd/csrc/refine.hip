@@ -86,6 +86,9 @@ struct IO {
   const float* center_lo; const float* offset_lo; const float* gauss;
   float* p_center; float* p_offset; float* p_weight;
   float* r_center; float* r_offset; float* r_weight;
+  // validation mode (get_ins_map, dataset/utils.py:795-892): every class, no instance cap, instance table instead of maps
+  int val, ignore, min_mask, v_cap;
+  int* v_ins_map; float* v_table; int* v_count;
 };
 
 __device__ __forceinline__ float center_up(const IO& io, int b, int cls, int Y, int X) {
@@ -127,7 +130,7 @@ __global__ void pseudo_paint_kernel(IO io, WS ws) {
     int r = ws.L8[p];
     if (r >= 0) {
       unsigned a = ws.area[r];
-      if (a >= (unsigned)MIN_MASK) {
+      if (a >= (unsigned)io.min_mask) {
         int cx = (int)(ws.sumx[r] / a), cy = (int)(ws.sumy[r] / a);
         bool acc = ws.pcnt[r] == 1u;
         int b = p / HW;
@@ -152,11 +155,13 @@ __global__ void pseudo_paint_kernel(IO io, WS ws) {
         }
       }
     }
-    int b = p / HW;
-    long q = p - (long)b * HW;
-    io.p_weight[p] = wgt;
-    io.p_offset[((long)b * 2) * HW + q] = oy;
-    io.p_offset[((long)b * 2 + 1) * HW + q] = ox;
+    if (io.p_weight) {
+      int b = p / HW;
+      long q = p - (long)b * HW;
+      io.p_weight[p] = wgt;
+      io.p_offset[((long)b * 2) * HW + q] = oy;
+      io.p_offset[((long)b * 2 + 1) * HW + q] = ox;
+    }
   }
 }
 
@@ -397,8 +402,9 @@ __global__ void group_kernel(IO io, WS ws) {
     }
     ws.ins_id[p] = (uint8_t)min(id, 255);
     atomicMax(&ws.ct[cid].nmax, id);
-    if (id <= MAX_INST) {
-      Inst& in = ws.inst[(long)cid * (MAX_INST + 1) + id];
+    if (io.val) io.v_ins_map[p] = ct.cstart + id - 1;      // one table row per centre (sorted by contour)
+    if (io.val || id <= MAX_INST) {
+      Inst& in = io.val ? ws.inst[ct.cstart + id - 1] : ws.inst[(long)cid * (MAX_INST + 1) + id];
       atomicAdd(&in.cnt, 1u);
       atomicAdd(&in.sump, (double)io.prob_win[p]);
       float cv = ws.mark[p] ? 1.0f : center_up(io, b, ct.cls, y, x);
@@ -431,6 +437,46 @@ __global__ __launch_bounds__(256) void finalize_kernel(IO io, WS ws) {
       if (threadIdx.x == 0) { in.py = py; in.px = px; in.conf = (float)conf; in.valid = 1; }
       splat_one(io.r_center, io.cnew, io.H, io.W, io.sigma, io.gauss, ct.b, ct.cls, px, py);
     }
+  }
+}
+
+// Validation, --val_ignore off (modules/utils.py:599-602): a contour without any centre is one instance. A single centre
+// at the contour's centroid makes group_pixels assign every pixel to id 1.
+__global__ void fallback_center_kernel(IO io, WS ws) {
+  int n = min(ws.cnt->n_contour, CT_CAP);
+  for (int cid = blockIdx.x * blockDim.x + threadIdx.x; cid < n; cid += gridDim.x * blockDim.x) {
+    Contour& ct = ws.ct[cid];
+    if (ct.ncen != 0) continue;
+    int s = atomicAdd(&ws.cnt->n_center, 1);
+    if (s >= LIST_CAP) { ws.cnt->overflow = 1; continue; }
+    Center c;
+    c.cid = cid; c.y = ct.cy; c.x = ct.cx; c.pad = 0;
+    c.key = ((unsigned long long)cid << 34) | 1ull;
+    ws.cen[s] = c;
+    ct.ncen = 1;
+  }
+}
+
+// Validation scores (dataset/utils.py:866-880): seg_score = mean winning probability over the instance, center_score = the
+// largest (contour-masked) centre value on it, replaced by seg_score for clustered centres (marked 1.0); one row per centre:
+// {class, score, pixel count, contour id}; rows with count 0 (a centre that attracted no pixel) are dropped by the caller.
+__global__ void val_finalize_kernel(IO io, WS ws) {
+  int n = min(ws.cnt->n_center, min(LIST_CAP, io.v_cap));
+  if (blockIdx.x == 0 && threadIdx.x == 0) *io.v_count = n;
+  for (int gi = blockIdx.x * blockDim.x + threadIdx.x; gi < n; gi += gridDim.x * blockDim.x) {
+    const Inst& in = ws.inst[gi];
+    const Contour& ct = ws.ct[ws.cen_sorted[gi].cid];
+    float score = 0.f;
+    if (in.cnt > 0) {
+      float center_score = cl4::from_ordered_bits((unsigned)(in.amax >> 32));
+      const float seg_score = (float)(in.sump / (double)in.cnt);
+      if (center_score >= 1.f) center_score = seg_score;
+      score = (float)((double)center_score * (double)seg_score);
+    }
+    io.v_table[gi * 4 + 0] = (float)ct.cls;
+    io.v_table[gi * 4 + 1] = score;
+    io.v_table[gi * 4 + 2] = (float)in.cnt;
+    io.v_table[gi * 4 + 3] = (float)ws.cen_sorted[gi].cid;
   }
 }
 
@@ -494,6 +540,7 @@ extern "C" int cl4_label_generation(const cl4_label_io* d, void* workspace, size
   io.center_lo = d->center_lo; io.offset_lo = d->offset_lo; io.gauss = d->gauss;
   io.p_center = d->p_center; io.p_offset = d->p_offset; io.p_weight = d->p_weight;
   io.r_center = d->r_center; io.r_offset = d->r_offset; io.r_weight = d->r_weight;
+  io.val = 0; io.ignore = 1; io.min_mask = MIN_MASK; io.v_cap = 0; io.v_ins_map = nullptr; io.v_table = nullptr; io.v_count = nullptr;
 
   hipStream_t st = cl4::as_stream(stream);
   const int g = cl4::stream_grid(N, 256);
@@ -541,5 +588,59 @@ extern "C" int cl4_label_counters(const void* workspace, int b, int H, int W, in
   WS ws;
   layout(&ws, (char*)workspace, (long)b * H * W);
   hipMemcpyAsync(out5, ws.cnt, 5 * sizeof(int), hipMemcpyDeviceToDevice, cl4::as_stream(stream));
+  return cl4::launch_status();
+}
+
+// Validation post-processing (dataset/utils.py:795-892 get_ins_map): one image, full-resolution maps, every class.
+extern "C" int cl4_instance_map(const cl4_insmap_io* d, void* workspace, size_t workspace_bytes, void* stream) {
+  CL4_REQUIRE(d && workspace, "instance_map: null pointer");
+  CL4_REQUIRE(d->H > 0 && d->W > 0 && d->classes > 0 && d->classes < 255, "instance_map: bad dims");
+  CL4_REQUIRE(d->seg_map && d->prob_win && d->center && d->offset && d->ins_map && d->table && d->count && d->cap > 0,
+              "instance_map: null tensor");
+  CL4_REQUIRE(d->nms_kernel % 2 == 1 && (d->nms_kernel - 1) / 2 <= NR_MAX, "instance_map: --val_kernel %d unsupported (odd, <= 41)",
+              d->nms_kernel);
+  const long N = (long)d->H * d->W;
+  CL4_REQUIRE(N < 2147483647L, "instance_map: index overflow");
+  if (workspace_bytes < cl4_label_workspace_bytes(1, d->H, d->W)) { cl4::set_error("instance_map: workspace too small"); return CL4_ENOSPC; }
+  WS ws;
+  layout(&ws, (char*)workspace, N);
+  IO io{};
+  io.b = 1; io.H = d->H; io.W = d->W; io.cnew = d->classes; io.old_classes = 1; io.hc = d->H; io.wc = d->W;
+  io.center_ctot = d->classes; io.K = 0; io.sigma = 1; io.nms_r = (d->nms_kernel - 1) / 2; io.run_refine = 1;
+  io.pseudo_thresh = 2.f; io.refine_thresh = d->thresh; io.beta = d->beta;
+  io.seg_gt = d->seg_map; io.prob_win = d->prob_win; io.center_lo = d->center; io.offset_lo = d->offset;
+  io.val = 1; io.ignore = d->ignore; io.min_mask = d->min_mask; io.v_cap = d->cap;
+  io.v_ins_map = d->ins_map; io.v_table = d->table; io.v_count = d->count;
+
+  hipStream_t st = cl4::as_stream(stream);
+  const int g = cl4::stream_grid(N, 256);
+  hipMemsetAsync(ws.cnt, 0, sizeof(Counters), st);
+  hipMemsetAsync(ws.pcnt, 0, N * 4, st);
+  hipMemsetAsync(ws.cid_map, 0xFF, N * 4, st);
+  hipMemsetAsync(d->ins_map, 0xFF, N * 4, st);
+  int rc = cl4_ccl(io.seg_gt, 1, d->H, d->W, 8, ws.L8, stream);
+  if (rc) return rc;
+  rc = cl4_cc_stats(ws.L8, 1, d->H, d->W, ws.area, ws.sumx, ws.sumy, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pseudo_paint_kernel, dim3(g), dim3(256), 0, st, io, ws);      // registers the contours
+  hipMemsetAsync(ws.mark, 0, N, st);
+  hipMemsetAsync(ws.ins_id, 0, N, st);
+  hipMemsetAsync(ws.inst, 0, sizeof(Inst) * (size_t)CT_CAP * (MAX_INST + 1), st);
+  hipLaunchKernelGGL(weak_map_kernel, dim3(g), dim3(256), 0, st, io, ws);
+  rc = cl4_ccl(ws.weak, 1, d->H, d->W, 4, ws.L4, stream);
+  if (rc) return rc;
+  rc = cl4_cc_stats(ws.L4, 1, d->H, d->W, ws.area4, ws.sumx4, ws.sumy4, stream);
+  if (rc) return rc;
+  dim3 gn(cl4::cdiv(d->H, NT) * cl4::cdiv(d->W, NT), 1);
+  hipLaunchKernelGGL(nms_center_kernel, gn, dim3(256), 0, st, io, ws);
+  hipLaunchKernelGGL(cluster_candidate_kernel, dim3(g), dim3(256), 0, st, io, ws);
+  hipLaunchKernelGGL(background_candidate_kernel, dim3(64), dim3(256), 0, st, io, ws);
+  hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(1), 0, st, ws);
+  hipLaunchKernelGGL(cluster_merge_kernel, dim3(64), dim3(256), 0, st, io, ws);
+  if (!d->ignore) hipLaunchKernelGGL(fallback_center_kernel, dim3(64), dim3(256), 0, st, io, ws);
+  hipLaunchKernelGGL(center_sort_kernel, dim3(256), dim3(256), 0, st, ws);
+  hipLaunchKernelGGL(center_range_kernel, dim3(64), dim3(256), 0, st, ws);
+  hipLaunchKernelGGL(group_kernel, dim3(g), dim3(256), 0, st, io, ws);
+  hipLaunchKernelGGL(val_finalize_kernel, dim3(64), dim3(256), 0, st, io, ws);
   return cl4::launch_status();
 }

@@ -956,3 +956,45 @@ def semseg_hist_(hist, logits, labels, n_classes, flip=False, zero_below=0, want
     call("cl4_semseg_hist", ptr(logits), ptr(labels), ptr(hist), ptr(pred), nb, c, H, W, int(bool(flip)), int(n_classes),
          int(zero_below), stream())
     return pred
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Validation post-processing (get_ins_map, dataset/utils.py:795-892) — label.hip / refine.hip
+# ---------------------------------------------------------------------------------------------------------------------
+VAL_MIN_MASK = 50        # MINIMUM_MASK_SIZE of dataset/utils.py:147 (training uses 20)
+
+
+def val_seg(logits, flip=False, cls_label=None):
+    """softmax -> flip average of the probabilities -> (val_clean mask) -> arg-max. Returns (seg_map u8 [H,W], prob [H,W])."""
+    _f32c(logits, "val_seg logits")
+    nb, c, H, W = logits.shape
+    seg_map = torch.empty((H, W), dtype=torch.uint8, device=logits.device)
+    prob = torch.empty((H, W), dtype=torch.float32, device=logits.device)
+    call("cl4_val_seg", ptr(logits), ptr(cls_label) if cls_label is not None else None, ptr(seg_map), ptr(prob), nb, c, H, W,
+         int(bool(flip)), stream())
+    return seg_map, prob
+
+
+def instance_map(seg_map, prob_win, center, offset, thresh=0.1, nms_kernel=41, beta=3.0, ignore=False, min_mask=VAL_MIN_MASK,
+                 cap=4096):
+    """get_ins_map's instance part for one image. center [C,H,W], offset [2,H,W]. Returns (ins_map int32 [H,W], table [n,4] =
+    class / score / pixels / contour, device tensors); n is read back from the device (one small D2H copy)."""
+    H, W = seg_map.shape
+    _f32c(center, "instance_map center"), _f32c(offset, "instance_map offset"), _f32c(prob_win, "instance_map prob")
+    if seg_map.dtype != torch.uint8 or tuple(center.shape[1:]) != (H, W) or tuple(offset.shape) != (2, H, W):
+        raise RuntimeError("instance_map: seg_map u8 [H,W], center [C,H,W], offset [2,H,W] expected")
+    dev = seg_map.device
+    ins = torch.empty((H, W), dtype=torch.int32, device=dev)
+    table = torch.zeros((cap, 4), dtype=torch.float32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    d = _hip.InsmapIO()
+    d.H, d.W, d.classes, d.nms_kernel, d.min_mask, d.ignore, d.cap = H, W, center.shape[0], int(nms_kernel), int(min_mask), int(bool(ignore)), cap
+    d.thresh, d.beta = float(thresh), float(beta)
+    pv = lambda t: ptr(t).value
+    d.seg_map, d.prob_win, d.center, d.offset = pv(seg_map), pv(prob_win), pv(center), pv(offset)
+    d.ins_map, d.table, d.count = pv(ins), pv(table), pv(count)
+    nbytes = _hip.load().cl4_label_workspace_bytes(1, H, W)
+    ws = _workspace(dev, nbytes)
+    call("cl4_instance_map", C.byref(d), ptr(ws), ws.numel(), stream())
+    n = int(count.item())
+    return ins, table[:n]

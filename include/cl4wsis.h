@@ -378,6 +378,24 @@ int cl4_transpose_flip_weight(const float* w, float* wt, int cout, int cin, int 
 int cl4_semseg_hist(const float* logits, const long long* labels, unsigned long long* hist, unsigned char* pred, int nb, int c, int H,
                     int W, int flip, int n_classes, int zero_below, void* stream);
 
+/* Validation post-processing — get_ins_map (dataset/utils.py:795-892, called from Trainer.validate train.py:622-626):
+ * cl4_val_seg: per-sample softmax of the full-resolution logits [nb,c,H,W] (nb = 2 = [image, flipped image] with flip),
+ *   flip average of the probabilities, optional --val_clean label mask [c-1], arg-max -> seg_map u8 [H,W] + its probability;
+ * cl4_instance_map: per class and 8-connected component of >= min_mask pixels (50 in validation, dataset/utils.py:147):
+ *   get_instance_segmentation (thresh / nms_kernel / beta / ignore = --val_thresh / --val_kernel / --beta / --val_ignore) ->
+ *   ins_map int32 [H,W] (row of `table`, -1 = none) and table [count,4] = {class (0-based fg), score, pixels, contour};
+ *   rows with 0 pixels are centres that attracted no pixel (the reference skips them). Workspace:
+ *   cl4_label_workspace_bytes(1, H, W). `center` [classes,H,W] is the (flip-averaged) centre map, `offset` [2,H,W]. */
+int cl4_val_seg(const float* logits, const float* cls_label, unsigned char* seg_map, float* prob_win, int nb, int c, int H, int W,
+                int flip, void* stream);
+typedef struct cl4_insmap_io {
+  int32_t H, W, classes, nms_kernel, min_mask, ignore, cap;
+  float thresh, beta;
+  const uint8_t* seg_map; const float* prob_win; const float* center; const float* offset;
+  int32_t* ins_map; float* table; int32_t* count;
+} cl4_insmap_io;
+int cl4_instance_map(const cl4_insmap_io* d, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

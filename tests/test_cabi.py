@@ -42,7 +42,8 @@ def test_struct_layouts_match_header_field_order():
     from cl4wsis_amd import _hip
     src = open(os.path.join(ROOT, "include", "cl4wsis.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    for cname, st in (("cl4_conv_desc", _hip.ConvDesc), ("cl4_label_io", _hip.LabelIO), ("cl4_p2_loss_io", _hip.P2LossIO)):
+    for cname, st in (("cl4_conv_desc", _hip.ConvDesc), ("cl4_label_io", _hip.LabelIO), ("cl4_p2_loss_io", _hip.P2LossIO),
+                      ("cl4_insmap_io", _hip.InsmapIO)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, re.S).group(1)
         fields = []
         for decl in body.split(";"):
