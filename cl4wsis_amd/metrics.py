@@ -79,3 +79,85 @@ class StreamSegMetrics:
             for i, name in enumerate(["Class IoU", "Class Acc", "Class Prec"]):
                 s += f"{name}:'\t: {results['Agg'][i]}\n"
         return s
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Instance-segmentation AP (train.py:653-693 eval_detection_voc, metrics/voc_evaluation.py:11-140). chainercv's mask_iou and
+# calc_detection_voc_ap are third-party code that is not part of the reference tree: restated from their documented
+# behaviour (parity unpinned at that boundary).
+# ---------------------------------------------------------------------------------------------------------------------
+def mask_iou(a, b):
+    a, b = a.reshape(len(a), -1).astype(np.float64), b.reshape(len(b), -1).astype(np.float64)
+    inter = a @ b.T
+    union = a.sum(1)[:, None] + b.sum(1)[None, :] - inter
+    return np.where(union > 0, inter / np.maximum(union, 1e-12), 0.0)
+
+
+def calc_detection_voc_ap(prec, rec, use_07_metric=False):
+    ap = np.empty(len(prec))
+    for l in range(len(prec)):
+        if prec[l] is None or rec[l] is None:
+            ap[l] = np.nan
+            continue
+        if use_07_metric:
+            ap[l] = 0
+            for t in np.arange(0., 1.1, 0.1):
+                p = 0 if np.sum(rec[l] >= t) == 0 else np.max(np.nan_to_num(prec[l])[rec[l] >= t])
+                ap[l] += p / 11
+        else:
+            mpre = np.concatenate(([0], np.nan_to_num(prec[l]), [0]))
+            mrec = np.concatenate(([0], rec[l], [1]))
+            mpre = np.maximum.accumulate(mpre[::-1])[::-1]
+            i = np.where(mrec[1:] != mrec[:-1])[0]
+            ap[l] = np.sum((mrec[i + 1] - mrec[i]) * mpre[i + 1])
+    return ap
+
+
+class DetectionAccumulator:
+    """n_pos / score / match bookkeeping of Trainer.eval_detection_voc (train.py:653-693) for one IoU threshold."""
+
+    def __init__(self):
+        from collections import defaultdict
+        self.n_pos, self.score, self.match = defaultdict(int), defaultdict(list), defaultdict(list)
+
+    def update(self, gt_label, gt_mask, pred_label, pred_mask, pred_score, iou_thresh):
+        for l in np.unique(np.concatenate((pred_label, gt_label)).astype(int)):
+            keep = pred_label == l
+            pm, ps = pred_mask[keep], pred_score[keep]
+            order = ps.argsort()[::-1]
+            pm, ps = pm[order], ps[order]
+            gm = gt_mask[gt_label == l]
+            self.n_pos[l] += int((gt_label == l).sum())
+            self.score[l].extend(ps)
+            if len(pm) == 0:
+                continue
+            if len(gm) == 0:
+                self.match[l].extend((0,) * pm.shape[0])
+                continue
+            iou = mask_iou(pm, gm)
+            gt_index = iou.argmax(axis=1)
+            gt_index[iou.max(axis=1) < iou_thresh] = -1
+            selec = np.zeros(gm.shape[0], dtype=bool)
+            for g in gt_index:
+                if g >= 0:
+                    self.match[l].append(0 if selec[g] else 1)
+                    selec[g] = True
+                else:
+                    self.match[l].append(0)
+
+    def ap(self, use_07_metric=False):
+        """metrics/voc_evaluation.py:11-140."""
+        if not self.n_pos:
+            return np.zeros(0)
+        n_fg = max(self.n_pos.keys()) + 1
+        prec, rec = [None] * n_fg, [None] * n_fg
+        for l in self.n_pos.keys():
+            score_l = np.array(self.score[l])
+            match_l = np.array(self.match[l], dtype=np.int8)
+            match_l = match_l[score_l.argsort()[::-1]]
+            tp, fp = np.cumsum(match_l == 1), np.cumsum(match_l == 0)
+            with np.errstate(all="ignore"):
+                prec[l] = tp / (fp + tp)
+            if self.n_pos[l] > 0:
+                rec[l] = tp / self.n_pos[l]
+        return calc_detection_voc_ap(prec, rec, use_07_metric=use_07_metric)

@@ -361,7 +361,59 @@ class Trainer:
         return (epoch_loss, reg)
 
     def validate(self, valid_loader, opts):
-        raise NotImplementedError("Trainer.validate (VOC instance AP) is row 1 of SURVEY.md §8(f) — not built yet")
+        """train.py:588-651 — instance-segmentation validation: eval forward (optionally [image, flipped image]), outputs to
+        the ground-truth size, get_ins_map on the device (cl4_val_seg + cl4_instance_map), VOC mask AP at IoU 0.5:0.05:0.9
+        on the host (cl4wsis_amd.metrics: restatement of the chainercv helpers the reference imports). Returns
+        {'ap': per-class AP averaged over the thresholds, 'map': their mean} like the reference (on every rank)."""
+        from . import metrics as MT
+        iou_thresholds = np.arange(0.5, 0.95, 0.05).tolist()
+        acc = [MT.DetectionAccumulator() for _ in iou_thresholds]
+        model, device = self.model, self.device
+        model.eval()
+        for img, seg, mask, mask_label, fname in valid_loader:
+            gt_mask = np.asarray(mask)[0].astype(bool)
+            gt_label = np.asarray(mask_label)[0] - 1                      # -1 removes the background class
+            pred_label, pred_mask, pred_score = self.predict_instances(img, tuple(mask.shape[-2:]), opts)
+            for a, thr in zip(acc, iou_thresholds):
+                a.update(gt_label, gt_mask, pred_label, pred_mask, pred_score, thr)
+        ap_masks = np.zeros((len(iou_thresholds), self.tot_classes - 1))
+        for i, a in enumerate(acc):
+            ap = a.ap()
+            ap_masks[i, :len(ap)] = ap[:self.tot_classes - 1]
+            ap_masks[i, len(ap):] = np.nan
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)      # classes absent from predictions and ground truth: nan
+            ap_05_95 = np.nanmean(ap_masks, axis=0)
+            result = {"ap": ap_05_95, "map": np.nanmean(ap_05_95)}
+        model.train()
+        return result
+
+    def predict_instances(self, img, target_size, opts, cls_label=None):
+        """One validation image -> (pred_label [R], pred_mask [R,H,W] bool, pred_score [R]) — train.py:616-626 +
+        dataset/utils.py:795-892. `img` [1,3,h,w]; `target_size` the ground-truth (original image) size."""
+        images = img.to(self.device, dtype=torch.float32).contiguous()
+        if images.shape[0] != 1:
+            raise RuntimeError("validate: batch size 1 expected (train.py:608-618)")
+        if opts.val_flip:
+            images = torch.cat([images, ops.flip_w(images)], dim=0)
+        out = self.model(images)[0]                                       # interpolate=True: align_corners=True to the input size
+        up = {k: ops.resize_bilinear(v, tuple(target_size), False) for k, v in out.items()}
+        lab = None
+        if opts.val_clean and cls_label is not None:
+            lab = cls_label.to(self.device, dtype=torch.float32).reshape(-1).contiguous()
+        seg_map, prob = ops.val_seg(up["seg"], flip=opts.val_flip, cls_label=lab)
+        center = up["center"]
+        if opts.val_flip:
+            center = ops.scale_(ops.add_act(center[:1].contiguous(), ops.flip_w(center[1:].contiguous()), ops.ACT_NONE, 0.0), 0.5)
+        ins, table = ops.instance_map(seg_map, prob, center[0].contiguous(), up["offset"][0].contiguous(), thresh=opts.val_thresh,
+                                      nms_kernel=opts.val_kernel, beta=opts.beta, ignore=opts.val_ignore)
+        ins, table = ins.cpu().numpy(), table.cpu().numpy()
+        keep = [i for i in range(len(table)) if table[i, 2] > 0]
+        if not keep:                                                      # dataset/utils.py:882-885
+            return np.zeros(1, dtype=np.int64), np.zeros((1,) + tuple(target_size), dtype=bool), np.zeros(1)
+        return (np.array([int(table[i, 0]) for i in keep]), np.stack([ins == i for i in keep], 0),
+                np.array([float(table[i, 1]) for i in keep]))
 
     def validate_semseg(self, loader, metrics, opts, eval_pseudolabeler=False):
         """train.py:695-745 — semantic validation: eval forward (optionally [image, flipped image]), logits to image size,

@@ -74,3 +74,57 @@ def test_validate_semseg_matches_reference_pipeline(gpu):
     assert res["Total samples"] == 3 and abs(res["Overall Acc"] - np.diag(ref).sum() / ref.sum()) < 2e-3
     iu = np.diag(ref) / (ref.sum(1) + ref.sum(0) - np.diag(ref) + 1e-6)
     assert abs(res["Mean IoU"] - iu[ref.sum(1) != 0].mean()) < 2e-3
+
+
+def test_validate_instance_ap(gpu, monkeypatch):
+    """Trainer.validate end to end on structured network outputs (the model's forward is replaced by the synthetic maps of
+    oracle.synth.insmap_inputs so that the instances are meaningful): predictions equal the oracle's get_ins_map on the same
+    maps, and the AP over IoU 0.5:0.95 equals the same accumulation run on the oracle's predictions."""
+    from collections import OrderedDict
+    from cl4wsis_amd import metrics as MT
+    from cl4wsis_amd.train import Trainer
+    from oracle import labels as L, synth
+    crop = 65
+    opts = p2_opts(crop)
+    opts.val_flip = True
+    torch.manual_seed(0)
+    tr = Trainer(_Log(), gpu, opts)
+    cases = [(3, 129, 129), (6, 161, 145), (5, 145, 129)]
+    store = {}
+
+    def fake_forward(images, **kw):
+        seg, center, offset = store["cur"]
+        return OrderedDict(seg=seg.to(gpu), center=center.to(gpu), offset=offset.to(gpu)), {}
+
+    monkeypatch.setattr(tr.model, "forward", fake_forward)
+    loader, ref_preds = [], []
+    for seed, H, W in cases:
+        seg, center, offset = synth.insmap_inputs(seed, H, W, True)
+        _, lab, msk, sc = L.get_ins_map(seg, center, offset, val_flip=True)
+        ref_preds.append((lab, msk, sc))
+        # ground truth: the oracle's instances, one of them shifted (IoU < 1) and one dropped
+        gt_masks, gt_labels = msk.copy(), lab.copy() + 1
+        gt_masks[0] = np.roll(gt_masks[0], 3, axis=1)
+        gt_masks, gt_labels = gt_masks[:-1], gt_labels[:-1]
+        loader.append(((seg, center, offset), torch.zeros(1, H, W), torch.from_numpy(gt_masks)[None], torch.from_numpy(gt_labels)[None], "x"))
+
+    class _Loader:
+        def __iter__(self):
+            for maps, seg_t, m, ml, fn in loader:
+                store["cur"] = maps
+                yield torch.zeros(1, 3, maps[0].shape[-2], maps[0].shape[-1]), seg_t, m, ml, fn
+
+    res = tr.validate(_Loader(), opts)
+    thr = np.arange(0.5, 0.95, 0.05).tolist()
+    acc = [MT.DetectionAccumulator() for _ in thr]
+    for (lab, msk, sc), (_, _, m, ml, _) in zip(ref_preds, loader):
+        for a, t in zip(acc, thr):
+            a.update(ml.numpy()[0] - 1, m.numpy()[0].astype(bool), lab, msk, sc, t)
+    ap = np.full((len(thr), 20), np.nan)
+    for i, a in enumerate(acc):
+        v = a.ap()
+        ap[i, :len(v)] = v[:20]
+    with np.errstate(all="ignore"):
+        ref_ap = np.nanmean(ap, axis=0)
+    np.testing.assert_allclose(res["ap"], ref_ap, rtol=1e-6, equal_nan=True)
+    assert 0.0 < res["map"] <= 1.0 and abs(res["map"] - np.nanmean(ref_ap)) < 1e-9
