@@ -9,8 +9,16 @@ weight (strided convs: zero-inserted output gradient). Gradients go to the buffe
 """
 import torch
 
+import os
+
 from . import ops
 from .nn import CACHE, packed_weight
+
+# Arithmetic of the convolutions of the step-0 / phase-1 training paths (forward, input and weight gradients):
+# 0 = exact fp32 MFMA (default: gradients as accurate as the reference's fp32 CPU arithmetic), 1 = bf16x3 split products
+# (~4e-6 relative per layer — still far tighter than the fp16 autocast the reference trains under on GPUs, train.py:252 —
+# and about twice as fast; opt-in with CL4_TRAIN_PRECISION=1).
+PRECISION = int(os.environ.get("CL4_TRAIN_PRECISION", "0"))
 
 
 class _Rec:
@@ -18,7 +26,7 @@ class _Rec:
 
 
 def _dgrad_weight(conv):
-    return CACHE.get(conv, "dgrad", (conv.weight,), lambda: ops.dgrad_weight(conv.weight.detach()))
+    return CACHE.get(conv, ("dgrad", PRECISION), (conv.weight,), lambda: ops.dgrad_weight(conv.weight.detach(), PRECISION))
 
 
 def conv_abn_train(x, conv, bn, group=None):
@@ -26,7 +34,7 @@ def conv_abn_train(x, conv, bn, group=None):
     k = conv.kernel_size[0]
     r = _Rec()
     r.x = x
-    r.z = ops.conv2d(x, packed_weight(conv, 0), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0])
+    r.z = ops.conv2d(x, packed_weight(conv, PRECISION), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0])
     act, slope = bn.act_code()
     r.y, r.mean, r.var, r.count = ops.abn_train_forward(r.z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                         bn.momentum, bn.eps, act, slope, group)
@@ -40,7 +48,7 @@ def conv_abn_backward(r, conv, bn, dy, grad_of, need_dx=True, group=None):
     dz = ops.abn_train_backward(r.z, dy, r.mean, r.var, bn.weight.detach(), bn.bias.detach(), grad_of(bn.weight), grad_of(bn.bias),
                                 r.count, bn.eps, act, slope, group)
     k = conv.kernel_size[0]
-    ops.conv2d_wgrad(r.x, dz, grad_of(conv.weight), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], precision=0)
+    ops.conv2d_wgrad(r.x, dz, grad_of(conv.weight), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], precision=PRECISION)
     if not need_dx:
         return None
     return ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(r.x.shape[2:]), k, stride=conv.stride[0], pad=conv.padding[0],

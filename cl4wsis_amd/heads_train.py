@@ -3,6 +3,7 @@ PseudoLabeler (SURVEY.md §8 A3, A4, A8 with gradients; phase 1 / step 0). Same 
 import torch
 
 from . import ops
+from . import body_train as BT
 from .body_train import _Rec, _dgrad_weight, conv_abn_backward, conv_abn_train
 from .nn import CACHE, packed_weight
 
@@ -24,8 +25,12 @@ def _abn_bwd(rec, bn, dy, grad_of, group):
 
 
 def _conv1x1_bwd(x, conv, dz, grad_of, need_dx=True):
-    ops.conv2d_wgrad(x, dz, grad_of(conv.weight), 1, precision=0)
-    return ops.conv2d(dz, conv.weight.detach().reshape(conv.out_channels, conv.in_channels), 1) if need_dx else None
+    ops.conv2d_wgrad(x, dz, grad_of(conv.weight), 1, precision=BT.PRECISION)
+    if not need_dx:
+        return None
+    if BT.PRECISION:
+        return ops.conv2d(dz, _dgrad_weight(conv), 1)
+    return ops.conv2d(dz, conv.weight.detach().reshape(conv.out_channels, conv.in_channels), 1)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -36,13 +41,13 @@ def deeplab_forward(head, x, group=None):
     hid = head.hidden
     cat = torch.empty((n, 4 * hid, h, w), dtype=torch.float32, device=x.device)
     for i, conv in enumerate(head.map_convs):
-        ops.conv2d(x, packed_weight(conv, 0), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0], out=cat, out_coff=i * hid)
+        ops.conv2d(x, packed_weight(conv, BT.PRECISION), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0], out=cat, out_coff=i * hid)
     a, r_map = _abn_fwd(cat, head.map_bn, group)
-    out = ops.conv2d(a, packed_weight(head.red_conv, 0), 1)
+    out = ops.conv2d(a, packed_weight(head.red_conv, BT.PRECISION), 1)
     g = ops.global_mean(x)                                            # [n, cin, 1, 1]
-    pz = ops.conv2d(g, packed_weight(head.global_pooling_conv, 0), 1)
+    pz = ops.conv2d(g, packed_weight(head.global_pooling_conv, BT.PRECISION), 1)
     pa, r_pool = _abn_fwd(pz, head.global_pooling_bn, group)
-    pr = ops.conv2d(pa, packed_weight(head.pool_red_conv, 0), 1)      # [n, cout, 1, 1]
+    pr = ops.conv2d(pa, packed_weight(head.pool_red_conv, BT.PRECISION), 1)      # [n, cout, 1, 1]
     ops.add_per_plane_(out, pr)                                       # out += pool.repeat(...)
     y, r_red = _abn_fwd(out, head.red_bn, group)
     return y, (x, a, r_map, g, pa, r_pool, r_red)
@@ -65,7 +70,7 @@ def deeplab_backward(head, tape, dy, grad_of, group=None):
     dx = None
     for i, conv in enumerate(head.map_convs):
         k, p, d = conv.kernel_size[0], conv.padding[0], conv.dilation[0]
-        ops.conv2d_wgrad(x, dcat, grad_of(conv.weight), k, pad=p, dil=d, dy_coff=i * hid, cout=hid, precision=0)
+        ops.conv2d_wgrad(x, dcat, grad_of(conv.weight), k, pad=p, dil=d, dy_coff=i * hid, cout=hid, precision=BT.PRECISION)
         if k == 1:
             part = ops.conv2d(dcat, conv.weight.detach().reshape(hid, cin), 1, in_coff=i * hid, cin=hid)
         else:
@@ -86,7 +91,7 @@ def cls_backward(cls, x, dy, grad_of, need_dx=True):
     for m in cls:
         co = m.out_channels
         if m.weight.requires_grad:
-            ops.conv2d_wgrad(x, dy, grad_of(m.weight), 1, dy_coff=off, cout=co, precision=0)
+            ops.conv2d_wgrad(x, dy, grad_of(m.weight), 1, dy_coff=off, cout=co, precision=BT.PRECISION)
             ops.bias_grad_(grad_of(m.bias), dy, c=co, coff=off)
         if need_dx:
             part = ops.conv2d(dy, m.weight.detach().reshape(co, m.in_channels), 1, in_coff=off, cin=co)
@@ -107,7 +112,7 @@ def pseudolabeler_forward(pl, x, group=None):
 
 def pseudolabeler_backward(pl, tape, dy, grad_of, need_dx=True, group=None):
     r1, r2, a2 = tape
-    ops.conv2d_wgrad(a2, dy, grad_of(pl.cls.weight), 1, precision=0)
+    ops.conv2d_wgrad(a2, dy, grad_of(pl.cls.weight), 1, precision=BT.PRECISION)
     ops.bias_grad_(grad_of(pl.cls.bias), dy)
     da2 = ops.conv2d(dy, pl.cls.weight.detach().reshape(pl.cls.out_channels, pl.cls.in_channels), 1)
     da1 = conv_abn_backward(r2, pl.conv2, pl.norm2, da2, grad_of, group=group)

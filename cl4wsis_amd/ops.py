@@ -881,12 +881,12 @@ def add_per_plane_(y, v, scale=1.0):
     return y
 
 
-def dgrad_weight(w):
+def dgrad_weight(w, precision=0):
     """[cout,cin,k,k] -> packed operand of the input-gradient convolution (a stride-1 conv over dy with cin' = cout)."""
     cout, cin, k, _ = w.shape
     wt = torch.empty((cin, cout, k, k), dtype=torch.float32, device=w.device)
     call("cl4_transpose_flip_weight", ptr(w), ptr(wt), cout, cin, k, stream())
-    return pack_conv_weight(wt, 0)
+    return pack_conv_weight(wt, precision if bf16x3_ok(cin) else 0)
 
 
 def conv2d_dgrad(dy, wd, in_size, k, stride=1, pad=0, dil=1):
