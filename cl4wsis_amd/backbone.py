@@ -10,7 +10,7 @@ from collections import OrderedDict
 import torch.nn as nn
 
 from . import ops
-from .nn import ABN, conv_abn
+from .nn import ABN, conv_abn, packed_weight
 
 
 class _Holder(nn.Module):
@@ -105,3 +105,114 @@ def net_resnet101(**kw):
 
 def net_resnet152(**kw):
     return ResNet(_NETS["152"], **kw)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# WiderResNet-38 A2 (coco-voc configuration, argparser.py:13-17): pre-activation identity-mapping blocks
+# ---------------------------------------------------------------------------------------------------------------------
+def _abn_eval(x, bn):
+    """Stand-alone InPlaceABN in eval mode (running statistics) — the pre-activation `bn1` of a block reads the SUM of the
+    previous block, so it cannot ride in a producing convolution's epilogue."""
+    act, slope = bn.act_code()
+    return ops.bn_apply(x, bn.running_mean, bn.running_var, bn.weight.detach(), bn.bias.detach(), eps=bn.eps, act=act, slope=slope)
+
+
+class IdentityResidualBlock(nn.Module):
+    """modules/residual.py:101-181 (eval path; Dropout2d of mod6 / mod7 is the identity in eval mode)."""
+
+    def __init__(self, in_channels, channels, stride=1, dilation=1, norm_act=ABN, dropout=None):
+        super().__init__()
+        if len(channels) not in (2, 3):
+            raise ValueError("channels must contain either two or three values")
+        self.bn1 = norm_act(in_channels)
+        if len(channels) == 2:
+            layers = [("conv1", nn.Conv2d(in_channels, channels[0], 3, stride=stride, padding=dilation, dilation=dilation, bias=False)),
+                      ("bn2", norm_act(channels[0])),
+                      ("conv2", nn.Conv2d(channels[0], channels[1], 3, padding=dilation, dilation=dilation, bias=False))]
+        else:
+            layers = [("conv1", nn.Conv2d(in_channels, channels[0], 1, stride=stride, bias=False)),
+                      ("bn2", norm_act(channels[0])),
+                      ("conv2", nn.Conv2d(channels[0], channels[1], 3, padding=dilation, dilation=dilation, bias=False)),
+                      ("bn3", norm_act(channels[1])),
+                      ("conv3", nn.Conv2d(channels[1], channels[2], 1, bias=False))]
+        self.convs = _Holder(OrderedDict(layers))
+        if stride != 1 or in_channels != channels[-1]:
+            self.proj_conv = nn.Conv2d(in_channels, channels[-1], 1, stride=stride, bias=False)
+
+    def forward(self, x, ret_prev=False):
+        if self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("train-mode WiderResNet blocks are not built (coco-voc phase 2 freezes the body)")
+        c = self.convs
+        a = _abn_eval(x, self.bn1)
+        if hasattr(self, "proj_conv"):
+            pc = self.proj_conv
+            shortcut = ops.conv2d(a, packed_weight(pc), 1, stride=pc.stride[0])
+        else:
+            shortcut = x
+        y = conv_abn(a, c.conv1, c.bn2)
+        if hasattr(c, "conv3"):
+            y = conv_abn(y, c.conv2, c.bn3)
+            last = c.conv3
+        else:
+            last = c.conv2
+        out = ops.conv2d(y, packed_weight(last), last.kernel_size[0], pad=last.padding[0], dil=last.dilation[0], post=shortcut)
+        return (out, a) if ret_prev else out
+
+
+class WiderResNetA2(nn.Module):
+    """models/wide_resnet.py:82-207 — returns [bn1 of the first block of mod4..mod7, bn_out] with keep_outputs."""
+
+    def __init__(self, structure, norm_act=ABN, classes=0, dilation=True, output_stride=None, keep_outputs=False):
+        super().__init__()
+        if len(structure) != 6:
+            raise ValueError("Expected a structure with six values")
+        self.structure, self.dilation, self.keep_outputs = structure, dilation, keep_outputs
+        self.mod1 = _Holder(OrderedDict([("conv1", nn.Conv2d(3, 64, 3, stride=1, padding=1, bias=False))]))
+        in_ch = 64
+        channels = [(128, 128), (256, 256), (512, 512), (512, 1024), (512, 1024, 2048), (1024, 2048, 4096)]
+        for mod_id, num in enumerate(structure):
+            blocks = OrderedDict()
+            for b in range(num):
+                if not dilation:
+                    dil, stride = 1, (2 if b == 0 and 2 <= mod_id <= 4 else 1)
+                else:
+                    dil = 2 if mod_id == 3 else (4 if mod_id > 3 else 1)
+                    stride = 2 if b == 0 and mod_id == 2 else 1
+                blocks[f"block{b + 1}"] = IdentityResidualBlock(in_ch, channels[mod_id], stride=stride, dilation=dil, norm_act=norm_act)
+                in_ch = channels[mod_id][-1]
+            self.add_module(f"mod{mod_id + 2}", nn.Sequential(blocks))
+        self.out_channels = in_ch
+        self.bn_out = norm_act(in_ch)
+
+    def forward(self, img):
+        mc = self.mod1.conv1
+        out = ops.conv2d(img, packed_weight(mc), 3, pad=1)
+        for name in ("mod2", "mod3"):               # pool2 / pool3: MaxPool2d(3, 2, 1) in front of mod2 / mod3
+            out = ops.maxpool3x3s2(out)
+            for blk in getattr(self, name):
+                out = blk(out)
+        prevs = []
+        for name in ("mod4", "mod5", "mod6", "mod7"):
+            for i, blk in enumerate(getattr(self, name)):
+                if i == 0:
+                    out, a = blk(out, ret_prev=True)
+                    prevs.append(a)
+                else:
+                    out = blk(out)
+        out7 = _abn_eval(out, self.bn_out)
+        return prevs + [out7] if self.keep_outputs else out7
+
+
+_WNETS = {"16": [1, 1, 1, 1, 1, 1], "20": [1, 1, 1, 3, 1, 1], "38": [3, 3, 6, 3, 1, 1]}
+
+
+def net_wider_resnet38_a2(**kw):
+    return WiderResNetA2(_WNETS["38"], **kw)
+
+
+def net_wider_resnet20_a2(**kw):
+    return WiderResNetA2(_WNETS["20"], **kw)
+
+
+def net_wider_resnet16_a2(**kw):
+    return WiderResNetA2(_WNETS["16"], **kw)

@@ -193,16 +193,16 @@ __global__ __launch_bounds__(256) void peak_topk_kernel(PeakCand* __restrict__ c
 // ---------------------------------------------------------------------------------------------
 // Semantic pseudo ground truth — train.py:263,438-449. One workgroup per 16 output rows of one image.
 // ---------------------------------------------------------------------------------------------
-constexpr int SEG_ROWS = 16;
-constexpr int SEG_MAXC = 32;
+constexpr int SEG_ROWS = 16;   // output rows per workgroup (halved until the low-resolution band fits LDS)
+constexpr int SEG_MAXC = 96;   // 21 on VOC, 81 on coco-voc
 
 __global__ __launch_bounds__(256) void seg_pseudo_gt_kernel(const float* __restrict__ seg2b, const float* __restrict__ l1h,
                                                             int bs, int C, int h, int w, int H, int W, int old_classes,
-                                                            int no_mask, int band, uint8_t* __restrict__ seg_gt,
+                                                            int no_mask, int band, int seg_rows, uint8_t* __restrict__ seg_gt,
                                                             float* __restrict__ old_w, float* __restrict__ prob_win) {
   extern __shared__ float lds[];  // [C][band][w] flip-TTA mean of the logits
   const int b = blockIdx.y;
-  const int Y0 = blockIdx.x * SEG_ROWS;
+  const int Y0 = blockIdx.x * seg_rows;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   const int ylo = bilin_half_pixel(Y0, sy, h).i0;
   const long plane = (long)h * w;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void seg_pseudo_gt_kernel(const float* __restr
     else if (c >= old_classes) m = l1h[b * (C - 1) + c - 1];
     mask[c] = m;
   }
-  const int rows = min(SEG_ROWS, H - Y0);
+  const int rows = min(seg_rows, H - Y0);
   for (int i = threadIdx.x; i < rows * W; i += blockDim.x) {
     int yy = i / W, X = i - yy * W;
     int Y = Y0 + yy;
@@ -452,13 +452,19 @@ extern "C" int cl4_seg_pseudo_gt(const float* seg2b, const float* l1h, int bs, i
   CL4_REQUIRE(seg2b && l1h && seg_gt && old_w && prob_win, "seg_pseudo_gt: null pointer");
   CL4_REQUIRE(bs > 0 && C > 1 && C <= SEG_MAXC && h > 0 && w > 0 && H > 0 && W > 0, "seg_pseudo_gt: bad dims (C <= %d)", SEG_MAXC);
   CL4_REQUIRE(old_classes >= 1 && old_classes <= C, "seg_pseudo_gt: old_classes out of range");
-  int band = (int)((float)SEG_ROWS * (float)h / (float)H) + 3;
-  if (band > h) band = h;
-  size_t lds = (size_t)C * band * w * sizeof(float);
+  int rows = SEG_ROWS, band;
+  size_t lds;
+  for (;;) {
+    band = (int)((float)rows * (float)h / (float)H) + 3;
+    if (band > h) band = h;
+    lds = (size_t)C * band * w * sizeof(float);
+    if (lds <= 64 * 1024 || rows == 1) break;
+    rows /= 2;
+  }
   CL4_REQUIRE(lds <= 64 * 1024, "seg_pseudo_gt: low-res band does not fit LDS");
-  dim3 g(cl4::cdiv(H, SEG_ROWS), bs);
+  dim3 g(cl4::cdiv(H, rows), bs);
   hipLaunchKernelGGL(seg_pseudo_gt_kernel, g, dim3(256), lds, cl4::as_stream(stream), seg2b, l1h, bs, C, h, w, H, W,
-                     old_classes, no_mask, band, seg_gt, old_w, prob_win);
+                     old_classes, no_mask, band, rows, seg_gt, old_w, prob_win);
   return cl4::launch_status();
 }
 

@@ -29,12 +29,11 @@ def get_norm(opts):
 
 def get_body(opts, norm):
     """segmentation_module.py:32-58."""
-    if opts.backbone == "wider_resnet38_a2":
-        raise NotImplementedError("WiderResNet38-A2 (coco-voc, config 5) is a later §8 row")
     ctor = getattr(backbone, f"net_{opts.backbone}")
     body = ctor(norm_act=norm, output_stride=opts.output_stride, keep_outputs=(opts.model == "PanopticDeepLab"))
     if not opts.no_pretrained:
-        path = f"pretrained/{opts.backbone}_iabn_sync.pth.tar"
+        path = ("pretrained/wide_resnet38_ipabn_lr_256.pth.tar" if opts.backbone == "wider_resnet38_a2"
+                else f"pretrained/{opts.backbone}_iabn_sync.pth.tar")
         pre = torch.load(path, map_location="cpu")
         state = {(k[7:] if "module" in k else k): v for k, v in pre["state_dict"].items()}
         state.pop("classifier.fc.weight", None)

@@ -72,6 +72,41 @@ def resnet_body(x, sd, p="body", structure=RESNET101, output_stride=16, training
     return outs
 
 
+WRN_CHANNELS = [(128, 128), (256, 256), (512, 512), (512, 1024), (512, 1024, 2048), (1024, 2048, 4096)]
+WRN38 = (3, 3, 6, 3, 1, 1)
+
+
+def identity_block(x, sd, p, channels, stride, dil):
+    """IdentityResidualBlock.forward (eval) — modules/residual.py:168-181. Returns (out, bn1)."""
+    a = _abn(x, sd, p + ".bn1")
+    shortcut = F.conv2d(a, sd[p + ".proj_conv.weight"], stride=stride) if (p + ".proj_conv.weight") in sd else x
+    if len(channels) == 2:
+        y = _abn(F.conv2d(a, sd[p + ".convs.conv1.weight"], stride=stride, padding=dil, dilation=dil), sd, p + ".convs.bn2")
+        y = F.conv2d(y, sd[p + ".convs.conv2.weight"], padding=dil, dilation=dil)
+    else:
+        y = _abn(F.conv2d(a, sd[p + ".convs.conv1.weight"], stride=stride), sd, p + ".convs.bn2")
+        y = _abn(F.conv2d(y, sd[p + ".convs.conv2.weight"], padding=dil, dilation=dil), sd, p + ".convs.bn3")
+        y = F.conv2d(y, sd[p + ".convs.conv3.weight"])
+    return y + shortcut, a
+
+
+def wider_resnet_a2_body(x, sd, p="body", structure=WRN38):
+    """WiderResNetA2.forward with keep_outputs, dilation=True (output stride 8) — models/wide_resnet.py:122-207."""
+    out = F.conv2d(x, sd[p + ".mod1.conv1.weight"], padding=1)
+    prevs = []
+    in_ch = 64
+    for mod_id, num in enumerate(structure):
+        if mod_id < 2:
+            out = F.max_pool2d(out, 3, stride=2, padding=1)
+        for b in range(num):
+            dil = 2 if mod_id == 3 else (4 if mod_id > 3 else 1)
+            stride = 2 if b == 0 and mod_id == 2 else 1
+            out, a = identity_block(out, sd, f"{p}.mod{mod_id + 2}.block{b + 1}", WRN_CHANNELS[mod_id], stride, dil)
+            if b == 0 and mod_id >= 2:
+                prevs.append(a)
+    return prevs + [_abn(out, sd, p + ".bn_out")]
+
+
 def deeplab_head(x, sd, p="head", pooling=32, training=False, output_stride=16):
     """DeeplabV3.forward / _global_pooling — modules/deeplab.py:54-89."""
     dils = [6, 12, 18] if output_stride == 16 else [12, 24, 32]
@@ -152,11 +187,18 @@ def instance_head(x, sd, p="instance_head.classifier", training=False):
     return pred
 
 
+def _body(x, sd):
+    """ResNet (output stride 16) or, when the state dict holds `body.mod7`, WiderResNet-38 A2 (output stride 8)."""
+    if any(k.startswith("body.mod7.") for k in sd):
+        return wider_resnet_a2_body(x, sd), 8
+    return resnet_body(x, sd), 16
+
+
 def forward_seg(x, sd, pooling=32, training=False):
     """IncrementalInstanceSegmentationModule.forward_seg(interpolate=False) — segmentation_module.py:400-426."""
-    outs = resnet_body(x, sd)
+    outs, os_ = _body(x, sd)
     feats = {f"res{i + 1}": o for i, o in enumerate(outs)}
-    seg = incremental_classifier(deeplab_head(outs[-1], sd, pooling=pooling, training=training), sd)
+    seg = incremental_classifier(deeplab_head(outs[-1], sd, pooling=pooling, training=training, output_stride=os_), sd)
     return OrderedDict(seg=seg), {"body": outs[-1], "features": feats}
 
 

@@ -158,6 +158,34 @@ def insmap_fixture(R, seed, H, W, flip):
     print(f"insmap_s{seed:02d}.npz", len(lab), "instances, classes", np.unique(lab))
 
 
+def wrn_fixture(R):
+    """Reference WiderResNet-38 A2 body + DeepLabV3 (output stride 8) + classifiers of the coco-voc configuration in eval mode
+    (argparser.py:13-17; crop 65 instead of 448). Stores the five feature maps' checksums and the semantic logits."""
+    ap = R["argparser"]
+    args = ["--dataset", "coco-voc", "--task", "voc", "--step", "1", "--weakly", "--phase", "2", "--alpha", "0.9", "--loss_de", "1",
+            "--lr_policy", "warmup", "--affinity", "--optim", "adam", "--weight_decay", "0", "--lr", "5e-5", "--batch_size", "32",
+            "--no_pretrained"]
+    opts = ap.modify_command_options(ap.get_argparser().parse_args(args))
+    assert opts.backbone == "wider_resnet38_a2" and opts.output_stride == 8
+    opts.crop_size, opts.pooling = CROP, CROP // 8
+    sm = R["segmentation_module"]
+    torch.manual_seed(0)
+    model = sm.make_model(opts, classes=[61, 20])
+    model.load_state_dict(weights.fill_(model.state_dict(), seed=MODEL_SEED + 20))
+    model.eval()
+    g = torch.Generator().manual_seed(25)
+    x = torch.randn(2, 3, CROP, CROP, generator=g)
+    with torch.no_grad():
+        o, f = model(x, interpolate=False)
+    out = {"seg": o["seg"].numpy(), "center": o["center"].numpy(), "offset": o["offset"].numpy()}
+    for k, v in f["features"].items():
+        out["feat_" + k + "_shape"] = np.array(v.shape)
+        out["feat_" + k + "_slice"] = v[:, ::17, ::3, ::3].numpy().copy()
+        out["feat_" + k + "_norm"] = np.array(v.double().norm().item())
+    np.savez_compressed(os.path.join(HERE, "model_wrn38_c65.npz"), **out)
+    print("model_wrn38_c65.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
 def label_fixture(R, seed, b, H, W):
     inp = synth.label_stage_inputs(seed, b=b, H=H, W=W)
     oc, tot = inp["old_classes"], inp["tot_classes"]
@@ -302,6 +330,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     model_fixture(R)
     model_p1_fixture(R)
+    wrn_fixture(R)
     for case in INSMAP_CASES:
         insmap_fixture(R, *case)
     for case in LABEL_CASES:

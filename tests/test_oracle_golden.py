@@ -64,6 +64,38 @@ def test_model_restatement_matches_reference():
     assert rel_err(cam, torch.from_numpy(gold["cam_lo"])) < 1e-5
 
 
+def _wrn_opts(crop=65):
+    from cl4wsis_amd import argparser
+    args = ["--dataset", "coco-voc", "--task", "voc", "--step", "1", "--weakly", "--phase", "2", "--alpha", "0.9", "--loss_de", "1",
+            "--lr_policy", "warmup", "--affinity", "--optim", "adam", "--weight_decay", "0", "--lr", "5e-5", "--batch_size", "32",
+            "--no_pretrained"]
+    opts = argparser.modify_command_options(argparser.get_argparser().parse_args(args))
+    assert opts.backbone == "wider_resnet38_a2" and opts.output_stride == 8 and opts.crop_size == 448
+    opts.crop_size, opts.pooling = crop, crop // 8
+    return opts
+
+
+def test_wider_resnet38_restatement_matches_reference():
+    """coco-voc configuration (argparser.py:13-17): WiderResNet-38 A2 body, DeepLabV3 at output stride 8, 61+20 classes."""
+    from cl4wsis_amd import segmentation_module as sm
+    from oracle import model as M, weights
+    gold = np.load(os.path.join(GOLD, "model_wrn38_c65.npz"))
+    opts = _wrn_opts()
+    torch.manual_seed(0)
+    model = sm.make_model(opts, classes=[61, 20])
+    sd = weights.fill_(model.state_dict(), seed=21)
+    g = torch.Generator().manual_seed(25)
+    x = torch.randn(2, 3, 65, 65, generator=g)
+    with torch.no_grad():
+        o, aux = M.forward_full(x, sd, pooling=opts.pooling)
+    for k in ("seg", "center", "offset"):
+        assert rel_err(o[k], torch.from_numpy(gold[k])) < 1e-5, k
+    for k, v in aux["features"].items():
+        assert tuple(v.shape) == tuple(gold[f"feat_{k}_shape"])
+        assert rel_err(v[:, ::17, ::3, ::3], torch.from_numpy(gold[f"feat_{k}_slice"])) < 1e-5
+        assert abs(v.double().norm().item() - float(gold[f"feat_{k}_norm"])) < 1e-5 * float(gold[f"feat_{k}_norm"])
+
+
 def test_phase1_train_mode_restatement_matches_reference():
     """Train-mode body + DeepLabV3 + classifiers (phase-1 model, branch 'none') and PseudoLabeler: outputs, running
     statistics and the gradient norm of all 337 parameters against the reference's own modules under autograd."""
