@@ -105,7 +105,7 @@ _decl("cl4_dropout_mask_dev", _P, _L, _P, C.c_uint64, _F, _P)
 _decl("cl4_dwconv5_fwd", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_dwconv5_wgrad", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 
-_decl("cl4_cam_smooth", _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P)
+_decl("cl4_cam_smooth", _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P, C.c_size_t, _P)
 _decl("cl4_peak_extract", _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_seg_pseudo_gt", _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P)
 _decl("cl4_ccl", _P, _I, _I, _I, _I, _P, _P)
@@ -170,7 +170,7 @@ def load():
     for nm, at in (("cl4_peak_workspace_bytes", [C.c_int, C.c_int]), ("cl4_label_workspace_bytes", [C.c_int] * 3),
                    ("cl4_p2_loss_workspace_bytes", [C.c_int] * 6), ("cl4_pamr_workspace_bytes", [C.c_int] * 5),
                    ("cl4_ngwp_workspace_bytes", [C.c_int] * 2), ("cl4_balanced_ce_workspace_bytes", [C.c_int] * 4),
-                   ("cl4_bce_ignore_workspace_bytes", []), ("cl4_p1loss_workspace_bytes", [C.c_int] * 4)):
+                   ("cl4_bce_ignore_workspace_bytes", []), ("cl4_p1loss_workspace_bytes", [C.c_int] * 4), ("cl4_cam_smooth_workspace_bytes", [C.c_int] * 4)):
         getattr(lib, nm).restype = C.c_size_t
         getattr(lib, nm).argtypes = at
     for name, args in PROTOTYPES.items():

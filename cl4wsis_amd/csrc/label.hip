@@ -79,6 +79,66 @@ __global__ __launch_bounds__(256) void cam_smooth_kernel(const float* __restrict
   }
 }
 
+// The same computation for maps that do not fit LDS (coco-voc: 20 new classes at 56x56): four small launches through a
+// global scratch [b, cnew, hw] + per-plane maxima; identical arithmetic and summation order.
+__global__ __launch_bounds__(256) void cam_peak_kernel(const float* __restrict__ int_masks, int ctot, int hw, int cnew,
+                                                       float* __restrict__ peak) {   // grid (cnew, b)
+  __shared__ float red[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* src = int_masks + ((long)b * ctot + (ctot - cnew) + c) * hw;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) m = fmaxf(m, src[i]);
+  m = block_max(m, red);
+  if (threadIdx.x == 0) peak[b * cnew + c] = m;
+}
+
+__global__ __launch_bounds__(256) void cam_conv_kernel(const float* __restrict__ int_masks, int ctot, int hw, const float* __restrict__ pg_w,
+                                                       const float* __restrict__ pg_b, const float* __restrict__ label, int cnew,
+                                                       float alpha, const float* __restrict__ peak, float* __restrict__ ys, int b) {
+  const long p = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (p >= (long)b * hw) return;
+  const int n = (int)(p / hw), q = (int)(p % hw);
+  const float* src = int_masks + ((long)n * ctot + (ctot - cnew)) * hw + q;
+  for (int c = 0; c < cnew; ++c) {
+    float acc = 0.f;
+    for (int k = 0; k < cnew; ++k) {
+      const float v = fmaxf(src[(long)k * hw], 0.f);
+      const float z = (v < peak[n * cnew + k] * alpha) ? 0.f : v;
+      acc += pg_w[c * cnew + k] * z;
+    }
+    acc += pg_b[c];
+    ys[((long)n * cnew + c) * hw + q] = fmaxf(acc, 0.f) * label[n * cnew + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void cam_den_kernel(const float* __restrict__ ys, int hw, int cnew, float* __restrict__ den) {  // grid (cnew, b)
+  __shared__ float red[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* src = ys + ((long)b * cnew + c) * hw;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) m = fmaxf(m, src[i]);
+  m = block_max(m, red);
+  if (threadIdx.x == 0) den[b * cnew + c] = m + 1e-5f;
+}
+
+__global__ __launch_bounds__(256) void cam_avg_kernel(const float* __restrict__ ys, const float* __restrict__ den, int h, int w, long planes,
+                                                      float* __restrict__ cam) {
+  const int hw = h * w;
+  const long total = planes * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pl = i / hw;
+    const int p = (int)(i - pl * hw), y = p / w, x = p - y * w;
+    const float d = den[pl];
+    float s = 0.f;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        int yy = y + dy, xx = x + dx;
+        if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) s += ys[pl * hw + yy * w + xx] / d;
+      }
+    cam[i] = s / 9.f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // peak_extract — wss/utils.py:3-25, fused with the bilinear upsample of train.py:431:
 // the full-resolution CAM is never written to HBM. Tile = 32x32 outputs + halo R=(kernel-1)/2.
@@ -413,14 +473,35 @@ __global__ __launch_bounds__(256) void val_seg_kernel(const float* __restrict__ 
 
 }  // namespace
 
+extern "C" size_t cl4_cam_smooth_workspace_bytes(int b, int cnew, int h, int w) {
+  if (b <= 0 || cnew <= 0 || h <= 0 || w <= 0) return 0;
+  if ((size_t)2 * cnew * h * w * sizeof(float) <= 64 * 1024) return 0;          // everything stays in LDS
+  return ((size_t)b * cnew * h * w + (size_t)2 * b * cnew) * sizeof(float);
+}
+
 extern "C" int cl4_cam_smooth(const float* int_masks, int b, int ctot, int h, int w, const float* pg_w, const float* pg_b,
-                              const float* label_new, int cnew, float alpha, float* cam, void* stream) {
+                              const float* label_new, int cnew, float alpha, float* cam, void* workspace, size_t workspace_bytes,
+                              void* stream) {
   CL4_REQUIRE(int_masks && pg_w && pg_b && label_new && cam, "cam_smooth: null pointer");
   CL4_REQUIRE(b > 0 && cnew > 0 && cnew <= ctot && h > 0 && w > 0, "cam_smooth: bad dims");
+  hipStream_t st = cl4::as_stream(stream);
   size_t lds = (size_t)2 * cnew * h * w * sizeof(float);
-  CL4_REQUIRE(lds <= 64 * 1024, "cam_smooth: %d x %dx%d does not fit LDS", cnew, h, w);
-  hipLaunchKernelGGL(cam_smooth_kernel, dim3(b), dim3(256), lds, cl4::as_stream(stream), int_masks, ctot, h, w, pg_w, pg_b,
-                     label_new, cnew, alpha, cam);
+  if (lds <= 64 * 1024) {
+    hipLaunchKernelGGL(cam_smooth_kernel, dim3(b), dim3(256), lds, st, int_masks, ctot, h, w, pg_w, pg_b, label_new, cnew, alpha, cam);
+    return cl4::launch_status();
+  }
+  const size_t need = cl4_cam_smooth_workspace_bytes(b, cnew, h, w);
+  if (!workspace || workspace_bytes < need) { cl4::set_error("cam_smooth: workspace too small (%zu bytes needed)", need); return CL4_ENOSPC; }
+  const int hw = h * w;
+  float* ys = (float*)workspace;
+  float* peak = ys + (size_t)b * cnew * hw;
+  float* den = peak + (size_t)b * cnew;
+  hipLaunchKernelGGL(cam_peak_kernel, dim3(cnew, b), dim3(256), 0, st, int_masks, ctot, hw, cnew, peak);
+  hipLaunchKernelGGL(cam_conv_kernel, dim3(cl4::cdiv((long)b * hw, 256)), dim3(256), 0, st, int_masks, ctot, hw, pg_w, pg_b, label_new, cnew,
+                     alpha, (const float*)peak, ys, b);
+  hipLaunchKernelGGL(cam_den_kernel, dim3(cnew, b), dim3(256), 0, st, (const float*)ys, hw, cnew, den);
+  hipLaunchKernelGGL(cam_avg_kernel, dim3(cl4::stream_grid((long)b * cnew * hw, 256)), dim3(256), 0, st, (const float*)ys, (const float*)den,
+                     h, w, (long)b * cnew, cam);
   return cl4::launch_status();
 }
 

@@ -509,8 +509,10 @@ def cam_smooth(int_masks, pg_weight, pg_bias, label_new, alpha=0.7):
     b, ctot, h, w = int_masks.shape
     cnew = pg_weight.shape[0]
     cam = torch.empty((b, cnew, h, w), dtype=torch.float32, device=int_masks.device)
+    need = _hip.load().cl4_cam_smooth_workspace_bytes(b, cnew, h, w)
+    ws = _workspace(int_masks.device, need) if need else None
     call("cl4_cam_smooth", ptr(int_masks), b, ctot, h, w, ptr(pg_weight.reshape(cnew, cnew)), ptr(pg_bias), ptr(label_new),
-         cnew, C.c_float(alpha), ptr(cam), stream())
+         cnew, C.c_float(alpha), ptr(cam), ptr(ws), ws.numel() if ws is not None else 0, stream())
     return cam
 
 

@@ -194,8 +194,10 @@ int cl4_dwconv5_wgrad(const float* x, const float* dy, float* dw, int n, int c, 
 /* PeakGenerator eval (PAM -> 1x1 conv -> relu*label -> /max) + 3x3 smoothing — wss/modules.py:354-368,390-434,
  * wss/utils.py:28-32. int_masks [b,ctot,h,w] (the last cnew channels are used), pg_w [cnew,cnew], pg_b [cnew],
  * label_new [b,cnew] -> cam [b,cnew,h,w] (new-class channels only; old-class channels are identically zero). */
+size_t cl4_cam_smooth_workspace_bytes(int b, int cnew, int h, int w);   /* 0 when the maps fit LDS (VOC: 5 x 33x33) */
 int cl4_cam_smooth(const float* int_masks, int b, int ctot, int h, int w, const float* pg_w, const float* pg_b,
-                   const float* label_new, int cnew, float alpha, float* cam, void* stream);
+                   const float* label_new, int cnew, float alpha, float* cam, void* workspace, size_t workspace_bytes,
+                   void* stream);
 /* Bilinear upsample (align_corners=False) to HxW fused with peak_extract (wss/utils.py:3-25): kernel x kernel max-pool
  * NMS + top-K per (b,c). conf/ys/xs: [b,c,K]; slots beyond the positive peaks hold conf=0,y=x=0. Ties: lowest index. */
 size_t cl4_peak_workspace_bytes(int b, int c);
