@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int NC_MAX = 8;   // new classes handled by the PeakGenerator kernels (5 on VOC 15-5, 1..8 supported)
+constexpr int NC_MAX = 24;  // new classes handled by the PeakGenerator kernels (5 on VOC 15-5, 10 on 10-10, 20 on coco-voc)
 
 __device__ __forceinline__ double block_sum_d(double v) {
   __shared__ double red[4];

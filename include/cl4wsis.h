@@ -319,7 +319,7 @@ size_t cl4_p1loss_workspace_bytes(int b, int tot, int h, int w);
 /* PeakGenerator.forward (training: PAM -> 1x1 conv nc->nc -> nGWP logit, wss/modules.py:354-423) + the peak loss
  * BCE-with-logits(logit, labels) of train.py:334-336,344-345. x [b,ctot,h,w] (the generator reads the last nc channels),
  * weight [nc,nc], bias [nc], labels [b,nc]; writes logit [b,nc], loss [1] and, when dx != NULL, dx [b,ctot,h,w]
- * (old-class channels zero) and ACCUMULATES into dweight [nc,nc] / dbias [nc]. 1 <= nc <= 8. */
+ * (old-class channels zero) and ACCUMULATES into dweight [nc,nc] / dbias [nc]. 1 <= nc <= 24. */
 int cl4_peakgen_train_loss(const float* x, const float* weight, const float* bias, const float* labels, int b, int ctot, int h,
                            int w, int nc, float alpha, float* logit, float* loss, float* dx, float* dweight, float* dbias,
                            void* workspace, size_t workspace_bytes, void* stream);

@@ -201,3 +201,37 @@ def test_graph_replay_matches_eager(gpu, monkeypatch):
     assert d.max() < 3.2 * 5e-4
     assert (d > 2e-4).float().mean() < 1e-5
     assert (we - wg).abs().mean() < 1e-5
+
+
+def test_trainer_step_voc_10_10(gpu):
+    """BASELINE config 4 (VOC 10-10 step 1 phase 2: 11 old + 10 new classes) through the same Trainer against the oracle."""
+    from cl4wsis_amd.train import Trainer
+    from oracle import step as ostep, weights
+    crop = 97
+    opts = p2_opts(crop)
+    opts.task = "10-10"
+    opts.max_iters, opts.start_decay = 1000, 1000
+    torch.manual_seed(0)
+    tr = Trainer(_Log(), gpu, opts)
+    assert tr.old_classes == 11 and tr.tot_classes == 21
+    sds = []
+    for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
+        sd = weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=61 + i)
+        m.load_state_dict(sd)
+        sds.append({k: v.clone() for k, v in sd.items()})
+    tr._realias()
+    new, old, pl, pg = sds
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, crop, crop, generator=g)
+    l1h = torch.zeros(2, 20); l1h[0, 12] = 1; l1h[1, 10] = 1; l1h[1, 19] = 1
+    keep = torch.rand(2, 256, 7, 7, generator=g) >= 0.5
+    ref = ostep.p2_step(new, old, pl, pg, x, l1h, 11, pooling=opts.pooling, dropout_mask=keep.float(), lr=opts.lr * opts.lr_head)
+    out = tr.step((x, l1h), dropout_keep=keep.to(torch.uint8).to(gpu))
+    torch.cuda.synchronize()
+    mism = out["seg_gt"].cpu().long() != ref["seg_gt"]
+    if mism.any():
+        top2 = ref["soft"].topk(2, dim=1).values
+        assert (top2[:, 0] - top2[:, 1])[mism].max() < 1e-5
+    for v, k in zip(out["losses"].cpu().tolist(), ("center_old", "offset_old", "center_new", "offset_new")):
+        r = float(ref[k].detach())
+        assert abs(v - r) <= 1e-3 * max(abs(r), 1e-3), (k, v, r)

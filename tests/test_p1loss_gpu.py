@@ -114,3 +114,20 @@ def test_l_seg(gpu, icarl):
     assert _rel(loss[0], ref.detach()) < TOL
     assert _rel(dseg, sr.grad) < TOL
     assert sr.grad[3].abs().max().item() == 0.0 and dseg[3].abs().max().item() == 0.0
+
+
+def test_peakgen_ten_and_twenty_new_classes(gpu):
+    """VOC 10-10 (10 new classes) and coco-voc (20): the PeakGenerator training kernels beyond the 15-5 width."""
+    from cl4wsis_amd import ops
+    for nc, c in ((10, 21), (20, 81)):
+        g = torch.Generator().manual_seed(nc)
+        x = torch.randn(2, c, 9, 9, generator=g)
+        wt = torch.randn(nc, nc, 1, 1, generator=g) * 0.4
+        bias = torch.randn(nc, generator=g) * 0.1
+        lab = (torch.rand(2, nc, generator=g) < 0.3).float()
+        xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        ref, rlogit = wss.peakgen_train_loss(xr, wr, br, lab)
+        ref.backward()
+        loss, logit, dx, dw, db = ops.peakgen_train_loss(x.to(gpu), wt.to(gpu), bias.to(gpu), lab.to(gpu))
+        assert _rel(loss[0], ref.detach()) < TOL and _rel(logit, rlogit.detach()) < TOL
+        assert _rel(dx, xr.grad) < TOL and _rel(dw, wr.grad.reshape(nc, nc)) < TOL and _rel(db, br.grad) < TOL
