@@ -479,16 +479,20 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // computed once per tile and lane, and each gather is a buffer_load with the lane's byte offset in a VGPR and the
 // channel offset in an SGPR (out-of-image lanes carry an out-of-range offset and read 0 through the descriptor's
 // bounds check). TAP = false keeps the generic ci-major decode (stem 7x7 with cin = 3).
-template <int BM, int BN, int KS, bool SPLIT, bool TAP>
+// P = 2: "bf16x3" (x = hi + lo, three products). P = 3: "bf16x6" (x = hi + mid + lo, 24 mantissa bits; the six products
+// hh, hm, mh, hl, lh, mm keep every term down to 2^-24: fp32-level accuracy at 2/16 of the fp32 MFMA cycles). P = 3 is
+// built for 64x64 tiles only (48 KB of LDS for the two stages).
+template <int BM, int BN, int KS, bool SPLIT, bool TAP, int P = 2>
 __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, const float* __restrict__ zero_page) {
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KHW = KS * KS;
   constexpr int KG = BK2 / 8;               // 4 k-groups of 8 per K-tile
   constexpr int NITEM = BN / 64;            // (pixel, k-group) items per loader lane
-  constexpr int A_INSTR = KG * 2 * BM / 64 / 4;   // dwordx4 LDS-DMA instructions per loader wave
-  constexpr int A_CHUNKS = KG * 2 * BM;     // 16-byte chunks of the weight tile
-  constexpr int B_CHUNKS = KG * 2 * BN;
+  static_assert(P == 2 || (P == 3 && BM == 64 && BN == 64), "three planes: 64x64 tiles only");
+  constexpr int A_INSTR = KG * P * BM / 64 / 4;   // dwordx4 loads per loader wave and K-tile
+  constexpr int A_CHUNKS = KG * P * BM;     // 16-byte chunks of the weight tile
+  constexpr int B_CHUNKS = KG * P * BN;
 
   __shared__ u32x4 lds[2][A_CHUNKS + B_CHUNKS];
 
@@ -599,21 +603,28 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
       u32x4* Bs = lds[buf] + A_CHUNKS;
 #pragma unroll
       for (int it = 0; it < NITEM; ++it) {
-        bf16x8 hi, lo;
+        bf16x8 hi, mid, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           hi[j] = (__bf16)xr[it][j];
-          lo[j] = (__bf16)(xr[it][j] - (float)hi[j]);
+          const float r1 = xr[it][j] - (float)hi[j];
+          if (P == 3) {
+            mid[j] = (__bf16)r1;
+            lo[j] = (__bf16)(r1 - (float)mid[j]);
+          } else {
+            lo[j] = (__bf16)r1;
+          }
         }
-        Bs[((kg0 + it) * 2 + 0) * BN + pl] = __builtin_bit_cast(u32x4, hi);
-        Bs[((kg0 + it) * 2 + 1) * BN + pl] = __builtin_bit_cast(u32x4, lo);
+        Bs[((kg0 + it) * P + 0) * BN + pl] = __builtin_bit_cast(u32x4, hi);
+        if (P == 3) Bs[((kg0 + it) * P + 1) * BN + pl] = __builtin_bit_cast(u32x4, mid);
+        Bs[((kg0 + it) * P + P - 1) * BN + pl] = __builtin_bit_cast(u32x4, lo);
       }
     };
     // Weight tile through registers as well (buffer_load_dwordx4, A_PER_LANE 16-byte chunks per lane and K-tile): with
     // LDS-DMA the tile had to be issued and awaited inside the same iteration (its landing zone is the LDS stage itself),
     // which exposed one full L2 round trip per K-tile; two register sets keep two tiles of BOTH operands in flight.
     constexpr int A_PER_LANE = A_INSTR;
-    const unsigned w_bytes = (unsigned)((long)KGtot * 2 * a.cout * 16);
+    const unsigned w_bytes = (unsigned)((long)KGtot * P * a.cout * 16);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, w_bytes, 0x00020000);
     u32x4 ar0[A_PER_LANE], ar1[A_PER_LANE];
     auto loadA = [&](u32x4 (&ar)[A_PER_LANE], int kt) {
@@ -621,12 +632,12 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
       for (int i = 0; i < A_PER_LANE; ++i) {
         const int ii = wave * A_PER_LANE + i;            // wave-uniform chunk row: (kg, plane, 64-wide m segment)
         const int seg = ii % (BM / 64);
-        const int kp = ii / (BM / 64);                   // kg*2 + plane
+        const int kp = ii / (BM / 64);                   // kg*P + plane
         const int m = m0 + seg * 64 + lane;
-        const int kgg = (kbeg + kt * BK2) / 8 + (kp >> 1);
+        const int kgg = (kbeg + kt * BK2) / 8 + kp / P;
         const bool kok = kgg < KGtot && (kgg * 8) < kend;             // scalar
         const unsigned voff = (kok && m < a.cout) ? (unsigned)m * 16u : 0x80000000u;
-        const int soff = __builtin_amdgcn_readfirstlane(kok ? (kgg * 2 + (kp & 1)) * a.cout * 16 : 0);
+        const int soff = __builtin_amdgcn_readfirstlane(kok ? (kgg * P + kp % P) * a.cout * 16 : 0);
         ar[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, soff, 0);
       }
     };
@@ -718,16 +729,18 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
 #pragma unroll
     for (int s2 = 0; s2 < KG / 2; ++s2) {
       const int kg = 2 * s2 + lh;
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        ah[i] = __builtin_bit_cast(bf16x8, As[(kg * 2 + 0) * BM + i * 32]);
-        al[i] = __builtin_bit_cast(bf16x8, As[(kg * 2 + 1) * BM + i * 32]);
+        ah[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 0) * BM + i * 32]);
+        if (P == 3) am[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 1) * BM + i * 32]);
+        al[i] = __builtin_bit_cast(bf16x8, As[(kg * P + P - 1) * BM + i * 32]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = __builtin_bit_cast(bf16x8, Bs[(kg * 2 + 0) * BN + j * 32]);
-        bl[j] = __builtin_bit_cast(bf16x8, Bs[(kg * 2 + 1) * BN + j * 32]);
+        bh[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 0) * BN + j * 32]);
+        if (P == 3) bm[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 1) * BN + j * 32]);
+        bl[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + P - 1) * BN + j * 32]);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -738,6 +751,11 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
 #else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if (P == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
 #endif
         }
@@ -766,15 +784,15 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
   if (!SPLIT) fused_epilogue<TM, TN>(a, acc, m0 + wm * WTM, n0 + wn * WTN, lr, lh, HWo);
 }
 
-// w [cout][K] fp32 -> wq [ceil(K/8)][plane: hi, lo][cout][8] bf16 (zero padded along K).
+// w [cout][K] fp32 -> wq [ceil(K/8)][plane: hi, (mid,) lo][cout][8] bf16 (zero padded along K); planes = 2 or 3.
 __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, bf16x8* __restrict__ wq, int cout, int K, int cin,
-                                          int khw, int tap_major) {
+                                          int khw, int tap_major, int planes) {
   const int KGtot = (K + 7) / 8;
   const long total = (long)KGtot * cout;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int m = i % cout;
     const int kg = i / cout;
-    bf16x8 hi, lo;
+    bf16x8 hi, mid, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = kg * 8 + j;                      // position in the kernel's K order
@@ -786,10 +804,13 @@ __global__ void pack_weight_bf16x3_kernel(const float* __restrict__ w, bf16x8* _
       }
       const float v = k < K ? w[(long)m * K + ksrc] : 0.f;
       hi[j] = (__bf16)v;
-      lo[j] = (__bf16)(v - (float)hi[j]);
+      const float r1 = v - (float)hi[j];
+      mid[j] = (__bf16)r1;
+      lo[j] = planes == 3 ? (__bf16)(r1 - (float)mid[j]) : mid[j];
     }
-    wq[((long)kg * 2 + 0) * cout + m] = hi;
-    wq[((long)kg * 2 + 1) * cout + m] = lo;
+    wq[((long)kg * planes + 0) * cout + m] = hi;
+    if (planes == 3) wq[((long)kg * planes + 1) * cout + m] = mid;
+    wq[((long)kg * planes + planes - 1) * cout + m] = lo;
   }
 }
 
@@ -1008,11 +1029,11 @@ struct PlanKey {
 std::map<PlanKey, FwdPlan>& plan_table() { static std::map<PlanKey, FwdPlan> t; return t; }
 std::mutex& plan_mutex() { static std::mutex m; return m; }
 
-FwdPlan make_plan(int impl, int tile, int splits, int cout, int K) {
+FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision = 0) {
   FwdPlan p{1, 128, 1, 0};
   if (impl != 2 || cout % 4 != 0 || cout < 64) return p;
   p.impl = 2;
-  p.tile = (tile == 128 && cout >= 128) ? 128 : 64;
+  p.tile = (tile == 128 && cout >= 128 && precision != 2) ? 128 : 64;      // bf16x6 (precision 2): 64x64 tiles only
   const int ktiles = cl4::cdiv(K, BK2);
   int s = splits < 1 ? 1 : splits;
   if (s > ktiles) s = ktiles;
@@ -1034,19 +1055,19 @@ FwdPlan plan_fwd(const PlanKey& key) {
     auto it = plan_table().find(key);
     if (it != plan_table().end()) return it->second;
   }
-  const int cout = key.cout, npix = key.npix, K = key.K;
+  const int cout = key.cout, npix = key.npix, K = key.K, precision = key.hin % 4;
   if (impl != 2 || cout % 4 != 0 || cout < 64) return FwdPlan{1, 128, 1, 0};
-  if (force_tile || force_split) return make_plan(2, force_tile ? force_tile : 128, force_split ? force_split : 1, cout, K);
+  if (force_tile || force_split) return make_plan(2, force_tile ? force_tile : 128, force_split ? force_split : 1, cout, K, precision);
   const int ktiles = cl4::cdiv(K, BK2);
   double best = 1e30;
-  FwdPlan bestp = make_plan(2, 64, 1, cout, K);
+  FwdPlan bestp = make_plan(2, 64, 1, cout, K, precision);
   for (int tile = 64; tile <= 128; tile += 64) {
-    if (tile == 128 && cout < 128) continue;
+    if (tile == 128 && (cout < 128 || precision == 2)) continue;
     const long wgs = (long)cl4::cdiv(cout, tile) * cl4::cdiv(npix, tile);
     const double t_tile = tile == 128 ? 2.4 : 0.65;   // us per K-tile of one workgroup at ~70 % MFMA issue
     const double t_fixed = tile == 128 ? 5.0 : 2.5;   // prologue + epilogue
     for (int s = 1; s <= 32 && s <= ktiles / 2 + (ktiles < 2); ++s) {
-      const FwdPlan p = make_plan(2, tile, s, cout, K);
+      const FwdPlan p = make_plan(2, tile, s, cout, K, precision);
       if (p.splits != s && s != 1) continue;
       const long rounds = (wgs * p.splits + 255) / 256;
       double t = rounds * ((double)(p.kchunk / BK2) * t_tile + t_fixed);
@@ -1059,7 +1080,32 @@ FwdPlan plan_fwd(const PlanKey& key) {
 
 template <int KS>
 int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes, int precision) {
-  const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 2 + precision});
+  const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 4 + precision});
+  if (precision == 2) {
+    static float* zp6 = nullptr;
+    if (!zp6 && hipGetSymbolAddress((void**)&zp6, HIP_SYMBOL(g_zero_page)) != hipSuccess) return (int)hipGetLastError();
+    a.kchunk = pl.kchunk;
+    a.ws = nullptr;
+    if (pl.splits > 1) {
+      const size_t need = (size_t)pl.splits * a.cout * a.npix * sizeof(float);
+      if (!workspace || workspace_bytes < need) { cl4::set_error("conv2d_fwd: workspace too small for split-K"); return CL4_ENOSPC; }
+      a.ws = (float*)workspace;
+    }
+    const dim3 g(cl4::cdiv(a.cout, 64), cl4::cdiv(a.npix, 64), pl.splits);
+    const float* z = zp6;
+    const bool tapmaj = a.cin % 32 == 0;
+    if (tapmaj && (long)a.n * a.in_ctot * a.hin * a.win * 4 >= 0x7FFFFFFFL) {
+      cl4::set_error("conv2d_fwd(bf16x6): input tensor >= 2 GiB is not addressable by the 32-bit buffer offsets");
+      return CL4_EINVAL;
+    }
+    if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
+    else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
+    if (pl.splits > 1) {
+      const long total = (long)a.cout * a.npix;
+      hipLaunchKernelGGL(conv_splitk_epilogue, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, a, pl.splits);
+    }
+    return cl4::launch_status();
+  }
   if (precision == 1) {
     static float* zp3 = nullptr;
     if (!zp3 && hipGetSymbolAddress((void**)&zp3, HIP_SYMBOL(g_zero_page)) != hipSuccess) return (int)hipGetLastError();
@@ -1344,7 +1390,16 @@ extern "C" int cl4_pack_conv_weight_bf16x3(const float* w, void* wq, int cout, i
   const int K = cin * kh * kw;
   const long total = (long)((K + 7) / 8) * cout;
   hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), w,
-                     (bf16x8*)wq, cout, K, cin, kh * kw, (cin % 32 == 0) ? 1 : 0);
+                     (bf16x8*)wq, cout, K, cin, kh * kw, (cin % 32 == 0) ? 1 : 0, 2);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_pack_conv_weight_bf16x6(const float* w, void* wq, int cout, int cin, int kh, int kw, void* stream) {
+  CL4_REQUIRE(w && wq && cout > 0 && cin > 0 && kh > 0 && kw > 0, "pack_conv_weight_bf16x6: bad arguments");
+  const int K = cin * kh * kw;
+  const long total = (long)((K + 7) / 8) * cout;
+  hipLaunchKernelGGL(pack_weight_bf16x3_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), w,
+                     (bf16x8*)wq, cout, K, cin, kh * kw, (cin % 32 == 0) ? 1 : 0, 3);
   return cl4::launch_status();
 }
 
@@ -1360,7 +1415,7 @@ extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
   if (!d || d->cout <= 0 || d->n <= 0) return 0;
   const int K = d->cin * d->kh * d->kw;
   const int npix = d->n * d->hout * d->wout;
-  const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin * 2 + d->precision});
+  const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin * 4 + d->precision});
   return pl.splits > 1 ? (size_t)pl.splits * d->cout * npix * sizeof(float) : 0;
 }
 
@@ -1370,12 +1425,12 @@ extern "C" int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int til
   int rc = check_desc(d);
   if (rc) return rc;
   const int K = d->cin * d->kh * d->kw;
-  const PlanKey key{d->cout, d->n * d->hout * d->wout, K, d->kh, d->stride, d->dil, d->hin * 2 + d->precision};
+  const PlanKey key{d->cout, d->n * d->hout * d->wout, K, d->kh, d->stride, d->dil, d->hin * 4 + d->precision};
   std::lock_guard<std::mutex> g(plan_mutex());
   if (impl == 0) { plan_table().erase(key); return CL4_OK; }
   CL4_REQUIRE(impl == 1 || impl == 2, "set_plan: impl must be 0, 1 or 2");
   CL4_REQUIRE(tile == 64 || tile == 128, "set_plan: tile must be 64 or 128");
-  plan_table()[key] = make_plan(impl, tile, splits, d->cout, K);
+  plan_table()[key] = make_plan(impl, tile, splits, d->cout, K, d->precision);
   return CL4_OK;
 }
 
@@ -1385,8 +1440,8 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
   int rc = check_desc(d);
   if (rc) return rc;
   CL4_REQUIRE(x && wp && y, "conv2d_fwd: null tensor");
-  CL4_REQUIRE(d->precision == 0 || d->precision == 1, "conv2d_fwd: precision %d unknown (0 fp32, 1 bf16x3)", d->precision);
-  CL4_REQUIRE(d->precision == 0 || (d->cout % 4 == 0 && d->cout >= 64), "conv2d_fwd: bf16x3 needs cout %% 4 == 0 and cout >= 64");
+  CL4_REQUIRE(d->precision >= 0 && d->precision <= 2, "conv2d_fwd: precision %d unknown (0 fp32, 1 bf16x3, 2 bf16x6)", d->precision);
+  CL4_REQUIRE(d->precision == 0 || (d->cout % 4 == 0 && d->cout >= 64), "conv2d_fwd: bf16x3 / bf16x6 need cout %% 4 == 0 and cout >= 64");
   ConvArgs a;
   a.x = x; a.wp = wp; a.scale = scale; a.shift = shift; a.pre = pre; a.post = post; a.y = y;
   a.n = d->n; a.cin = d->cin; a.hin = d->hin; a.win = d->win; a.cout = d->cout;

@@ -21,11 +21,12 @@ from . import ops
 from .nn import ABN, CACHE, conv_abn, conv_bias, packed_weight
 
 EPS = 1e-5
-# The trainable sub-net keeps the exact fp32 MFMA kernels: gradients through batch-statistics BN + ReLU amplify operand
-# noise (measured on a 75-sample batch: median gradient error 5e-4 with fp32 products vs 1e-2 with the bf16x3 split), and
-# it is only 6 % of the step's FLOPs. The frozen, no-grad networks (old model, flip-TTA semantic forward, PseudoLabeler)
-# run at ops.CONV_PRECISION (bf16x3 by default).
-TRAIN_PRECISION = int(__import__("os").environ.get("CL4_TRAIN_PRECISION", "0"))
+# Arithmetic of the trainable sub-net's convolutions. Gradients through batch-statistics BN + ReLU amplify operand noise
+# (measured on a 75-sample batch: median gradient error 5e-4 with fp32-exact products vs 1e-2 with the bf16x3 split), so
+# the default is "bf16x6" (2): three bf16 planes per operand, six products, fp32-level accuracy on the fast MFMA pipe
+# (about twice the speed of the fp32 MFMA kernels). 0 = exact fp32 MFMA, 1 = bf16x3 (fastest, ~4e-6 per layer). The frozen,
+# no-grad networks (old model, flip-TTA semantic forward, PseudoLabeler) run at ops.CONV_PRECISION (bf16x3 by default).
+TRAIN_PRECISION = int(__import__("os").environ.get("CL4_TRAIN_PRECISION", "2"))
 
 
 class DeeplabV3(nn.Module):

@@ -25,7 +25,7 @@ def _abn_bwd(rec, bn, dy, grad_of, group):
 
 
 def _conv1x1_bwd(x, conv, dz, grad_of, need_dx=True):
-    ops.conv2d_wgrad(x, dz, grad_of(conv.weight), 1, precision=BT.PRECISION)
+    ops.conv2d_wgrad(x, dz, grad_of(conv.weight), 1, precision=BT.WGRAD_PRECISION)
     if not need_dx:
         return None
     if BT.PRECISION:
@@ -70,7 +70,7 @@ def deeplab_backward(head, tape, dy, grad_of, group=None):
     dx = None
     for i, conv in enumerate(head.map_convs):
         k, p, d = conv.kernel_size[0], conv.padding[0], conv.dilation[0]
-        ops.conv2d_wgrad(x, dcat, grad_of(conv.weight), k, pad=p, dil=d, dy_coff=i * hid, cout=hid, precision=BT.PRECISION)
+        ops.conv2d_wgrad(x, dcat, grad_of(conv.weight), k, pad=p, dil=d, dy_coff=i * hid, cout=hid, precision=BT.WGRAD_PRECISION)
         if k == 1:
             part = ops.conv2d(dcat, conv.weight.detach().reshape(hid, cin), 1, in_coff=i * hid, cin=hid)
         else:
@@ -91,7 +91,7 @@ def cls_backward(cls, x, dy, grad_of, need_dx=True):
     for m in cls:
         co = m.out_channels
         if m.weight.requires_grad:
-            ops.conv2d_wgrad(x, dy, grad_of(m.weight), 1, dy_coff=off, cout=co, precision=BT.PRECISION)
+            ops.conv2d_wgrad(x, dy, grad_of(m.weight), 1, dy_coff=off, cout=co, precision=BT.WGRAD_PRECISION)
             ops.bias_grad_(grad_of(m.bias), dy, c=co, coff=off)
         if need_dx:
             part = ops.conv2d(dy, m.weight.detach().reshape(co, m.in_channels), 1, in_coff=off, cin=co)
@@ -112,7 +112,7 @@ def pseudolabeler_forward(pl, x, group=None):
 
 def pseudolabeler_backward(pl, tape, dy, grad_of, need_dx=True, group=None):
     r1, r2, a2 = tape
-    ops.conv2d_wgrad(a2, dy, grad_of(pl.cls.weight), 1, precision=BT.PRECISION)
+    ops.conv2d_wgrad(a2, dy, grad_of(pl.cls.weight), 1, precision=BT.WGRAD_PRECISION)
     ops.bias_grad_(grad_of(pl.cls.bias), dy)
     da2 = ops.conv2d(dy, pl.cls.weight.detach().reshape(pl.cls.out_channels, pl.cls.in_channels), 1)
     da1 = conv_abn_backward(r2, pl.conv2, pl.norm2, da2, grad_of, group=group)

@@ -61,7 +61,8 @@ def conv_out_size(h, k, stride, pad, dil):
 
 
 # Arithmetic of the dense forward convolutions: 0 = exact fp32 MFMA, 1 = "bf16x3" (fp32 operands split into bf16
-# hi + lo, three bf16 MFMA products with fp32 accumulation; ~4e-6 relative error per layer, 3/16 of the MFMA cycles).
+# hi + lo, three bf16 MFMA products with fp32 accumulation; ~4e-6 relative error per layer, 3/16 of the MFMA cycles),
+# 2 = "bf16x6" (hi + mid + lo, six products: fp32-level accuracy at 6/16 of the fp32 MFMA cycles).
 CONV_PRECISION = int(os.environ.get("CL4_CONV_PRECISION", "1"))
 
 
@@ -88,10 +89,12 @@ def pack_conv_weight(w, precision=None):
     K = cin * kh * kw
     if precision is None:
         precision = CONV_PRECISION
-    if precision == 1 and bf16x3_ok(cout):
-        wq = torch.empty(((K + 7) // 8) * 2 * cout * 16, dtype=torch.uint8, device=w.device)
-        call("cl4_pack_conv_weight_bf16x3", ptr(w.contiguous()), ptr(wq), cout, cin, kh, kw, stream())
-        return PackedWeight(wq, K, cout, 1)
+    if precision in (1, 2) and bf16x3_ok(cout):
+        planes = 2 if precision == 1 else 3
+        wq = torch.empty(((K + 7) // 8) * planes * cout * 16, dtype=torch.uint8, device=w.device)
+        call("cl4_pack_conv_weight_bf16x3" if precision == 1 else "cl4_pack_conv_weight_bf16x6", ptr(w.contiguous()), ptr(wq),
+             cout, cin, kh, kw, stream())
+        return PackedWeight(wq, K, cout, precision)
     wp = torch.empty((K, cout), dtype=torch.float32, device=w.device)
     call("cl4_pack_conv_weight", ptr(w.contiguous()), ptr(wp), cout, cin, kh, kw, stream())
     return PackedWeight(wp, K, cout, 0)
@@ -137,7 +140,9 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=3):
     for impl, tile, splits in _CANDIDATES:
         if impl == 2 and (d.cout % 4 or d.cout < 64):
             continue
-        if impl == 1 and d.precision == 1:
+        if impl == 1 and d.precision != 0:
+            continue
+        if d.precision == 2 and tile != 64:        # bf16x6 is built for 64x64 tiles only
             continue
         if impl == 2 and (tile == 128 and d.cout < 128 or splits > max(1, K // 64)):
             continue
@@ -213,7 +218,7 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
                    wp.precision)
     wp = wp.data
     if TIMER is not None:
-        e0, e1 = TIMER.span("conv_fwd_bf16x3" if d.precision == 1 else "conv_fwd_f32", 2.0 * n * hout * wout * cout * K,
+        e0, e1 = TIMER.span(("conv_fwd_f32", "conv_fwd_bf16x3", "conv_fwd_bf16x6")[d.precision], 2.0 * n * hout * wout * cout * K,
                             (n, cin, hin, cout, k, stride, dil))
         e0.record()
     if AUTOTUNE:

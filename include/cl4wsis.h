@@ -68,7 +68,8 @@ typedef struct cl4_conv_desc {
   float   slope1;
   int32_t act2;
   float   slope2;
-  int32_t precision; /* 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: bf16x3 split MFMA */
+  int32_t precision; /* 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: bf16x3; 2: bf16x6 (three bf16 planes, six products:
+                      * fp32-level accuracy on the bf16 MFMA pipe) */
 } cl4_conv_desc;
 
 /* w: [cout, cin, kh, kw] (PyTorch layout) -> wp: [cin*kh*kw, cout]. */
@@ -79,6 +80,9 @@ int cl4_pack_conv_weight(const float* w, float* wp, int cout, int cin, int kh, i
  * order (k = ci*kh*kw + ky*kw + kx) otherwise. cl4_conv2d_fwd with desc.precision = 1 takes this buffer as `wp` and accumulates
  * hi*hi + hi*lo + lo*hi on the bf16 MFMA pipe in fp32 (~4e-6 relative error per layer; needs cout % 4 == 0, cout >= 64). */
 int cl4_pack_conv_weight_bf16x3(const float* w, void* wq, int cout, int cin, int kh, int kw, void* stream);
+/* precision 2 ("bf16x6"): x = hi + mid + lo (3 x bf16 = 24 mantissa bits); wq [ceil(K/8)][3 planes][cout][8 x bf16] =
+ * ceil(K/8)*3*cout*16 bytes, same K order as bf16x3. The kernel issues hh, hm, mh, hl, lh, mm (drops terms below 2^-24). */
+int cl4_pack_conv_weight_bf16x6(const float* w, void* wq, int cout, int cin, int kh, int kw, void* stream);
 
 /* Bytes of scratch cl4_conv2d_fwd needs for this shape (0 unless the launch plan splits K: small grids on the 33x33
  * maps are split across grid.z into partial slabs [splits][cout][npix] that a second pass reduces in a fixed order). */

@@ -1,7 +1,10 @@
 """GPU parity of the train-mode ResNet body (cl4wsis_amd/body_train.py: batch-statistics InPlaceABN forward + the
 hand-written backward) against the oracle restatement differentiated by PyTorch autograd in float64 on the CPU.
 Outputs and running statistics: 1e-4 relative. Gradients: relative L2 per tensor (a pre-activation within fp32
-resolution of zero flips its leaky-ReLU slope, so max-norm is not meaningful): max < 3e-2, median < 1e-3."""
+resolution of zero flips its leaky-ReLU slope, so max-norm is not meaningful): max < 3e-2, median < 5e-3.
+Why 5e-3 and not fp32 resolution: at these crops the top activation holds ~1e5 elements, and ONE slope flip there changes
+every gradient below it by 1/sqrt(1e5) ~ 3e-3 relative; whether a flip happens is a coin toss of the last bits of the forward
+(measured: fp32-exact products 2.5e-6 with no flip, bf16x6 products — same per-conv error as fp32 — 2.7e-3 with exactly one)."""
 import pytest
 import torch
 
@@ -56,7 +59,7 @@ def test_body_forward_backward(gpu, structure, crop):
         errs.append(((got - ref).norm() / (ref.norm() + 1e-30)).item())
     errs = torch.tensor(errs)
     assert len(errs) == len(names)
-    assert errs.max() < 3e-2 and errs.median() < 1e-3, (errs.max(), errs.median())
+    assert errs.max() < 3e-2 and errs.median() < 5e-3, (errs.max(), errs.median())
     # running statistics were updated with momentum 0.1 (unbiased variance)
     for name, b in body.named_buffers():
         if name.endswith("running_mean") or name.endswith("running_var"):

@@ -25,11 +25,11 @@ def _rel_err(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
-# precision 0: exact fp32 MFMA; 1: bf16x3 split (falls back to fp32 for cout < 64 / cout % 4 != 0)
-TOL = {0: 1e-5, 1: 5e-5}
+# precision 0: exact fp32 MFMA; 1: bf16x3 split; 2: bf16x6 (both fall back to fp32 for cout < 64 / cout % 4 != 0)
+TOL = {0: 1e-5, 1: 5e-5, 2: 2e-6}
 
 
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_fwd_plain(gpu, case, precision):
     from cl4wsis_amd import ops
@@ -44,13 +44,13 @@ def test_conv_fwd_plain(gpu, case, precision):
     assert _rel_err(y.cpu(), ref) < TOL[precision]
 
 
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("plan", [(2, 64, 1), (2, 64, 3), (2, 128, 1), (2, 128, 4), (1, 128, 1)])
 def test_conv_fwd_pinned_plans(gpu, plan, precision):
     """Every launch plan (kernel variant, tile, K split) computes the same convolution."""
     import ctypes as C
     from cl4wsis_amd import _hip, ops
-    if plan[0] == 1 and precision == 1:
+    if plan[0] == 1 and precision != 0:
         pytest.skip("the register-staged kernel is fp32 only")
     g = torch.Generator().manual_seed(21)
     n, cin, h, w, cout, k, pad, dil = 3, 160, 21, 19, 192, 3, 2, 2
@@ -84,7 +84,7 @@ def test_conv_fwd_fused_epilogue(gpu):
     z = F.leaky_relu(F.batch_norm(z, mean, var, gamma, beta, False, 0.0, 1e-5), 0.01)
     ref = F.relu(z + post)
     scale, shift = ops.bn_fold(gamma.to(gpu), beta.to(gpu), mean.to(gpu), var.to(gpu), 1e-5)
-    for precision in (0, 1):
+    for precision in (0, 1, 2):
         y = ops.conv2d(x.to(gpu), ops.pack_conv_weight(wt.to(gpu), precision), 3, pad=1, scale=scale, shift=shift,
                        pre=pre.to(gpu), post=post.to(gpu), act1=ops.ACT_LEAKY, slope1=0.01, act2=ops.ACT_RELU)
         torch.cuda.synchronize()

@@ -33,3 +33,10 @@ dt = (time.perf_counter() - t0) / steps
 print(json.dumps({"workload": f"VOC 15-5 step 1 phase 1, epoch {epoch} (>= pseudo_ep: full loss stack), batch {b}, 513x513, Trainer.step eager",
                   "ms_per_step": 1e3 * dt, "images_per_s": b / dt, "peak_mem_GB": torch.cuda.max_memory_allocated() / 2**30,
                   "losses": {k: float(v) for k, v in out["losses"].items()}}))
+if len(sys.argv) > 4:      # per-kind time of the conv launches of one more step (HIP events on the launch stream)
+    from cl4wsis_amd import ops
+    ops.TIMER = ops.KernelTimer()
+    tr._step_phase1((images, l1h), cur_epoch=epoch)
+    torch.cuda.synchronize()
+    for kind, (n, fl, ms) in sorted(ops.TIMER.summary().items(), key=lambda kv: -kv[1][2]):
+        print(f"{kind:18s} launches {n:4d}  {ms:8.2f} ms  {fl / ms / 1e9:7.1f} TFLOP/s")
