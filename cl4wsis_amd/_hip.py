@@ -56,6 +56,13 @@ class P2LossIO(C.Structure):
     ]
 
 
+class SampleDesc(C.Structure):
+    """cl4_sample_desc (include/cl4wsis.h): one decoded photo of an input batch and its crop / flip draw."""
+    _fields_ = [("img_off", C.c_int64), ("lbl_off", C.c_int64), ("H", C.c_int32), ("W", C.c_int32),
+                ("ci", C.c_int32), ("cj", C.c_int32), ("ch", C.c_int32), ("cw", C.c_int32), ("flip", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class InsmapIO(C.Structure):
     _fields_ = [
         ("H", C.c_int32), ("W", C.c_int32), ("classes", C.c_int32), ("nms_kernel", C.c_int32), ("min_mask", C.c_int32),
@@ -149,6 +156,10 @@ _decl("cl4_binarize", _P, _P, _P, _I, _I, _I, _I, _P)
 _decl("cl4_balanced_mask_loss_ce", _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_bce_ignore_mean", _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)
 
+_decl("cl4_input_batch", _P, C.c_size_t, _P, C.c_size_t, C.POINTER(SampleDesc), _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float),
+      _P, _P, _P, _P, _P, C.c_size_t, _P)
+_decl("cl4_target_generation", _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.c_size_t, _P)
+
 _lib = None
 
 
@@ -171,9 +182,12 @@ def load():
     for nm, at in (("cl4_peak_workspace_bytes", [C.c_int, C.c_int]), ("cl4_label_workspace_bytes", [C.c_int] * 3),
                    ("cl4_p2_loss_workspace_bytes", [C.c_int] * 6), ("cl4_pamr_workspace_bytes", [C.c_int] * 5),
                    ("cl4_ngwp_workspace_bytes", [C.c_int] * 2), ("cl4_balanced_ce_workspace_bytes", [C.c_int] * 4),
-                   ("cl4_bce_ignore_workspace_bytes", []), ("cl4_p1loss_workspace_bytes", [C.c_int] * 4), ("cl4_cam_smooth_workspace_bytes", [C.c_int] * 4)):
+                   ("cl4_bce_ignore_workspace_bytes", []), ("cl4_p1loss_workspace_bytes", [C.c_int] * 4), ("cl4_cam_smooth_workspace_bytes", [C.c_int] * 4),
+                   ("cl4_input_workspace_bytes", [C.c_int] * 5), ("cl4_target_generation_workspace_bytes", [C.c_int])):
         getattr(lib, nm).restype = C.c_size_t
         getattr(lib, nm).argtypes = at
+    lib.cl4_input_ksize.restype = C.c_int
+    lib.cl4_input_ksize.argtypes = [C.c_int, C.c_int]
     for name, args in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = args

@@ -1005,3 +1005,84 @@ def instance_map(seg_map, prob_win, center, offset, thresh=0.1, nms_kernel=41, b
     call("cl4_instance_map", C.byref(d), ptr(ws), ws.numel(), stream())
     n = int(count.item())
     return ins, table[:n]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Input pipeline (dataset/__init__.py:14-27, dataset/dataset.py:202-221, dataset/utils.py:299-350) — input.hip
+# ---------------------------------------------------------------------------------------------------------------------
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+_input_ws = {}
+
+
+def _ws_u8(cache, device, nbytes):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        cache[key] = ws
+    return ws
+
+
+def input_batch(images, descs, out_hw, labels=None, lut=None, want_mask=True, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """Crop + Pillow-exact resample + flip + ToTensor + Normalize of a packed batch of decoded photos.
+
+    images: uint8 device tensor, the photos packed back to back (H x W x 3 each); labels: the same for the H x W x 2
+    (semantic id, instance id) labels, or None; descs: list of (img_off, lbl_off, H, W, ci, cj, ch, cw, flip);
+    lut: uint8[256] device tensor (LabelTransform) or None. Returns (img f32 [b,3,oh,ow], seg int64 [b,oh,ow] | None,
+    mask uint8 [b,oh,ow] | None)."""
+    b = len(descs)
+    oh, ow = out_hw
+    if images.dtype != torch.uint8 or (labels is not None and labels.dtype != torch.uint8):
+        raise RuntimeError("input_batch: uint8 packed buffers expected")
+    arr = (_hip.SampleDesc * b)()
+    lib = _hip.load()
+    max_ch = ks = 0
+    for k, d in enumerate(descs):
+        io, lo, H, W, ci, cj, ch, cw, flip = (int(v) for v in d)
+        arr[k] = _hip.SampleDesc(io, lo, H, W, ci, cj, ch, cw, flip, 0)
+        max_ch = max(max_ch, ch)
+        ks = max(ks, lib.cl4_input_ksize(cw, ow), lib.cl4_input_ksize(ch, oh))
+    dev = images.device
+    img = torch.empty((b, 3, oh, ow), dtype=torch.float32, device=dev)
+    seg = torch.empty((b, oh, ow), dtype=torch.int64, device=dev) if labels is not None else None
+    mask = torch.empty((b, oh, ow), dtype=torch.uint8, device=dev) if labels is not None and want_mask else None
+    need = lib.cl4_input_workspace_bytes(b, oh, ow, max(max_ch, 1), max(ks, 1))
+    ws = _ws_u8(_input_ws, dev, need)
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    call("cl4_input_batch", ptr(images), images.numel(), ptr(labels), labels.numel() if labels is not None else 0, arr, b, oh, ow,
+         m3, s3, ptr(lut), ptr(img), ptr(seg), ptr(mask), ptr(ws), ws.numel(), stream())
+    return img, seg, mask
+
+
+_gauss_tables = {}
+
+
+def gaussian_table(sigma, device):
+    """float32 device copy of the reference's float64 gaussian stamp (dataset/utils.py:182-192 == modules/utils.py:49-59)."""
+    key = (int(sigma), device.index)
+    if key not in _gauss_tables:
+        import numpy as np
+        size = 6 * sigma + 3
+        x = np.arange(0, size, 1, float)
+        y = x[:, np.newaxis]
+        x0 = y0 = 3 * sigma + 1
+        g = np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2))
+        _gauss_tables[key] = torch.from_numpy(g.astype(np.float32)).to(device).contiguous()
+    return _gauss_tables[key]
+
+
+def target_generation(seg_map, mask, num_classes, sigma=8):
+    """label_generation of the supervised loader for a batch: (center [b,C,H,W], offset [b,2,H,W], weight [b,1,H,W])."""
+    if seg_map.dtype != torch.int64 or mask.dtype != torch.uint8 or seg_map.shape != mask.shape or seg_map.dim() != 3:
+        raise RuntimeError("target_generation: int64 seg_map and uint8 mask of the same [b,H,W] shape expected")
+    b, H, W = seg_map.shape
+    dev = seg_map.device
+    center = torch.empty((b, num_classes, H, W), dtype=torch.float32, device=dev)
+    offset = torch.empty((b, 2, H, W), dtype=torch.float32, device=dev)
+    weight = torch.empty((b, 1, H, W), dtype=torch.float32, device=dev)
+    need = _hip.load().cl4_target_generation_workspace_bytes(b)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    call("cl4_target_generation", ptr(seg_map), ptr(mask), b, H, W, int(num_classes), int(sigma), ptr(gaussian_table(sigma, dev)),
+         ptr(center), ptr(offset), ptr(weight), ptr(ws), need, stream())
+    return center, offset, weight

@@ -402,6 +402,40 @@ typedef struct cl4_insmap_io {
 } cl4_insmap_io;
 int cl4_instance_map(const cl4_insmap_io* d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- input pipeline ---------------------------------------------------------------------------
+ * Replaces the per-sample pixel work of the reference's loader: get_dataset's transform stacks (dataset/__init__.py:14-27 over
+ * dataset/transform.py: RandomResizedCrop :582-660 / Resize :61-93, RandomHorizontalFlip :317-340, ToTensor :419-445,
+ * Normalize :452-478), LabelTransform + instance gating (dataset/dataset.py:104-108,212-214) and label_generation
+ * (dataset/utils.py:299-350). The arithmetic is Pillow's (the reference transforms PIL images): BILINEAR = Resample.c two-pass
+ * fixed-point convolution, NEAREST = Geometry.c ImagingScaleAffine; results are bit-identical to the reference's tensors. */
+typedef struct cl4_sample_desc {
+  long long img_off;   /* byte offset of this sample's H x W x 3 uint8 RGB photo in the packed `images` buffer */
+  long long lbl_off;   /* byte offset of its H x W x 2 uint8 (semantic id, instance id) label in `labels` */
+  int H, W;            /* source size */
+  int ci, cj, ch, cw;  /* crop box: top, left, height, width (RandomResizedCrop.get_params; the whole image for Resize) */
+  int flip;            /* RandomHorizontalFlip drew a flip */
+  int reserved;
+} cl4_sample_desc;
+
+/* Pillow's filter window length for resampling in_size -> out_size with the triangle filter. */
+int cl4_input_ksize(int in_size, int out_size);
+size_t cl4_input_workspace_bytes(int b, int out_h, int out_w, int max_ch, int ksize);
+/* images/labels: DEVICE buffers of packed uint8 photos / labels; descs: HOST array of b descriptors (validated, then copied).
+ * mean/std: HOST float[3]. lut: DEVICE uint8[256] LabelTransform mapping or NULL. Outputs (device): out_img float32
+ * [b,3,out_h,out_w]; out_seg int64 [b,out_h,out_w] (mapped semantic ids) and out_mask uint8 [b,out_h,out_w] (instance ids gated by
+ * seg > 0) when labels != NULL. workspace >= cl4_input_workspace_bytes(b, out_h, out_w, max crop height, max cl4_input_ksize). */
+int cl4_input_batch(const uint8_t* images, size_t images_bytes, const uint8_t* labels, size_t labels_bytes,
+                    const cl4_sample_desc* descs, int b, int out_h, int out_w, const float* mean, const float* std,
+                    const uint8_t* lut, float* out_img, long long* out_seg, uint8_t* out_mask, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* label_generation (dataset/utils.py:299-350) for a batch: centre heat-maps [b,num_classes,H,W] (gaussian of dataset/utils.py:
+ * 182-192 uploaded as float32 [(6 sigma+3)^2]), offsets [b,2,H,W] and weights [b,1,H,W] from seg_map int64 [b,H,W] and the
+ * instance-id map uint8 [b,H,W] (ids 0 and 255 ignored). Outputs are fully overwritten. */
+size_t cl4_target_generation_workspace_bytes(int b);
+int cl4_target_generation(const long long* seg_map, const uint8_t* mask, int b, int H, int W, int num_classes, int sigma,
+                          const float* gauss, float* center, float* offset, float* weight, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,32 @@ def insmap_inputs(seed, H, W, flip):
     center = center.clamp(0, 0.95)
     offset = up(inp["offset_lo"][:nb])
     return seg, center, offset
+
+
+def dataset_sample(seed, H=120, W=160, n_inst=4, classes=(3, 16, 17, 20), void=True):
+    """One synthetic annotated photo for the input-pipeline tests: a smooth uint8 RGB image, a semantic map (VOC class ids,
+    255 = void rim), an instance-id map and the 20-way image-level label vector (what VOCInstanceSegmentation.__getitem__
+    hands to the dataset wrapper, dataset/voc.py:280-324)."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    img = np.zeros((H, W, 3))
+    for c in range(3):
+        for _ in range(4):
+            fy, fx, ph = rs.uniform(0.01, 0.3), rs.uniform(0.01, 0.3), rs.uniform(0, 6.28)
+            img[:, :, c] += rs.uniform(20, 60) * np.sin(fy * yy + fx * xx + ph)
+    img = np.clip(img + 128 + rs.normal(0, 12, img.shape), 0, 255).astype(np.uint8)
+    seg = np.zeros((H, W), dtype=np.uint8)
+    mask = np.zeros((H, W), dtype=np.uint8)
+    l1h = np.zeros(20)
+    for k in range(n_inst):
+        cy, cx = rs.uniform(0.15, 0.85) * H, rs.uniform(0.15, 0.85) * W
+        ry, rx = rs.uniform(0.08, 0.25) * H, rs.uniform(0.08, 0.25) * W
+        blob = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1
+        cls = classes[rs.randint(len(classes))]
+        if void:
+            rim = (((yy - cy) / (ry + 2)) ** 2 + ((xx - cx) / (rx + 2)) ** 2 < 1) & ~blob
+            seg[rim & (seg == 0)] = 255
+        seg[blob] = cls
+        mask[blob] = k + 1
+        l1h[cls - 1] = 1
+    return img, seg, mask, l1h

@@ -33,6 +33,9 @@ INSMAP_CASES = [(0, 129, 129, False), (3, 129, 129, True), (6, 161, 145, True)]
 LABEL_CASES = [(0, 2, 129, 129), (3, 3, 129, 129), (5, 2, 97, 145), (6, 2, 193, 193)]
 
 
+DATASET_CASES = [(0, 120, 160, 97, 1, True), (1, 150, 110, 129, 0, True), (2, 90, 200, 65, 1, False)]   # seed, H, W, crop, step, masking
+
+
 def ref_opts(R, crop):
     ap = R["argparser"]
     args = ["--dataset", "voc", "--task", "15-5", "--step", "1", "--weakly", "--phase", "2", "--alpha", "0.5",
@@ -186,6 +189,47 @@ def wrn_fixture(R):
     print("model_wrn38_c65.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
+def dataset_fixture(R, seed, H, W, size, step, masking):
+    """The reference's IncrementalInstanceSegmentationDataset.__getitem__ (dataset/dataset.py:187-221: concat_PIL, LabelTransform,
+    instance gating, label_generation, LabelSelection) on synthetic annotated photos. dataset/__init__.py and voc.py need
+    torchvision + pycocotools (absent), so dataset/dataset.py is loaded through a bare package object whose __path__ is the
+    reference directory, `make_dataset` returns the in-memory samples, and the transform is the Pillow restatement of
+    get_dataset's Compose (oracle/dataset.py — torchvision's functional ops on PIL images are thin Pillow wrappers)."""
+    import importlib
+    import random
+    import types
+    from PIL import Image
+    from oracle import dataset as ods
+    if "refds" not in sys.modules:
+        pkg = types.ModuleType("refds")
+        pkg.__path__ = [os.path.join(ref_harness.REF, "dataset")]
+        sys.modules["refds"] = pkg
+    rd = importlib.import_module("refds.dataset")
+    from cl4wsis_amd import tasks
+    step_dict = tasks.get_task_dict("voc", "15-5", step)
+    samples = [synth.dataset_sample(seed * 10 + k, H, W) for k in range(3)]
+
+    class DS(rd.IncrementalInstanceSegmentationDataset):
+        def make_dataset(self, root, ann_file, **kw):
+            return [(Image.fromarray(i), Image.fromarray(s), Image.fromarray(m), l) for (i, s, m, l) in samples]
+
+    def transform(img, lbl):
+        t, l, _ = ods.train_transform(np.array(img), np.array(lbl), size)
+        return t, torch.from_numpy(l)
+
+    ds = DS("", step_dict, train=True, transform=transform, idxs_path="none", masking=masking, step=step, weakly=True)
+    out = {"step": step, "masking": int(masking), "size": size, "seed": seed}
+    for k, (i, s, m, l) in enumerate(samples):
+        random.seed(1000 * seed + k)
+        img, seg_map, center, offset, weight, l1h = ds[k]
+        out.update({f"in_img{k}": i, f"in_seg{k}": s, f"in_mask{k}": m, f"in_l1h{k}": l,
+                    f"img{k}": img.numpy(), f"seg_map{k}": seg_map.numpy(), f"center{k}": center, f"offset{k}": offset,
+                    f"weight{k}": weight, f"l1h{k}": np.asarray(l1h)})
+    path = os.path.join(HERE, f"dataset_s{seed:02d}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def label_fixture(R, seed, b, H, W):
     inp = synth.label_stage_inputs(seed, b=b, H=H, W=W)
     oc, tot = inp["old_classes"], inp["tot_classes"]
@@ -333,6 +377,8 @@ if __name__ == "__main__":
     wrn_fixture(R)
     for case in INSMAP_CASES:
         insmap_fixture(R, *case)
+    for case in DATASET_CASES:
+        dataset_fixture(R, *case)
     for case in LABEL_CASES:
         label_fixture(R, *case)
     for case in WSS_CASES:
