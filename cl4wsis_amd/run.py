@@ -114,15 +114,20 @@ def main(opts):
     np.random.seed(opts.random_seed)
     random.seed(opts.random_seed)
     opts.batch_size = opts.batch_size // world                       # run.py:66
-    try:
-        from dataset import get_dataset                              # the reference's pipeline, if present
+    supervised = opts.step == 0 and not opts.weakly
+    if os.path.isfile(os.path.join(opts.data_root, "voc", "pascal_sbd_train.json")):
+        # the real photos: host decode + device-side crop / resample / normalise / target generation (cl4wsis_amd/dataset)
+        from .dataset import DeviceLoader, get_dataset
         train_dst, val_dst, test_dst, labels, n_classes = get_dataset(opts)
-    except ImportError:
+        sampler = DistributedSampler(train_dst, num_replicas=world, rank=rank) if world > 1 else None
+        loader = DeviceLoader(train_dst, opts.batch_size, device, sampler=sampler, shuffle=True, num_workers=opts.num_workers,
+                              drop_last=True, supervised=supervised)
+    else:
         n_img = int(os.environ.get("CL4_SYNTH_LEN", "10582"))        # VOC 2012 aug train size
-        train_dst = SyntheticVOC(n_img, opts.crop_size, opts.random_seed, supervised=opts.step == 0 and not opts.weakly)
-    sampler = DistributedSampler(train_dst, num_replicas=world, rank=rank) if world > 1 else None
-    loader = data.DataLoader(train_dst, batch_size=opts.batch_size, sampler=sampler, shuffle=sampler is None,
-                             num_workers=opts.num_workers, drop_last=True)
+        train_dst = SyntheticVOC(n_img, opts.crop_size, opts.random_seed, supervised=supervised)
+        sampler = DistributedSampler(train_dst, num_replicas=world, rank=rank) if world > 1 else None
+        loader = data.DataLoader(train_dst, batch_size=opts.batch_size, sampler=sampler, shuffle=sampler is None,
+                                 num_workers=opts.num_workers, drop_last=True)
     opts.max_iters = opts.epochs * len(loader)
     opts.start_decay = opts.pseudo_ep * len(loader)
     logger = _Logger(rank)

@@ -409,8 +409,8 @@ int cl4_instance_map(const cl4_insmap_io* d, void* workspace, size_t workspace_b
  * (dataset/utils.py:299-350). The arithmetic is Pillow's (the reference transforms PIL images): BILINEAR = Resample.c two-pass
  * fixed-point convolution, NEAREST = Geometry.c ImagingScaleAffine; results are bit-identical to the reference's tensors. */
 typedef struct cl4_sample_desc {
-  long long img_off;   /* byte offset of this sample's H x W x 3 uint8 RGB photo in the packed `images` buffer */
-  long long lbl_off;   /* byte offset of its H x W x 2 uint8 (semantic id, instance id) label in `labels` */
+  int64_t img_off;     /* byte offset of this sample's H x W x 3 uint8 RGB photo in the packed `images` buffer */
+  int64_t lbl_off;     /* byte offset of its H x W x 2 uint8 (semantic id, instance id) label in `labels` */
   int H, W;            /* source size */
   int ci, cj, ch, cw;  /* crop box: top, left, height, width (RandomResizedCrop.get_params; the whole image for Resize) */
   int flip;            /* RandomHorizontalFlip drew a flip */

@@ -30,11 +30,14 @@ def test_ctypes_prototypes_cover_header():
     assert lib.cl4_abi_version() == 1
     size_fns = {"cl4_conv2d_fwd_workspace_bytes", "cl4_bn_workspace_bytes", "cl4_peak_workspace_bytes", "cl4_label_workspace_bytes", "cl4_p2_loss_workspace_bytes",
                 "cl4_pamr_workspace_bytes", "cl4_ngwp_workspace_bytes", "cl4_balanced_ce_workspace_bytes",
-                "cl4_bce_ignore_workspace_bytes", "cl4_p1loss_workspace_bytes", "cl4_cam_smooth_workspace_bytes", "cl4_abi_version", "cl4_last_error"}
+                "cl4_bce_ignore_workspace_bytes", "cl4_p1loss_workspace_bytes", "cl4_cam_smooth_workspace_bytes", "cl4_abi_version", "cl4_last_error",
+                "cl4_input_ksize", "cl4_input_workspace_bytes", "cl4_target_generation_workspace_bytes"}
     for n in _declared():
         assert n in _hip.PROTOTYPES or n in size_fns, f"{n} has no ctypes prototype"
     assert lib.cl4_label_workspace_bytes(1, 65, 65) > 65 * 65 * 40
     assert lib.cl4_bn_workspace_bytes(128) == 128 * 32 * 2 * 8
+    assert lib.cl4_input_ksize(500, 513) == 3 and lib.cl4_input_ksize(1000, 400) == 7      # Pillow: ceil(max(scale, 1)) * 2 + 1
+    assert lib.cl4_input_workspace_bytes(2, 65, 65, 100, 3) >= 2 * 100 * 65 * 3
 
 
 def test_struct_layouts_match_header_field_order():
@@ -43,7 +46,7 @@ def test_struct_layouts_match_header_field_order():
     src = open(os.path.join(ROOT, "include", "cl4wsis.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     for cname, st in (("cl4_conv_desc", _hip.ConvDesc), ("cl4_label_io", _hip.LabelIO), ("cl4_p2_loss_io", _hip.P2LossIO),
-                      ("cl4_insmap_io", _hip.InsmapIO)):
+                      ("cl4_insmap_io", _hip.InsmapIO), ("cl4_sample_desc", _hip.SampleDesc)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, re.S).group(1)
         fields = []
         for decl in body.split(";"):

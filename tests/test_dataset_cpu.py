@@ -1,0 +1,84 @@
+"""Host side of the input pipeline (cl4wsis_amd/dataset): COCO-format index + mask decoding, the incremental image filter,
+label mapping / LabelSelection and the augmentation plans — against the oracle restatement (oracle/dataset.py, pinned by the
+reference fixtures in test_oracle_dataset.py). No GPU: RawSamples are inspected before the device stage."""
+import random
+
+import numpy as np
+
+from cl4wsis_amd import argparser
+from cl4wsis_amd.dataset import coco_index as ci
+from oracle import dataset as ods
+from util import make_mini_voc
+
+
+def _opts(root, step=1, extra=()):
+    p = argparser.get_argparser()
+    o = p.parse_args(["--dataset", "voc", "--task", "15-5", "--step", str(step), "--data_root", str(root), "--crop_size", "65",
+                      "--crop_size_val", "70", *extra])
+    return argparser.modify_command_options(o)
+
+
+def test_rle_codecs_roundtrip_and_polygon():
+    rs = np.random.RandomState(0)
+    m = (rs.rand(17, 23) > 0.6).astype(np.uint8)
+    flat = m.T.reshape(-1)
+    edges = np.flatnonzero(np.diff(np.concatenate([[0], flat.astype(np.int8), [0]])))
+    counts = np.diff(np.concatenate([[0], edges, [flat.size]]))
+    assert np.array_equal(ci.ann_to_mask({"size": [17, 23], "counts": counts.tolist()}, 17, 23), m)
+    # compressed string: encode with the published scheme (5 bits per char, continuation 0x20, delta to cnts[i-2] from i > 2)
+    s = ""
+    for i, c in enumerate(counts.tolist()):
+        x = c - int(counts[i - 2]) if i > 2 else c
+        more = True
+        while more:
+            ch = x & 0x1f
+            x >>= 5
+            more = not ((x == 0 and not (ch & 0x10)) or (x == -1 and (ch & 0x10)))
+            s += chr((ch | (0x20 if more else 0)) + 48)
+    assert np.array_equal(ci.ann_to_mask({"size": [17, 23], "counts": s}, 17, 23), m)
+    # polygons: an axis-aligned rectangle covers [x0, x1) x [y0, y1); two polygons are united
+    r = ci.ann_to_mask([[2, 3, 10, 3, 10, 8, 2, 8]], 12, 14)
+    assert r.sum() == 40 and r[3:8, 2:10].all()
+    u = ci.ann_to_mask([[2, 3, 10, 3, 10, 8, 2, 8], [0, 0, 3, 0, 3, 4, 0, 4]], 12, 14)
+    assert u.sum() == 40 + 12 - 1 and u[0:4, 0:3].all()
+
+
+def test_incremental_filter_and_items(tmp_path):
+    from cl4wsis_amd.dataset import get_dataset
+    truth = make_mini_voc(tmp_path)
+    train, val, test, labels_cum, n = get_dataset(_opts(tmp_path))
+    assert n == 21 and labels_cum == list(range(21))
+    # overlap protocol, step 1: only photos that contain a new class (16..20) are kept for training; val keeps everything
+    assert len(train) == 4 and len(val) == 3 and len(test) == 3
+    kept = [s for k, s in enumerate(truth["train"]) if k % 3]
+    mapping, order, labels = ods.label_mapping({0: list(range(16)), 1: list(range(16, 21))}, 1, True, True)
+    assert np.array_equal(train.mapping, mapping) and train.total_classes == 20
+    for k in range(len(train)):
+        img, seg, inst, l1h = kept[k]
+        random.seed(100 + k)
+        raw = train[k]
+        random.seed(100 + k)
+        i, j, h, w = ods.random_resized_crop_params(img.shape[1], img.shape[0])
+        flip = random.random() < 0.5
+        assert raw.plan.crop == (i, j, h, w) and raw.plan.flip == flip and raw.plan.out_hw == (65, 65)
+        assert np.array_equal(raw.image, img)
+        # masking=True drops the old-class annotations before the maps are built (dataset/voc.py:291-293)
+        new = seg >= 16
+        assert np.array_equal(raw.label[:, :, 0], np.where(new, seg, 0))
+        assert np.array_equal(raw.label[:, :, 1] > 0, new)
+        assert np.array_equal(raw.l1h, ods.label_selection(l1h, order, labels, True))
+    v = val[1]
+    img, seg, inst, _ = truth["val"][1]
+    assert v.plan.out_hw == ods.resize_output_size(img.shape[1], img.shape[0], 70) and v.plan.crop == (0, 0) + img.shape[:2]
+    assert np.array_equal(v.label[:, :, 0], seg) and v.masks.shape[0] == len(v.mask_label) == len(np.unique(inst)) - 1
+    assert v.path == "val_001.png"
+
+
+def test_disjoint_protocol_rejects_future_classes(tmp_path):
+    from cl4wsis_amd.dataset.voc import check_if_insert
+    a = [{"category_id": 16}, {"category_id": 3}]
+    assert check_if_insert(a, True, list(range(1, 21)), [16, 17])
+    assert check_if_insert(a, False, [1, 2, 3, 16, 17], [16, 17])
+    assert not check_if_insert(a + [{"category_id": 19}], False, [1, 2, 3, 16, 17], [16, 17])
+    assert not check_if_insert([{"category_id": 3}], True, list(range(1, 21)), [16, 17])
+    assert check_if_insert([{"category_id": 3}], True, list(range(1, 21)), [16, 17], is_train=False)

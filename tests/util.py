@@ -16,6 +16,13 @@ def p2_opts(crop=513, extra=()):
     return argparser.modify_command_options(argparser.get_argparser().parse_args(args))
 
 
+class QuietLogger:
+    def info(self, *a, **k):
+        pass
+
+    debug = add_scalar = info
+
+
 def rel_err(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
@@ -35,3 +42,49 @@ def s0_opts(crop=513, extra=()):
     args = ["--dataset", "voc", "--task", "15-5", "--step", "0", "--bce", "--lr", "5e-5", "--epochs", "100", "--optim", "adam",
             "--weight_decay", "0", "--crop_size", str(crop), "--batch_size", "16", "--no_pretrained"] + list(extra)
     return argparser.modify_command_options(argparser.get_argparser().parse_args(args))
+
+
+def make_mini_voc(root, n_train=6, n_val=3, seed=0):
+    """A tiny Pascal-VOC-shaped tree under `root` (voc/JPEGImages/*.png + COCO-format pascal_sbd_{train,val}.json with
+    uncompressed-RLE instance masks) built from oracle.synth.dataset_sample. Returns {split: [(img, seg, inst, l1h), ...]}."""
+    import json
+    import os
+    import numpy as np
+    from PIL import Image
+    from oracle import synth
+    os.makedirs(os.path.join(root, "voc", "JPEGImages"), exist_ok=True)
+    out = {}
+    img_id = ann_id = 0
+    for split, n in (("train", n_train), ("val", n_val)):
+        images, anns, samples = [], [], []
+        for k in range(n):
+            H, W = 90 + 10 * (k % 3), 120 + 7 * k
+            classes = (3, 16, 17, 20) if k % 3 else (2, 5)          # every third photo holds old classes only
+            img, seg, inst, l1h = synth.dataset_sample(seed * 100 + img_id, H, W, n_inst=3, classes=classes, void=False)
+            img_id += 1
+            name = f"{split}_{k:03d}.png"
+            Image.fromarray(img).save(os.path.join(root, "voc", "JPEGImages", name))
+            images.append({"id": img_id, "file_name": name, "height": H, "width": W})
+            keep = []
+            for iid in np.unique(inst):
+                if iid == 0:
+                    continue
+                m = inst == iid
+                flat = m.T.reshape(-1).astype(np.int8)               # column-major
+                edges = np.flatnonzero(np.diff(np.concatenate([[0], flat, [0]])))
+                counts = np.diff(np.concatenate([[0], edges, [flat.size]])).tolist()
+                ys, xs = np.where(m)
+                ann_id += 1
+                anns.append({"id": ann_id, "image_id": img_id, "category_id": int(seg[m][0]), "iscrowd": 0,
+                             "bbox": [int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)],
+                             "area": int(m.sum()), "segmentation": {"size": [H, W], "counts": counts}})
+                keep.append(int(iid))
+            # instance ids as the dataset numbers them: position of the annotation in the image's list, 1-based
+            renum = np.zeros(256, dtype=np.uint8)
+            for pos, iid in enumerate(keep):
+                renum[iid] = pos + 1
+            samples.append((img, seg, renum[inst], l1h))
+        with open(os.path.join(root, "voc", f"pascal_sbd_{split}.json"), "w") as f:
+            json.dump({"images": images, "annotations": anns, "categories": [{"id": i} for i in range(1, 21)]}, f)
+        out[split] = samples
+    return out
