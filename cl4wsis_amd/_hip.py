@@ -91,6 +91,7 @@ _decl("cl4_pack_conv_weight_bf16x3", _P, _P, _I, _I, _I, _I, _P)
 _decl("cl4_pack_conv_weight_bf16x6", _P, _P, _I, _I, _I, _I, _P)
 _decl("cl4_conv2d_fwd", C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_conv2d_fwd_set_plan", C.POINTER(ConvDesc), _I, _I, _I)
+_decl("cl4_conv2d_fwd_clear_plans")
 _decl("cl4_conv2d_wgrad", C.POINTER(ConvDesc), _P, _P, _P, _P)
 _decl("cl4_bn_fold", _P, _P, _P, _P, _F, _P, _P, _I, _P)
 

@@ -1434,6 +1434,12 @@ extern "C" int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int til
   return CL4_OK;
 }
 
+extern "C" int cl4_conv2d_fwd_clear_plans(void) {
+  std::lock_guard<std::mutex> g(plan_mutex());
+  plan_table().clear();
+  return CL4_OK;
+}
+
 extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const float* wp, const float* scale,
                               const float* shift, const float* pre, const float* post, float* y, void* workspace,
                               size_t workspace_bytes, void* stream) {

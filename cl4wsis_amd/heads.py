@@ -29,6 +29,15 @@ EPS = 1e-5
 TRAIN_PRECISION = int(__import__("os").environ.get("CL4_TRAIN_PRECISION", "2"))
 
 
+def _dx_1x1(dz, conv):
+    """Input gradient of a 1x1 conv. Exact fp32: the PyTorch weight [cout, cin] already is the packed [K=cout][M=cin] operand of
+    the transposed GEMM; bf16x3 / bf16x6: the transposed weight in split planes (cached until the optimiser touches it)."""
+    if TRAIN_PRECISION and ops.bf16x3_ok(conv.in_channels):
+        wd = CACHE.get(conv, ("dgrad", TRAIN_PRECISION), (conv.weight,), lambda: ops.dgrad_weight(conv.weight.detach(), TRAIN_PRECISION))
+        return ops.conv2d(dz, wd, 1)
+    return ops.conv2d(dz, conv.weight.detach().reshape(conv.out_channels, conv.in_channels), 1)
+
+
 class DeeplabV3(nn.Module):
     """modules/deeplab.py:8-89."""
 
@@ -354,7 +363,7 @@ class InstanceBranch:
         dz1 = ops.bn_train_bwd(z1, dy, m1, v1, bn1.weight.detach(), bn1.bias.detach(), G(bn1.weight), G(bn1.bias), bn1.eps)
         ops.conv2d_wgrad(a, dz1, G(pw.weight), 1)
         # input gradient of a 1x1 conv: the PyTorch weight [cout, cin] already is the packed [K=cout][M=cin] operand
-        da = ops.conv2d(dz1, pw.weight.detach().reshape(pw.out_channels, pw.in_channels), 1)
+        da = _dx_1x1(dz1, pw)
         dz0 = ops.bn_train_bwd(z0, da, m0, v0, bn0.weight.detach(), bn0.bias.detach(), G(bn0.weight), G(bn0.bias), bn0.eps)
         ops.dwconv5_wgrad_(G(dw.weight), x, dz0)
         return ops.dwconv5(dz0, dw.weight.detach(), flip=True) if need_dx else None
@@ -406,7 +415,7 @@ class InstanceBranch:
                                    dy_coff=cy)
             ops.conv2d_wgrad(l, dlz, G(conv.weight), 1)
             if feature_grads is not None:
-                feature_grads[d.low_level_key[si]] = ops.conv2d(dlz, conv.weight.detach().reshape(conv.out_channels, conv.in_channels), 1)
+                feature_grads[d.low_level_key[si]] = _dx_1x1(dlz, conv)
             dy = ops.resize_bilinear_bwd(dcat, tuple(prev_hw), True, dy_coff=0, c=cy)
             i -= 2
         # ASPP ------------------------------------------------------------------------------------------
@@ -417,7 +426,7 @@ class InstanceBranch:
                                keep=keep, keep_scale=kscale)
         pconv0 = aspp.project[0]
         ops.conv2d_wgrad(cat5, dpz, G(pconv0.weight), 1)
-        dcat5 = ops.conv2d(dpz, pconv0.weight.detach().reshape(pconv0.out_channels, pconv0.in_channels), 1)
+        dcat5 = _dx_1x1(dpz, pconv0)
         cout = aspp.convs[0][0].out_channels
         dx = None
         for j in range(4):
@@ -437,7 +446,7 @@ class InstanceBranch:
         pconv = aspp.convs[4].aspp_pooling[1]
         ops.conv2d_wgrad(g, dgp, G(pconv.weight), 1)
         if feature_grads is not None:
-            dg = ops.conv2d(dgp, pconv.weight.detach().reshape(pconv.out_channels, pconv.in_channels), 1)
+            dg = _dx_1x1(dgp, pconv)
             feature_grads[d.feature_key] = ops.add_per_plane_(dx, dg, 1.0 / (h * w))
         self._flush_ready()
         return grads

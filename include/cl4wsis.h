@@ -91,6 +91,8 @@ size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d);
  * `splits` K-slices); impl 0 forgets it (back to the built-in heuristic). Results never depend on the plan beyond
  * fp32 summation order. The host autotuner (cl4wsis_amd/ops.py) times the candidates once per shape in warm-up. */
 int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int tile, int splits);
+/* Forget every pinned plan (back to the heuristic); the autotuner's choices depend on timing, so tests reset them. */
+int cl4_conv2d_fwd_clear_plans(void);
 int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const float* wp,
                    const float* scale, const float* shift,
                    const float* pre, const float* post, float* y,

@@ -20,3 +20,15 @@ def gpu():
     from cl4wsis_amd import _hip
     _hip.load()  # raises loudly when the HIP library is missing
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _reset_conv_plans(request):
+    """The warm-up autotuner pins launch plans by TIMING (process-wide table); a plan changes the summation order of a conv and
+    with it the last bits that decide ReLU-mask flips in the ill-conditioned tiny-crop gradient tests. Forget the plans after
+    every GPU test so that each test sees the deterministic heuristic plans whatever ran before it."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        from cl4wsis_amd import _hip, ops
+        ops.AUTOTUNE = False
+        _hip.call("cl4_conv2d_fwd_clear_plans")

@@ -70,6 +70,29 @@ def test_conv_fwd_pinned_plans(gpu, plan, precision):
     assert _rel_err(y.cpu(), ref) < TOL[precision]
 
 
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_autotuner_keeps_the_result(gpu, precision):
+    """ops.AUTOTUNE times the candidate plans of a new shape and pins the fastest (what Trainer / bench do during warm-up);
+    whatever it picks, the convolution is the same within the arithmetic's tolerance, and clear_plans forgets the choice."""
+    from cl4wsis_amd import _hip, ops
+    g = torch.Generator().manual_seed(4)
+    n, cin, h, cout, k = 4, 256, 33, 256, 3
+    x = torch.randn(n, cin, h, h, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * 9) ** 0.5
+    ref = F.conv2d(x.double(), wt.double(), padding=1).float()
+    xd, wp = x.to(gpu), ops.pack_conv_weight(wt.to(gpu), precision)
+    y0 = ops.conv2d(xd, wp, k, pad=1)
+    ops.AUTOTUNE = True
+    try:
+        y1 = ops.conv2d(xd, wp, k, pad=1)
+    finally:
+        ops.AUTOTUNE = False
+    _hip.call("cl4_conv2d_fwd_clear_plans")
+    y2 = ops.conv2d(xd, wp, k, pad=1)
+    assert _rel_err(y1.cpu(), ref) < TOL[precision] and _rel_err(y0.cpu(), ref) < TOL[precision]
+    assert torch.equal(y0, y2)                      # heuristic plan again: bit-identical to the first call
+
+
 def test_conv_fwd_fused_epilogue(gpu):
     from cl4wsis_amd import ops
     g = torch.Generator().manual_seed(7)

@@ -62,7 +62,9 @@ def test_networks_match_reference_golden(gpu):
     # batch-stat BN over 2x5x5 samples is ill-conditioned: the reference's own fp32 gradients sit 1e-3..1e-2 away from a
     # float64 evaluation (tests/test_model_gpu.py), and a 1e-4 change of the input features moves single tensors by <1 %.
     np.testing.assert_allclose(norms, gold["grad_norms"], rtol=2e-2)
-    assert np.median(np.abs(norms / gold["grad_norms"] - 1)) < 2e-3
+    med = float(np.median(np.abs(norms / gold["grad_norms"] - 1)))
+    print("GRADNORM median", med, "max", float(np.abs(norms / gold["grad_norms"] - 1).max()))
+    assert med < 2e-3, med
     pl.eval(); pg.eval()
     im = pl(f2["body"][:2])
     assert rel_err(im.cpu(), torch.from_numpy(gold["int_masks"])) < NET_TOL

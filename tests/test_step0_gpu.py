@@ -16,8 +16,15 @@ class _Log:
     debug = info
 
 
-def test_step0_matches_oracle(gpu):
+@pytest.mark.parametrize("precision", [0, 2])
+def test_step0_matches_oracle(gpu, monkeypatch, precision):
+    """precision 0 (exact fp32 products, rounding correlated with the CPU oracle): strict statistical bar; precision 2 (bf16x6,
+    the default; fp32-level accuracy with independent rounding): rms bar — see test_phase1_gpu.py."""
+    from cl4wsis_amd import body_train, heads
     from cl4wsis_amd.train import Trainer
+    monkeypatch.setattr(body_train, "PRECISION", precision)
+    monkeypatch.setattr(body_train, "WGRAD_PRECISION", 0)
+    monkeypatch.setattr(heads, "TRAIN_PRECISION", precision)
     from oracle import step as ostep, weights
     crop = 65
     opts = s0_opts(crop)
@@ -51,7 +58,7 @@ def test_step0_matches_oracle(gpu):
     # At crop 65 the 100-layer body normalises over a few dozen samples per channel: BOTH fp32 evaluations (CPU oracle and
     # this GPU path) sit 5-10 % from the float64 gradient, by about the same amount. The bar is the reference's own
     # arithmetic, statistically (see test_phase1_gpu.py): median ratio < 2, at most 3 % of the tensors beyond 3x.
-    ratios = []
+    ratios, so, sc = [], 0.0, 0.0
     for k, p in tr.model.named_parameters():
         g64 = ref64["grads"][k]
         if g64.norm() == 0:
@@ -59,6 +66,13 @@ def test_step0_matches_oracle(gpu):
         ours = ((tr._grad_map[id(p)].double().cpu() - g64).norm() / g64.norm()).item()
         cpu32 = ((ref["grads"][k].double() - g64).norm() / g64.norm()).item()
         ratios.append(ours / (cpu32 + 1e-5))
+        so += ours ** 2
+        sc += cpu32 ** 2
     ratios = torch.tensor(ratios)
     assert len(ratios) > 370
-    assert ratios.median() < 2 and (ratios > 3).float().mean() < 0.03, (ratios.median(), (ratios > 3).float().mean())
+    print("S0STAT precision", precision, "median ratio", ratios.median().item(), "frac>3", (ratios > 3).float().mean().item(),
+          "rms ours", (so / len(ratios)) ** 0.5, "rms cpu32", (sc / len(ratios)) ** 0.5)
+    if precision == 0:
+        assert ratios.median() < 2 and (ratios > 3).float().mean() < 0.03, (ratios.median(), (ratios > 3).float().mean())
+    else:
+        assert so ** 0.5 < 5 * sc ** 0.5 + 1e-4, (so, sc)
