@@ -201,7 +201,10 @@ def main():
             "algorithmic_tflops_whole_step": ALGO_GFLOP_PER_IMAGE * GLOBAL_BATCH * a.steps / elapsed / 1e3,
             "final_losses": dict(zip(("center_old", "offset_old", "center_new", "offset_new"), losses)),
         }
-        for kind, pk in (("conv_fwd_f32", PEAK_FP32_MFMA_TFLOPS), ("conv_wgrad", PEAK_FP32_MFMA_TFLOPS)):
+        from cl4wsis_amd import ops as _ops
+        wgrad_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if _ops.WGRAD_PRECISION == 1 else PEAK_FP32_MFMA_TFLOPS
+        for kind, pk in (("conv_fwd_bf16x6", PEAK_BF16_MFMA_TFLOPS / 6.0), ("conv_fwd_f32", PEAK_FP32_MFMA_TFLOPS),
+                         ("conv_wgrad", wgrad_peak)):
             if kind in summ:
                 kn, kf, kms = summ[kind]
                 res[kind] = {"achieved": kf / (kms * 1e-3) / 1e12, "peak": pk, "unit": "TFLOP/s",
