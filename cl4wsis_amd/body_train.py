@@ -14,13 +14,12 @@ import os
 from . import ops
 from .nn import CACHE, packed_weight
 
-# Arithmetic of the convolutions of the step-0 / phase-1 training paths (forward and input gradients; weight gradients use
-# exact fp32 products unless PRECISION == 1): 2 (default) = bf16x6, three bf16 planes per operand and six products — fp32-level
+# Arithmetic of the convolutions of the step-0 / phase-1 training paths (forward, input and weight gradients): 2 (default) = bf16x6, three bf16 planes per operand and six products — fp32-level
 # accuracy (the gradient parity bar of the tests) at about twice the speed of the fp32 MFMA kernels; 0 = exact fp32 MFMA;
 # 1 = bf16x3 (~4e-6 relative per layer — still far tighter than the fp16 autocast the reference trains under on GPUs,
 # train.py:252 — fastest, outside the strict gradient bar).
 PRECISION = int(os.environ.get("CL4_TRAIN_PRECISION", "2"))
-WGRAD_PRECISION = 1 if PRECISION == 1 else 0
+WGRAD_PRECISION = PRECISION      # 2: bf16x6 for k >= 3, exact fp32 for 1x1 (cl4_conv2d_wgrad picks the faster of the two)
 
 
 class _Rec:

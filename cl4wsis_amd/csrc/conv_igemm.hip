@@ -18,6 +18,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
   constexpr int KHW = KS * KS;
   constexpr int KG = BK2 / 8;               // 4 k-groups of 8 per K-tile
   constexpr int NITEM = BN / 64;            // (pixel, k-group) items per loader lane
-  static_assert(P == 2 || (P == 3 && BM == 64 && BN == 64), "three planes: 64x64 tiles only");
+  static_assert(P == 2 || P == 3, "two (bf16x3) or three (bf16x6) planes");   // 128x128x3 planes = 96 KB LDS: one workgroup per CU
   constexpr int A_INSTR = KG * P * BM / 64 / 4;   // dwordx4 loads per loader wave and K-tile
   constexpr int A_CHUNKS = KG * P * BM;     // 16-byte chunks of the weight tile
   constexpr int B_CHUNKS = KG * P * BN;
@@ -1033,7 +1034,7 @@ FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision
   FwdPlan p{1, 128, 1, 0};
   if (impl != 2 || cout % 4 != 0 || cout < 64) return p;
   p.impl = 2;
-  p.tile = (tile == 128 && cout >= 128 && precision != 2) ? 128 : 64;      // bf16x6 (precision 2): 64x64 tiles only
+  p.tile = (tile == 128 && cout >= 128) ? 128 : 64;
   const int ktiles = cl4::cdiv(K, BK2);
   int s = splits < 1 ? 1 : splits;
   if (s > ktiles) s = ktiles;
@@ -1062,7 +1063,7 @@ FwdPlan plan_fwd(const PlanKey& key) {
   double best = 1e30;
   FwdPlan bestp = make_plan(2, 64, 1, cout, K, precision);
   for (int tile = 64; tile <= 128; tile += 64) {
-    if (tile == 128 && (cout < 128 || precision == 2)) continue;
+    if (tile == 128 && (cout < 128 || (precision == 2 && ktiles < 64))) continue;   // bf16x6 at 128x128: 96 KB LDS, one WG per CU — long K only
     const long wgs = (long)cl4::cdiv(cout, tile) * cl4::cdiv(npix, tile);
     const double t_tile = tile == 128 ? 2.4 : 0.65;   // us per K-tile of one workgroup at ~70 % MFMA issue
     const double t_fixed = tile == 128 ? 5.0 : 2.5;   // prologue + epilogue
@@ -1091,15 +1092,20 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
       if (!workspace || workspace_bytes < need) { cl4::set_error("conv2d_fwd: workspace too small for split-K"); return CL4_ENOSPC; }
       a.ws = (float*)workspace;
     }
-    const dim3 g(cl4::cdiv(a.cout, 64), cl4::cdiv(a.npix, 64), pl.splits);
+    const dim3 g(cl4::cdiv(a.cout, pl.tile), cl4::cdiv(a.npix, pl.tile), pl.splits);
     const float* z = zp6;
     const bool tapmaj = a.cin % 32 == 0;
     if (tapmaj && (long)a.n * a.in_ctot * a.hin * a.win * 4 >= 0x7FFFFFFFL) {
       cl4::set_error("conv2d_fwd(bf16x6): input tensor >= 2 GiB is not addressable by the 32-bit buffer offsets");
       return CL4_EINVAL;
     }
-    if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
-    else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
+    if (pl.tile == 128) {
+      if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
+      else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
+    } else {
+      if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
+      else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
+    }
     if (pl.splits > 1) {
       const long total = (long)a.cout * a.npix;
       hipLaunchKernelGGL(conv_splitk_epilogue, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, a, pl.splits);
@@ -1175,27 +1181,35 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
   return cl4::launch_status();
 }
 
-// bf16x3 weight gradient: same staging as conv_wgrad_f32 (lane = pixel along K, rows fixed per thread), but the tiles are
-// split into bf16 hi / lo planes on their way into LDS and multiplied with three v_mfma_f32_32x32x16_bf16 per fragment
-// pair (1/5 of the MFMA cycles of the fp32 kernel; ~4e-6 relative error, like the forward kernel). LDS image per plane:
-// [row][4 k-groups of 8 bf16], 64-byte rows, the 16-byte k-group slots XOR-swizzled with (row >> 2) & 3 so that the
-// ds_read_b128 fragment reads (32 rows x one k-group) are bank-conflict free without padding (4 planes x 2 stages of
-// a 128-row tile = 64 KB).
-template <int BM, int BN, int KS>
-__global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16x3(WgradArgs a) {
+// bf16 split-product weight gradient: same staging as conv_wgrad_f32 (lane = pixel along K, rows fixed per thread), but the
+// tiles are split into P bf16 planes on their way into LDS — P = 2: hi/lo, three v_mfma_f32_32x32x16_bf16 per fragment pair
+// ("bf16x3", ~4e-6 relative, like the forward kernel); P = 3: hi/mid/lo, six products ("bf16x6", fp32-level accuracy). LDS
+// image per plane: [row][4 k-groups of 8 bf16], 64-byte rows, the 16-byte k-group slots XOR-swizzled with (row >> 2) & 3 so
+// that the ds_read_b128 fragment reads (32 rows x one k-group) are bank-conflict free without padding (2P planes x 2 stages
+// of a 128-row tile = 64 KB for P = 2, 96 KB for P = 3).
+// Wave specialisation like the forward kernel: waves 0-3 are loaders (global loads -> bf16 split -> LDS) with TWO register
+// sets — the loads of K-tile t+2 are issued before tile t+1 (issued one phase earlier) is converted and stored, so every
+// load has a whole phase to land — while waves 4-7 only read LDS fragments and issue MFMAs; one workgroup barrier per
+// K-tile. (The earlier single-role kernel waited the full L2/HBM latency every K-tile: 75-120 TFLOP/s.) All loads are
+// unconditional (out-of-range offsets past the end), which keeps the compiler's vmcnt accounting exact.
+template <int BM, int BN, int KS, int P>
+__global__ __launch_bounds__(2 * NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KHW = KS * KS;
   constexpr int RA = BM * BKP / NTHREADS;
   constexpr int RB = BN * BKP / NTHREADS;
   static_assert(BKP == 32, "one K tile = 4 k-groups of 8 pixels");
+  static_assert(P == 2 || P == 3, "two (bf16x3) or three (bf16x6) planes");
 
-  __shared__ __attribute__((aligned(16))) unsigned short Ash[2][2][BM * BKP];   // [stage][plane][row*32 + swizzled k]
-  __shared__ __attribute__((aligned(16))) unsigned short Bsh[2][2][BN * BKP];
+  __shared__ __attribute__((aligned(16))) unsigned short Ash[2][P][BM * BKP];   // [stage][plane][row*32 + swizzled k]
+  __shared__ __attribute__((aligned(16))) unsigned short Bsh[2][P][BN * BKP];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave8 < 4;               // waves 0-3 stage the tiles, waves 4-7 run the MFMAs (wave-uniform roles)
+  const int wave = wave8 & 3;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM;
   const int j0 = blockIdx.y * BN;
@@ -1210,9 +1224,11 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16x3(WgradArgs a) {
 
   // Per staged B row (ci, tap): element offset relative to the pixel's (iy0, ix0) corner and the tap's bit in the
   // per-pixel validity mask (computed once per K tile and lane for all KS*KS taps).
-  int b_off[RB];
-  typedef unsigned long long mask_t;       // one bit per filter tap (49 taps for the 7x7 stem)
-  mask_t b_bit[RB];
+  int b_off[RB];                               // byte offset of the row's (ci, tap) relative to the pixel's corner
+  typedef typename std::conditional<(KHW <= 25), unsigned, unsigned long long>::type mask_t;   // one bit per filter tap
+  constexpr bool SMALL_MASK = KHW <= 25;       // 32-bit tap mask: bit 31 is never set and doubles as "row out of range"
+  int b_sh[RB];                                // SMALL_MASK: 31 - tap, so that (vmask << b_sh) has the tap's bit as its sign
+  mask_t b_bit[SMALL_MASK ? 1 : RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
     int row = wave * (BN / 4) + 2 * r + rsub;
@@ -1222,8 +1238,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16x3(WgradArgs a) {
     int ci = jc / KHW;
     int t = jc - ci * KHW;
     int ky = t / KS;
-    b_off[r] = (a.in_coff + ci) * HWi + ky * a.dil * a.win + (t - ky * KS) * a.dil;
-    b_bit[r] = ok ? (mask_t)1 << t : (mask_t)0;
+    b_off[r] = ((a.in_coff + ci) * HWi + ky * a.dil * a.win + (t - ky * KS) * a.dil) * 4;
+    b_sh[r] = ok ? 31 - t : 0;
+    if (!SMALL_MASK) b_bit[r] = ok ? (mask_t)1 << t : (mask_t)0;
   }
   // 32-bit buffer addressing (host guarantees < 2 GiB tensors): masked elements read 0 through an out-of-range offset
   constexpr unsigned OOB = 0x80000000u;
@@ -1231,10 +1248,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16x3(WgradArgs a) {
   const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (unsigned)((long)a.n * a.out_ctot * HWo * 4), 0x00020000);
   const bool m_interior = m0 + BM <= a.cout;   // uniform
 
-  float ra[RA], rb[RB];
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, float (&ra)[RA], float (&rb)[RB]) {
     int p = pbeg + kt * BKP + pl;
-    bool pv = p < pend;
+    bool pv = p < pend;                        // false for every lane of a tile past the end: all offsets out of range
     int pc = pv ? p : 0;
     int n = pc / HWo;
     int hw = pc - n * HWo;
@@ -1252,37 +1268,71 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16x3(WgradArgs a) {
         vmask |= in ? (mask_t)1 << (ky * KS + kx) : (mask_t)0;
       }
     vmask = pv ? vmask : (mask_t)0;
+    // Branch-free offset selects (a ?: makes hipcc split a load into divergent paths that it then drains with vmcnt(0)).
+    // A rows: row r of this lane is 2r rows further down -> the same vector offset plus a SCALAR offset r * 2*HWo*4.
+    const unsigned pvm = 0u - (unsigned)pv;
+    const unsigned a_v = (unsigned)(dybase + (m0 + wave * (BM / 4) + rsub) * HWo) * 4u;
+    const int a2 = 2 * HWo * 4;
+    if (m_interior) {                          // uniform
+      const unsigned voff = (a_v & pvm) | (OOB & ~pvm);
 #pragma unroll
-    for (int r = 0; r < RA; ++r) {
-      int co = m0 + wave * (BM / 4) + 2 * r + rsub;
-      const unsigned off = (pv && (m_interior || co < a.cout)) ? (unsigned)(dybase + co * HWo) * 4u : OOB;
-      ra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, off, 0, 0));
+      for (int r = 0; r < RA; ++r) ra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, voff, r * a2, 0));
+    } else {
+#pragma unroll
+      for (int r = 0; r < RA; ++r) {
+        const int co = m0 + wave * (BM / 4) + 2 * r + rsub;
+        const unsigned m = pvm & (0u - (unsigned)(co < a.cout));
+        ra[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, ((a_v + r * a2) & m) | (OOB & ~m), 0, 0));
+      }
     }
+    const unsigned x4 = (unsigned)xbase * 4u;
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      const unsigned off = (vmask & b_bit[r]) ? (unsigned)(xbase + b_off[r]) * 4u : OOB;
-      rb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+      unsigned m;
+      if (SMALL_MASK) m = (unsigned)((int)((unsigned)vmask << b_sh[r]) >> 31);
+      else m = 0u - (unsigned)((vmask & b_bit[SMALL_MASK ? 0 : r]) != 0);
+      rb[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ((x4 + (unsigned)b_off[r]) & m) | (OOB & ~m), 0, 0));
     }
   };
   // element (row, k = pl) -> bf16 index row*32 + ((k>>3) ^ ((row>>2)&3))*8 + (k&7). Neighbouring lanes hold neighbouring
-  // k of the same row: even lanes fetch the odd neighbour's hi half (DPP row_shl:1) and store the hi pair, odd lanes fetch
-  // the even neighbour's lo half (row_shr:1) and store the lo pair — one ds_write_b32 per element instead of two b16.
+  // k of the same row, and a lane stores whole bf16 PAIRS: it pulls the neighbour's fp32 value through DPP and converts both
+  // with one v_cvt_pk_bf16_f32 — even lanes (k, k+1) of the hi plane, odd lanes (k-1, k) of the lo plane (of the residuals),
+  // one ds_write_b32 per element; for P = 3 the even lanes also store the mid pair. Rows of one lane are 2r apart, so
+  // (row >> 2) & 3 == (r >> 1) & 3 is known at compile time: four per-lane base indices, everything else is immediate.
   const bool odd = pl & 1;
-  auto store_pair = [&](unsigned short* base_hi, unsigned short* base_lo, int row, float v) {
-    const __bf16 hb = (__bf16)v;
-    const unsigned hi = __builtin_bit_cast(unsigned short, hb);
-    const unsigned lo = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hb));
-    const unsigned nb_hi = __builtin_amdgcn_update_dpp(0u, hi, 0x101, 0xf, 0xf, true);   // lane+1
-    const unsigned nb_lo = __builtin_amdgcn_update_dpp(0u, lo, 0x111, 0xf, 0xf, true);   // lane-1
-    const unsigned word = odd ? (nb_lo | (lo << 16)) : (hi | (nb_hi << 16));
-    const int idx = row * BKP + (((pl >> 3) ^ ((row >> 2) & 3)) << 3) + (pl & 6);
-    *reinterpret_cast<unsigned*>((odd ? base_lo : base_hi) + idx) = word;
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
+  auto pk = [](float lo, float hi) { f32x2v f = {lo, hi}; return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2)); };
+  auto next_of = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, v), 0x101, 0xf, 0xf, true)); };
+  auto prev_of = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, __builtin_bit_cast(unsigned, v), 0x111, 0xf, 0xf, true)); };
+  auto store_rows = [&](unsigned short* base, auto rows_c, const auto& vals) {
+    constexpr int ROWS = decltype(rows_c)::value;
+    constexpr int NV = sizeof(vals) / sizeof(float);     // compile-time trip count: the values stay in registers
+    int lane_idx[4];
+#pragma unroll
+    for (int sw = 0; sw < 4; ++sw)
+      lane_idx[sw] = (odd ? (P - 1) * ROWS * BKP : 0) + (wave * (ROWS / 4) + rsub) * BKP + (((pl >> 3) ^ sw) << 3) + (pl & 6);
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      const float v = vals[r];
+      const unsigned hi2 = pk(v, next_of(v));                                  // low half: bf16(v) of this lane
+      const float r1 = v - __builtin_bit_cast(float, hi2 << 16);
+      const int idx = lane_idx[(r >> 1) & 3] + 2 * r * BKP;
+      if (P == 2) {
+        const unsigned lo2 = pk(prev_of(r1), r1);
+        *reinterpret_cast<unsigned*>(base + idx) = odd ? lo2 : hi2;
+      } else {
+        const unsigned mid2 = pk(r1, next_of(r1));
+        const float r2 = r1 - __builtin_bit_cast(float, mid2 << 16);
+        const unsigned lo2 = pk(prev_of(r2), r2);
+        *reinterpret_cast<unsigned*>(base + idx) = odd ? lo2 : hi2;
+        if (!odd) *reinterpret_cast<unsigned*>(base + idx + ROWS * BKP) = mid2;
+      }
+    }
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < RA; ++r) store_pair(Ash[buf][0], Ash[buf][1], wave * (BM / 4) + 2 * r + rsub, ra[r]);
-#pragma unroll
-    for (int r = 0; r < RB; ++r) store_pair(Bsh[buf][0], Bsh[buf][1], wave * (BN / 4) + 2 * r + rsub, rb[r]);
+  auto store_tile = [&](int buf, const float (&ra)[RA], const float (&rb)[RB]) {
+    store_rows(&Ash[buf][0][0], std::integral_constant<int, BM>{}, ra);
+    store_rows(&Bsh[buf][0][0], std::integral_constant<int, BN>{}, rb);
   };
 
   f32x16 acc[TM][TN];
@@ -1293,42 +1343,65 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_bf16x3(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (pend - pbeg + BKP - 1) / BKP;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
   const int lr = lane & 31, lh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int kg = 2 * s2 + lh;
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      bf16x8 af[TM][P], bfr[TN][P];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wm * WTM + i * 32 + lr;
         const int o = row * BKP + ((kg ^ ((row >> 2) & 3)) << 3);
-        ah[i] = *reinterpret_cast<const bf16x8*>(&Ash[buf][0][o]);
-        al[i] = *reinterpret_cast<const bf16x8*>(&Ash[buf][1][o]);
+#pragma unroll
+        for (int q = 0; q < P; ++q) af[i][q] = *reinterpret_cast<const bf16x8*>(&Ash[buf][q][o]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * WTN + j * 32 + lr;
         const int o = row * BKP + ((kg ^ ((row >> 2) & 3)) << 3);
-        bh[j] = *reinterpret_cast<const bf16x8*>(&Bsh[buf][0][o]);
-        bl[j] = *reinterpret_cast<const bf16x8*>(&Bsh[buf][1][o]);
+#pragma unroll
+        for (int q = 0; q < P; ++q) bfr[j][q] = *reinterpret_cast<const bf16x8*>(&Bsh[buf][q][o]);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          // smallest products first; planes: 0 = hi, P-1 = lo, (1 = mid for P = 3)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][P - 1], bfr[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][P - 1], acc[i][j], 0, 0, 0);
+          if (P == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+  };
+
+  const int nk = (pend - pbeg + BKP - 1) / BKP;
+  if (loader) {
+    float ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+    load_tile(0, ra0, rb0);
+    load_tile(1, ra1, rb1);
+    store_tile(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {        // tile kt is in LDS stage 0, tile kt+1 in register set 1
+      load_tile(kt + 2, ra0, rb0);
+      store_tile(1, ra1, rb1);
+      __syncthreads();
+      load_tile(kt + 3, ra1, rb1);
+      store_tile(0, ra0, rb0);
+      __syncthreads();
+    }
+    return;
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    compute(0);
+    __syncthreads();
+    if (kt + 1 < nk) compute(1);                // uniform
     __syncthreads();
   }
 
@@ -1352,22 +1425,39 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   const bool small_m = a.cout <= 64;
   const int BMv = small_m ? 64 : 128;
   const int gm = cl4::cdiv(a.cout, BMv), gn = cl4::cdiv(a.Nj, 128);
-  // Split K so that the grid has >= ~4 workgroups per CU, each slice a multiple of BKP.
-  int tiles = cl4::cdiv(a.npix, BKP);
+  // Split K (pixels) so that the grid fills the chip in whole rounds: `slots` workgroups are resident at once (2 per CU for
+  // the 64 KB kernels, 1 per CU for the 96 KB bf16x6 tile); among the split counts near 1024 / (gm*gn) pick the one whose last
+  // round is fullest (fewest splits on ties: every split adds one atomic pass over dW). Each slice is a multiple of BKP.
+  const int tiles = cl4::cdiv(a.npix, BKP);
+  const int slots = (a.precision == 2 && KS > 1 && !small_m) ? 256 : 512;
   int want = cl4::cdiv(1024, gm * gn);
   if (want < 1) want = 1;
   if (want > tiles) want = tiles;
-  int tiles_per = cl4::cdiv(tiles, want);
+  int best_s = want;
+  double best_eff = 0.0;
+  for (int sp = cl4::cdiv(want, 2); sp <= 2 * want + 1 && sp <= tiles; ++sp) {
+    const int per = cl4::cdiv(tiles, sp);
+    const long wgs = (long)gm * gn * cl4::cdiv(tiles, per);
+    const long rounds = (wgs + slots - 1) / slots;
+    const double eff = (double)((long)gm * gn * tiles) / (double)(rounds * slots * per);     // useful K-tiles per slot-K-tile
+    if (eff > best_eff + 0.02) { best_eff = eff; best_s = sp; }
+  }
+  const int tiles_per = cl4::cdiv(tiles, best_s);
   a.chunk = tiles_per * BKP;
-  int gz = cl4::cdiv(a.npix, a.chunk);
+  const int gz = cl4::cdiv(a.npix, a.chunk);
   dim3 g(gm, gn, gz);
   // bf16x3 MFMA path: 32-bit buffer offsets, so both tensors must stay below 2 GiB (always true on the phase-2 path)
   const long lim = (1L << 31) - 4096;
-  const bool split3 = a.precision == 1 && (long)a.n * a.in_ctot * a.hin * a.win * 4 < lim && (long)a.n * a.out_ctot * a.hout * a.wout * 4 < lim;
-  if (split3 && small_m)
-    hipLaunchKernelGGL((conv_wgrad_bf16x3<64, 128, KS>), g, dim3(NTHREADS), 0, st, a);
+  // bf16x6 (precision 2) pays off for k >= 3 (114 vs 88 TFLOP/s on the ASPP 3x3); for 1x1 the exact fp32 kernel is as fast
+  const bool split3 = (a.precision == 1 || (a.precision == 2 && KS > 1)) && (long)a.n * a.in_ctot * a.hin * a.win * 4 < lim && (long)a.n * a.out_ctot * a.hout * a.wout * 4 < lim;
+  if (split3 && a.precision == 2 && small_m)
+    hipLaunchKernelGGL((conv_wgrad_bf16<64, 128, KS, 3>), g, dim3(2 * NTHREADS), 0, st, a);
+  else if (split3 && a.precision == 2)
+    hipLaunchKernelGGL((conv_wgrad_bf16<128, 128, KS, 3>), g, dim3(2 * NTHREADS), 0, st, a);
+  else if (split3 && small_m)
+    hipLaunchKernelGGL((conv_wgrad_bf16<64, 128, KS, 2>), g, dim3(2 * NTHREADS), 0, st, a);
   else if (split3)
-    hipLaunchKernelGGL((conv_wgrad_bf16x3<128, 128, KS>), g, dim3(NTHREADS), 0, st, a);
+    hipLaunchKernelGGL((conv_wgrad_bf16<128, 128, KS, 2>), g, dim3(2 * NTHREADS), 0, st, a);
   else if (small_m)
     hipLaunchKernelGGL((conv_wgrad_f32<64, 128, KS>), g, dim3(NTHREADS), 0, st, a);
   else
@@ -1478,7 +1568,7 @@ extern "C" int cl4_conv2d_wgrad(const cl4_conv_desc* d, const float* x, const fl
   a.n = d->n; a.cin = d->cin; a.hin = d->hin; a.win = d->win; a.cout = d->cout;
   a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.hout = d->hout; a.wout = d->wout;
   a.in_ctot = d->in_ctot; a.in_coff = d->in_coff; a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
-  CL4_REQUIRE(d->precision == 0 || d->precision == 1, "conv2d_wgrad: precision %d unknown (0 fp32, 1 bf16x3)", d->precision);
+  CL4_REQUIRE(d->precision >= 0 && d->precision <= 2, "conv2d_wgrad: precision %d unknown (0 fp32, 1 bf16x3, 2 bf16x6)", d->precision);
   a.precision = d->precision;
   a.Nj = d->cin * d->kh * d->kw;
   a.npix = d->n * d->hout * d->wout;

@@ -142,8 +142,6 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=3):
             continue
         if impl == 1 and d.precision != 0:
             continue
-        if d.precision == 2 and tile != 64:        # bf16x6 is built for 64x64 tiles only
-            continue
         if impl == 2 and (tile == 128 and d.cout < 128 or splits > max(1, K // 64)):
             continue
         call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, tile, splits)

@@ -139,7 +139,8 @@ def test_conv_channel_slices(gpu):
     (2, 32, 33, 33, 48, 3, 2, 1, 1),       # strided 3x3
     (1, 24, 33, 33, 40, 3, 1, 12, 12),     # ASPP dilation
 ])
-def test_conv_wgrad(gpu, case):
+@pytest.mark.parametrize("precision", [0, 1, 2])
+def test_conv_wgrad(gpu, case, precision):
     from cl4wsis_amd import ops
     n, cin, h, w, cout, k, s, p, d = case
     g = torch.Generator().manual_seed(11)
@@ -150,9 +151,25 @@ def test_conv_wgrad(gpu, case):
     y.backward(dy)
     ref = wt.grad.float()
     dw = torch.zeros(cout, cin, k, k, device=gpu)
-    ops.conv2d_wgrad(x.float().to(gpu), dy.float().to(gpu), dw, k, stride=s, pad=p, dil=d)
+    ops.conv2d_wgrad(x.float().to(gpu), dy.float().to(gpu), dw, k, stride=s, pad=p, dil=d, precision=precision)
     torch.cuda.synchronize()
-    assert _rel_err(dw.cpu(), ref) < 1e-5
+    assert _rel_err(dw.cpu(), ref) < {0: 2e-6, 1: 1e-5, 2: 2e-6}[precision]
+
+
+def test_conv_wgrad_many_k_tiles_and_accumulate(gpu):
+    """Pixel counts that are not a multiple of the K tile pair (odd number of tiles, ragged last tile) through the two-set
+    register pipeline of the bf16 kernels, and accumulation into a non-zero dw."""
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for n, h, w in ((1, 5, 7), (1, 8, 8), (3, 9, 11), (5, 33, 33)):
+        x = torch.randn(n, 72, h, w, generator=g, dtype=torch.float64)
+        wt = torch.zeros(136, 72, 3, 3, dtype=torch.float64, requires_grad=True)
+        dy = torch.randn(n, 136, h, w, generator=g, dtype=torch.float64)
+        F.conv2d(x, wt, padding=1).backward(dy)
+        for precision in (1, 2):
+            dw = torch.ones(136, 72, 3, 3, device=gpu)
+            ops.conv2d_wgrad(x.float().to(gpu), dy.float().to(gpu), dw, 3, pad=1, precision=precision)
+            assert _rel_err(dw.cpu() - 1, wt.grad.float()) < 2e-5, (n, h, w, precision)
 
 
 def test_bad_arguments_raise(gpu):
