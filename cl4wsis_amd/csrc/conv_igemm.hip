@@ -483,15 +483,22 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // P = 2: "bf16x3" (x = hi + lo, three products). P = 3: "bf16x6" (x = hi + mid + lo, 24 mantissa bits; the six products
 // hh, hm, mh, hl, lh, mm keep every term down to 2^-24: fp32-level accuracy at 2/16 of the fp32 MFMA cycles). P = 3 is
 // built for 64x64 tiles only (48 KB of LDS for the two stages).
-template <int BM, int BN, int KS, bool SPLIT, bool TAP, int P = 2>
-__global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, const float* __restrict__ zero_page) {
+// LW / NS: loader waves and register sets per loader wave. 4 / 2 is the shape of all bf16x3 launches and of the 64x64 bf16x6
+// tile (two workgroups per CU keep enough bytes in flight). The 128x128 bf16x6 tile owns a whole CU (96 KB LDS); alone,
+// 4 loader waves x 2 sets keep only 80 KB in flight (latency-bound at ~150 TFLOP/s, r01i probe), and a wave cannot have more
+// than 63 vector-memory instructions outstanding — so that tile runs 8 loader waves x 4 sets (768 threads, 11 loads per
+// lane and K-tile, 160 KB in flight).
+template <int BM, int BN, int KS, bool SPLIT, bool TAP, int P = 2, int LW = 4, int NS = 2>
+__global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf16x3(ConvArgs a, const float* __restrict__ zero_page) {
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KHW = KS * KS;
   constexpr int KG = BK2 / 8;               // 4 k-groups of 8 per K-tile
-  constexpr int NITEM = BN / 64;            // (pixel, k-group) items per loader lane
+  constexpr int NITEM = BN * KG / (LW * 64);   // (pixel, k-group) items per loader lane
+  static_assert(NITEM == 1 || NITEM == 2, "loader mapping");
+  static_assert(NS % 2 == 0, "the LDS stage of a register set must be static");
   static_assert(P == 2 || P == 3, "two (bf16x3) or three (bf16x6) planes");   // 128x128x3 planes = 96 KB LDS: one workgroup per CU
-  constexpr int A_INSTR = KG * P * BM / 64 / 4;   // dwordx4 loads per loader wave and K-tile
+  constexpr int A_INSTR = KG * P * BM / 64 / LW;   // dwordx4 loads per loader wave and K-tile
   constexpr int A_CHUNKS = KG * P * BM;     // 16-byte chunks of the weight tile
   constexpr int B_CHUNKS = KG * P * BN;
 
@@ -501,8 +508,8 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
   const int lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave8 >= 4;
-  const int wave = wave8 & 3;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wave = loader ? wave8 - 4 : wave8;         // index within the role: 0..LW-1 loaders, 0..3 MFMA waves
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
   // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs in dispatch order, so ids that
   // are congruent mod 8 share an L2. Remap so that each XCD walks a CONTIGUOUS range of logical tiles with the M index
   // fastest: the M tiles that re-read one pixel tile (and neighbouring pixel tiles that share halo rows) meet in one L2.
@@ -523,8 +530,8 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
 
   if (loader) {
     // item -> (pixel, k-group): BN=128: pixel = lane + 64*(wave&1), k-groups {2*(wave>>1), +1}; BN=64: pixel = lane, kg = wave
-    const int pseg = NITEM == 2 ? (wave & 1) : 0;
-    const int kg0 = NITEM == 2 ? 2 * (wave >> 1) : wave;
+    const int pseg = BN == 128 ? (wave & 1) : 0;
+    const int kg0 = BN == 128 ? NITEM * (wave >> 1) : wave;
     const int pl = lane + 64 * pseg;
     const int p = n0 + pl;
     const bool pvalid = p < a.npix;
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
     // Two static register sets (tile t lives in set t & 1): the gathers of tile t+3 are issued right after tile t+1 has
     // been converted, i.e. a whole K-tile of MFMA time before they are needed — with a single set the loader was a
     // serial load -> wait(full memory latency) -> convert chain.
-    float xr0[NITEM][8], xr1[NITEM][8];
+    float xr[NS][NITEM][8];
     // Branch-free gather: the per-lane base pointer is fixed, the tap offset is wave-uniform (scalar), and lanes whose
     // tap falls into the padding / past K / past the last pixel read the zero page instead (a pointer select, no
     // branch). Every lane therefore ALWAYS issues exactly 8*NITEM loads per K-tile — the counted vmcnt waits below
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
     constexpr int A_PER_LANE = A_INSTR;
     const unsigned w_bytes = (unsigned)((long)KGtot * P * a.cout * 16);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, w_bytes, 0x00020000);
-    u32x4 ar0[A_PER_LANE], ar1[A_PER_LANE];
+    u32x4 ar[NS][A_PER_LANE];
     auto loadA = [&](u32x4 (&ar)[A_PER_LANE], int kt) {
 #pragma unroll
       for (int i = 0; i < A_PER_LANE; ++i) {
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
       }
     };
     constexpr int TILE_LOADS = 8 * NITEM + A_PER_LANE;   // vector-memory instructions per lane and K-tile
-    constexpr int PF_PER_LANE = (BM * (BN / 32) + 255) / 256;     // residual-prefetch touches per loader lane
+    constexpr int PF_PER_LANE = (BM * (BN / 32) + 64 * LW - 1) / (64 * LW);     // residual-prefetch touches per loader lane
     // One loader half-iteration while the MFMA waves consume tile t: retire the loads of tile t+1 (issued two
     // half-iterations ago; only tile t+2's stay in flight), split / store it into the other LDS stage, refill the register
     // set with tile t+3. The sequence is deliberately free of conditionals: tiles past the end of K are "loaded" through
@@ -660,28 +667,29 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
     // the queue to vmcnt(0) before each conversion — which serialised the loader on one memory round trip per K-tile.
     auto half = [&](float (&cur)[NITEM][8], u32x4 (&acur)[A_PER_LANE], int t) {
       const int nb = (t + 1) & 1;
-      wait_vmcnt<TILE_LOADS>();
+      wait_vmcnt<(NS - 1) * TILE_LOADS>();
 #if !(CL4_DBG & 2)
       cvt_store(cur, nb);
       storeA(acur, nb);
 #endif
 #if !(CL4_DBG & 1)
-      gload(cur, t + 3);
-      loadA(acur, t + 3);
+      gload(cur, t + 1 + NS);
+      loadA(acur, t + 1 + NS);
 #endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
 
-    gload(xr0, 0);
-    loadA(ar0, 0);
-    gload(xr1, 1);
-    loadA(ar1, 1);
-    wait_vmcnt<TILE_LOADS>();
-    cvt_store(xr0, 0);
-    storeA(ar0, 0);
-    gload(xr0, 2);
-    loadA(ar0, 2);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      gload(xr[s_], s_);
+      loadA(ar[s_], s_);
+    }
+    wait_vmcnt<(NS - 1) * TILE_LOADS>();
+    cvt_store(xr[0], 0);
+    storeA(ar[0], 0);
+    gload(xr[0], NS);
+    loadA(ar[0], NS);
     // Pull the residual tile of the fused epilogue towards L2 now: the MFMA waves read it in four dependent batches after
     // the K loop, and with the lines still in HBM each batch paid a full memory round trip (the epilogue of a K = 256
     // layer took as long as its K loop). One dword per 32-pixel row segment touches every line of the tile but the last
@@ -702,9 +710,9 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nk; t += 2) {       // 1 + 2*ceil(nk/2) barriers; the MFMA waves add one when nk is odd
-      half(xr1, ar1, t);                    // tile t+1 (odd) lives in set 1
-      half(xr0, ar0, t + 1);                // tile t+2 (even) lives in set 0
+    for (int t = 0; t < nk; t += NS) {      // 1 + NS*ceil(nk/NS) barriers; the MFMA waves pad theirs to the same count
+#pragma unroll
+      for (int j_ = 0; j_ < NS; ++j_) half(xr[(j_ + 1) % NS], ar[(j_ + 1) % NS], t + j_);   // tile t+j+1 lives in set (j+1) % NS
     }
     if (!SPLIT && (a.post || a.pre)) {
       wait_vmcnt<0>();
@@ -765,7 +773,7 @@ __global__ __launch_bounds__(V2_THREADS, 4) void conv_igemm_bf16x3(ConvArgs a, c
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  if (nk & 1) __builtin_amdgcn_s_barrier();   // pairs with the loaders' padded half-iteration
+  for (int e_ = nk % NS; e_ != 0 && e_ < NS; ++e_) __builtin_amdgcn_s_barrier();   // pairs with the loaders' padded half-iterations
 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -1100,8 +1108,8 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
       return CL4_EINVAL;
     }
     if (pl.tile == 128) {
-      if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
-      else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
+      if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true, 3, 8, 4>), g, dim3(768), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false, 3, 8, 4>), g, dim3(768), 0, st, a, z); }
+      else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true, 3, 8, 4>), g, dim3(768), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false, 3, 8, 4>), g, dim3(768), 0, st, a, z); }
     } else {
       if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
       else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
