@@ -46,6 +46,9 @@ struct ConvArgs {
   float neg1, neg2;   // branch-free activations: act(v) = v > 0 ? v : v * neg  (none: 1, relu: 0, leaky: slope)
   float* ws;    // split-K partial slabs [splits][cout][npix] (v2 kernel only)
   int kchunk;   // k range per split (multiple of 32)
+  // bf16 kernels (1-D launches): logical tile = tile_base + (workgroup % ntile_l), M index fastest over gx tiles; the split-K
+  // slabs cover the pixels [ws_p0, ws_p0 + ws_npix) only ("main + split tail" plans split just the last partial round)
+  int gx, ntile_l, tile_base, ws_p0, ws_npix;
 };
 
 
@@ -431,11 +434,11 @@ __global__ __launch_bounds__(V2_THREADS, 2) void conv_igemm_f32_v2(ConvArgs a, c
 
 // Split-K second pass: sum the partial slabs in a fixed order (bitwise reproducible) and apply the fused epilogue.
 __global__ void conv_splitk_epilogue(ConvArgs a, int splits) {
-  const long total = (long)a.cout * a.npix;
+  const long total = (long)a.cout * a.ws_npix;
   const int HWo = a.hout * a.wout;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int co = i / a.npix;
-    const int p = i - (long)co * a.npix;
+    const int co = i / a.ws_npix;
+    const int p = a.ws_p0 + (int)(i - (long)co * a.ws_npix);
     float v = 0.f;
     for (int z = 0; z < splits; ++z) v += a.ws[(long)z * total + i];
     const int n = p / HWo;
@@ -513,12 +516,13 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
   // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs in dispatch order, so ids that
   // are congruent mod 8 share an L2. Remap so that each XCD walks a CONTIGUOUS range of logical tiles with the M index
   // fastest: the M tiles that re-read one pixel tile (and neighbouring pixel tiles that share halo rows) meet in one L2.
-  const unsigned gx = gridDim.x, gxy = gridDim.x * gridDim.y, total = gxy * gridDim.z;
-  const unsigned id = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
+  const unsigned total = gridDim.x;            // 1-D launch: ntile_l tiles x splits
+  const unsigned id = blockIdx.x;
   const unsigned q8 = total >> 3, r8 = total & 7, xcd = id & 7;
   const unsigned lid = a.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3) : id;
-  const unsigned bz = lid / gxy, rem2 = lid - bz * gxy;
-  const unsigned by_ = rem2 / gx, bx_ = rem2 - by_ * gx;
+  const unsigned bz = lid / (unsigned)a.ntile_l;
+  const unsigned tile_ = (unsigned)a.tile_base + (lid - bz * (unsigned)a.ntile_l);
+  const unsigned by_ = tile_ / (unsigned)a.gx, bx_ = tile_ - by_ * (unsigned)a.gx;
   const int m0 = bx_ * BM;
   const int n0 = by_ * BN;
   const int HWo = a.hout * a.wout;
@@ -780,13 +784,13 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
     const int p = n0 + wn * WTN + j * 32 + lr;
     if (!SPLIT || p >= a.npix) continue;
     {
-      float* wsp = a.ws + ((long)bz * a.cout) * a.npix + p;
+      float* wsp = a.ws + ((long)bz * a.cout) * a.ws_npix + (p - a.ws_p0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (co < a.cout) wsp[(long)co * a.npix] = acc[i][j][r];
+          if (co < a.cout) wsp[(long)co * a.ws_npix] = acc[i][j][r];
         }
     }
   }
@@ -1026,6 +1030,8 @@ struct FwdPlan {
   int tile;    // 128 or 64 (v2)
   int splits;
   int kchunk;
+  int tail;    // bf16 kernels: > 0 = "main + split tail": whole rounds of tiles run unsplit with the fused epilogue, only the
+               // last partial round is split `tail` ways (kchunk is then the tail's K range); 0 = plain
 };
 
 // Measured plans (cl4_conv2d_fwd_set_plan, filled by the host-side autotuner during warm-up) override the heuristic.
@@ -1039,16 +1045,18 @@ std::map<PlanKey, FwdPlan>& plan_table() { static std::map<PlanKey, FwdPlan> t; 
 std::mutex& plan_mutex() { static std::mutex m; return m; }
 
 FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision = 0) {
-  FwdPlan p{1, 128, 1, 0};
+  FwdPlan p{1, 128, 1, 0, 0};
   if (impl != 2 || cout % 4 != 0 || cout < 64) return p;
   p.impl = 2;
   p.tile = (tile == 128 && cout >= 128) ? 128 : 64;
   const int ktiles = cl4::cdiv(K, BK2);
-  int s = splits < 1 ? 1 : splits;
+  int s = splits < 0 ? -splits : (splits < 1 ? 1 : splits);
   if (s > ktiles) s = ktiles;
   const int per = cl4::cdiv(ktiles, s);
   p.kchunk = per * BK2;
-  p.splits = cl4::cdiv(K, p.kchunk);
+  const int actual = cl4::cdiv(K, p.kchunk);
+  if (splits < 0 && precision != 0 && actual > 1) { p.tail = actual; p.splits = 1; }
+  else p.splits = actual;
   return p;
 }
 
@@ -1065,7 +1073,7 @@ FwdPlan plan_fwd(const PlanKey& key) {
     if (it != plan_table().end()) return it->second;
   }
   const int cout = key.cout, npix = key.npix, K = key.K, precision = key.hin % 4;
-  if (impl != 2 || cout % 4 != 0 || cout < 64) return FwdPlan{1, 128, 1, 0};
+  if (impl != 2 || cout % 4 != 0 || cout < 64) return FwdPlan{1, 128, 1, 0, 0};
   if (force_tile || force_split) return make_plan(2, force_tile ? force_tile : 128, force_split ? force_split : 1, cout, K, precision);
   const int ktiles = cl4::cdiv(K, BK2);
   double best = 1e30;
@@ -1087,66 +1095,84 @@ FwdPlan plan_fwd(const PlanKey& key) {
   return bestp;
 }
 
+// "Main + split tail" geometry of a bf16 plan: the first `main` logical tiles (whole rounds of the resident-workgroup
+// slots, a multiple of the M-tile count so that the tail starts on a pixel-tile boundary) run unsplit; returns main (0 =
+// the plan degenerates to a plain launch) and the first tail pixel.
+struct TailGeom { int gx, ntiles, main, p0; };
+TailGeom tail_geometry(const FwdPlan& pl, int cout, int npix, int precision) {
+  TailGeom g;
+  g.gx = cl4::cdiv(cout, pl.tile);
+  g.ntiles = g.gx * cl4::cdiv(npix, pl.tile);
+  g.main = 0;
+  g.p0 = 0;
+  if (pl.tail > 0) {
+    int slots = (precision == 2 && pl.tile == 128) ? 256 : 512;     // resident workgroups: one / two per CU
+    if (g.ntiles < slots + slots / 16) slots = 256;
+    int m = (g.ntiles / slots) * slots;
+    m -= m % g.gx;
+    if (m > 0 && m < g.ntiles) { g.main = m; g.p0 = (m / g.gx) * pl.tile; }
+  }
+  return g;
+}
+
 template <int KS>
 int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes, int precision) {
   const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 4 + precision});
-  if (precision == 2) {
-    static float* zp6 = nullptr;
-    if (!zp6 && hipGetSymbolAddress((void**)&zp6, HIP_SYMBOL(g_zero_page)) != hipSuccess) return (int)hipGetLastError();
-    a.kchunk = pl.kchunk;
-    a.ws = nullptr;
-    if (pl.splits > 1) {
-      const size_t need = (size_t)pl.splits * a.cout * a.npix * sizeof(float);
-      if (!workspace || workspace_bytes < need) { cl4::set_error("conv2d_fwd: workspace too small for split-K"); return CL4_ENOSPC; }
-      a.ws = (float*)workspace;
-    }
-    const dim3 g(cl4::cdiv(a.cout, pl.tile), cl4::cdiv(a.npix, pl.tile), pl.splits);
-    const float* z = zp6;
-    const bool tapmaj = a.cin % 32 == 0;
-    if (tapmaj && (long)a.n * a.in_ctot * a.hin * a.win * 4 >= 0x7FFFFFFFL) {
-      cl4::set_error("conv2d_fwd(bf16x6): input tensor >= 2 GiB is not addressable by the 32-bit buffer offsets");
-      return CL4_EINVAL;
-    }
-    if (pl.tile == 128) {
-      if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true, 3, 8, 4>), g, dim3(768), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false, 3, 8, 4>), g, dim3(768), 0, st, a, z); }
-      else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true, 3, 8, 4>), g, dim3(768), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false, 3, 8, 4>), g, dim3(768), 0, st, a, z); }
-    } else {
-      if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
-      else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
-    }
-    if (pl.splits > 1) {
-      const long total = (long)a.cout * a.npix;
-      hipLaunchKernelGGL(conv_splitk_epilogue, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, a, pl.splits);
-    }
-    return cl4::launch_status();
-  }
-  if (precision == 1) {
+  if (precision == 1 || precision == 2) {
     static float* zp3 = nullptr;
     if (!zp3 && hipGetSymbolAddress((void**)&zp3, HIP_SYMBOL(g_zero_page)) != hipSuccess) return (int)hipGetLastError();
+    const float* z = zp3;
+    const bool tapmaj = a.cin % 32 == 0;   // must match cl4_pack_conv_weight_bf16x3 / _bf16x6
+    if (tapmaj && (long)a.n * a.in_ctot * a.hin * a.win * 4 >= 0x7FFFFFFFL) {
+      cl4::set_error("conv2d_fwd(bf16 split): input tensor >= 2 GiB is not addressable by the 32-bit buffer offsets");
+      return CL4_EINVAL;
+    }
+    const TailGeom tg = tail_geometry(pl, a.cout, a.npix, precision);
+    const bool hybrid = tg.main > 0;
+    const int nsplit = hybrid ? pl.tail : pl.splits;
+    a.gx = tg.gx;
     a.kchunk = pl.kchunk;
     a.ws = nullptr;
-    if (pl.splits > 1) {
-      const size_t need = (size_t)pl.splits * a.cout * a.npix * sizeof(float);
+    a.ws_p0 = hybrid ? tg.p0 : 0;
+    a.ws_npix = a.npix - a.ws_p0;
+    if (nsplit > 1) {
+      const size_t need = (size_t)nsplit * a.cout * a.ws_npix * sizeof(float);
       if (!workspace || workspace_bytes < need) { cl4::set_error("conv2d_fwd: workspace too small for split-K"); return CL4_ENOSPC; }
       a.ws = (float*)workspace;
     }
-    const dim3 g(cl4::cdiv(a.cout, pl.tile), cl4::cdiv(a.npix, pl.tile), pl.splits);
-    const float* z = zp3;
-    const bool tapmaj = a.cin % 32 == 0;   // must match cl4_pack_conv_weight_bf16x3
-    if (tapmaj && (long)a.n * a.in_ctot * a.hin * a.win * 4 >= 0x7FFFFFFFL) {
-      cl4::set_error("conv2d_fwd(bf16x3): input tensor >= 2 GiB is not addressable by the 32-bit buffer offsets");
-      return CL4_EINVAL;
-    }
-    if (pl.tile == 128) {
-      if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false>), g, dim3(V2_THREADS), 0, st, a, z); }
-      else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false>), g, dim3(V2_THREADS), 0, st, a, z); }
+    // one launch of `ntile` logical tiles starting at `base`, unsplit (fused epilogue) or split `sp` ways (slabs)
+    auto go = [&](int base, int ntile, int sp) {
+      a.tile_base = base;
+      a.ntile_l = ntile;
+      const dim3 g((unsigned)ntile * (unsigned)(sp > 1 ? sp : 1));
+      const bool split = sp > 1;
+      if (precision == 2) {
+        if (pl.tile == 128) {
+          if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true, 3, 8, 4>), g, dim3(768), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false, 3, 8, 4>), g, dim3(768), 0, st, a, z); }
+          else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true, 3, 8, 4>), g, dim3(768), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false, 3, 8, 4>), g, dim3(768), 0, st, a, z); }
+        } else {
+          if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
+          else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
+        }
+      } else {
+        if (pl.tile == 128) {
+          if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false>), g, dim3(V2_THREADS), 0, st, a, z); }
+          else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false>), g, dim3(V2_THREADS), 0, st, a, z); }
+        } else {
+          if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false>), g, dim3(V2_THREADS), 0, st, a, z); }
+          else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false>), g, dim3(V2_THREADS), 0, st, a, z); }
+        }
+      }
+    };
+    if (hybrid) {
+      go(0, tg.main, 1);
+      go(tg.main, tg.ntiles - tg.main, nsplit);
     } else {
-      if (pl.splits > 1) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false>), g, dim3(V2_THREADS), 0, st, a, z); }
-      else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false>), g, dim3(V2_THREADS), 0, st, a, z); }
+      go(0, tg.ntiles, nsplit);
     }
-    if (pl.splits > 1) {
-      const long total = (long)a.cout * a.npix;
-      hipLaunchKernelGGL(conv_splitk_epilogue, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, a, pl.splits);
+    if (nsplit > 1) {
+      const long total = (long)a.cout * a.ws_npix;
+      hipLaunchKernelGGL(conv_splitk_epilogue, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, a, nsplit);
     }
     return cl4::launch_status();
   }
@@ -1514,6 +1540,10 @@ extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
   const int K = d->cin * d->kh * d->kw;
   const int npix = d->n * d->hout * d->wout;
   const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin * 4 + d->precision});
+  if (d->precision != 0 && pl.impl == 2 && pl.tail > 0) {
+    const TailGeom tg = tail_geometry(pl, d->cout, npix, d->precision);
+    return tg.main > 0 ? (size_t)pl.tail * d->cout * (npix - tg.p0) * sizeof(float) : 0;   // degenerate: plain unsplit launch
+  }
   return pl.splits > 1 ? (size_t)pl.splits * d->cout * npix * sizeof(float) : 0;
 }
 
@@ -1555,6 +1585,7 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
   a.K = d->cin * d->kh * d->kw;
   a.npix = d->n * d->hout * d->wout;
   a.ws = nullptr; a.kchunk = 0;
+  a.gx = 1; a.ntile_l = 1; a.tile_base = 0; a.ws_p0 = 0; a.ws_npix = a.npix;
   static const int xcd_default = env_int("CL4_XCD_REMAP", 1);
   a.xcd_remap = xcd_default;
   a.neg1 = d->act1 == CL4_ACT_NONE ? 1.f : (d->act1 == CL4_ACT_RELU ? 0.f : d->slope1);

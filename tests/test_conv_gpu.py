@@ -93,6 +93,30 @@ def test_autotuner_keeps_the_result(gpu, precision):
     assert torch.equal(y0, y2)                      # heuristic plan again: bit-identical to the first call
 
 
+@pytest.mark.parametrize("precision", [1, 2])
+@pytest.mark.parametrize("plan", [(2, 64, -4), (2, 128, -8), (2, 64, -16)])
+def test_conv_fwd_main_plus_split_tail(gpu, plan, precision):
+    """Plans with splits < 0: the whole rounds of tiles run unsplit, the last partial round is split — same convolution
+    (fused epilogue on both parts), on a grid with more tiles than resident-workgroup slots and a ragged last pixel tile."""
+    import ctypes as C
+    from cl4wsis_amd import _hip, ops
+    g = torch.Generator().manual_seed(8)
+    n, cin, h, w, cout, k = 5, 64, 65, 67, 256, 3          # 21775 pixels: 4 x 341 tiles of 64, 2 x 171 tiles of 128
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * 9) ** 0.5
+    post = torch.randn(n, cout, h, w, generator=g)
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x.double(), wt.double(), padding=1).float() * scale[None, :, None, None] + shift[None, :, None, None]) + post
+    xd = x.to(gpu)
+    wp = ops.pack_conv_weight(wt.to(gpu), precision)
+    d = ops._conv_desc(xd, cin, 0, cout, k, 1, 1, 1, cout, 0, ops.ACT_RELU, 0.0, 0, 0.0, wp.precision)
+    _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), *plan)
+    assert _hip.load().cl4_conv2d_fwd_workspace_bytes(C.byref(d)) > 0            # the tail is split on this shape
+    y = ops.conv2d(xd, wp, k, pad=1, scale=scale.to(gpu), shift=shift.to(gpu), post=post.to(gpu), act1=ops.ACT_RELU)
+    torch.cuda.synchronize()
+    assert _rel_err(y.cpu(), ref) < TOL[precision]
+
+
 def test_conv_fwd_fused_epilogue(gpu):
     from cl4wsis_amd import ops
     g = torch.Generator().manual_seed(7)
