@@ -19,7 +19,10 @@ from .nn import CACHE, packed_weight
 # 1 = bf16x3 (~4e-6 relative per layer — still far tighter than the fp16 autocast the reference trains under on GPUs,
 # train.py:252 — fastest, outside the strict gradient bar).
 PRECISION = int(os.environ.get("CL4_TRAIN_PRECISION", "2"))
-WGRAD_PRECISION = PRECISION      # 2: bf16x6 for k >= 3, exact fp32 for 1x1 (cl4_conv2d_wgrad picks the faster of the two)
+# Weight gradients: a dW rounding error stays in that tensor (it does not propagate through BN / ReLU masks like a forward or
+# input-gradient error does), so the 4e-6 of bf16x3 is harmless there and twice as fast as either fp32-level kernel — the same
+# choice phase 2 makes (ops.WGRAD_PRECISION). 0 keeps exact fp32 products with PRECISION == 0.
+WGRAD_PRECISION = 0 if PRECISION == 0 else 1
 
 
 class _Rec:

@@ -4,6 +4,7 @@ classifier, instance decoder and heads all train (Adam), the instance branch bac
 + 200 * Weighted_MSE(centre) + 0.01 * Weighted_L1(offset) against the loader's ground-truth maps."""
 import torch
 
+from . import body_train as BT
 from . import body_train, heads_train, ops
 
 
@@ -36,9 +37,9 @@ class Step0:
         pseudo = {"center": center_maps, "offset": offset_maps, "weight": weights}
         l4, dcen, doff = ops.p2_loss(pred["center"], pred["offset"], None, None, self._zero_w, pseudo, None, (H, W),
                                      center_weight=2 * tr.center_loss_weight, offset_weight=2 * tr.offset_loss_weight)
-        # backward (the whole network trains: exact fp32 weight gradients everywhere, like phase 1)
+        # backward: the instance branch's weight gradients follow the arithmetic of the rest of the network (body_train)
         fg = {}
-        saved, ops.WGRAD_PRECISION = ops.WGRAD_PRECISION, 0
+        saved, ops.WGRAD_PRECISION = ops.WGRAD_PRECISION, BT.WGRAD_PRECISION
         try:
             branch.backward(itape, {"center": dcen, "offset": doff}, grads=tr._grad_map, feature_grads=fg)
         finally:

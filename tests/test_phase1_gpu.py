@@ -26,7 +26,7 @@ def test_phase1_step_matches_oracle(gpu, monkeypatch, cur_epoch, precision):
     from cl4wsis_amd import body_train
     from cl4wsis_amd.train import Trainer
     monkeypatch.setattr(body_train, "PRECISION", precision)
-    monkeypatch.setattr(body_train, "WGRAD_PRECISION", 0)
+    monkeypatch.setattr(body_train, "WGRAD_PRECISION", 0 if precision == 0 else 1)      # the defaults that go with each precision
     from oracle import step as ostep, weights
     crop = 65
     opts = p1_opts(crop)

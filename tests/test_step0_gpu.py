@@ -23,7 +23,7 @@ def test_step0_matches_oracle(gpu, monkeypatch, precision):
     from cl4wsis_amd import body_train, heads
     from cl4wsis_amd.train import Trainer
     monkeypatch.setattr(body_train, "PRECISION", precision)
-    monkeypatch.setattr(body_train, "WGRAD_PRECISION", 0)
+    monkeypatch.setattr(body_train, "WGRAD_PRECISION", 0 if precision == 0 else 1)      # the defaults that go with each precision
     monkeypatch.setattr(heads, "TRAIN_PRECISION", precision)
     from oracle import step as ostep, weights
     crop = 65
