@@ -491,7 +491,11 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // 4 loader waves x 2 sets keep only 80 KB in flight (latency-bound at ~150 TFLOP/s, r01i probe), and a wave cannot have more
 // than 63 vector-memory instructions outstanding — so that tile runs 8 loader waves x 4 sets (768 threads, 11 loads per
 // lane and K-tile, 160 KB in flight).
-template <int BM, int BN, int KS, bool SPLIT, bool TAP, int P = 2, int LW = 4, int NS = 2>
+// PERS (non-split only): a PERSISTENT workgroup walks several output tiles. Its K-tile stream is continuous across tiles —
+// the loaders' register sets already hold the first K-tiles of the next tile while the MFMA waves drain the accumulators of
+// the previous one — so the pipeline is filled once per workgroup instead of once per tile and no workgroup is re-dispatched
+// per tile (short-K 1x1 layers spent more time on those two than in their eight K-tiles, tools/probe_epilogue.py).
+template <int BM, int BN, int KS, bool SPLIT, bool TAP, int P = 2, int LW = 4, int NS = 2, bool PERS = false>
 __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf16x3(ConvArgs a, const float* __restrict__ zero_page) {
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -500,6 +504,7 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
   constexpr int NITEM = BN * KG / (LW * 64);   // (pixel, k-group) items per loader lane
   static_assert(NITEM == 1 || NITEM == 2, "loader mapping");
   static_assert(NS % 2 == 0, "the LDS stage of a register set must be static");
+  static_assert(!(PERS && SPLIT), "persistent tiles are unsplit");
   static_assert(P == 2 || P == 3, "two (bf16x3) or three (bf16x6) planes");   // 128x128x3 planes = 96 KB LDS: one workgroup per CU
   constexpr int A_INSTR = KG * P * BM / 64 / LW;   // dwordx4 loads per loader wave and K-tile
   constexpr int A_CHUNKS = KG * P * BM;     // 16-byte chunks of the weight tile
@@ -520,32 +525,143 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
   const unsigned id = blockIdx.x;
   const unsigned q8 = total >> 3, r8 = total & 7, xcd = id & 7;
   const unsigned lid = a.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3) : id;
-  const unsigned bz = lid / (unsigned)a.ntile_l;
-  const unsigned tile_ = (unsigned)a.tile_base + (lid - bz * (unsigned)a.ntile_l);
-  const unsigned by_ = tile_ / (unsigned)a.gx, bx_ = tile_ - by_ * (unsigned)a.gx;
-  const int m0 = bx_ * BM;
-  const int n0 = by_ * BN;
+  const unsigned bz = PERS ? 0u : lid / (unsigned)a.ntile_l;
+  // PERS: this workgroup is the (id >> 3)-th of the wgx workgroups on its XCD and walks the XCD's contiguous logical range
+  // [t_first - (id >> 3), ...) with stride wgx; otherwise one tile.
+  unsigned t_first = lid - bz * (unsigned)a.ntile_l, t_stride = 1u;
+  int cnt = 1;
+  if (PERS) {
+    const unsigned nt = (unsigned)a.ntile_l;
+    if (a.xcd_remap) {
+      const unsigned tq = nt >> 3, tr = nt & 7;
+      const unsigned x_start = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, x_len = tq + (xcd < tr ? 1u : 0u);
+      const unsigned wgx = q8 + (xcd < r8 ? 1u : 0u), j = id >> 3;
+      t_first = x_start + j;
+      t_stride = wgx;
+      cnt = j < x_len ? (int)((x_len - j + wgx - 1) / wgx) : 0;
+    } else {
+      t_first = id;
+      t_stride = total;
+      cnt = id < nt ? (int)((nt - id + total - 1) / total) : 0;
+    }
+    if (cnt == 0) return;                      // whole workgroup, before any barrier
+  }
+  int m0, n0;
+  auto tile_origin = [&](int ti) {             // logical tile ti of this workgroup -> (m0, n0)
+    const unsigned tile_ = (unsigned)a.tile_base + t_first + (unsigned)ti * t_stride;
+    const unsigned by_ = tile_ / (unsigned)a.gx, bx_ = tile_ - by_ * (unsigned)a.gx;
+    m0 = bx_ * BM;
+    n0 = by_ * BN;
+  };
+  tile_origin(0);
   const int HWo = a.hout * a.wout;
   const int HWi = a.hin * a.win;
   const int kbeg = SPLIT ? bz * a.kchunk : 0;
   const int kend = SPLIT ? min(a.K, kbeg + a.kchunk) : a.K;
   const int nk = (kend - kbeg + BK2 - 1) / BK2;
+  const int TOT = PERS ? cnt * nk : nk;        // K-tiles this workgroup streams
   const int lr = lane & 31, lh = lane >> 5;
+
+  // Wide epilogue (unsplit 8-wave launches): the MFMA waves park their accumulators in LDS (the K-tile stages are free by
+  // then) and ALL eight waves — the loaders have nothing else to do — stream the tile out row by row: lane = pixel, so a wave
+  // instruction covers 256 contiguous bytes of one channel row (the register epilogue wrote two 128-byte runs per instruction),
+  // twice as many waves keep residual loads in flight and each issues a batch of 8 rows before touching the data. The
+  // arithmetic per element is exactly fused_epilogue's.
+  constexpr bool WIDE = !SPLIT && !PERS && LW == 4;
+  auto wide_epilogue = [&]() {
+    const float* stage = reinterpret_cast<const float*>(&lds[0][0]);       // [BM][BN] fp32, <= the two K-tile stages
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int RPW = BM / 8, PPL = BN / 64, RB = 8;
+    long ybase[PPL], rbase[PPL];
+    bool pv[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+      const int p = n0 + lane + 64 * q;
+      pv[q] = p < a.npix;
+      const int pc = pv[q] ? p : 0;
+      const int n = pc / HWo;
+      const int hw = pc - n * HWo;
+      ybase[q] = ((long)n * a.out_ctot + a.out_coff) * HWo + hw;
+      rbase[q] = (long)n * a.cout * HWo + hw;
+    }
+#pragma unroll 1
+    for (int r0 = 0; r0 < RPW; r0 += RB) {
+      const int row0 = wave8 * RPW + r0;
+      float v[RB][PPL], t[RB][PPL];
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) v[rr][q] = stage[(row0 + rr) * BN + lane + 64 * q];
+      if (a.pre) {
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+          for (int q = 0; q < PPL; ++q) t[rr][q] = a.pre[rbase[q] + (long)min(m0 + row0 + rr, a.cout - 1) * HWo];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+          for (int q = 0; q < PPL; ++q) v[rr][q] += t[rr][q];
+      }
+      if (a.post) {                              // issue the residual loads before the arithmetic that does not need them
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+          for (int q = 0; q < PPL; ++q) t[rr][q] = a.post[rbase[q] + (long)min(m0 + row0 + rr, a.cout - 1) * HWo];
+      }
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        const int cc = min(m0 + row0 + rr, a.cout - 1);
+        const float sc = a.scale ? a.scale[cc] : 1.f;
+        const float sh = a.shift ? a.shift[cc] : 0.f;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+          const float u = v[rr][q] * sc + sh;
+          v[rr][q] = u > 0.f ? u : u * a.neg1;
+        }
+      }
+      if (a.post) {
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+          for (int q = 0; q < PPL; ++q) v[rr][q] += t[rr][q];
+      }
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        const int co = m0 + row0 + rr;
+        if (co >= a.cout) continue;                // wave-uniform
+#pragma unroll
+        for (int q = 0; q < PPL; ++q)
+          if (pv[q]) a.y[ybase[q] + (long)co * HWo] = v[rr][q] > 0.f ? v[rr][q] : v[rr][q] * a.neg2;
+      }
+    }
+  };
 
   if (loader) {
     // item -> (pixel, k-group): BN=128: pixel = lane + 64*(wave&1), k-groups {2*(wave>>1), +1}; BN=64: pixel = lane, kg = wave
     const int pseg = BN == 128 ? (wave & 1) : 0;
     const int kg0 = BN == 128 ? NITEM * (wave >> 1) : wave;
     const int pl = lane + 64 * pseg;
-    const int p = n0 + pl;
-    const bool pvalid = p < a.npix;
-    const int pc = pvalid ? p : 0;
-    const int n = pc / HWo;
-    const int hw = pc - n * HWo;
-    const int oy = hw / a.wout;
-    const int ox = hw - oy * a.wout;
-    const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-    const float* xptr = a.x + ((long)n * a.in_ctot + a.in_coff) * HWi + (long)iy0 * a.win + ix0;
+    // per-tile loader state (recomputed when the issue cursor enters a new tile of a persistent workgroup)
+    bool pvalid, tile_ok = true;
+    int iy0, ix0, lane_base;
+    const float* xptr;
+    auto set_tile = [&](int ti) {
+      tile_ok = ti < cnt;                      // past the last tile: every load goes out of range (zeros, no traffic)
+      tile_origin(tile_ok ? ti : 0);
+      const int p = n0 + pl;
+      pvalid = tile_ok && p < a.npix;
+      const int pc = pvalid ? p : 0;
+      const int n = pc / HWo;
+      const int hw = pc - n * HWo;
+      const int oy = hw / a.wout;
+      const int ox = hw - oy * a.wout;
+      iy0 = oy * a.stride - a.pad;
+      ix0 = ox * a.stride - a.pad;
+      xptr = a.x + ((long)n * a.in_ctot + a.in_coff) * HWi + (long)iy0 * a.win + ix0;
+      lane_base = (int)((((long)n * a.in_ctot + a.in_coff) * HWi + (long)iy0 * a.win + ix0) * 4);
+    };
+    set_tile(0);
     const bf16x8* wq = reinterpret_cast<const bf16x8*>(a.wp);   // [K/8][2][cout] chunks of 8 bf16
     const int KGtot = (a.K + 7) / 8;
 
@@ -559,7 +675,6 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
     // rely on that number — and all of them are in flight together.
     const unsigned x_bytes = (unsigned)((long)a.n * a.in_ctot * HWi * 4);   // < 2^31, checked on the host for TAP
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, TAP ? x_bytes : 0u, 0x00020000);
-    const int lane_base = (int)((((long)n * a.in_ctot + a.in_coff) * HWi + (long)iy0 * a.win + ix0) * 4);
     auto gload = [&](float (&xr)[NITEM][8], int kt) {
       if constexpr (TAP) {
         // K order (shared with cl4_pack_conv_weight_bf16x3): k = (cb*KHW + tap)*32 + cil — all KHW taps of a 32-channel
@@ -647,7 +762,7 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
         const int kp = ii / (BM / 64);                   // kg*P + plane
         const int m = m0 + seg * 64 + lane;
         const int kgg = (kbeg + kt * BK2) / 8 + kp / P;
-        const bool kok = kgg < KGtot && (kgg * 8) < kend;             // scalar
+        const bool kok = tile_ok && kgg < KGtot && (kgg * 8) < kend;             // scalar
         const unsigned voff = (kok && m < a.cout) ? (unsigned)m * 16u : 0x80000000u;
         const int soff = __builtin_amdgcn_readfirstlane(kok ? (kgg * P + kp % P) * a.cout * 16 : 0);
         ar[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, soff, 0);
@@ -669,6 +784,39 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
     // out-of-range buffer offsets (no memory traffic, zeros) and stored into the idle LDS stage. With any data-dependent
     // skip in the loop the compiler's own s_waitcnt insertion must assume the shortest path at every join and drains
     // the queue to vmcnt(0) before each conversion — which serialised the loader on one memory round trip per K-tile.
+    // Issue cursor: the next K-tile to load is (ti_i, kt_i). Non-persistent: kt_i simply runs past nk (loads out of range).
+    int ti_i = 0, kt_i = 0;
+    float pf[PF_PER_LANE];
+    auto prefetch_residual = [&]() {
+      // Pull the residual tile of the fused epilogue towards L2: the MFMA waves read it in four dependent batches after the
+      // K loop, and with the lines still in HBM each batch paid a full memory round trip (the epilogue of a K = 256 layer took
+      // as long as its K loop). One dword per 32-pixel row segment touches every line of the tile but the last partial one.
+      // The loads are younger than the sets in flight, so the counted waits only become (harmlessly) stricter; the destination
+      // registers stay live until the loop is over.
+      if (!SPLIT && (a.post || a.pre) && tile_ok) {
+        const float* r = a.post ? a.post : a.pre;
+#pragma unroll
+        for (int i = 0; i < PF_PER_LANE; ++i) {
+          const int item = (wave * 64 + lane) * PF_PER_LANE + i;   // (row, segment)
+          const int co = min(m0 + min(item / (BN / 32), BM - 1), a.cout - 1);
+          const int pp = min(n0 + (item % (BN / 32)) * 32, a.npix - 1);
+          const int pn = pp / HWo;
+          const float* g = r + ((long)pn * a.cout + co) * HWo + (pp - pn * HWo);
+          asm volatile("global_load_dword %0, %1, off" : "=v"(pf[i]) : "v"(g) : "memory");
+        }
+      }
+    };
+    auto issue = [&](float (&cur)[NITEM][8], u32x4 (&acur)[A_PER_LANE]) {
+      if (PERS && kt_i == nk) {                // uniform: the cursor enters the next tile
+        kt_i = 0;
+        ++ti_i;
+        set_tile(ti_i);
+        prefetch_residual();
+      }
+      gload(cur, kt_i);
+      loadA(acur, kt_i);
+      ++kt_i;
+    };
     auto half = [&](float (&cur)[NITEM][8], u32x4 (&acur)[A_PER_LANE], int t) {
       const int nb = (t + 1) & 1;
       wait_vmcnt<(NS - 1) * TILE_LOADS>();
@@ -677,44 +825,24 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
       storeA(acur, nb);
 #endif
 #if !(CL4_DBG & 1)
-      gload(cur, t + 1 + NS);
-      loadA(acur, t + 1 + NS);
+      issue(cur, acur);
+#else
+      ++kt_i;
 #endif
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
 
 #pragma unroll
-    for (int s_ = 0; s_ < NS; ++s_) {
-      gload(xr[s_], s_);
-      loadA(ar[s_], s_);
-    }
+    for (int s_ = 0; s_ < NS; ++s_) issue(xr[s_], ar[s_]);
     wait_vmcnt<(NS - 1) * TILE_LOADS>();
     cvt_store(xr[0], 0);
     storeA(ar[0], 0);
-    gload(xr[0], NS);
-    loadA(ar[0], NS);
-    // Pull the residual tile of the fused epilogue towards L2 now: the MFMA waves read it in four dependent batches after
-    // the K loop, and with the lines still in HBM each batch paid a full memory round trip (the epilogue of a K = 256
-    // layer took as long as its K loop). One dword per 32-pixel row segment touches every line of the tile but the last
-    // partial one. The loads are younger than tile 2's, so the counted waits below only become (harmlessly) stricter; the
-    // destination registers stay live until the loop is over.
-    float pf[PF_PER_LANE];
-    if (!SPLIT && (a.post || a.pre)) {
-      const float* r = a.post ? a.post : a.pre;
-#pragma unroll
-      for (int i = 0; i < PF_PER_LANE; ++i) {
-        const int item = (wave * 64 + lane) * PF_PER_LANE + i;   // (row, segment)
-        const int co = min(m0 + min(item / (BN / 32), BM - 1), a.cout - 1);
-        const int pp = min(n0 + (item % (BN / 32)) * 32, a.npix - 1);
-        const int pn = pp / HWo;
-        const float* g = r + ((long)pn * a.cout + co) * HWo + (pp - pn * HWo);
-        asm volatile("global_load_dword %0, %1, off" : "=v"(pf[i]) : "v"(g) : "memory");
-      }
-    }
+    issue(xr[0], ar[0]);
+    if (ti_i == 0) prefetch_residual();        // first tile (later tiles: when the issue cursor reaches them)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nk; t += NS) {      // 1 + NS*ceil(nk/NS) barriers; the MFMA waves pad theirs to the same count
+    for (int t = 0; t < TOT; t += NS) {     // 1 + NS*ceil(TOT/NS) barriers; the MFMA waves pad theirs to the same count
 #pragma unroll
       for (int j_ = 0; j_ < NS; ++j_) half(xr[(j_ + 1) % NS], ar[(j_ + 1) % NS], t + j_);   // tile t+j+1 lives in set (j+1) % NS
     }
@@ -723,6 +851,7 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
 #pragma unroll
       for (int i = 0; i < PF_PER_LANE; ++i) asm volatile("" ::"v"(pf[i]));
     }
+    if constexpr (WIDE) wide_epilogue();
     return;
   }
 
@@ -736,9 +865,20 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   __builtin_amdgcn_s_barrier();
-  for (int kt = 0; kt < nk; ++kt) {
-    const u32x4* As = lds[kt & 1] + wm * WTM + lr;
-    const u32x4* Bs = lds[kt & 1] + A_CHUNKS + wn * WTN + lr;
+  int gk = 0;                                  // K-tiles consumed so far (its parity is the LDS stage)
+  for (int ti = 0; ti < (PERS ? cnt : 1); ++ti) {
+  if (PERS && ti > 0) {
+    tile_origin(ti);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  for (int kt = 0; kt < nk; ++kt, ++gk) {
+    const u32x4* As = lds[gk & 1] + wm * WTM + lr;
+    const u32x4* Bs = lds[gk & 1] + A_CHUNKS + wn * WTN + lr;
 #pragma unroll
     for (int s2 = 0; s2 < KG / 2; ++s2) {
       const int kg = 2 * s2 + lh;
@@ -777,7 +917,12 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  for (int e_ = nk % NS; e_ != 0 && e_ < NS; ++e_) __builtin_amdgcn_s_barrier();   // pairs with the loaders' padded half-iterations
+  // persistent: drain this tile while the loaders (blocked at their next barrier, their register sets already filled with
+  // the next tile's first K-tiles) wait
+  if (PERS) fused_epilogue<TM, TN>(a, acc, m0 + wm * WTM, n0 + wn * WTN, lr, lh, HWo);
+  }
+  for (int e_ = TOT % NS; e_ != 0 && e_ < NS; ++e_) __builtin_amdgcn_s_barrier();   // pairs with the loaders' padded half-iterations
+  if (PERS) return;
 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -793,6 +938,18 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
           if (co < a.cout) wsp[(long)co * a.ws_npix] = acc[i][j][r];
         }
     }
+  }
+  if constexpr (WIDE) {
+    float* stage = reinterpret_cast<float*>(&lds[0][0]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * WTN + j * 32 + lr] = acc[i][j][r];
+    wide_epilogue();
+    return;
   }
   if (!SPLIT) fused_epilogue<TM, TN>(a, acc, m0 + wm * WTM, n0 + wn * WTN, lr, lh, HWo);
 }
@@ -1129,6 +1286,7 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
     }
     const TailGeom tg = tail_geometry(pl, a.cout, a.npix, precision);
     const bool hybrid = tg.main > 0;
+    static const int persist = env_int("CL4_CONV_PERSIST", 0);   // measured: a loss at 128x128 (epilogue spills), +5 % at 64x64
     const int nsplit = hybrid ? pl.tail : pl.splits;
     a.gx = tg.gx;
     a.kchunk = pl.kchunk;
@@ -1154,6 +1312,11 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
           if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
           else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
         }
+      } else if (!split && persist && ntile > 512) {
+        // persistent workgroups: 512 resident slots (two per CU) walk ntile / 512 tiles each
+        const dim3 gp(512);
+        if (pl.tile == 128) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); }
+        else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); }
       } else {
         if (pl.tile == 128) {
           if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false>), g, dim3(V2_THREADS), 0, st, a, z); }

@@ -117,6 +117,30 @@ def test_conv_fwd_main_plus_split_tail(gpu, plan, precision):
     assert _rel_err(y.cpu(), ref) < TOL[precision]
 
 
+@pytest.mark.parametrize("k,cin", [(1, 64), (3, 32), (1, 40)])
+@pytest.mark.parametrize("tile", [64, 128])
+def test_conv_fwd_persistent_tiles(gpu, tile, k, cin):
+    """More output tiles than resident workgroups: persistent workgroups walk several tiles each (uneven counts: 546 tiles of
+    128x128 on 512 workgroups), K-tile stream continuous across tile boundaries, fused residual epilogue per tile.
+    cin = 40 takes the generic (not tap-major) loader."""
+    import ctypes as C
+    from cl4wsis_amd import _hip, ops
+    g = torch.Generator().manual_seed(12)
+    n, h, w, cout = 8, 65, 67, 256                          # 34840 pixels
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    post = torch.randn(n, cout, h, w, generator=g)
+    shift = torch.randn(cout, generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), padding=k // 2).float() + shift[None, :, None, None] + post, 0.01)
+    xd = x.to(gpu)
+    wp = ops.pack_conv_weight(wt.to(gpu), 1)
+    d = ops._conv_desc(xd, cin, 0, cout, k, 1, k // 2, 1, cout, 0, 0, 0.0, ops.ACT_LEAKY, 0.01, wp.precision)
+    _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 2, tile, 1)
+    y = ops.conv2d(xd, wp, k, pad=k // 2, shift=shift.to(gpu), post=post.to(gpu), act2=ops.ACT_LEAKY, slope2=0.01)
+    torch.cuda.synchronize()
+    assert _rel_err(y.cpu(), ref) < TOL[1]
+
+
 def test_conv_fwd_fused_epilogue(gpu):
     from cl4wsis_amd import ops
     g = torch.Generator().manual_seed(7)
