@@ -567,12 +567,13 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
   // instruction covers 256 contiguous bytes of one channel row (the register epilogue wrote two 128-byte runs per instruction),
   // twice as many waves keep residual loads in flight and each issues a batch of 8 rows before touching the data. The
   // arithmetic per element is exactly fused_epilogue's.
-  constexpr bool WIDE = !SPLIT && !PERS && LW == 4;
+  constexpr bool WIDE = !SPLIT && !PERS;       // LW = 8 (12 waves): waves 0-7 stream, the other loaders only join the barrier
   auto wide_epilogue = [&]() {
     const float* stage = reinterpret_cast<const float*>(&lds[0][0]);       // [BM][BN] fp32, <= the two K-tile stages
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    constexpr int RPW = BM / 8, PPL = BN / 64, RB = 8;
+    if (LW > 4 && wave8 >= 8) return;
+    constexpr int RPW = BM / 8, PPL = BN / 64, RB = 8;   // rows per batch: 16 measured slower (registers), 4 no better
     long ybase[PPL], rbase[PPL];
     bool pv[PPL];
 #pragma unroll
