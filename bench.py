@@ -162,13 +162,13 @@ def main():
         # committed result of the two separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 correction,
         # WRITE_SIZE exact) over the last eager step of this same command (tools/pmc_traffic.py); null when absent.
         traffic, traffic_note = None, "no PMC file"
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01j_pmc_traffic.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01k_pmc_traffic.json")
         if os.path.exists(pmc) and b == GLOBAL_BATCH:
             with open(pmc) as f:
                 t = json.load(f)["conv_igemm_bf16x3"]
             traffic = t["hbm_bytes_per_launch"]
             traffic_note = ("bytes per launch, average over the %d conv_igemm_bf16x3 launches of one step; rocprofv3 --pmc FETCH_SIZE "
-                            "(x2) + WRITE_SIZE in separate passes, profiles/r01j_pmc_traffic.json" % t["launches_per_step"])
+                            "(x2) + WRITE_SIZE in separate passes, profiles/r01k_pmc_traffic.json" % t["launches_per_step"])
         # algorithmic operand bytes of the same launches: input + output activations (fp32) + split weights (4 B / weight);
         # epilogue operands (residual, scale / shift) not counted
         alg_bytes, alg_n = 0.0, 0

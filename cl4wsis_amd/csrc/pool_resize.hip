@@ -161,31 +161,6 @@ __global__ void resize_bwd_kernel(const float* __restrict__ dy, float* __restric
     if (a.sx == 0.f) { ox_lo = 0; ox_hi = a.wout - 1; }
     const float* dyp = dy + ((long)n * a.out_ctot + a.out_coff + c) * a.hout * a.wout;
     float acc = 0.f;
-    constexpr int XC = 12;                      // x candidates kept in registers (2x / 4x upsampling need 6..10)
-    if (ox_hi - ox_lo < XC) {
-      // the x weights do not depend on oy: evaluate the forward's (x0, x1, lx) once per candidate column, then every row
-      // costs one (y0, y1, ly) and a short dot product (the plain double loop below re-derived them for every (oy, ox))
-      float wxs[XC];
-#pragma unroll
-      for (int j = 0; j < XC; ++j) {
-        const int ox = ox_lo + j;
-        int x0, x1; float lx;
-        src_index(min(ox, a.wout - 1), a.sx, a.align, a.win, x0, x1, lx);
-        const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
-        wxs[j] = ox <= ox_hi ? wx : 0.f;
-      }
-      for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-        int y0, y1; float ly;
-        src_index(oy, a.sy, a.align, a.hin, y0, y1, ly);
-        const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
-        if (wy == 0.f) continue;
-        const float* row = dyp + oy * a.wout + ox_lo;
-        // same summation order as the double loop: ox ascending, zero-weight candidates skipped
-#pragma unroll
-        for (int j = 0; j < XC; ++j)
-          if (wxs[j] != 0.f) acc += wy * wxs[j] * row[j];
-      }
-    } else
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
       int y0, y1; float ly;
       src_index(oy, a.sy, a.align, a.hin, y0, y1, ly);

@@ -1,9 +1,9 @@
 set -e
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r01j
-timeout -k 10 500 python bench.py --steps 20 --warmup 5 > gpurun_out/r01j/bench.json 2> gpurun_out/r01j/bench.err
-tail -c 600 gpurun_out/r01j/bench.json
+mkdir -p gpurun_out/r01k
+timeout -k 10 500 python bench.py --steps 20 --warmup 5 > gpurun_out/r01k/bench.json 2> gpurun_out/r01k/bench.err
+tail -c 600 gpurun_out/r01k/bench.json
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01j/prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r01j/prof_bench.json 2> $R/gpurun_out/r01j/prof.err
-ls -R $R/gpurun_out/r01j/prof | head -20
+cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01k/prof -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r01k/prof_bench.json 2> $R/gpurun_out/r01k/prof.err
+ls -R $R/gpurun_out/r01k/prof | head -20
