@@ -433,26 +433,35 @@ __global__ __launch_bounds__(V2_THREADS, 2) void conv_igemm_f32_v2(ConvArgs a, c
 }
 
 // Split-K second pass: sum the partial slabs in a fixed order (bitwise reproducible) and apply the fused epilogue.
+// Split-K reduction + fused epilogue over the slab region: grid = (pixel chunks of 256, cout) — one channel row segment per
+// workgroup, lane = pixel (coalesced slab reads, residual reads and output writes), one division per thread; the slabs are
+// summed in a fixed order (z = 0 .. splits-1) so the result does not depend on scheduling.
 __global__ void conv_splitk_epilogue(ConvArgs a, int splits) {
+  const int co = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.ws_npix) return;
   const long total = (long)a.cout * a.ws_npix;
-  const int HWo = a.hout * a.wout;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int co = i / a.ws_npix;
-    const int p = a.ws_p0 + (int)(i - (long)co * a.ws_npix);
-    float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += a.ws[(long)z * total + i];
-    const int n = p / HWo;
-    const int hw = p - n * HWo;
-    const long r = ((long)n * a.cout + co) * HWo + hw;
-    if (a.pre) v += a.pre[r];
-    const float sc = a.scale ? a.scale[co] : 1.f;
-    const float sh = a.shift ? a.shift[co] : 0.f;
-    v = v * sc + sh;
-    v = v > 0.f ? v : v * a.neg1;
-    if (a.post) v += a.post[r];
-    v = v > 0.f ? v : v * a.neg2;
-    a.y[((long)n * a.out_ctot + a.out_coff + co) * HWo + hw] = v;
+  const float* w = a.ws + (long)co * a.ws_npix + i;
+  float v = 0.f;
+  int z = 0;
+  for (; z + 4 <= splits; z += 4) {              // four independent loads in flight, same summation order
+    const float t0 = w[(long)z * total], t1 = w[(long)(z + 1) * total], t2 = w[(long)(z + 2) * total], t3 = w[(long)(z + 3) * total];
+    v += t0; v += t1; v += t2; v += t3;
   }
+  for (; z < splits; ++z) v += w[(long)z * total];
+  const int HWo = a.hout * a.wout;
+  const int p = a.ws_p0 + i;
+  const int n = p / HWo;
+  const int hw = p - n * HWo;
+  const long r = ((long)n * a.cout + co) * HWo + hw;
+  if (a.pre) v += a.pre[r];
+  const float sc = a.scale ? a.scale[co] : 1.f;
+  const float sh = a.shift ? a.shift[co] : 0.f;
+  v = v * sc + sh;
+  v = v > 0.f ? v : v * a.neg1;
+  if (a.post) v += a.post[r];
+  v = v > 0.f ? v : v * a.neg2;
+  a.y[((long)n * a.out_ctot + a.out_coff + co) * HWo + hw] = v;
 }
 
 
@@ -1336,7 +1345,7 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
     }
     if (nsplit > 1) {
       const long total = (long)a.cout * a.ws_npix;
-      hipLaunchKernelGGL(conv_splitk_epilogue, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, a, nsplit);
+      hipLaunchKernelGGL(conv_splitk_epilogue, dim3(cl4::cdiv(a.ws_npix, 256), a.cout), dim3(256), 0, st, a, nsplit);
     }
     return cl4::launch_status();
   }
@@ -1361,7 +1370,7 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
     }
     if (pl.splits > 1) {
       const long total = (long)a.cout * a.npix;
-      hipLaunchKernelGGL(conv_splitk_epilogue, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, a, pl.splits);
+      hipLaunchKernelGGL(conv_splitk_epilogue, dim3(cl4::cdiv(a.ws_npix, 256), a.cout), dim3(256), 0, st, a, pl.splits);
     }
     return cl4::launch_status();
   }
