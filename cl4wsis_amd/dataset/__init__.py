@@ -7,6 +7,7 @@ from . import transform
 from .dataset import IncrementalInstanceSegmentationDataset, LabelSelection, RawSample  # noqa: F401
 from .loader import DeviceLoader  # noqa: F401
 from .transform import *  # noqa: F401,F403
+from .coco import COCO, COCOIncremental  # noqa: F401
 from .voc import VOCasCOCOSegmentationIncremental, VOCInstanceSegmentation, VOCInstanceSegmentationIncremental  # noqa: F401
 
 MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
@@ -32,11 +33,14 @@ def get_dataset(opts):
     labels_cum = labels_old + labels
     if opts.dataset == "voc":
         t_dataset = dataset = VOCInstanceSegmentationIncremental
-    elif opts.dataset == "coco-voc" and opts.step > 0:
-        dataset = VOCasCOCOSegmentationIncremental
-        t_dataset = None                                  # COCO 2017 sources (dataset/coco.py) are outside the VOC hot path
+    elif opts.dataset == "coco-voc":
+        if opts.step == 0:
+            t_dataset = dataset = COCOIncremental
+        else:
+            dataset = VOCasCOCOSegmentationIncremental
+            t_dataset = COCOIncremental
     else:
-        raise NotImplementedError(f"dataset {opts.dataset!r} step {opts.step}: only the Pascal-VOC sources are built (DESIGN.md §8f)")
+        raise NotImplementedError
     if opts.overlap and opts.dataset == "voc":
         path_base += "-ov"
     os.makedirs(path_base, exist_ok=True)
@@ -49,10 +53,8 @@ def get_dataset(opts):
                       idxs_path=path_base + f"/val-{opts.step}.npy", masking_value=0, masking=False, overlap=opts.overlap,
                       step=opts.step, weakly=opts.weakly, ann_file=ann + "/pascal_sbd_val.json")
     image_set = "train" if opts.val_on_trainset else "val"
-    test_dst = None
-    if t_dataset is not None:
-        test_dst = t_dataset(root=opts.data_root, step_dict=step_dict, train=False, val_on_trainset=opts.val_on_trainset,
-                             transform=test_transform, masking=False, masking_value=255, weakly=opts.weakly,
-                             idxs_path=path_base + f"/test_on_{image_set}-{opts.step}.npy", step=opts.step,
-                             ann_file=ann + f"/pascal_sbd_{image_set}.json")
+    test_dst = t_dataset(root=opts.data_root, step_dict=step_dict, train=False, val_on_trainset=opts.val_on_trainset,
+                         transform=test_transform, masking=False, masking_value=255, weakly=opts.weakly,
+                         idxs_path=path_base + f"/test_on_{image_set}-{opts.step}.npy", step=opts.step,
+                         ann_file=ann + f"/pascal_sbd_{image_set}.json")
     return train_dst, val_dst, test_dst, labels_cum, len(labels_cum)

@@ -82,3 +82,39 @@ def test_disjoint_protocol_rejects_future_classes(tmp_path):
     assert not check_if_insert(a + [{"category_id": 19}], False, [1, 2, 3, 16, 17], [16, 17])
     assert not check_if_insert([{"category_id": 3}], True, list(range(1, 21)), [16, 17])
     assert check_if_insert([{"category_id": 3}], True, list(range(1, 21)), [16, 17], is_train=False)
+
+
+def test_coco_source_and_coco_voc_step0(tmp_path):
+    """coco-voc step 0 (COCOIncremental over dataset/coco.py's COCO): split files, polygon + RLE masks, the 91-way image-level
+    labels reduced to the protocol's class order, instances of classes outside the step gated away by the label map."""
+    import os
+    from cl4wsis_amd.dataset import get_dataset
+    from cl4wsis_amd import tasks
+    from util import make_mini_coco
+    truth = make_mini_coco(tmp_path)
+    p = argparser.get_argparser()
+    o = argparser.modify_command_options(p.parse_args(["--dataset", "coco-voc", "--task", "voc", "--step", "0", "--data_root", str(tmp_path),
+                                                       "--crop_size", "65", "--crop_size_val", "70"]))
+    base = os.path.join(str(tmp_path), "coco-voc", "voc")
+    os.makedirs(base, exist_ok=True)
+    np.save(os.path.join(base, "train-0.npy"), np.arange(5))            # the protocol's image subset (here: everything)
+    train, val, test, labels_cum, n = get_dataset(o)
+    td = tasks.get_task_dict("coco-voc", "voc", 0)
+    assert n == len(td[0]) == 61 and len(train) == 5 and len(val) == 2 and len(test) == 2
+    random.seed(0)
+    raw = train[0]
+    H, W, boxes = truth["train"][0]
+    assert raw.image.shape == (H, W, 3) and raw.label.shape == (H, W, 2) and raw.l1h.shape == (60,)
+    for j, (cat, x0, y0, w, h) in enumerate(boxes):
+        assert (raw.label[y0:y0 + h, x0:x0 + w, 0] == cat).all() and (raw.label[y0:y0 + h, x0:x0 + w, 1] == j + 1).all()
+    assert (raw.label[:, :, 0] > 0).sum() == sum(w * h for (_, _, _, w, h) in boxes)
+    # image-level labels: position of each present class in the protocol order (background dropped), classes of later steps masked
+    order = [c for s in sorted(td) for c in td[s]]
+    for cat in (8, 10, 11):
+        assert raw.l1h[order.index(cat) - 1] == 1
+    assert raw.l1h.sum() == 3
+    # second photo holds a VOC class (id 1, a later step): its pixels map to 0 through the LabelTransform LUT
+    raw1 = train[1]
+    assert train.lut[1] == 0 and train.lut[8] == order.index(8)
+    v = val[0]
+    assert v.masks.shape[0] == len(v.mask_label) == len(truth["val"][0][2]) and v.path.endswith(".jpg")

@@ -88,3 +88,50 @@ def make_mini_voc(root, n_train=6, n_val=3, seed=0):
             json.dump({"images": images, "annotations": anns, "categories": [{"id": i} for i in range(1, 21)]}, f)
         out[split] = samples
     return out
+
+
+def make_mini_coco(root, n_train=5, n_val=2, seed=3):
+    """A tiny COCO-2017-shaped tree under `root`/coco (split/*.txt, annotations/instances_*2017.json with polygon AND RLE
+    masks, images/*2017/*.jpg). Category ids: 8, 10, 11 (non-VOC, step 0 of coco-voc) and 1, 2 (VOC classes)."""
+    import json
+    import os
+    import numpy as np
+    from PIL import Image
+    out = {}
+    rs = np.random.RandomState(seed)
+    img_id = ann_id = 0
+    for split, n in (("train", n_train), ("val", n_val)):
+        os.makedirs(os.path.join(root, "coco", "split"), exist_ok=True)
+        os.makedirs(os.path.join(root, "coco", "annotations"), exist_ok=True)
+        os.makedirs(os.path.join(root, "coco", "images", f"{split}2017"), exist_ok=True)
+        images, anns, names, truth = [], [], [], []
+        for k in range(n):
+            H, W = 80 + 8 * k, 100 + 5 * k
+            img_id += 1
+            name = f"{img_id:012d}"
+            Image.fromarray(rs.randint(0, 256, (H, W, 3)).astype(np.uint8)).save(os.path.join(root, "coco", "images", f"{split}2017", name + ".jpg"), quality=95)
+            images.append({"id": img_id, "file_name": name + ".jpg", "height": H, "width": W})
+            names.append(name)
+            boxes = []
+            cats = [8, 10, 11] if k % 2 == 0 else [1, 8]
+            for j, cat in enumerate(cats):                      # disjoint axis-aligned boxes: polygon for even j, RLE for odd j
+                x0, y0, w, h = 5 + 30 * j, 10 + 5 * j, 20, 25 + 3 * k
+                ann_id += 1
+                if j % 2 == 0:
+                    segm = [[x0, y0, x0 + w, y0, x0 + w, y0 + h, x0, y0 + h]]
+                else:
+                    m = np.zeros((H, W), dtype=np.int8)
+                    m[y0:y0 + h, x0:x0 + w] = 1
+                    flat = m.T.reshape(-1)
+                    edges = np.flatnonzero(np.diff(np.concatenate([[0], flat, [0]])))
+                    segm = {"size": [H, W], "counts": np.diff(np.concatenate([[0], edges, [flat.size]])).tolist()}
+                anns.append({"id": ann_id, "image_id": img_id, "category_id": cat, "iscrowd": 0, "bbox": [x0, y0, w, h],
+                             "area": w * h, "segmentation": segm})
+                boxes.append((cat, x0, y0, w, h))
+            truth.append((H, W, boxes))
+        with open(os.path.join(root, "coco", "split", f"{split}.txt"), "w") as f:
+            f.write("".join(nm + "\n" for nm in names))
+        with open(os.path.join(root, "coco", "annotations", f"instances_{split}2017.json"), "w") as f:
+            json.dump({"images": images, "annotations": anns, "categories": [{"id": i} for i in range(1, 92)]}, f)
+        out[split] = truth
+    return out
