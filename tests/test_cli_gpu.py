@@ -50,3 +50,23 @@ def test_step0_phase1_phase2_chain(gpu, tmp_path, monkeypatch):
     assert not torch.equal(c2["model_state"][ki], c0["model_state"][ki])
     for ck in (c0, c1, c2):
         assert all(torch.isfinite(v).all() for v in ck["model_state"].values() if v.is_floating_point())
+
+
+def test_cli_trains_from_a_voc_tree_through_the_device_loader(gpu, tmp_path, monkeypatch):
+    """run.main finds <data_root>/voc/pascal_sbd_train.json and switches from the synthetic loader to cl4wsis_amd.dataset
+    (host decode, device-side crop / resample / normalise / label_generation): one supervised step-0 epoch and one weakly
+    supervised phase-2 epoch on the tiny VOC-shaped tree, with worker processes."""
+    from util import make_mini_voc
+    make_mini_voc(tmp_path / "data", n_train=8, n_val=2)
+    common = ["--dataset", "voc", "--task", "15-5", "--crop_size", "65", "--batch_size", "2", "--epochs", "1", "--num_workers", "2",
+              "--no_pretrained", "--name", "D", "--print_interval", "1", "--data_root", str(tmp_path / "data")]
+    _run(common + ["--step", "0", "--bce", "--lr", "5e-5", "--optim", "adam", "--weight_decay", "0"], tmp_path, monkeypatch)
+    ck0 = tmp_path / "checkpoints/step/voc-15-5/D_0.pth"
+    c0 = torch.load(ck0, map_location="cpu")
+    assert all(torch.isfinite(v).all() for v in c0["model_state"].values() if v.is_floating_point())
+    _run(common + ["--step", "1", "--weakly", "--alpha", "0.5", "--loss_de", "1", "--lr_policy", "warmup", "--affinity", "--phase", "2",
+                   "--optim", "adam", "--lr", "5e-5", "--weight_decay", "0", "--step_ckpt", str(ck0)], tmp_path, monkeypatch)
+    c1 = torch.load(tmp_path / "checkpoints/step/voc-15-5/D_1.pth", map_location="cpu")
+    ki = "module.decoder.instance_decoder.aspp.convs.0.0.weight"
+    assert not torch.equal(c1["model_state"][ki], c0["model_state"][ki])
+    assert all(torch.isfinite(v).all() for v in c1["model_state"].values() if v.is_floating_point())
