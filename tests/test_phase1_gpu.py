@@ -21,7 +21,7 @@ def test_phase1_step_matches_oracle(gpu, monkeypatch, cur_epoch, precision):
     """precision 0 = exact fp32 products (the reference's arithmetic; its rounding — and with it the discrete decisions of this
     ill-conditioned tiny-crop step — follows the CPU oracle's closely): the strict statistical bar. precision 2 = bf16x6, the
     default: per-conv error equal to fp32 (tests/test_conv_gpu.py, 2e-6) and the same distance to float64 on the body alone
-    (tools/dbg_x6_r101.py: 2.3e-4 forward vs 3.0e-4 for CPU fp32), but its rounding is independent of the CPU's, so at 2x5x5
+    (tests/tools/dbg_x6_r101.py: 2.3e-4 forward vs 3.0e-4 for CPU fp32), but its rounding is independent of the CPU's, so at 2x5x5
     samples the thresholded pseudo labels / ReLU masks flip elsewhere: an rms bar relative to the CPU oracle's own distance."""
     from cl4wsis_amd import body_train
     from cl4wsis_amd.train import Trainer

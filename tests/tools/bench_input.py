@@ -2,8 +2,11 @@
 flip, ToTensor + Normalize, label map + LUT, and (supervised) label_generation — against the oracle (Pillow + numpy on the
 host cores, what the reference's loader workers do per sample).
 usage: bench_input.py [batch] [iters]"""
+import os, sys
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
+
 import os, sys, time, json, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from cl4wsis_amd import ops

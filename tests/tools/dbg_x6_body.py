@@ -1,4 +1,8 @@
 """Per-parameter gradient difference of the train-mode body between conv precisions (debug aid)."""
+import os, sys
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
+
 import torch
 from cl4wsis_amd import body_train as BT
 from cl4wsis_amd.backbone import ResNet

@@ -1,5 +1,9 @@
 """Train-mode ResNet-101 body at crop 65, b=2: forward / gradient distance to a float64 evaluation for each conv precision
 and for the CPU fp32 oracle, over a few seeds (debug aid for the conditioning of the phase-1 gradient test)."""
+import os, sys
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
+
 import sys
 import torch
 from cl4wsis_amd import body_train as BT, ops

@@ -3,8 +3,10 @@ batch of two with cross-rank ABN statistics and the bucketed gradient average; r
 (world-size-1 semantics emulated by a fresh Trainer on the full batch in a second launch) — see --single.
 usage: torchrun --nproc-per-node 2 tools/rehearse_p1_ddp.py      |      python tools/rehearse_p1_ddp.py --single"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
+
+import os, sys
 import torch
 from util import p1_opts
 from cl4wsis_amd.parallel import init_distributed
