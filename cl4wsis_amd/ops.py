@@ -127,7 +127,7 @@ _tuned = {}
 _CANDIDATES = [(1, 128, 1)] + [(2, t, s) for t in (128, 64) for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, -4, -8, -16)]   # s < 0: main + split tail
 
 
-def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=3):
+def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
     """Measure-don't-guess: run each candidate plan of this shape a few times (HIP events on the launch stream) and pin
     the fastest through cl4_conv2d_fwd_set_plan. The output is simply rewritten, so tuning is side-effect free."""
     key = (d.n, d.cin, d.hin, d.win, d.cout, d.kh, d.stride, d.pad, d.dil, d.precision, x.device.index)
