@@ -1197,8 +1197,10 @@ struct FwdPlan {
   int tile;    // 128 or 64 (v2)
   int splits;
   int kchunk;
-  int tail;    // bf16 kernels: > 0 = "main + split tail": whole rounds of tiles run unsplit with the fused epilogue, only the
-               // last partial round is split `tail` ways (kchunk is then the tail's K range); 0 = plain
+  int tail;    // bf16 kernels: > 1 = "main + split tail": whole rounds of tiles run unsplit with the fused epilogue, only the
+               // last partial round is split `tail` ways (kchunk is then the tail's K range); 1 = "main + small-tile tail": the
+               // last partial round of a 128x128 plan runs as 64x64 tiles (4x the workgroups, a quarter of the work each — for
+               // short-K layers where splitting K further is pointless); 0 = plain
 };
 
 // Measured plans (cl4_conv2d_fwd_set_plan, filled by the host-side autotuner during warm-up) override the heuristic.
@@ -1222,7 +1224,8 @@ FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision
   const int per = cl4::cdiv(ktiles, s);
   p.kchunk = per * BK2;
   const int actual = cl4::cdiv(K, p.kchunk);
-  if (splits < 0 && precision != 0 && actual > 1) { p.tail = actual; p.splits = 1; }
+  if (splits == -1 && precision != 0 && p.tile == 128) { p.tail = 1; p.splits = 1; }     // main + SMALL-TILE tail (64x64, unsplit)
+  else if (splits < 0 && precision != 0 && actual > 1) { p.tail = actual; p.splits = 1; }
   else p.splits = actual;
   return p;
 }
@@ -1297,7 +1300,7 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
     const TailGeom tg = tail_geometry(pl, a.cout, a.npix, precision);
     const bool hybrid = tg.main > 0;
     static const int persist = env_int("CL4_CONV_PERSIST", 0);   // measured: a loss at 128x128 (epilogue spills), +5 % at 64x64
-    const int nsplit = hybrid ? pl.tail : pl.splits;
+    const int nsplit = hybrid ? (pl.tail == 1 ? 1 : pl.tail) : pl.splits;
     a.gx = tg.gx;
     a.kchunk = pl.kchunk;
     a.ws = nullptr;
@@ -1309,13 +1312,14 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
       a.ws = (float*)workspace;
     }
     // one launch of `ntile` logical tiles starting at `base`, unsplit (fused epilogue) or split `sp` ways (slabs)
-    auto go = [&](int base, int ntile, int sp) {
+    auto go = [&](int base, int ntile, int sp, int tile) {
       a.tile_base = base;
       a.ntile_l = ntile;
+      a.gx = cl4::cdiv(a.cout, tile);
       const dim3 g((unsigned)ntile * (unsigned)(sp > 1 ? sp : 1));
       const bool split = sp > 1;
       if (precision == 2) {
-        if (pl.tile == 128) {
+        if (tile == 128) {
           if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true, 3, 8, 4>), g, dim3(768), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false, 3, 8, 4>), g, dim3(768), 0, st, a, z); }
           else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true, 3, 8, 4>), g, dim3(768), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false, 3, 8, 4>), g, dim3(768), 0, st, a, z); }
         } else {
@@ -1325,10 +1329,10 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
       } else if (!split && persist && ntile > 512) {
         // persistent workgroups: 512 resident slots (two per CU) walk ntile / 512 tiles each
         const dim3 gp(512);
-        if (pl.tile == 128) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); }
+        if (tile == 128) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); }
         else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); }
       } else {
-        if (pl.tile == 128) {
+        if (tile == 128) {
           if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false>), g, dim3(V2_THREADS), 0, st, a, z); }
           else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false>), g, dim3(V2_THREADS), 0, st, a, z); }
         } else {
@@ -1337,11 +1341,16 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
         }
       }
     };
-    if (hybrid) {
-      go(0, tg.main, 1);
-      go(tg.main, tg.ntiles - tg.main, nsplit);
+    if (hybrid && pl.tail == 1) {               // small-tile tail: the 64x64 tiles that cover the pixels from p0 on
+      go(0, tg.main, 1, pl.tile);
+      const int gx64 = cl4::cdiv(a.cout, 64);
+      const int base64 = (tg.p0 / 64) * gx64;
+      go(base64, gx64 * cl4::cdiv(a.npix, 64) - base64, 1, 64);
+    } else if (hybrid) {
+      go(0, tg.main, 1, pl.tile);
+      go(tg.main, tg.ntiles - tg.main, nsplit, pl.tile);
     } else {
-      go(0, tg.ntiles, nsplit);
+      go(0, tg.ntiles, nsplit, pl.tile);
     }
     if (nsplit > 1) {
       const long total = (long)a.cout * a.ws_npix;
@@ -1715,7 +1724,7 @@ extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
   const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin * 4 + d->precision});
   if (d->precision != 0 && pl.impl == 2 && pl.tail > 0) {
     const TailGeom tg = tail_geometry(pl, d->cout, npix, d->precision);
-    return tg.main > 0 ? (size_t)pl.tail * d->cout * (npix - tg.p0) * sizeof(float) : 0;   // degenerate: plain unsplit launch
+    return (tg.main > 0 && pl.tail > 1) ? (size_t)pl.tail * d->cout * (npix - tg.p0) * sizeof(float) : 0;   // small-tile tail / degenerate: no slabs
   }
   return pl.splits > 1 ? (size_t)pl.splits * d->cout * npix * sizeof(float) : 0;
 }

@@ -124,7 +124,7 @@ def _conv_workspace(device, nbytes):
 
 AUTOTUNE = False      # set True during warm-up (Trainer / bench): time the launch plans of every new conv shape once
 _tuned = {}
-_CANDIDATES = [(1, 128, 1)] + [(2, t, s) for t in (128, 64) for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, -4, -8, -16)]   # s < 0: main + split tail
+_CANDIDATES = [(1, 128, 1)] + [(2, t, s) for t in (128, 64) for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, -1, -4, -8, -16)]   # s < 0: main + split tail (-1: small-tile tail)
 
 
 def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
@@ -144,11 +144,13 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
             continue
         if impl == 2 and (tile == 128 and d.cout < 128 or abs(splits) > max(1, K // 64)):
             continue
+        if splits == -1 and tile != 128:
+            continue
         if splits < 0 and d.precision == 0:
             continue
         call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, tile, splits)
         need = lib.cl4_conv2d_fwd_workspace_bytes(C.byref(d))
-        sig = (impl, tile, need, splits < 0)
+        sig = (impl, tile, need, splits < 0, splits == -1)
         if sig in seen or need > (1 << 30):
             continue
         seen.add(sig)

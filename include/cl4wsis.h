@@ -90,7 +90,8 @@ size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d);
 /* Pin the launch plan of this convolution shape: impl 1 = register-staged kernel, 2 = LDS-DMA kernel (tile 64|128,
  * `splits` K-slices); impl 0 forgets it (back to the built-in heuristic). splits < 0 (bf16x3 / bf16x6 kernels) selects
  * "main + split tail": the whole rounds of output tiles that fill the chip run unsplit with the fused epilogue and only
- * the last partial round is split |splits| ways. Results never depend on the plan beyond fp32 summation order. The host autotuner (cl4wsis_amd/ops.py) times the candidates once per shape in warm-up. */
+ * the last partial round is split |splits| ways (splits = -1 with tile 128: the last partial round runs as unsplit 64x64
+ * tiles instead — for short-K layers). Results never depend on the plan beyond fp32 summation order. The host autotuner (cl4wsis_amd/ops.py) times the candidates once per shape in warm-up. */
 int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int tile, int splits);
 /* Forget every pinned plan (back to the heuristic); the autotuner's choices depend on timing, so tests reset them. */
 int cl4_conv2d_fwd_clear_plans(void);

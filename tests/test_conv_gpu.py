@@ -94,7 +94,7 @@ def test_autotuner_keeps_the_result(gpu, precision):
 
 
 @pytest.mark.parametrize("precision", [1, 2])
-@pytest.mark.parametrize("plan", [(2, 64, -4), (2, 128, -8), (2, 64, -16)])
+@pytest.mark.parametrize("plan", [(2, 64, -4), (2, 128, -8), (2, 64, -16), (2, 128, -1)])
 def test_conv_fwd_main_plus_split_tail(gpu, plan, precision):
     """Plans with splits < 0: the whole rounds of tiles run unsplit, the last partial round is split — same convolution
     (fused epilogue on both parts), on a grid with more tiles than resident-workgroup slots and a ragged last pixel tile."""
@@ -111,7 +111,8 @@ def test_conv_fwd_main_plus_split_tail(gpu, plan, precision):
     wp = ops.pack_conv_weight(wt.to(gpu), precision)
     d = ops._conv_desc(xd, cin, 0, cout, k, 1, 1, 1, cout, 0, ops.ACT_RELU, 0.0, 0, 0.0, wp.precision)
     _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), *plan)
-    assert _hip.load().cl4_conv2d_fwd_workspace_bytes(C.byref(d)) > 0            # the tail is split on this shape
+    ws = _hip.load().cl4_conv2d_fwd_workspace_bytes(C.byref(d))
+    assert (ws > 0) == (plan[2] != -1)          # split tails need slabs; the small-tile tail (-1) does not
     y = ops.conv2d(xd, wp, k, pad=1, scale=scale.to(gpu), shift=shift.to(gpu), post=post.to(gpu), act1=ops.ACT_RELU)
     torch.cuda.synchronize()
     assert _rel_err(y.cpu(), ref) < TOL[precision]
