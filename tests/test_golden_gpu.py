@@ -175,34 +175,45 @@ def test_graph_replay_matches_eager(gpu, monkeypatch):
     g = torch.Generator().manual_seed(8)
     batches = [(torch.randn(2, 3, crop, crop, generator=g), torch.eye(20)[[16 + i % 4, 15]].clone()) for i in range(3)]
 
+    # A small learning rate keeps the two runs' weights within ~1e-6 of each other, so that the discrete decisions of the label
+    # stage (which sees the trainable branch's own predictions from iteration 2 on) do not flip between the runs — at the
+    # reference's 5e-4 one run in four kept an instance the other dropped. The Adam arithmetic under test is scale-free.
+    LR = 5e-6
+    # both runs on the heuristic launch plans: the warm-up autotuner picks by timing and could give the two Trainers different
+    # summation orders, which is not what this test is about
+    monkeypatch.setenv("CL4_AUTOTUNE", "0")
+
     def run(graph):
         monkeypatch.setenv("CL4_GRAPH", "1" if graph else "0")
         opts = p2_opts(crop)
+        opts.lr = LR / 10                            # the instance branch trains at 10 x lr (train.py:144-185)
         opts.max_iters, opts.start_decay = 50, 1     # the schedule changes the learning rate every iteration
         torch.manual_seed(0)
         tr = Trainer(_Log(), gpu, opts)
         for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
             m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=31 + i))
         tr._realias()
+        w0 = torch.cat([p.detach().flatten() for p in tr._branch.trainable_parameters()]).cpu()
         losses = []
         for x, l in batches:
             losses.append(tr.step((x, l))["losses"].clone())
         torch.cuda.synchronize()
         assert (tr._graph is not None) == graph
         w = torch.cat([p.detach().flatten() for p in tr._branch.trainable_parameters()]).cpu()
+        assert torch.isfinite(w).all() and not torch.equal(w, w0)
         return torch.stack(losses).cpu(), w, tr.optimizer.param_groups[0]["lr"]
 
     le, we, lre = run(False)
     lg, wg, lrg = run(True)
-    assert lre == lrg and lre < 5e-4
+    assert lre == lrg and lre < LR
     assert torch.allclose(le, lg, rtol=2e-3, atol=1e-6), (le, lg)
     # Adam turns a gradient of ~1e-8 into a step of +-lr, so a weight whose gradient is numerically zero can move by up to
     # 3 * lr differently in two runs that differ only in the order of the fp32 atomics of the split-K weight gradient
     # (two EAGER runs show the same: tools/dbg_graph_eager.py). Such weights are a handful out of 15.7 M.
     d = (we - wg).abs()
-    assert d.max() < 3.2 * 5e-4
-    assert (d > 2e-4).float().mean() < 1e-5
-    assert (we - wg).abs().mean() < 1e-5
+    assert d.max() < 3.2 * LR
+    assert (d > 0.4 * LR).float().mean() < 1e-5
+    assert d.mean() < 0.02 * LR
 
 
 def test_trainer_step_voc_10_10(gpu):
