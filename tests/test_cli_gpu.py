@@ -15,6 +15,7 @@ def _run(args, tmp, monkeypatch):
     from cl4wsis_amd import argparser, run
     monkeypatch.chdir(tmp)
     monkeypatch.setenv("CL4_SYNTH_LEN", "4")
+    monkeypatch.setenv("CL4_AUTOTUNE", "1")               # the CLI flow runs with the warm-up autotuner, like production
     opts = argparser.modify_command_options(argparser.get_argparser().parse_args(args))
     run.main(opts)
 
