@@ -26,14 +26,20 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b) {
 // grid (c, SPLIT): partial[(c*SPLIT + s)*2 + {0,1}] = {sum x, sum x^2} over this block's share.
 __global__ void bn_stats_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, BnShape s) {
   const int c = blockIdx.x, sp = blockIdx.y;
-  const long per_c = (long)s.n * s.hw;
+  const int per_c = s.n * s.hw;                // checked on the host: < 2^31
+  const int step = SPLIT * blockDim.x;
   double a = 0.0, b = 0.0;
-  for (long i = (long)sp * blockDim.x + threadIdx.x; i < per_c; i += (long)SPLIT * blockDim.x) {
-    int n = i / s.hw;
-    int p = i - (long)n * s.hw;
-    float v = x[((long)n * s.ctot + s.coff + c) * s.hw + p];
+  // flattened (n, p) index walked without divisions: one division for the start, then carry p over image boundaries
+  int i = sp * blockDim.x + threadIdx.x;
+  int n = i / s.hw, p = i - n * s.hw;
+  const float* xc = x + (long)(s.coff + c) * s.hw;
+  const long img = (long)s.ctot * s.hw;
+  for (; i < per_c; i += step) {
+    const float v = xc[n * img + p];
     a += (double)v;
     b += (double)v * (double)v;
+    p += step;
+    while (p >= s.hw) { p -= s.hw; ++n; }
   }
   block_reduce2(a, b);
   if (threadIdx.x == 0) {
@@ -103,22 +109,23 @@ __global__ void bn_bwd_sums_to_float_kernel(const double* __restrict__ sums, flo
 }
 
 // y = act((x - mean) * rstd * gamma + beta); optional inverted-dropout mask (uint8 keep flags, scale 1/(1-p)).
+// grid = (n*c planes, chunks of hw): per-plane constants are computed once per workgroup, no per-element divisions.
 __global__ void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
                                 const float* __restrict__ var, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int act, float slope, BnShape s, int y_ctot,
                                 int y_coff, const uint8_t* __restrict__ keep, float keep_scale) {
-  long total = (long)s.n * s.c * s.hw;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int p = i % s.hw;
-    long t = i / s.hw;
-    int c = t % s.c;
-    int n = t / s.c;
-    float rstd = 1.f / sqrtf(var[c] + eps);
-    float v = x[((long)n * s.ctot + s.coff + c) * s.hw + p];
-    v = (v - mean[c]) * rstd * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+  const int plane = blockIdx.x;                // n * c + c  (x: up to 2^31 planes; y: chunks of hw)
+  const int n = plane / s.c, c = plane - n * s.c;
+  const float rstd = 1.f / sqrtf(var[c] + eps);
+  const float mu = mean[c], g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+  const float* xp = x + ((long)n * s.ctot + s.coff + c) * s.hw;
+  float* yp = y + ((long)n * y_ctot + y_coff + c) * s.hw;
+  const uint8_t* kp = keep ? keep + (long)plane * s.hw : nullptr;
+  for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < s.hw; p += gridDim.y * blockDim.x) {
+    float v = (xp[p] - mu) * rstd * g + bb;
     v = cl4::apply_act(v, act, slope);
-    if (keep) v = keep[i] ? v * keep_scale : 0.f;
-    y[((long)n * y_ctot + y_coff + c) * s.hw + p] = v;
+    if (kp) v = kp[p] ? v * keep_scale : 0.f;
+    yp[p] = v;
   }
 }
 
@@ -137,19 +144,26 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
                                       float slope, BnShape s, int dy_ctot, int dy_coff, const uint8_t* __restrict__ keep,
                                       float keep_scale) {
   const int c = blockIdx.x, sp = blockIdx.y;
-  const long per_c = (long)s.n * s.hw;
+  const int per_c = s.n * s.hw;
+  const int step = SPLIT * blockDim.x;
   const float mu = mean[c], rstd = 1.f / sqrtf(var[c] + eps);
   const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
   double a = 0.0, b = 0.0;
-  for (long i = (long)sp * blockDim.x + threadIdx.x; i < per_c; i += (long)SPLIT * blockDim.x) {
-    int n = i / s.hw;
-    int p = i - (long)n * s.hw;
-    float xh = (x[((long)n * s.ctot + s.coff + c) * s.hw + p] - mu) * rstd;
-    float d = dy[((long)n * dy_ctot + dy_coff + c) * s.hw + p];
-    if (keep) d = keep[((long)n * s.c + c) * s.hw + p] ? d * keep_scale : 0.f;
+  int i = sp * blockDim.x + threadIdx.x;
+  int n = i / s.hw, p = i - n * s.hw;
+  const float* xc = x + (long)(s.coff + c) * s.hw;
+  const float* dc = dy + (long)(dy_coff + c) * s.hw;
+  const uint8_t* kc = keep ? keep + (long)c * s.hw : nullptr;
+  const long ximg = (long)s.ctot * s.hw, dimg = (long)dy_ctot * s.hw, kimg = (long)s.c * s.hw;
+  for (; i < per_c; i += step) {
+    float xh = (xc[n * ximg + p] - mu) * rstd;
+    float d = dc[n * dimg + p];
+    if (kc) d = kc[n * kimg + p] ? d * keep_scale : 0.f;
     d = act_grad(d, xh * g + bb, act, slope);
     a += (double)d;
     b += (double)d * (double)xh;
+    p += step;
+    while (p >= s.hw) { p -= s.hw; ++n; }
   }
   block_reduce2(a, b);
   if (threadIdx.x == 0) {
@@ -180,20 +194,21 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ sum_dz, const float* __restrict__ sum_dz_xh, float eps, int act,
                                     float slope, float invn, BnShape s, int dy_ctot, int dy_coff,
                                     const uint8_t* __restrict__ keep, float keep_scale) {
-  long total = (long)s.n * s.c * s.hw;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int p = i % s.hw;
-    long t = i / s.hw;
-    int c = t % s.c;
-    int n = t / s.c;
-    float rstd = 1.f / sqrtf(var[c] + eps);
-    float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
-    long xi = ((long)n * s.ctot + s.coff + c) * s.hw + p;
-    float xh = (x[xi] - mean[c]) * rstd;
-    float d = dy[((long)n * dy_ctot + dy_coff + c) * s.hw + p];
-    if (keep) d = keep[i] ? d * keep_scale : 0.f;
+  const int plane = blockIdx.x;                // grid = (n*c planes, chunks of hw), like bn_apply_kernel
+  const int n = plane / s.c, c = plane - n * s.c;
+  const float rstd = 1.f / sqrtf(var[c] + eps);
+  const float mu = mean[c], g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+  const float sa = sum_dz[c] * invn, sb = sum_dz_xh[c] * invn;
+  const float* xp = x + ((long)n * s.ctot + s.coff + c) * s.hw;
+  float* dxp = dx + ((long)n * s.ctot + s.coff + c) * s.hw;
+  const float* dp = dy + ((long)n * dy_ctot + dy_coff + c) * s.hw;
+  const uint8_t* kp = keep ? keep + (long)plane * s.hw : nullptr;
+  for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < s.hw; p += gridDim.y * blockDim.x) {
+    float xh = (xp[p] - mu) * rstd;
+    float d = dp[p];
+    if (kp) d = kp[p] ? d * keep_scale : 0.f;
     d = act_grad(d, xh * g + bb, act, slope);
-    dx[xi] = g * rstd * (d - sum_dz[c] * invn - xh * sum_dz_xh[c] * invn);
+    dxp[p] = g * rstd * (d - sa - xh * sb);
   }
 }
 
@@ -248,6 +263,7 @@ __global__ void random_labels_kernel(int* __restrict__ out, long n, uint64_t see
 
 int check_shape(const BnShape& s) {
   CL4_REQUIRE(s.n > 0 && s.c > 0 && s.hw > 0, "bn: non-positive dims");
+  CL4_REQUIRE((long)s.n * s.hw < 2147483647L && (long)s.n * s.c < 2147483647L, "bn: n*hw / n*c overflow int32");
   CL4_REQUIRE(s.coff >= 0 && s.coff + s.c <= s.ctot, "bn: channel slice out of range");
   return CL4_OK;
 }
@@ -280,7 +296,7 @@ extern "C" int cl4_bn_apply(const float* x, float* y, int n, int c, int hw, int 
   CL4_REQUIRE(x && y && mean && var, "bn_apply: null pointer");
   CL4_REQUIRE(y_coff >= 0 && y_coff + c <= y_ctot, "bn_apply: output slice out of range");
   long total = (long)n * c * hw;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, mean,
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, cl4::as_stream(stream), x, y, mean,
                      var, gamma, beta, eps, act, slope, s, y_ctot, y_coff, keep, keep_scale);
   return cl4::launch_status();
 }
@@ -304,7 +320,7 @@ extern "C" int cl4_bn_train_bwd(const float* x, const float* dy, float* dx, int 
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, sums + c,
                      dgamma, dbeta, c);
   long total = (long)n * c * hw;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, x, dy, dx, mean, var, gamma,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, st, x, dy, dx, mean, var, gamma,
                      beta, sums, sums + c, eps, act, 0.f, 1.f / (float)((long)n * hw), s, dy_ctot, dy_coff, keep, keep_scale);
   return cl4::launch_status();
 }
@@ -368,7 +384,7 @@ extern "C" int cl4_bn_sync_bwd_apply(const float* x, const float* dy, float* dx,
   hipStream_t st = cl4::as_stream(stream);
   hipLaunchKernelGGL(bn_bwd_sums_to_float_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, sums, fsum, fsum + c, c);
   long total = (long)n * c * hw;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, x, dy, dx, mean, var, gamma,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, st, x, dy, dx, mean, var, gamma,
                      beta, fsum, fsum + c, eps, act, slope, (float)(1.0 / count), s, dy_ctot, dy_coff, keep, keep_scale);
   return cl4::launch_status();
 }
