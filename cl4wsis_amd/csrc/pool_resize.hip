@@ -112,15 +112,13 @@ struct ResizeArgs {
   float sy, sx;
 };
 
+// grid = (n*c planes, chunks of the output plane): one 32-bit division per element instead of four 64-bit ones
 __global__ void resize_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, ResizeArgs a) {
-  long total = (long)a.n * a.c * a.hout * a.wout;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int ox = i % a.wout;
-    long t = i / a.wout;
-    int oy = t % a.hout;
-    t /= a.hout;
-    int c = t % a.c;
-    int n = t / a.c;
+  const int plane = blockIdx.x;
+  const int n = plane / a.c, c = plane - n * a.c;
+  const int per = a.hout * a.wout;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < per; i += gridDim.y * blockDim.x) {
+    const int oy = i / a.wout, ox = i - oy * a.wout;
     int y0, y1, x0, x1;
     float ly, lx;
     src_index(oy, a.sy, a.align, a.hin, y0, y1, ly);
@@ -138,15 +136,12 @@ __global__ void resize_fwd_kernel(const float* __restrict__ x, float* __restrict
 // forward footprint touched it. The candidate output range is bounded from the scale and each
 // candidate recomputes the forward's own (i0,i1,l1), so forward and backward can never disagree.
 __global__ void resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, ResizeArgs a, int accumulate) {
-  long total = (long)a.n * a.c * a.hin * a.win;
+  const int plane = blockIdx.x;                // grid = (n*c planes, chunks of the input plane)
+  const int n = plane / a.c, c = plane - n * a.c;
+  const int per = a.hin * a.win;
   const float ry = a.sy > 0.f ? 1.f / a.sy : 0.f, rx = a.sx > 0.f ? 1.f / a.sx : 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int ix = i % a.win;
-    long t = i / a.win;
-    int iy = t % a.hin;
-    t /= a.hin;
-    int c = t % a.c;
-    int n = t / a.c;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < per; i += gridDim.y * blockDim.x) {
+    const int iy = i / a.win, ix = i - iy * a.win;
     // outputs whose source coordinate falls in (iy-1, iy+1). align_corners: src = dst*s -> dst in ((iy-1)/s, (iy+1)/s);
     // half-pixel: src = (dst+0.5)*s - 0.5 -> dst in ((iy-0.5)/s - 0.5, (iy+1.5)/s - 0.5). One conservative range covers both
     // (the +1.5 matters for large upsampling factors: 33 -> 513 spans 15.5 outputs per input); the clamped borders take
@@ -259,7 +254,7 @@ extern "C" int cl4_resize_bilinear_fwd(const float* x, float* y, int n, int c, i
   int rc = fill_resize(a, n, c, hin, win, hout, wout, align_corners, in_ctot, in_coff, out_ctot, out_coff);
   if (rc) return rc;
   long total = (long)n * c * hout * wout;
-  hipLaunchKernelGGL(resize_fwd_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, a);
+  hipLaunchKernelGGL(resize_fwd_kernel, dim3(a.n * a.c, cl4::cdiv((long)a.hout * a.wout, 1024) < 64 ? cl4::cdiv((long)a.hout * a.wout, 1024) : 64), dim3(256), 0, cl4::as_stream(stream), x, y, a);
   return cl4::launch_status();
 }
 
@@ -271,7 +266,7 @@ extern "C" int cl4_resize_bilinear_bwd(const float* dy, float* dx, int n, int c,
   int rc = fill_resize(a, n, c, hin, win, hout, wout, align_corners, in_ctot, in_coff, out_ctot, out_coff);
   if (rc) return rc;
   long total = (long)n * c * hin * win;
-  hipLaunchKernelGGL(resize_bwd_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), dy, dx, a,
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(a.n * a.c, cl4::cdiv((long)a.hin * a.win, 1024) < 64 ? cl4::cdiv((long)a.hin * a.win, 1024) : 64), dim3(256), 0, cl4::as_stream(stream), dy, dx, a,
                      accumulate);
   return cl4::launch_status();
 }
