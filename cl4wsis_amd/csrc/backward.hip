@@ -48,12 +48,10 @@ __device__ __forceinline__ int window_argmax(const float* __restrict__ xp, int o
 
 __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long planes,
                                         int hin, int win, int hout, int wout) {
-  const long total = planes * hin * win;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int ix = i % win;
-    const long t = i / win;
-    const int iy = t % hin;
-    const long pl = t / hin;
+  const long pl = blockIdx.x;                  // grid = (planes, chunks of the input plane)
+  const int per = hin * win;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < per; i += gridDim.y * blockDim.x) {
+    const int iy = i / win, ix = i - iy * win;
     const float* xp = x + pl * hin * win;
     const float* dp = dy + pl * hout * wout;
     // windows containing (iy, ix): 2*o - 1 <= i <= 2*o + 1  ->  o in [ceil((i-1)/2), floor((i+1)/2)]
@@ -63,7 +61,7 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float
     for (int oy = oy_lo; oy <= oy_hi; ++oy)
       for (int ox = ox_lo; ox <= ox_hi; ++ox)
         if (window_argmax(xp, oy, ox, hin, win) == iy * win + ix) acc += dp[oy * wout + ox];
-    dx[i] = acc;
+    dx[pl * per + i] = acc;
   }
 }
 
@@ -146,8 +144,8 @@ extern "C" int cl4_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, 
                                     void* stream) {
   CL4_REQUIRE(x && dy && dx && planes > 0, "maxpool_bwd: bad arguments");
   CL4_REQUIRE(hout == (hin + 2 - 3) / 2 + 1 && wout == (win + 2 - 3) / 2 + 1, "maxpool_bwd: output size mismatch");
-  const long total = planes * hin * win;
-  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, dy, dx,
+  const int chunks = cl4::cdiv((long)hin * win, 1024) < 64 ? cl4::cdiv((long)hin * win, 1024) : 64;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((unsigned)planes, chunks), dim3(256), 0, cl4::as_stream(stream), x, dy, dx,
                      planes, hin, win, hout, wout);
   return cl4::launch_status();
 }

@@ -9,12 +9,11 @@ namespace {
 // models/resnet.py:63 nn.MaxPool2d(3, stride=2, padding=1) (implicit -inf padding).
 __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int hin, int win,
                                     int hout, int wout) {
-  long total = planes * hout * wout;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int ox = i % wout;
-    long t = i / wout;
-    int oy = t % hout;
-    long pl = t / hout;
+  // grid = (planes, chunks of the output plane): one 32-bit division per element
+  const long pl = blockIdx.x;
+  const int per = hout * wout;
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < per; i += gridDim.y * blockDim.x) {
+    const int oy = i / wout, ox = i - oy * wout;
     const float* xp = x + pl * hin * win;
     float m = -INFINITY;
     int iy0 = oy * 2 - 1, ix0 = ox * 2 - 1;
@@ -29,7 +28,7 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restri
         m = fmaxf(m, xp[iy * win + ix]);
       }
     }
-    y[i] = m;
+    y[pl * per + i] = m;
   }
 }
 
@@ -207,8 +206,8 @@ __global__ void copy_channels_kernel(const float* __restrict__ x, float* __restr
 extern "C" int cl4_maxpool3x3s2(const float* x, float* y, long planes, int hin, int win, int hout, int wout, void* stream) {
   CL4_REQUIRE(x && y && planes > 0, "maxpool: bad arguments");
   CL4_REQUIRE(hout == (hin + 2 - 3) / 2 + 1 && wout == (win + 2 - 3) / 2 + 1, "maxpool: output size mismatch");
-  long total = planes * hout * wout;
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y,
+  const int chunks = cl4::cdiv((long)hout * wout, 1024) < 64 ? cl4::cdiv((long)hout * wout, 1024) : 64;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)planes, chunks), dim3(256), 0, cl4::as_stream(stream), x, y,
                      planes, hin, win, hout, wout);
   return cl4::launch_status();
 }
