@@ -3,6 +3,7 @@
 // and weight gradient. Per-channel K=25: HBM/LDS-bound, no MFMA. A workgroup owns a 32x32 output
 // tile of one (n, c) plane; the 36x36 halo tile is staged through LDS once and every lane reads its
 // 5x5 window from LDS (row stride 37 floats: conflict-free for the 32-lane row reads).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -49,6 +50,72 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
 #pragma unroll
       for (int kx = 0; kx < 5; ++kx) acc = fmaf(wk[ky * 5 + kx], tile[ly + ky][lx + kx], acc);
     if (oy < a.h && ox < a.w) yp[(long)oy * a.w + ox] = acc;
+  }
+}
+
+
+// Streaming form of the same convolution: no LDS, no workgroup barrier. A wave owns a strip of 60 output columns (lanes
+// 2..61; the two lanes on either side only carry the halo) and slides down a chunk of rows: per input row one coalesced
+// load per lane and four cross-lane shifts give the row's 5-wide window, which is kept for the five output rows it
+// contributes to. Loads are issued eight rows ahead, so a CU keeps ~64 KB in flight (the tile kernel above did one
+// load -> barrier -> compute -> store round trip per workgroup and ran at 2 TB/s of plane traffic). Every output
+// accumulates its 25 taps in the same (ky, kx) order as the tile kernel: bit-identical results.
+constexpr int SW = 60;       // output columns per wave
+constexpr int SROWS = 32;    // output rows per wave
+
+__global__ __launch_bounds__(256) void dwconv5_strip_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                            float* __restrict__ y, DwArgs a, int strips_x) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int plane = blockIdx.x;                // n * c + c
+  const int n = plane / a.c, c = plane - n * a.c;
+  const int unit = blockIdx.y * 4 + wave;      // (row chunk, strip)
+  const int chunk = unit / strips_x, strip = unit - chunk * strips_x;
+  const int r0 = chunk * SROWS;
+  if (r0 >= a.h) return;                       // wave-uniform, no barrier in this kernel
+  const int r1 = min(a.h, r0 + SROWS);
+  const int xs = strip * SW - 2 + lane;        // this lane's column
+  const bool xin = (unsigned)xs < (unsigned)a.w;
+  const bool xout = lane >= 2 && lane < 2 + SW && xin;
+  const float* xp = x + ((long)n * a.x_ctot + a.x_coff + c) * a.h * a.w;
+  float* yp = y + ((long)n * a.y_ctot + a.y_coff + c) * a.h * a.w;
+  float wr[25];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) wr[t] = wgt[c * 25 + (a.flip ? 24 - t : t)];   // wave-uniform (scalar loads)
+  auto load_row = [&](int iy) { return (xin && (unsigned)iy < (unsigned)a.h) ? xp[(long)iy * a.w + xs] : 0.f; };
+  float win[5][5];                             // win[ky][kx]: rows oy-2 .. oy+2 of the current output row
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) win[ky][kx] = 0.f;
+  constexpr int AHEAD = 8;
+  float q[AHEAD];
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i) q[i] = load_row(r0 - 2 + i);
+  // input rows r0-2 .. r1+1; output row oy is complete once input row oy+2 has been pushed
+  for (int iy = r0 - 2; iy < r1 + 2; iy += AHEAD) {
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) {
+      const float v = q[i];
+      q[i] = load_row(iy + i + AHEAD);         // refill the slot for AHEAD rows later (out-of-image rows load nothing)
+#pragma unroll
+      for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) win[ky][kx] = win[ky + 1][kx];
+      win[4][2] = v;
+      win[4][1] = __shfl_up(v, 1, 64);
+      win[4][0] = __shfl_up(v, 2, 64);
+      win[4][3] = __shfl_down(v, 1, 64);
+      win[4][4] = __shfl_down(v, 2, 64);
+      const int oy = iy + i - 2;
+      if (oy >= r0 && oy < r1) {               // wave-uniform
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 5; ++kx) acc = fmaf(wr[ky * 5 + kx], win[ky][kx], acc);
+        if (xout) yp[(long)oy * a.w + xs] = acc;
+      }
+    }
   }
 }
 
@@ -113,8 +180,16 @@ extern "C" int cl4_dwconv5_fwd(const float* x, const float* w, float* y, int n, 
   int rc = check(a);
   if (rc) return rc;
   CL4_REQUIRE(x && w && y, "dwconv5_fwd: null pointer");
-  dim3 g(cl4::cdiv(h, T) * cl4::cdiv(wd, T), c, n);
-  hipLaunchKernelGGL(dwconv5_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, w, y, a);
+  static const int tile_form = getenv("CL4_DWCONV_TILE") ? atoi(getenv("CL4_DWCONV_TILE")) : 0;   // 1: the LDS tile kernel
+  if (tile_form) {
+    dim3 g(cl4::cdiv(h, T) * cl4::cdiv(wd, T), c, n);
+    hipLaunchKernelGGL(dwconv5_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, w, y, a);
+  } else {
+    const int strips_x = cl4::cdiv(wd, SW);
+    const int units = strips_x * cl4::cdiv(h, SROWS);
+    dim3 g((unsigned)n * c, cl4::cdiv(units, 4));
+    hipLaunchKernelGGL(dwconv5_strip_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, w, y, a, strips_x);
+  }
   return cl4::launch_status();
 }
 

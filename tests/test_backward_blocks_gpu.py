@@ -89,3 +89,23 @@ def test_resize_bilinear_backward(gpu, case):
     assert _rel(dx, x.grad.float()) < 1e-5
     yd = ops.resize_bilinear(x.detach().float().to(gpu), (hout, wout), align)
     assert _rel(yd, y.detach().float()) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 129, 129), (1, 3, 7, 9), (3, 2, 33, 61), (1, 4, 64, 120), (2, 1, 1, 1)])
+def test_dwconv5_forward_and_input_gradient(gpu, shape):
+    """5x5 depthwise conv (streaming strip kernel: 60-column strips, 32-row chunks, halo lanes) against torch, forward and the
+    flipped-kernel input gradient, on sizes that are / are not multiples of the strip and chunk sizes."""
+    import torch.nn.functional as F
+    from cl4wsis_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(h * 131 + w)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(c, 1, 5, 5, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), padding=2, groups=c)
+    y = ops.dwconv5(x.to(gpu), wt.to(gpu))
+    assert ((y.double().cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-6
+    dy = torch.randn(n, c, h, w, generator=g)
+    xr = x.double().clone().requires_grad_(True)
+    F.conv2d(xr, wt.double(), padding=2, groups=c).backward(dy.double())
+    dx = ops.dwconv5(dy.to(gpu), wt.to(gpu), flip=True)
+    assert ((dx.double().cpu() - xr.grad).abs().max() / xr.grad.abs().max()).item() < 1e-6
