@@ -61,18 +61,18 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
 // load -> barrier -> compute -> store round trip per workgroup and ran at 2 TB/s of plane traffic). Every output
 // accumulates its 25 taps in the same (ky, kx) order as the tile kernel: bit-identical results.
 constexpr int SW = 60;       // output columns per wave
-constexpr int SROWS = 32;    // output rows per wave
+constexpr int SROWS = 32;    // output rows per wave (upper bound; the launch uses equal chunks)
 
 __global__ __launch_bounds__(256) void dwconv5_strip_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
-                                                            float* __restrict__ y, DwArgs a, int strips_x) {
+                                                            float* __restrict__ y, DwArgs a, int strips_x, int srows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int plane = blockIdx.x;                // n * c + c
   const int n = plane / a.c, c = plane - n * a.c;
   const int unit = blockIdx.y * 4 + wave;      // (row chunk, strip)
   const int chunk = unit / strips_x, strip = unit - chunk * strips_x;
-  const int r0 = chunk * SROWS;
+  const int r0 = chunk * srows;
   if (r0 >= a.h) return;                       // wave-uniform, no barrier in this kernel
-  const int r1 = min(a.h, r0 + SROWS);
+  const int r1 = min(a.h, r0 + srows);
   const int xs = strip * SW - 2 + lane;        // this lane's column
   const bool xin = (unsigned)xs < (unsigned)a.w;
   const bool xout = lane >= 2 && lane < 2 + SW && xin;
@@ -164,6 +164,74 @@ __global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restr
   }
 }
 
+
+// Streaming weight gradient: the same strips / row chunks / sliding window as dwconv5_strip_kernel; each lane adds
+// dy[oy][x] * window to 25 partial sums, the four waves of a workgroup are reduced through LDS and one atomic per tap and
+// workgroup goes to dw.
+__global__ __launch_bounds__(256) void dwconv5_wgrad_strip_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ dw, DwArgs a, int strips_x, int srows) {
+  __shared__ float red[4][25];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int plane = blockIdx.x;
+  const int n = plane / a.c, c = plane - n * a.c;
+  const int unit = blockIdx.y * 4 + wave;
+  const int chunk = unit / strips_x, strip = unit - chunk * strips_x;
+  const int r0 = chunk * srows;
+  const int r1 = min(a.h, r0 + srows);         // r0 >= h: empty range, the wave only joins the reduction
+  const int xs = strip * SW - 2 + lane;
+  const bool xin = (unsigned)xs < (unsigned)a.w;
+  const bool xout = lane >= 2 && lane < 2 + SW && xin;
+  const float* xp = x + ((long)n * a.x_ctot + a.x_coff + c) * a.h * a.w;
+  const float* dp = dy + ((long)n * a.y_ctot + a.y_coff + c) * a.h * a.w;
+  float acc[25];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) acc[t] = 0.f;
+  if (r0 < a.h) {
+    auto load_row = [&](int iy) { return (xin && (unsigned)iy < (unsigned)a.h) ? xp[(long)iy * a.w + xs] : 0.f; };
+    auto load_dy = [&](int oy) { return (xout && oy >= r0 && oy < r1) ? dp[(long)oy * a.w + xs] : 0.f; };
+    float win[5][5];
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) win[ky][kx] = 0.f;
+    constexpr int AHEAD = 8;
+    float q[AHEAD], gq[AHEAD];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) { q[i] = load_row(r0 - 2 + i); gq[i] = load_dy(r0 - 4 + i); }
+    for (int iy = r0 - 2; iy < r1 + 2; iy += AHEAD) {
+#pragma unroll
+      for (int i = 0; i < AHEAD; ++i) {
+        const float v = q[i], g = gq[i];         // input row iy+i completes the window of output row iy+i-2
+        q[i] = load_row(iy + i + AHEAD);
+        gq[i] = load_dy(iy + i - 2 + AHEAD);
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 5; ++kx) win[ky][kx] = win[ky + 1][kx];
+        win[4][2] = v;
+        win[4][1] = __shfl_up(v, 1, 64);
+        win[4][0] = __shfl_up(v, 2, 64);
+        win[4][3] = __shfl_down(v, 1, 64);
+        win[4][4] = __shfl_down(v, 2, 64);
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 5; ++kx) acc[ky * 5 + kx] = fmaf(g, win[ky][kx], acc[ky * 5 + kx]);   // g = 0 outside the chunk
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 25; ++t) {
+    const float sm = cl4::wave_sum(acc[t]);
+    if (lane == 0) red[wave][t] = sm;
+  }
+  __syncthreads();
+  if (threadIdx.x < 25) {
+    const float sm = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(&dw[c * 25 + threadIdx.x], sm);
+  }
+}
+
 int check(const DwArgs& a) {
   CL4_REQUIRE(a.n > 0 && a.c > 0 && a.h > 0 && a.w > 0, "dwconv5: non-positive dims");
   CL4_REQUIRE(a.n <= 65535 && a.c <= 65535, "dwconv5: n/c exceed grid limits");
@@ -186,9 +254,10 @@ extern "C" int cl4_dwconv5_fwd(const float* x, const float* w, float* y, int n, 
     hipLaunchKernelGGL(dwconv5_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, w, y, a);
   } else {
     const int strips_x = cl4::cdiv(wd, SW);
-    const int units = strips_x * cl4::cdiv(h, SROWS);
+    const int srows = cl4::cdiv(h, cl4::cdiv(h, SROWS));      // equal chunks of <= SROWS rows (129 rows: 5 x 26, not 4 x 32 + 1)
+    const int units = strips_x * cl4::cdiv(h, srows);
     dim3 g((unsigned)n * c, cl4::cdiv(units, 4));
-    hipLaunchKernelGGL(dwconv5_strip_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, w, y, a, strips_x);
+    hipLaunchKernelGGL(dwconv5_strip_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, w, y, a, strips_x, srows);
   }
   return cl4::launch_status();
 }
@@ -199,11 +268,20 @@ extern "C" int cl4_dwconv5_wgrad(const float* x, const float* dy, float* dw, int
   int rc = check(a);
   if (rc) return rc;
   CL4_REQUIRE(x && dy && dw, "dwconv5_wgrad: null pointer");
-  const int ntiles = cl4::cdiv(h, T) * cl4::cdiv(wd, T);
-  int groups = cl4::cdiv(2048, (long)c * n);           // ~8 workgroups per CU in total
-  if (groups > ntiles) groups = ntiles;
-  if (groups < 1) groups = 1;
-  dim3 g(groups, c, n);
-  hipLaunchKernelGGL(dwconv5_wgrad_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, dy, dw, a);
+  static const int tile_form = getenv("CL4_DWCONV_TILE") ? atoi(getenv("CL4_DWCONV_TILE")) : 0;   // 1: the LDS tile kernel
+  if (tile_form) {
+    const int ntiles = cl4::cdiv(h, T) * cl4::cdiv(wd, T);
+    int groups = cl4::cdiv(2048, (long)c * n);           // ~8 workgroups per CU in total
+    if (groups > ntiles) groups = ntiles;
+    if (groups < 1) groups = 1;
+    dim3 g(groups, c, n);
+    hipLaunchKernelGGL(dwconv5_wgrad_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, dy, dw, a);
+  } else {
+    const int strips_x = cl4::cdiv(wd, SW);
+    const int srows = cl4::cdiv(h, cl4::cdiv(h, SROWS));
+    const int units = strips_x * cl4::cdiv(h, srows);
+    dim3 g((unsigned)n * c, cl4::cdiv(units, 4));
+    hipLaunchKernelGGL(dwconv5_wgrad_strip_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, dy, dw, a, strips_x, srows);
+  }
   return cl4::launch_status();
 }

@@ -93,8 +93,8 @@ def test_resize_bilinear_backward(gpu, case):
 
 @pytest.mark.parametrize("shape", [(2, 5, 129, 129), (1, 3, 7, 9), (3, 2, 33, 61), (1, 4, 64, 120), (2, 1, 1, 1)])
 def test_dwconv5_forward_and_input_gradient(gpu, shape):
-    """5x5 depthwise conv (streaming strip kernel: 60-column strips, 32-row chunks, halo lanes) against torch, forward and the
-    flipped-kernel input gradient, on sizes that are / are not multiples of the strip and chunk sizes."""
+    """5x5 depthwise conv (streaming strip kernels: 60-column strips, row chunks, halo lanes) against torch: forward, the
+    flipped-kernel input gradient and the weight gradient, on sizes that are / are not multiples of the strip and chunk sizes."""
     import torch.nn.functional as F
     from cl4wsis_amd import ops
     n, c, h, w = shape
@@ -109,3 +109,7 @@ def test_dwconv5_forward_and_input_gradient(gpu, shape):
     F.conv2d(xr, wt.double(), padding=2, groups=c).backward(dy.double())
     dx = ops.dwconv5(dy.to(gpu), wt.to(gpu), flip=True)
     assert ((dx.double().cpu() - xr.grad).abs().max() / xr.grad.abs().max()).item() < 1e-6
+    wr = wt.double().clone().requires_grad_(True)
+    F.conv2d(x.double(), wr, padding=2, groups=c).backward(dy.double())
+    dw = ops.dwconv5_wgrad_(torch.ones(c, 1, 5, 5, device=gpu), x.to(gpu), dy.to(gpu))      # accumulates into dw
+    assert ((dw.double().cpu() - 1 - wr.grad).abs().max() / wr.grad.abs().max()).item() < 2e-5
