@@ -66,6 +66,9 @@ class GradBuckets:
         self.fb = flat
         self.group = process_group
         self.world = world_size()
+        # single-rank rehearsal of the collective path (a 1-GPU box can still run RCCL with world size 1): behave as N > 1
+        self.solo = self.world == 1 and dist.is_initialized() and os.environ.get("CL4_FORCE_COLLECTIVES") == "1"
+        self.distributed = self.world > 1 or self.solo
         self.bounds = []            # (first tensor, last tensor exclusive)
         start, acc = 0, 0
         for i, n in enumerate(flat.sizes):
@@ -81,7 +84,7 @@ class GradBuckets:
                 self.bucket_of[i] = b
         self.is_cuda = flat.flat.is_cuda
         self.native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
-        self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.world > 1) else None
+        self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.distributed) else None
         self.reset()
 
     def reset(self):
@@ -93,7 +96,7 @@ class GradBuckets:
         lo, hi = self.bounds[b]
         chunk = self.fb.flat[self.fb.offsets[lo]:self.fb.offsets[hi]]
         self.launched[b] = True
-        if self.world == 1:
+        if not self.distributed:
             return
         if self.is_cuda:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
@@ -116,7 +119,7 @@ class GradBuckets:
         for b in range(len(self.bounds)):
             if not self.launched[b]:
                 self._launch(b)
-        if self.world > 1:
+        if self.distributed:
             if self.is_cuda:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
             else:

@@ -249,16 +249,16 @@ class Trainer:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 out = self._forward_backward(self._static["images"], self._static["l1h"], None)
-                if self.buckets.world == 1:
+                if not self.buckets.distributed:
                     opt.step(upload=False)
             self._static["out"] = out
-            opt._step -= 1 if self.buckets.world == 1 else 0   # capture only recorded the kernels
+            opt._step -= 1 if not self.buckets.distributed else 0   # capture only recorded the kernels
         self._static["images"].copy_(images)
         self._static["l1h"].copy_(l1h)
         opt.upload_lr()
         self._graph.replay()
         self._graph_active = True
-        if self.buckets.world == 1:
+        if not self.buckets.distributed:
             opt.note_replayed_step()
         else:                                   # gradients are averaged eagerly between the graph and the update
             for i in range(len(self.buckets.fb.sizes)):
@@ -320,7 +320,7 @@ class Trainer:
                                          old_w, pseudo, refined, (H, W), self.center_loss_weight, self.offset_loss_weight)
         # train.py:537 — backward of the trainable sub-net; gradient buckets are all-reduced as they complete
         self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map,
-                              on_ready=self._ready if (self.buckets.world > 1 and not torch.cuda.is_current_stream_capturing()) else None)
+                              on_ready=self._ready if (self.buckets.distributed and not torch.cuda.is_current_stream_capturing()) else None)
         return {"losses": losses, "seg_gt": seg_gt, "peaks": peaks, "pseudo": pseudo, "refined": refined,
                 "center": pred["center"], "offset": pred["offset"], "old_w": old_w}
 

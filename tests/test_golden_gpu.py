@@ -248,3 +248,44 @@ def test_trainer_step_voc_10_10(gpu):
     for v, k in zip(out["losses"].cpu().tolist(), ("center_old", "offset_old", "center_new", "offset_new")):
         r = float(ref[k].detach())
         assert abs(v - r) <= 1e-3 * max(abs(r), 1e-3), (k, v, r)
+
+
+def test_collective_path_over_rccl_single_rank(gpu, monkeypatch):
+    """The N > 1 training path (graph = forward .. backward; bucketed RCCL all-reduce (AVG) on the communication stream and Adam
+    after the replay) rehearsed on ONE GPU: a world-size-1 `nccl` (= RCCL) process group with CL4_FORCE_COLLECTIVES=1. Averaging
+    over one rank is the identity, so losses and weights must match the plain single-GPU run (Adam +-lr ambiguity aside)."""
+    import torch.distributed as dist
+    from cl4wsis_amd.train import Trainer
+    from oracle import weights
+    crop = 97
+    g = torch.Generator().manual_seed(18)
+    batches = [(torch.randn(2, 3, crop, crop, generator=g), torch.eye(20)[[16 + i % 4, 15]].clone()) for i in range(3)]
+    LR = 5e-6
+
+    def run():
+        opts = p2_opts(crop)
+        opts.lr = LR / 10
+        opts.max_iters, opts.start_decay = 50, 1
+        torch.manual_seed(0)
+        tr = Trainer(_Log(), gpu, opts)
+        for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
+            m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=31 + i))
+        tr._realias()
+        losses = [tr.step((x, l))["losses"].clone() for x, l in batches]
+        torch.cuda.synchronize()
+        w = torch.cat([p.detach().flatten() for p in tr._branch.trainable_parameters()]).cpu()
+        return torch.stack(losses).cpu(), w, tr
+
+    ls, ws, _ = run()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29577")
+    monkeypatch.setenv("CL4_FORCE_COLLECTIVES", "1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+    try:
+        ld, wd, tr = run()
+        assert tr.buckets.distributed and tr.buckets.native_avg and tr._graph is not None
+    finally:
+        dist.destroy_process_group()
+    assert torch.allclose(ls, ld, rtol=2e-3, atol=1e-6), (ls, ld)
+    d = (ws - wd).abs()
+    assert d.max() < 3.2 * LR and (d > 0.4 * LR).float().mean() < 1e-5 and d.mean() < 0.02 * LR
