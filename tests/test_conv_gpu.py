@@ -142,6 +142,31 @@ def test_conv_fwd_persistent_tiles(gpu, tile, k, cin):
     assert _rel_err(y.cpu(), ref) < TOL[1]
 
 
+@pytest.mark.parametrize("case", [(2, 128, 65, 65, 15), (1, 37, 40, 33, 2), (2, 512, 33, 33, 32), (3, 64, 129, 129, 5), (1, 16, 32, 32, 17)])
+def test_conv_thin_1x1(gpu, case):
+    """cout <= 32 1x1 convs (heads, low-level projections; the register-staged fp32 kernel): every epilogue operand, input and
+    output channel slices, ragged cin and pixel counts. (A scalar-weight streaming kernel for these layers was measured and
+    dropped: 313.7 vs 327.2 images/s — its per-FMA scalar weight loads serialise the wave.)"""
+    from cl4wsis_amd import ops
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    xfull = torch.randn(n, cin + 3, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    pre, post = torch.randn(n, cout, h, w, generator=g), torch.randn(n, cout, h, w, generator=g)
+    x = xfull[:, 2:2 + cin]
+    ref = F.conv2d(x.double(), wt.double()).float()
+    ref = F.leaky_relu((ref + pre) * scale[None, :, None, None] + shift[None, :, None, None], 0.2)
+    ref = F.relu(ref + post)
+    out = torch.full((n, cout + 4, h, w), 7.0, device=gpu)
+    wp = ops.pack_conv_weight(wt.to(gpu), 0)
+    ops.conv2d(xfull.to(gpu), wp, 1, scale=scale.to(gpu), shift=shift.to(gpu), pre=pre.to(gpu), post=post.to(gpu),
+               act1=ops.ACT_LEAKY, slope1=0.2, act2=ops.ACT_RELU, out=out, out_coff=1, in_coff=2, cin=cin)
+    torch.cuda.synchronize()
+    assert _rel_err(out[:, 1:1 + cout].cpu(), ref) < 1e-5
+    assert (out[:, 0] == 7).all() and (out[:, 1 + cout:] == 7).all()          # neighbouring channels untouched
+
+
 def test_conv_fwd_fused_epilogue(gpu):
     from cl4wsis_amd import ops
     g = torch.Generator().manual_seed(7)
