@@ -182,12 +182,14 @@ def main():
             "metric": "images/sec at batch 16, VOC 15-5 step-1 phase-2, 1/2/4/8 MI355X",
             "value": GLOBAL_BATCH * a.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32 (frozen-network convs as bf16x3 split products, fp32 accumulate)",
+            "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "VOC 15-5 step 1 phase 2 (BASELINE config 3), Trainer.step, global batch 16, "
                                    "513x513, ResNet101+DeepLabV3+Panoptic-DeepLab, run_refine on, random-init weights, "
                                    "label stage fed by the networks' own outputs (e2e-random mode)",
-                       "global_batch": GLOBAL_BATCH, "per_gpu_batch": b, "crop": CROP, "parallelism": f"dp{world}"},
+                       "global_batch": GLOBAL_BATCH, "per_gpu_batch": b, "crop": CROP, "parallelism": f"dp{world}",
+                       "arithmetic": "fp32 tensors; convolutions as split-bf16 MFMA products with fp32 accumulation (bf16x3 frozen networks, "
+                                     "bf16x6 = fp32-level for the differentiated convs, bf16x3 weight gradients)"},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_bf16x3 (cl4_conv2d_fwd precision 1): all its launches of 2 "
                                                     "eager steps run right after the timed region (graph replay and two-stream "
                                                     "overlap off), HIP events on the launch stream around every launch",
