@@ -72,7 +72,10 @@ def test_add_act_and_derivative(gpu):
 @pytest.mark.parametrize("case", [
     (5, 5, 65, 65, False),       # step 0 / validation: logits to image size, factor 13
     (33, 33, 513, 513, False),   # the full-size case, factor 15.5
-    (9, 9, 17, 17, True),        # decoder upsampling
+    (9, 9, 17, 17, True),        # decoder upsampling (exact 2x: the dedicated gather)
+    (33, 33, 65, 65, True),
+    (65, 65, 129, 129, True),
+    (3, 5, 5, 9, True),
     (7, 9, 33, 21, True),
     (17, 13, 9, 7, False),       # downsampling
     (4, 4, 4, 4, False),         # identity
