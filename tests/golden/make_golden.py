@@ -30,7 +30,7 @@ from oracle import synth, weights  # noqa: E402
 CROP = 65
 MODEL_SEED = 1
 INSMAP_CASES = [(0, 129, 129, False), (3, 129, 129, True), (6, 161, 145, True)]
-LABEL_CASES = [(0, 2, 129, 129), (3, 3, 129, 129), (5, 2, 97, 145), (6, 2, 193, 193)]
+LABEL_CASES = [(0, 2, 129, 129), (3, 3, 129, 129), (5, 2, 97, 145), (6, 2, 193, 193), (7, 2, 513, 513)]
 
 
 DATASET_CASES = [(0, 120, 160, 97, 1, True), (1, 150, 110, 129, 0, True), (2, 90, 200, 65, 1, False)]   # seed, H, W, crop, step, masking
@@ -230,8 +230,23 @@ def dataset_fixture(R, seed, H, W, size, step, masking):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
-def label_fixture(R, seed, b, H, W):
-    inp = synth.label_stage_inputs(seed, b=b, H=H, W=W)
+LABEL_EDGE_CASES = sorted(synth.EDGE_FIXTURES)      # hand-placed scenes, one per branch the seeded cases never take
+
+
+def label_edge_fixture(R, name, out_dir=HERE):
+    """label_edge_<name>.npz — the reference label stage on oracle.synth.label_stage_edge_inputs(name); see
+    tests/golden/trace_label_coverage.py for the proof that these fixtures execute the remaining statements."""
+    inp = synth.label_stage_edge_inputs(name)
+    b = inp["l1h"].shape[0]
+    # fixture c runs with the top_k the coco-voc task passes (train.py:498: 10000 -> modules/utils.py:496-497, same centres)
+    return label_fixture(R, -1, b, inp["H"], inp["W"], out_dir=out_dir, inp=inp, fname=f"label_edge_{name}.npz",
+                         top_k=10000 if name == "c" else None, extra={"edge_name": np.array(name)})
+
+
+def label_fixture(R, seed, b, H, W, out_dir=HERE, inp=None, fname=None, top_k=None, extra=None):
+    if inp is None:
+        inp = synth.label_stage_inputs(seed, b=b, H=H, W=W)
+    fname = fname or f"label_s{seed:02d}.npz"
     oc, tot = inp["old_classes"], inp["tot_classes"]
     wm, wu, bestie, loss = R["wss_modules"], R["wss_utils"], R["bestie"], R["loss"]
     l1h = inp["l1h"]
@@ -287,7 +302,7 @@ def label_fixture(R, seed, b, H, W):
     l1h_new = l1h.clone()
     l1h_new[:, :oc - 1] = 0
     refined = bestie.refine_label_generation(seg_max.clone(), center.clone(), offset.clone(), l1h_new.clone(),
-                                             seg_gt.clone(), None, A)
+                                             seg_gt.clone(), top_k, A)
     out.update(r_center=refined["center"][:, oc - 1:].numpy().copy(), r_offset=refined["offset"].numpy().copy(),
                r_weight=refined["weight"].numpy().copy())
     assert (refined["center"][:, :oc - 1] == 0).all()
@@ -305,8 +320,9 @@ def label_fixture(R, seed, b, H, W):
               0.5 * l1(offset, p_offset, p_weight) * 0.01]
     out["losses"] = np.array([float(v) for v in losses], dtype=np.float64)
     out["case"] = np.array([seed, b, H, W])
-    np.savez_compressed(os.path.join(HERE, f"label_s{seed:02d}.npz"), **out)
-    print(f"label_s{seed:02d}.npz", "peaks>=0.7:", int((conf >= 0.7).sum()), "pseudo px:", int(p_weight.gt(0).sum()),
+    out.update(extra or {})
+    np.savez_compressed(os.path.join(out_dir, fname), **out)
+    print(fname, "peaks>=0.7:", int((conf >= 0.7).sum()), "pseudo px:", int(p_weight.gt(0).sum()),
           "refined px:", int((refined['weight'] > 0).sum()), "losses:", out["losses"].round(4).tolist())
 
 
@@ -381,5 +397,7 @@ if __name__ == "__main__":
         dataset_fixture(R, *case)
     for case in LABEL_CASES:
         label_fixture(R, *case)
+    for name in LABEL_EDGE_CASES:
+        label_edge_fixture(R, name)
     for case in WSS_CASES:
         wss_fixture(R, *case)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import p2_opts, rel_err
+from util import label_inputs_for, p2_opts, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -72,7 +72,7 @@ def test_networks_match_reference_golden(gpu):
     assert rel_err(cam.cpu(), torch.from_numpy(gold["cam_lo"][:, 15:])) < NET_TOL
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "label_s*.npz"))))
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "label_*.npz"))))
 def test_label_stage_matches_reference_golden(gpu, path):
     """Bit-exact indices / labels against the reference's own outputs (not via the oracle)."""
     from cl4wsis_amd import ops
@@ -80,7 +80,7 @@ def test_label_stage_matches_reference_golden(gpu, path):
     from oracle.labels import gaussian
     gold = np.load(path)
     seed, b, H, W = (int(v) for v in gold["case"])
-    inp = synth.label_stage_inputs(seed, b=b, H=H, W=W)
+    inp = label_inputs_for(gold)
     d = {k: (v.to(gpu) if torch.is_tensor(v) else v) for k, v in inp.items()}
     oc = inp["old_classes"]
     label_new = d["l1h"][:, oc - 1:].contiguous()

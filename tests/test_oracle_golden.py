@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import p2_opts, rel_err
+from util import label_inputs_for, p2_opts, rel_err
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -129,14 +129,14 @@ def test_phase1_train_mode_restatement_matches_reference():
     assert rel_err(pl["norm2.running_mean"], torch.from_numpy(gold["rm_pl"])) < 1e-5
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "label_s*.npz"))))
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "label_*.npz"))))
 def test_label_stage_restatement_matches_reference(path):
     """cam, peaks, seg pseudo-GT, pseudo / refined labels, losses: the oracle equals the reference exactly
     (same PyTorch-CPU arithmetic; connected components through the same scipy restatement of OpenCV)."""
     from oracle import step, synth
     gold = np.load(path)
     seed, b, H, W = (int(v) for v in gold["case"])
-    inp = synth.label_stage_inputs(seed, b=b, H=H, W=W)
+    inp = label_inputs_for(gold)
     oc = inp["old_classes"]
     out = step.label_and_loss(inp["center_lo"], inp["offset_lo"], inp["old_center_lo"], inp["old_offset_lo"], inp["seg2b"],
                               inp["l1h"], inp["int_masks"], {"extra_conv4.weight": inp["pg_w"], "extra_conv4.bias": inp["pg_b"]},

@@ -135,3 +135,12 @@ def make_mini_coco(root, n_train=5, n_val=2, seed=3):
             json.dump({"images": images, "annotations": anns, "categories": [{"id": i} for i in range(1, 92)]}, f)
         out[split] = truth
     return out
+
+
+def label_inputs_for(gold):
+    """Inputs of a tests/golden/label_*.npz fixture, regenerated from its seed (label_sXX) or scene name (label_edge_X)."""
+    from oracle import synth
+    if "edge_name" in gold:
+        return synth.label_stage_edge_inputs(str(gold["edge_name"]))
+    seed, b, H, W = (int(v) for v in gold["case"])
+    return synth.label_stage_inputs(seed, b=b, H=H, W=W)
