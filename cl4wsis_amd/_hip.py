@@ -121,6 +121,7 @@ _decl("cl4_ccl", _P, _I, _I, _I, _I, _P, _P)
 _decl("cl4_cc_stats", _P, _I, _I, _I, _P, _P, _P, _P)
 _decl("cl4_label_generation", C.POINTER(LabelIO), _P, C.c_size_t, _P)
 _decl("cl4_label_counters", _P, _I, _I, _I, _P, _P)
+_decl("cl4_label_counters_accumulate", _P, _I, _I, _I, _P, _P)
 _decl("cl4_p2_loss", C.POINTER(P2LossIO), _P, C.c_size_t, _P)
 _decl("cl4_adam_step", _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P)
 _decl("cl4_adam_step_dev", _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _I, _P)
@@ -180,7 +181,7 @@ def load():
     lib.cl4_bn_workspace_bytes.argtypes = [C.c_int]
     lib.cl4_conv2d_fwd_workspace_bytes.restype = C.c_size_t
     lib.cl4_conv2d_fwd_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
-    for nm, at in (("cl4_peak_workspace_bytes", [C.c_int, C.c_int]), ("cl4_label_workspace_bytes", [C.c_int] * 3),
+    for nm, at in (("cl4_peak_workspace_bytes", [C.c_int] * 5), ("cl4_label_workspace_bytes", [C.c_int] * 3),
                    ("cl4_p2_loss_workspace_bytes", [C.c_int] * 6), ("cl4_pamr_workspace_bytes", [C.c_int] * 5),
                    ("cl4_ngwp_workspace_bytes", [C.c_int] * 2), ("cl4_balanced_ce_workspace_bytes", [C.c_int] * 4),
                    ("cl4_bce_ignore_workspace_bytes", []), ("cl4_p1loss_workspace_bytes", [C.c_int] * 4), ("cl4_cam_smooth_workspace_bytes", [C.c_int] * 4),

@@ -146,24 +146,54 @@ __global__ __launch_bounds__(256) void cam_avg_kernel(const float* __restrict__ 
 constexpr int PT = 32;
 constexpr int PMAXR = 7;                      // kernel 15
 constexpr int PTS = PT + 2 * PMAXR;           // 46
-constexpr int CAND_CAP = 8192;
+constexpr int PK_MAX = 64;                    // K <= 64 (25 in the reference)
 
 struct PeakCand {
-  float v;
+  float v;     // 0 = empty slot
   int idx;
 };
 
-__global__ __launch_bounds__(256) void peak_nms_kernel(const float* __restrict__ cam, int h, int w, int H, int W, int R,
-                                                       const float* __restrict__ label, PeakCand* __restrict__ cand,
-                                                       int* __restrict__ cand_cnt) {
+// key = (value bits << 32) | (0xFFFFFFFF - idx): max key = largest value, then smallest flat index (positive values only,
+// so the float bit pattern orders like the value)
+__device__ __forceinline__ unsigned long long peak_key(float v, int idx) {
+  return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
+}
+
+// workgroup-wide max of a 64-bit key (256 threads); every thread returns the winner
+__device__ __forceinline__ unsigned long long block_max_key(unsigned long long key, unsigned long long* best) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long other = __shfl_xor(key, o, 64);
+    key = other > key ? other : key;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = key;
+  __syncthreads();
+  key = best[0];
+  for (int q = 1; q < 4; ++q) key = best[q] > key ? best[q] : key;
+  return key;
+}
+
+// One workgroup per 32x32 output tile of one (b, c): upsample + 15x15 max-pool NMS in LDS, then the tile's OWN top-K
+// (value descending, ties by ascending flat index) is written to its K slots. A tile can contribute at most K entries to the
+// global top-K, so the second pass over tiles*K slots is exact whatever the number of plateau ties (the earlier global
+// candidate list with a fixed capacity dropped real peaks at 513x513, where near-zero plateaus yield > 8192 candidates).
+__global__ __launch_bounds__(256) void peak_nms_kernel(const float* __restrict__ cam, int h, int w, int H, int W, int R, int K,
+                                                       const float* __restrict__ label, PeakCand* __restrict__ cand) {
   extern __shared__ float lds[];
   float* lo = lds;                 // [h*w]
   float* val = lds + h * w;        // [PTS][PTS]
   float* rmax = val + PTS * PTS;   // [PTS][PT]
+  __shared__ unsigned long long keys[PT * PT];
+  __shared__ unsigned long long best[4];
   const int tiles_x = (W + PT - 1) / PT;
   const int ty0 = (blockIdx.x / tiles_x) * PT, tx0 = (blockIdx.x % tiles_x) * PT;
   const int c = blockIdx.y, b = blockIdx.z, C = gridDim.y;
-  if (label[b * C + c] == 0.f) return;  // unlabelled class: its CAM is identically zero, no positive peak
+  PeakCand* out = cand + (((long)(b * C + c)) * gridDim.x + blockIdx.x) * K;
+  if (label[b * C + c] == 0.f) {   // unlabelled class: its CAM is identically zero, no positive peak
+    for (int k = threadIdx.x; k < K; k += blockDim.x) out[k] = PeakCand{0.f, 0};
+    return;
+  }
   const float* plane = cam + ((long)b * C + c) * h * w;
   for (int i = threadIdx.x; i < h * w; i += blockDim.x) lo[i] = plane[i];
   __syncthreads();
@@ -190,56 +220,58 @@ __global__ __launch_bounds__(256) void peak_nms_kernel(const float* __restrict__
   for (int i = threadIdx.x; i < PT * PT; i += blockDim.x) {
     int y = i / PT, x = i - y * PT;
     int Y = ty0 + y, X = tx0 + x;
-    if (Y >= H || X >= W) continue;
-    float m = -INFINITY;
-    for (int d = 0; d <= 2 * R; ++d) m = fmaxf(m, rmax[(y + d) * PT + x]);
-    float v = val[(y + R) * PTS + x + R];
-    if (v == m && v > 0.f) {
-      int slot = atomicAdd(&cand_cnt[b * C + c], 1);
-      if (slot < CAND_CAP) {
-        cand[((long)(b * C + c)) * CAND_CAP + slot].v = v;
-        cand[((long)(b * C + c)) * CAND_CAP + slot].idx = Y * W + X;
-      }
+    unsigned long long key = 0ull;
+    if (Y < H && X < W) {
+      float m = -INFINITY;
+      for (int d = 0; d <= 2 * R; ++d) m = fmaxf(m, rmax[(y + d) * PT + x]);
+      float v = val[(y + R) * PTS + x + R];
+      if (v == m && v > 0.f) key = peak_key(v, Y * W + X);
     }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    unsigned long long key = 0ull;
+    for (int i = threadIdx.x; i < PT * PT; i += blockDim.x) key = keys[i] > key ? keys[i] : key;
+    key = block_max_key(key, best);
+    if (key == 0ull) {             // uniform: the tile has fewer than K candidates
+      for (int q = k + threadIdx.x; q < K; q += blockDim.x) out[q] = PeakCand{0.f, 0};
+      return;
+    }
+    const int idx = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
+    const int ly = idx / W - ty0, lx = idx % W - tx0;
+    if (threadIdx.x == 0) {
+      out[k] = PeakCand{__uint_as_float((unsigned)(key >> 32)), idx};
+      keys[ly * PT + lx] = 0ull;   // remove the winner
+    }
+    __syncthreads();
   }
 }
 
-// top-K of the candidates of one (b, c): value descending, ties by ascending flat index.
-__global__ __launch_bounds__(256) void peak_topk_kernel(PeakCand* __restrict__ cand, const int* __restrict__ cand_cnt, int W,
+// top-K of the n = tiles*K slots of one (b, c): value descending, ties by ascending flat index.
+__global__ __launch_bounds__(256) void peak_topk_kernel(PeakCand* __restrict__ cand, int n, int W,
                                                         int K, float* __restrict__ conf, int* __restrict__ ys,
                                                         int* __restrict__ xs) {
   __shared__ unsigned long long best[4];
   const int bc = blockIdx.x;
-  int n = cand_cnt[bc];
-  if (n > CAND_CAP) n = CAND_CAP;
-  PeakCand* cl = cand + (long)bc * CAND_CAP;
+  PeakCand* cl = cand + (long)bc * n;
   for (int k = 0; k < K; ++k) {
-    // key = (value bits << 32) | (0xFFFFFFFF - idx): max key = largest value, then smallest index
     unsigned long long key = 0ull;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       float v = cl[i].v;
       if (v > 0.f) {
-        unsigned long long kk = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)cl[i].idx);
+        unsigned long long kk = peak_key(v, cl[i].idx);
         key = kk > key ? kk : key;
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      unsigned long long other = __shfl_xor(key, o, 64);
-      key = other > key ? other : key;
-    }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = key;
-    __syncthreads();
-    key = best[0];
-    for (int q = 1; q < 4; ++q) key = best[q] > key ? best[q] : key;
+    key = block_max_key(key, best);
     float v = 0.f;
     int idx = 0;
     if (key != 0ull) {
       v = __uint_as_float((unsigned)(key >> 32));
       idx = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
       for (int i = threadIdx.x; i < n; i += blockDim.x)
-        if (cl[i].idx == idx) cl[i].v = -1.f;  // remove the winner
+        if (cl[i].idx == idx && cl[i].v > 0.f) cl[i].v = -1.f;  // remove the winner
     }
     if (threadIdx.x == 0) {
       conf[(long)bc * K + k] = v;
@@ -505,26 +537,25 @@ extern "C" int cl4_cam_smooth(const float* int_masks, int b, int ctot, int h, in
   return cl4::launch_status();
 }
 
-extern "C" size_t cl4_peak_workspace_bytes(int b, int c) {
-  return (size_t)b * c * (CAND_CAP * sizeof(PeakCand) + sizeof(int));
+extern "C" size_t cl4_peak_workspace_bytes(int b, int c, int H, int W, int K) {
+  return (size_t)b * c * cl4::cdiv(H, PT) * cl4::cdiv(W, PT) * K * sizeof(PeakCand);
 }
 
 extern "C" int cl4_peak_extract(const float* cam, const float* label_new, int b, int c, int h, int w, int H, int W, int kernel,
                                 int K, float* conf, int* ys, int* xs, void* workspace, size_t workspace_bytes, void* stream) {
   CL4_REQUIRE(cam && label_new && conf && ys && xs && workspace, "peak_extract: null pointer");
-  CL4_REQUIRE(b > 0 && c > 0 && h > 0 && w > 0 && H > 0 && W > 0 && K > 0, "peak_extract: bad dims");
+  CL4_REQUIRE(b > 0 && c > 0 && h > 0 && w > 0 && H > 0 && W > 0 && K > 0 && K <= PK_MAX, "peak_extract: bad dims (K <= 64)");
+  CL4_REQUIRE((long)H * W < 2147483647L, "peak_extract: flat index overflows int32");
   CL4_REQUIRE(kernel % 2 == 1 && kernel >= 1 && (kernel - 1) / 2 <= PMAXR, "peak_extract: kernel %d unsupported (odd, <= 15)", kernel);
-  if (workspace_bytes < cl4_peak_workspace_bytes(b, c)) { cl4::set_error("peak_extract: workspace too small"); return CL4_ENOSPC; }
+  if (workspace_bytes < cl4_peak_workspace_bytes(b, c, H, W, K)) { cl4::set_error("peak_extract: workspace too small"); return CL4_ENOSPC; }
   size_t lds = ((size_t)h * w + PTS * PTS + PTS * PT) * sizeof(float);
-  CL4_REQUIRE(lds <= 64 * 1024, "peak_extract: low-res map %dx%d does not fit LDS", h, w);
+  CL4_REQUIRE(lds <= 48 * 1024, "peak_extract: low-res map %dx%d does not fit LDS", h, w);
   hipStream_t st = cl4::as_stream(stream);
-  int* cnt = (int*)workspace;
-  PeakCand* cand = (PeakCand*)((char*)workspace + (((size_t)b * c * sizeof(int) + 15) / 16) * 16);
-  CL4_REQUIRE((char*)(cand + (size_t)b * c * CAND_CAP) <= (char*)workspace + workspace_bytes + 16, "peak_extract: workspace layout");
-  hipMemsetAsync(cnt, 0, (size_t)b * c * sizeof(int), st);
-  dim3 g(cl4::cdiv(H, PT) * cl4::cdiv(W, PT), c, b);
-  hipLaunchKernelGGL(peak_nms_kernel, g, dim3(256), lds, st, cam, h, w, H, W, (kernel - 1) / 2, label_new, cand, cnt);
-  hipLaunchKernelGGL(peak_topk_kernel, dim3(b * c), dim3(256), 0, st, cand, cnt, W, K, conf, ys, xs);
+  PeakCand* cand = (PeakCand*)workspace;
+  const int tiles = cl4::cdiv(H, PT) * cl4::cdiv(W, PT);
+  dim3 g(tiles, c, b);
+  hipLaunchKernelGGL(peak_nms_kernel, g, dim3(256), lds, st, cam, h, w, H, W, (kernel - 1) / 2, K, label_new, cand);
+  hipLaunchKernelGGL(peak_topk_kernel, dim3(b * c), dim3(256), 0, st, cand, tiles * K, W, K, conf, ys, xs);
   return cl4::launch_status();
 }
 

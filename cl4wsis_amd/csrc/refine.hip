@@ -591,6 +591,23 @@ extern "C" int cl4_label_counters(const void* workspace, int b, int H, int W, in
   return cl4::launch_status();
 }
 
+static __global__ void counters_accumulate_kernel(const Counters* cnt, int* acc5) {
+  const int v[5] = {cnt->n_contour, cnt->n_psplat, cnt->n_center, cnt->n_cand, cnt->overflow};
+  for (int i = 0; i < 4; ++i) acc5[i] = max(acc5[i], v[i]);
+  acc5[4] |= v[4];
+}
+
+// Sticky diagnostics for the training loop: acc5[0..3] = max over calls of {n_contour, n_psplat, n_center, n_cand},
+// acc5[4] |= overflow. Enqueue-only (graph-capturable); the trainer reads acc5 at its logging sync and raises when a
+// table capacity was hit, so truncated labels can never pass silently.
+extern "C" int cl4_label_counters_accumulate(const void* workspace, int b, int H, int W, int* acc5, void* stream) {
+  CL4_REQUIRE(workspace && acc5, "label_counters_accumulate: null pointer");
+  WS ws;
+  layout(&ws, (char*)workspace, (long)b * H * W);
+  hipLaunchKernelGGL(counters_accumulate_kernel, dim3(1), dim3(1), 0, cl4::as_stream(stream), ws.cnt, acc5);
+  return cl4::launch_status();
+}
+
 // Validation post-processing (dataset/utils.py:795-892 get_ins_map): one image, full-resolution maps, every class.
 extern "C" int cl4_instance_map(const cl4_insmap_io* d, void* workspace, size_t workspace_bytes, void* stream) {
   CL4_REQUIRE(d && workspace, "instance_map: null pointer");

@@ -530,7 +530,7 @@ def peak_extract(cam, label_new, size, kernel=15, K=25):
     conf = torch.empty((b, c, K), dtype=torch.float32, device=cam.device)
     ys = torch.empty((b, c, K), dtype=torch.int32, device=cam.device)
     xs = torch.empty_like(ys)
-    nbytes = _hip.load().cl4_peak_workspace_bytes(b, c) + 64
+    nbytes = _hip.load().cl4_peak_workspace_bytes(b, c, H, W, K)
     ws = _workspace(cam.device, nbytes)
     call("cl4_peak_extract", ptr(cam), ptr(label_new), b, c, h, w, H, W, kernel, K, ptr(conf), ptr(ys), ptr(xs), ptr(ws),
          ws.numel(), stream())
@@ -610,6 +610,18 @@ def label_counters(b, H, W, device):
     out = torch.empty(5, dtype=torch.int32, device=device)
     call("cl4_label_counters", ptr(ws), b, H, W, ptr(out), stream())
     return dict(zip(("n_contour", "n_psplat", "n_center", "n_cand", "overflow"), out.cpu().tolist()))
+
+
+def label_counters_accumulate_(acc5, b, H, W):
+    """acc5 (int32[5], device): running max of {n_contour, n_psplat, n_center, n_cand} and OR of the overflow flag of the
+    last label_generation. Enqueue-only."""
+    nbytes = _hip.load().cl4_label_workspace_bytes(b, H, W)
+    ws = _label_ws[(acc5.device.index, nbytes)]
+    call("cl4_label_counters_accumulate", ptr(ws), b, H, W, ptr(acc5), stream())
+    return acc5
+
+
+LABEL_COUNTER_NAMES = ("n_contour", "n_psplat", "n_center", "n_cand", "overflow")
 
 
 def p2_loss(center, offset, old_center, old_offset, old_w, pseudo, refined, size, center_weight=200.0,

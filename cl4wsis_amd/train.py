@@ -93,6 +93,7 @@ class Trainer:
         self._side_stream = torch.cuda.Stream(device=self.device) if os.environ.get("CL4_OVERLAP", "1") != "0" else None
         self._use_graph = os.environ.get("CL4_GRAPH", "1") != "0"
         self._graph, self._static, self._graph_active = None, None, False
+        self._label_acc = torch.zeros(5, dtype=torch.int32, device=self.device)   # sticky label-stage counters, see check_label_overflow
         self._seed_dev = torch.tensor([opts.random_seed * 1000003 + 7919 * (dist.get_rank() if dist.is_initialized() else 0)],
                                       dtype=torch.int64, device=self.device)
 
@@ -313,6 +314,7 @@ class Trainer:
             seg_gt, prob_win, label_new, peaks, pred["center"], pred["offset"], self._g_dev, oc, sigma=self.sigma,
             pseudo_thresh=opts.pseudo_thresh, refine_thresh=opts.refine_thresh, nms_kernel=opts.kernel, beta=opts.beta,
             run_refine=opts.run_refine)
+        ops.label_counters_accumulate_(self._label_acc, bs, H, W)
         if self._side_stream is not None:
             main.wait_stream(self._side_stream)      # the old model's centre / offset maps are consumed from here on
         # train.py:503-522 — blended targets + four weighted losses (+ gradient w.r.t. the low-resolution maps)
@@ -323,6 +325,21 @@ class Trainer:
                               on_ready=self._ready if (self.buckets.distributed and not torch.cuda.is_current_stream_capturing()) else None)
         return {"losses": losses, "seg_gt": seg_gt, "peaks": peaks, "pseudo": pseudo, "refined": refined,
                 "center": pred["center"], "offset": pred["offset"], "old_w": old_w}
+
+    def label_counters(self):
+        """Running maxima of the label stage's device-side table counts since construction + the sticky overflow flag
+        (forces a host sync)."""
+        return dict(zip(ops.LABEL_COUNTER_NAMES, self._label_acc.tolist()))
+
+    def check_label_overflow(self):
+        """The label kernels keep contours / centres / splats in fixed-capacity device tables (csrc/refine.hip CT_CAP,
+        LIST_CAP) and set a flag instead of writing past them. Truncated labels would be silently wrong targets, so the
+        flag is read wherever the loop synchronises with the host anyway and is fatal."""
+        c = self.label_counters()
+        if c["overflow"]:
+            raise RuntimeError(f"label stage: a device table capacity was exceeded (counters {c}); labels of at least one "
+                               "iteration were truncated")
+        return c
 
     def _ready(self, param):
         self.buckets.ready(self.optimizer.index[id(param)])
@@ -348,10 +365,14 @@ class Trainer:
             if (cur_step + 1) % print_int == 0:
                 v = interval.item() / print_int  # the only host sync, every print_int iterations
                 assert np.isfinite(v), f"l_reg: {v}"   # train.py:535
+                if self.weakly and self.opts.phase == 2:
+                    self.check_label_overflow()
                 logger.debug(f"Epoch {cur_epoch}, Batch {cur_step + 1}/{len(train_loader)}, Loss={v}")
                 if logger is not None and hasattr(logger, "add_scalar"):
                     logger.add_scalar("Loss/tot", v, cur_epoch * len(train_loader) + cur_step + 1, intermediate=True)
                 interval.zero_()
+        if self.weakly and self.opts.phase == 2:
+            self.check_label_overflow()
         reg = torch.zeros_like(total)
         if dist.is_initialized():
             dist.reduce(total, dst=0)

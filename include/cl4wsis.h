@@ -208,7 +208,7 @@ int cl4_cam_smooth(const float* int_masks, int b, int ctot, int h, int w, const 
                    void* stream);
 /* Bilinear upsample (align_corners=False) to HxW fused with peak_extract (wss/utils.py:3-25): kernel x kernel max-pool
  * NMS + top-K per (b,c). conf/ys/xs: [b,c,K]; slots beyond the positive peaks hold conf=0,y=x=0. Ties: lowest index. */
-size_t cl4_peak_workspace_bytes(int b, int c);
+size_t cl4_peak_workspace_bytes(int b, int c, int H, int W, int K);
 int cl4_peak_extract(const float* cam, const float* label_new, int b, int c, int h, int w, int H, int W, int kernel, int K,
                      float* conf, int* ys, int* xs, void* workspace, size_t workspace_bytes, void* stream);
 /* train.py:263,438-449: flip-TTA mean of seg2b [2b,C,h,w] -> upsample -> softmax -> label mask -> argmax.
@@ -248,6 +248,9 @@ size_t cl4_label_workspace_bytes(int b, int H, int W);
 int cl4_label_generation(const cl4_label_io* d, void* workspace, size_t workspace_bytes, void* stream);
 /* {n_contour, n_psplat, n_center, n_cand, overflow} of the last call on this workspace -> out5 (device). */
 int cl4_label_counters(const void* workspace, int b, int H, int W, int* out5, void* stream);
+/* Sticky form for the training loop (train.py:535 is the reference's only per-interval host check): acc5[0..3] = running
+   max of the four counts, acc5[4] |= overflow. Enqueue-only, graph-capturable. */
+int cl4_label_counters_accumulate(const void* workspace, int b, int H, int W, int* acc5, void* stream);
 
 /* train.py:503-522 with utils/loss.py:228-275: blending + four weighted losses, fused with the bilinear upsample of
  * the low-resolution maps; optionally the gradient w.r.t. center / offset (low resolution). */
