@@ -93,6 +93,7 @@ class Trainer:
         self._side_stream = torch.cuda.Stream(device=self.device) if os.environ.get("CL4_OVERLAP", "1") != "0" else None
         self._use_graph = os.environ.get("CL4_GRAPH", "1") != "0"
         self._graph, self._static, self._graph_active = None, None, False
+        self._label_override = None
         self._label_acc = torch.zeros(5, dtype=torch.int32, device=self.device)   # sticky label-stage counters, see check_label_overflow
         self._seed_dev = torch.tensor([opts.random_seed * 1000003 + 7919 * (dist.get_rank() if dist.is_initialized() else 0)],
                                       dtype=torch.int64, device=self.device)
@@ -305,13 +306,17 @@ class Trainer:
         self.peakgenerator.eval()
         int_masks = self.pseudolabeler(features["body"][:bs])
         label_new = l1h[:, oc - 1:].contiguous()
+        seg2b, lab_center, lab_offset = outputs["seg"], pred["center"], pred["offset"]
+        if self._label_override is not None:    # benchmark-only: see set_label_override (every network above still ran)
+            ov = self._label_override
+            int_masks, seg2b, lab_center, lab_offset = ov["int_masks"], ov["seg2b"], ov["center_lo"], ov["offset_lo"]
         cam = self.peakgenerator.cam(int_masks, label_new)
         peaks = ops.peak_extract(cam, label_new, (H, W), kernel=15, K=25)
         # train.py:438-449 — semantic pseudo ground truth
-        seg_gt, old_w, prob_win = ops.seg_pseudo_gt(outputs["seg"], l1h, oc, (H, W), no_mask=opts.no_mask)
+        seg_gt, old_w, prob_win = ops.seg_pseudo_gt(seg2b, l1h, oc, (H, W), no_mask=opts.no_mask)
         # train.py:451-500 — pseudo labels + refined labels
         pseudo, refined = ops.label_generation(
-            seg_gt, prob_win, label_new, peaks, pred["center"], pred["offset"], self._g_dev, oc, sigma=self.sigma,
+            seg_gt, prob_win, label_new, peaks, lab_center, lab_offset, self._g_dev, oc, sigma=self.sigma,
             pseudo_thresh=opts.pseudo_thresh, refine_thresh=opts.refine_thresh, nms_kernel=opts.kernel, beta=opts.beta,
             run_refine=opts.run_refine)
         ops.label_counters_accumulate_(self._label_acc, bs, H, W)
@@ -325,6 +330,22 @@ class Trainer:
                               on_ready=self._ready if (self.buckets.distributed and not torch.cuda.is_current_stream_capturing()) else None)
         return {"losses": losses, "seg_gt": seg_gt, "peaks": peaks, "pseudo": pseudo, "refined": refined,
                 "center": pred["center"], "offset": pred["offset"], "old_w": old_w}
+
+    def set_label_override(self, inputs):
+        """Benchmark hook (SURVEY.md §8(d) *structured-labels* mode): with random-init networks the label stage only ever sees
+        noise (mostly sub-20-px components), so its connected-component / peak / refine kernels do unrepresentative work.
+        `inputs` = {seg2b [2b,C,h,w], int_masks [b,C,h,w], center_lo [b,C-1,hc,wc], offset_lo [b,2,hc,wc]} (device tensors)
+        replaces what the label stage READS; every network still runs and the losses still act on the real predictions.
+        None restores the end-to-end path. The captured graph is dropped because the kernel arguments change."""
+        if inputs is not None:
+            inputs = {k: inputs[k].to(self.device, dtype=torch.float32).contiguous() for k in ("seg2b", "int_masks", "center_lo", "offset_lo")}
+        self._label_override = inputs
+        self._graph, self._static = None, None
+        if self._graph_active:
+            from .nn import CACHE
+            CACHE.clear()
+            self._graph_active = False
+        self._label_acc.zero_()
 
     def label_counters(self):
         """Running maxima of the label stage's device-side table counts since construction + the sticky overflow flag

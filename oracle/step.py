@@ -28,27 +28,31 @@ def label_and_loss(center_lo, offset_lo, old_center_lo, old_offset_lo, seg2b, l1
         cam = F.interpolate(cam, size=size, mode="bilinear", align_corners=False)
     center = F.interpolate(center_lo, size=size, mode="bilinear", align_corners=False)
     offset = F.interpolate(offset_lo, size=size, mode="bilinear", align_corners=False)
-    peak_conf, peak_y, peak_x = L.peak_extract(cam.detach(), kernel=15, K=K)
+    dev = center_lo.device      # cpu for the oracle proper; "cuda" only in bench.py's stock-ops comparator leg, where — like
+    # the reference on a GPU — everything below that is numpy / OpenCV-style host code works on .cpu() copies
+    peak_conf, peak_y, peak_x = L.peak_extract(cam.detach().float().cpu(), kernel=15, K=K)
     out.update(peak_conf=peak_conf, peak_y=peak_y, peak_x=peak_x)
     with torch.no_grad():
         seg_gt, old_w, soft, seg_up = L.seg_pseudo_gt(seg2b, l1h, old_classes, size, no_mask=no_mask)
     out.update(seg_gt=seg_gt, old_w=old_w, soft=soft)
-    cls_label = l1h.numpy().copy()
+    cls_label = l1h.cpu().numpy().copy()
     cls_label[:, :old_classes - 1] = 0
     g = L.gaussian(sigma)
     pc, po, pw = [], [], []
     for b in range(bs):
         pts = L.select_points(peak_conf, peak_y, peak_x, cls_label[b], b, pseudo_thresh)
-        c, o, w, _ = L.pseudo_label_generation(seg_gt[b].numpy(), pts, cls_label[b], tot - 1, sigma, g)
+        c, o, w, _ = L.pseudo_label_generation(seg_gt[b].cpu().numpy(), pts, cls_label[b], tot - 1, sigma, g)
         pc.append(torch.from_numpy(c)); po.append(torch.from_numpy(o)); pw.append(torch.from_numpy(w))
-    pseudo = {"center": torch.stack(pc), "offset": torch.stack(po), "weight": torch.stack(pw)}
+    pseudo = {"center": torch.stack(pc).to(dev), "offset": torch.stack(po).to(dev), "weight": torch.stack(pw).to(dev)}
     out["pseudo"] = {k: v.clone() for k, v in pseudo.items()}
     refined = None
     if run_refine:
         l1h_new = l1h.clone()
         l1h_new[:, :old_classes - 1] = 0
-        refined = L.refine_label_generation(seg_up.clone(), center.detach().clone(), offset.detach().clone(), l1h_new,
-                                            seg_gt.clone(), refine_thresh, kernel, beta, sigma)
+        host = lambda t: t.detach().float().cpu().clone()
+        refined = L.refine_label_generation(host(seg_up), host(center), host(offset), l1h_new.cpu(), seg_gt.cpu().clone(),
+                                            refine_thresh, kernel, beta, sigma)
+        refined = {k: v.to(dev) for k, v in refined.items()}
         out["refined"] = refined
     old_center = F.interpolate(old_center_lo, size=size, mode="bilinear", align_corners=False)
     old_offset = F.interpolate(old_offset_lo, size=size, mode="bilinear", align_corners=False)
@@ -67,23 +71,31 @@ def trainable_names(sd):
 
 
 def p2_step(sd_new, sd_old, sd_pl, sd_pg, images, l1h, old_classes, pooling=32, dropout_mask=None, lr=5e-4,
-            adam_state=None, step=1, betas=(0.9, 0.999), eps=1e-8, **label_kw):
+            adam_state=None, step=1, betas=(0.9, 0.999), eps=1e-8, autocast=False, **label_kw):
     """One phase-2 iteration on the CPU (train.py:241-541): returns losses, intermediates, gradients and applies Adam
-    to `sd_new` in place (torch.optim.Adam arithmetic)."""
+    to `sd_new` in place (torch.optim.Adam arithmetic). `autocast` (timing legs only): run the networks under
+    torch.autocast(float16) like the reference's amp.autocast block (train.py:252); outputs are widened to fp32 before the
+    label stage."""
     bs = images.shape[0]
     size = tuple(images.shape[-2:])
-    with torch.no_grad():
-        out_old, _ = M.forward_full(images, sd_old, pooling=pooling, training=False)
-        out2, aux = M.forward_seg(torch.cat([images, images.flip(-1)], 0), sd_new, pooling=pooling, training=False)
-    feats = {k: v[:bs].detach().clone() for k, v in aux["features"].items()}
     names = trainable_names(sd_new)
-    for k in names:
-        sd_new[k].requires_grad_(True)
-        sd_new[k].grad = None
-    ins = M.instance_decoder(feats, sd_new, training=True, dropout_mask=dropout_mask)
-    pred = M.instance_head(ins, sd_new, training=True)
-    with torch.no_grad():
-        int_masks = M.pseudolabeler(aux["body"][:bs], sd_pl)
+    with torch.autocast(device_type=images.device.type, dtype=torch.float16, enabled=autocast):
+        with torch.no_grad():
+            out_old, _ = M.forward_full(images, sd_old, pooling=pooling, training=False)
+            out2, aux = M.forward_seg(torch.cat([images, images.flip(-1)], 0), sd_new, pooling=pooling, training=False)
+        feats = {k: v[:bs].detach().clone() for k, v in aux["features"].items()}
+        for k in names:
+            sd_new[k].requires_grad_(True)
+            sd_new[k].grad = None
+        ins = M.instance_decoder(feats, sd_new, training=True, dropout_mask=dropout_mask)
+        pred = M.instance_head(ins, sd_new, training=True)
+        with torch.no_grad():
+            int_masks = M.pseudolabeler(aux["body"][:bs], sd_pl)
+    if autocast:
+        out_old = {k: v.float() for k, v in out_old.items()}
+        out2 = {k: v.float() for k, v in out2.items()}
+        pred = {k: v.float() for k, v in pred.items()}
+        int_masks = int_masks.float()
     out = label_and_loss(pred["center"], pred["offset"], out_old["center"], out_old["offset"], out2["seg"], l1h, int_masks,
                          sd_pg, size, old_classes, **label_kw)
     out["loss"].backward()
