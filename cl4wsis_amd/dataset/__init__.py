@@ -8,7 +8,8 @@ from .dataset import IncrementalInstanceSegmentationDataset, LabelSelection, Raw
 from .loader import DeviceLoader  # noqa: F401
 from .transform import *  # noqa: F401,F403
 from .coco import COCO, COCOIncremental  # noqa: F401
-from .voc import VOCasCOCOSegmentationIncremental, VOCInstanceSegmentation, VOCInstanceSegmentationIncremental  # noqa: F401
+from .voc import (VOCasCOCOSegmentationIncremental, VOCInstanceSegmentation, VOCInstanceSegmentationIncremental,  # noqa: F401
+                  VOCSegmentation)
 
 MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
 

@@ -49,6 +49,7 @@ class VOCInstanceSegmentation:
 
     def __init__(self, data_dir, ann_file, old_classes, new_classes, is_train=True, val_on_trainset=False, pseudo=None,
                  overlap=True, as_coco=False, masking=True):
+        # `as_coco` is stored and never read, exactly as in the reference: the coco-voc protocol uses VOCSegmentation below
         self.root = os.path.join(data_dir, "voc", "JPEGImages")
         self.coco = CocoIndex(ann_file)
         self.ids = sorted(self.coco.imgs.keys())
@@ -109,10 +110,70 @@ class VOCInstanceSegmentationIncremental(IncrementalInstanceSegmentationDataset)
                                        overlap=overlap, masking=masking)
 
 
+class VOCSegmentation:
+    """dataset/voc.py:46-172 — the file-list VOC source: `splits/{train_aug,val}[_ascoco].txt` rows "/JPEGImages/x.jpg
+    /SegmentationClassAug[AsCoco]/x.png", instance ids from SegmentationObjectAug, image-level labels from
+    `{voc,cocovoc}_1h_labels_{train,val}.npy`, optional image subset `indices`. With `as_coco` the semantic maps and the
+    label vectors are the pre-remapped COCO-id versions (91-way vectors), which is what coco-voc steps > 0 train on.
+    Train items: (image u8, seg u8, instance-id u8, labels); otherwise (image, seg, masks [R,H,W], mask labels [R], name)."""
+
+    def __init__(self, root, train=True, transform=None, indices=None, as_coco=False, saliency=False, pseudo=None):
+        self.root = os.path.expanduser(root)
+        self.transform, self.is_train, self.pseudo, self.as_coco = transform, train, pseudo, as_coco
+        self.image_set = "train" if train else "val"
+        voc_root = os.path.join(self.root, "voc")
+        if not os.path.isdir(voc_root):
+            raise RuntimeError("Dataset not found or corrupted. Download it")
+        assert os.path.exists(os.path.join(voc_root, "SegmentationClassAug")), "SegmentationClassAug not found"
+        name = ("train_aug" if train else "val") + ("_ascoco" if as_coco else "") + ".txt"
+        split_f = os.path.join(voc_root, "splits", name)
+        if not os.path.exists(split_f):
+            raise ValueError('Wrong image_set entered! Please use image_set="train" or image_set="trainval" or image_set="val"')
+        with open(split_f) as f:
+            rows = [x[:-1].split(" ") for x in f.readlines()]
+        self.file_names = [x[0][1:].split("/")[1] for x in rows]
+        ori = "SegmentationClassAugAsCoco" if as_coco else "SegmentationClassAug"
+        self.images = [(os.path.join(voc_root, x[0][1:]), os.path.join(voc_root, x[1][1:]),
+                        os.path.join(voc_root, x[1][1:].replace(ori, "SegmentationObjectAug"))) for x in rows]
+        if pseudo is not None and train:
+            rep = (ori, f"pseudo_data/{pseudo}/seg_{pseudo}_AsCoco") if as_coco else (ori, f"PseudoLabels/{pseudo}/rw/")
+            self.images = [(a, b.replace(*rep), c) for a, b, c in self.images]
+        lab = ("cocovoc" if as_coco else "voc") + f"_1h_labels_{self.image_set}.npy"
+        self.img_lvl_labels = np.load(os.path.join(voc_root, lab))
+        self.indices = indices if indices is not None else np.arange(len(self.images))
+
+    def __getitem__(self, index):
+        k = self.indices[index]
+        with Image.open(self.images[k][0]) as im:
+            img = np.array(im.convert("RGB"), dtype=np.uint8)
+        with Image.open(self.images[k][1]) as im:
+            seg = np.array(im)
+        with Image.open(self.images[k][2]) as im:
+            inst = np.array(im)
+        name = self.file_names[k].split(".")[0]
+        if not self.is_train:
+            masks, labels = [], []
+            for idx in np.unique(inst):
+                if idx != 0 and idx != 255:
+                    masks.append((inst == idx).astype(int))
+                    cls = np.unique(seg[inst == idx])
+                    assert len(cls) == 1, f"{cls}, {self.images[k][1]}, {self.images[k][2]}"
+                    labels.append(cls[0])
+            return img, seg.astype(np.uint8), np.stack(masks), np.array(labels), name
+        if self.pseudo is not None:
+            f = np.load(f"data/voc/{self.pseudo}/ins_seg_{self.pseudo}/{name}.npy", allow_pickle=True).item()
+            m = f["mask"].astype(np.uint8)
+            inst = np.max(m * (np.arange(m.shape[0], dtype=np.uint8) + 1)[:, None, None], axis=0)
+        return img, seg.astype(np.uint8), inst.astype(np.uint8), self.img_lvl_labels[k]
+
+    def __len__(self):
+        return len(self.indices)
+
+
 class VOCasCOCOSegmentationIncremental(IncrementalInstanceSegmentationDataset):
-    """dataset/voc.py:339-343 (coco-voc steps > 0: VOC images under the COCO class ids)."""
+    """dataset/voc.py:339-343 — coco-voc steps > 0: VOC images whose semantic maps / label vectors carry COCO class ids
+    (pre-remapped files, VOCSegmentation(as_coco=True)); the training subset is `indices` (coco-voc/voc/train-<step>.npy)."""
 
     def make_dataset(self, root, ann_file, old_classes, new_classes, is_train, val_on_trainset, pseudo=None, overlap=True,
                      indices=None, masking=True):
-        return VOCInstanceSegmentation(root, ann_file, old_classes, new_classes, is_train, val_on_trainset, pseudo,
-                                       overlap=overlap, as_coco=True, masking=masking)
+        return VOCSegmentation(root, is_train, transform=None, indices=indices, as_coco=True, saliency=None, pseudo=pseudo)

@@ -402,6 +402,16 @@ class Trainer:
         logger.info(f"Epoch {cur_epoch}, Class Loss={epoch_loss}, Reg Loss={reg}")
         return (epoch_loss, reg)
 
+    def _leave_graph_mode(self):
+        """Eager code after graph-replayed training must not trust the derived-tensor cache: during a replay the host-side
+        `CACHE.touch` calls of the optimizer / BN kernels do not run, so entries built by an earlier eager pass (eval-mode
+        packed weights `wp1`, folded BN scale/shift of the instance branch) would silently describe old weights. Every
+        eval entry point drops them first."""
+        from .nn import CACHE
+        if self._graph_active:
+            CACHE.clear()
+            self._graph_active = False
+
     def validate(self, valid_loader, opts):
         """train.py:588-651 — instance-segmentation validation: eval forward (optionally [image, flipped image]), outputs to
         the ground-truth size, get_ins_map on the device (cl4_val_seg + cl4_instance_map), VOC mask AP at IoU 0.5:0.05:0.9
@@ -411,6 +421,7 @@ class Trainer:
         iou_thresholds = np.arange(0.5, 0.95, 0.05).tolist()
         acc = [MT.DetectionAccumulator() for _ in iou_thresholds]
         model, device = self.model, self.device
+        self._leave_graph_mode()
         model.eval()
         for img, seg, mask, mask_label, fname in valid_loader:
             gt_mask = np.asarray(mask)[0].astype(bool)
@@ -434,6 +445,7 @@ class Trainer:
     def predict_instances(self, img, target_size, opts, cls_label=None):
         """One validation image -> (pred_label [R], pred_mask [R,H,W] bool, pred_score [R]) — train.py:616-626 +
         dataset/utils.py:795-892. `img` [1,3,h,w]; `target_size` the ground-truth (original image) size."""
+        self._leave_graph_mode()
         images = img.to(self.device, dtype=torch.float32).contiguous()
         if images.shape[0] != 1:
             raise RuntimeError("validate: batch size 1 expected (train.py:608-618)")
@@ -463,6 +475,7 @@ class Trainer:
         read back once; `metrics` is a cl4wsis_amd.metrics.StreamSegMetrics (same results dict as the reference's)."""
         metrics.reset()
         model, device = self.model, self.device
+        self._leave_graph_mode()
         model.eval()
         if eval_pseudolabeler:
             self.pseudolabeler.eval()

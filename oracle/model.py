@@ -231,8 +231,8 @@ def peak_generator_eval(x, sd, label, old_classes, alpha=0.7, p=""):
     m = F.softmax(y, dim=1).reshape(B, new, -1)
     logit = (y.reshape(B, new, -1) * m).sum(-1) / (1.0 + m.sum(-1))
     if old_classes > 0:
-        logit = torch.cat([torch.zeros(B, old_classes), logit], 1)
-        y = torch.cat([torch.zeros(B, old_classes, H, W), y], 1)
+        logit = torch.cat([logit.new_zeros(B, old_classes), logit], 1)
+        y = torch.cat([y.new_zeros(B, old_classes, H, W), y], 1)
     cam = F.relu(y) * label[:, :, None, None]
     cam = F.interpolate(cam, size=(H, W), mode="bilinear", align_corners=False)
     cam = cam / (F.adaptive_max_pool2d(cam, 1) + 1e-5)

@@ -118,3 +118,79 @@ def test_coco_source_and_coco_voc_step0(tmp_path):
     assert train.lut[1] == 0 and train.lut[8] == order.index(8)
     v = val[0]
     assert v.masks.shape[0] == len(v.mask_label) == len(truth["val"][0][2]) and v.path.endswith(".jpg")
+
+
+def _make_mini_voc_ascoco(root, n_train=4, n_val=2):
+    """The file-list VOC tree the coco-voc protocol reads for steps > 0 (reference dataset/voc.py:46-131 with as_coco=True):
+    JPEGImages, SegmentationClassAugAsCoco (semantic maps in COCO ids), SegmentationObjectAug (instance ids),
+    splits/{train_aug,val}_ascoco.txt, cocovoc_1h_labels_{train,val}.npy (91-way)."""
+    import os
+    from PIL import Image
+    from cl4wsis_amd import tasks
+    from oracle import synth
+    coco_of_voc = tasks.get_task_dict("coco-voc", "voc", 1)[1]           # COCO ids of VOC classes 1..20, in VOC order
+    voc = os.path.join(str(root), "voc")
+    for d in ("JPEGImages", "SegmentationClassAug", "SegmentationClassAugAsCoco", "SegmentationObjectAug", "splits"):
+        os.makedirs(os.path.join(voc, d), exist_ok=True)
+    truth = {}
+    for split, n, fname in (("train", n_train, "train_aug_ascoco.txt"), ("val", n_val, "val_ascoco.txt")):
+        rows, labels, samples = [], [], []
+        for k in range(n):
+            img, seg, inst, l1h = synth.dataset_sample(900 + 10 * k + (split == "val"), 70 + 6 * k, 90 + 4 * k, n_inst=3,
+                                                       classes=(1, 8, 15, 20), void=False)
+            seg_coco = np.zeros_like(seg)
+            for v in np.unique(seg):
+                if v:
+                    seg_coco[seg == v] = coco_of_voc[v - 1]
+            name = f"{split}_{k:02d}"
+            Image.fromarray(img).save(os.path.join(voc, "JPEGImages", name + ".png"))
+            Image.fromarray(seg_coco).save(os.path.join(voc, "SegmentationClassAugAsCoco", name + ".png"))
+            Image.fromarray(inst).save(os.path.join(voc, "SegmentationObjectAug", name + ".png"))
+            rows.append(f"/JPEGImages/{name}.png /SegmentationClassAugAsCoco/{name}.png\n")
+            lab = np.zeros(91)
+            lab[[coco_of_voc[v - 1] - 1 for v in np.unique(seg) if v]] = 1
+            labels.append(lab)
+            samples.append((img, seg_coco, inst, lab))
+        with open(os.path.join(voc, "splits", fname), "w") as f:
+            f.writelines(rows)
+        np.save(os.path.join(voc, f"cocovoc_1h_labels_{split}.npy"), np.stack(labels))
+        truth[split] = samples
+    return truth
+
+
+def test_coco_voc_step1_reads_the_as_coco_voc_tree(tmp_path):
+    """coco-voc step 1 (BASELINE config 5): the training source is the file-list VOC tree with COCO class ids
+    (VOCasCOCOSegmentationIncremental -> VOCSegmentation(as_coco=True), dataset/voc.py:339-343), restricted to the protocol's
+    image subset train-1.npy; image-level labels are the 91-way cocovoc vectors reduced by LabelSelection."""
+    import os
+    from cl4wsis_amd.dataset import get_dataset
+    from cl4wsis_amd import tasks
+    from util import make_mini_coco
+    make_mini_coco(tmp_path)                                            # the test split of coco-voc is COCO val2017
+    truth = _make_mini_voc_ascoco(tmp_path)
+    p = argparser.get_argparser()
+    o = argparser.modify_command_options(p.parse_args(["--dataset", "coco-voc", "--task", "voc", "--step", "1", "--data_root", str(tmp_path),
+                                                       "--crop_size", "65", "--crop_size_val", "70"]))
+    base = os.path.join(str(tmp_path), "coco-voc", "voc")
+    os.makedirs(base, exist_ok=True)
+    np.save(os.path.join(base, "train-1.npy"), np.array([2, 0, 3]))      # subset AND order of the protocol
+    train, val, test, labels_cum, n = get_dataset(o)
+    td = tasks.get_task_dict("coco-voc", "voc", 1)
+    order = [c for s in sorted(td) for c in td[s]]
+    assert n == 81 and len(train) == 3 and len(val) == 2 and len(test) == 2
+    for pos, k in enumerate((2, 0, 3)):
+        random.seed(7 + pos)
+        raw = train[pos]
+        img, seg_coco, inst, lab = truth["train"][k]
+        assert np.array_equal(raw.image, img)
+        assert np.array_equal(raw.label[:, :, 0], seg_coco) and np.array_equal(raw.label[:, :, 1], inst)
+        want = np.zeros(80)
+        for cid in np.flatnonzero(lab) + 1:
+            want[order.index(cid) - 1] = 1                              # all present ids are VOC classes = the new step
+        assert raw.l1h.shape == (80,) and np.array_equal(raw.l1h, want) and raw.l1h[:60].sum() == 0
+    # label map: COCO id -> position in the protocol order (61 old classes incl. background first, then the 20 VOC classes)
+    assert train.lut[1] == 61 and train.lut[order[-1]] == 80
+    v = val[1]
+    img, seg_coco, inst, lab = truth["val"][1]
+    assert np.array_equal(v.label[:, :, 0], seg_coco) and v.masks.shape[0] == len(v.mask_label) == len(np.unique(inst)) - 1
+    assert v.path == "val_01"

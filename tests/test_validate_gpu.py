@@ -128,3 +128,47 @@ def test_validate_instance_ap(gpu, monkeypatch):
         ref_ap = np.nanmean(ap, axis=0)
     np.testing.assert_allclose(res["ap"], ref_ap, rtol=1e-6, equal_nan=True)
     assert 0.0 < res["map"] <= 1.0 and abs(res["map"] - np.nanmean(ref_ap)) < 1e-9
+
+
+def test_eval_after_graph_training_sees_current_weights(gpu):
+    """train (HIP-graph replays) -> validate -> train -> validate: each eval pass must score the weights and BN running
+    statistics as they are NOW. During a replay the host-side cache invalidation of the optimizer does not run, so the eval-only
+    derived tensors (packed weights, folded BN of the instance branch) built by the first validation would otherwise be reused."""
+    from cl4wsis_amd.train import Trainer
+    from oracle import weights
+    crop = 97
+    opts = p2_opts(crop)
+    opts.val_flip = False
+    opts.max_iters, opts.start_decay = 1000, 1000
+    torch.manual_seed(0)
+    tr = Trainer(_Log(), gpu, opts)
+    for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
+        m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=31 + i))
+    tr._realias()
+    g = torch.Generator().manual_seed(8)
+    batches = [(torch.randn(2, 3, crop, crop, generator=g), torch.eye(20)[[16 + i % 4, 15]].clone()) for i in range(4)]
+    x_eval = torch.randn(1, 3, crop, crop, generator=g)
+
+    def eval_center():
+        tr.predict_instances(x_eval, (crop, crop), opts)       # the public eval entry (what validate() calls per image)
+        tr.model.eval()
+        c = tr.model(x_eval.to(gpu))[0]["center"].clone()
+        tr.model.train()
+        return c
+
+    for b in batches[:2]:
+        tr.step(b)
+    assert tr._graph is not None
+    c1 = eval_center()
+    for b in batches[2:]:
+        tr.step(b)
+    c2 = eval_center()
+    torch.cuda.synchronize()
+    assert not torch.allclose(c1, c2, rtol=1e-4, atol=1e-6)      # two more updates at lr 5e-4 moved the head
+    fresh = Trainer(_Log(), gpu, opts)
+    fresh.model.load_state_dict({k: v.clone() for k, v in tr.model.state_dict().items()})
+    fresh._realias()
+    fresh.model.eval()
+    ref = fresh.model(x_eval.to(gpu))[0]["center"]
+    torch.cuda.synchronize()
+    assert torch.allclose(c2, ref, rtol=1e-5, atol=1e-6), (c2 - ref).abs().max()
