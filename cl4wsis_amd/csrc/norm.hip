@@ -237,14 +237,21 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict
   if (threadIdx.x == 0) atomicAdd(&db[ch], (float)(part[0] + part[1] + part[2] + part[3]));
 }
 
-// Counter-based keep mask for nn.Dropout(p): splitmix64 of (seed, element index).
+__device__ __forceinline__ uint64_t splitmix64_mix(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// Counter-based keep mask for nn.Dropout(p): element i of the stream keyed by `seed` is mix(mix(seed) + G * (i + 1)).
+// The seed is hashed BEFORE the element counter is added: with z = seed + G * (i + 1) and a per-step seed advance that is a
+// multiple of G, step t+1's mask would be step t's mask shifted by one element (masks of successive iterations must be
+// independent draws, like nn.Dropout's).
 __global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, uint64_t seed, const uint64_t* seed_dev, float p) {
   if (seed_dev) seed = *seed_dev;   // device-resident seed: lets a captured HIP graph draw a new mask on every replay
+  const uint64_t key = splitmix64_mix(seed + 0x9E3779B97F4A7C15ull);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
+    uint64_t z = splitmix64_mix(key + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1));
     float u = (float)(z >> 40) * (1.f / 16777216.f);
     keep[i] = u >= p ? 1 : 0;
   }

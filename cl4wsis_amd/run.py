@@ -101,53 +101,104 @@ def save_ckpt(path, trainer, epoch, best_score):
 
 
 def main(opts):
+    """run.py:37-183 — same flow: loaders, Trainer, previous-step weights, resume / phase-1 weights, epoch loop with a checkpoint
+    per epoch and validation every `val_interval`, final checkpoint, test pass."""
     rank, world, local = init_distributed()
     device = torch.device("cuda", local) if torch.cuda.is_available() else None
     if device is None:
         raise SystemExit("cl4wsis_amd.run needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     opts.device_id = local
-    task_name = f"{opts.dataset}-{opts.task}" + ("-ov" if opts.overlap else "")
+    task_name = f"{opts.dataset}-{opts.task}" + ("-ov" if (opts.overlap and opts.dataset == "voc") else "")   # run.py:45-47
     os.makedirs(f"checkpoints/step/{task_name}", exist_ok=True)
-    path = f"checkpoints/step/{task_name}/{opts.name}_{opts.step}.pth"
+    ckpt_path = f"checkpoints/step/{task_name}/{opts.name}_{opts.step}.pth"
     torch.manual_seed(opts.random_seed)
     np.random.seed(opts.random_seed)
     random.seed(opts.random_seed)
     opts.batch_size = opts.batch_size // world                       # run.py:66
     supervised = opts.step == 0 and not opts.weakly
-    if os.path.isfile(os.path.join(opts.data_root, "voc", "pascal_sbd_train.json")):
+    logger = _Logger(rank)
+    val_loader = test_loader = None
+    real_data = os.path.isfile(os.path.join(opts.data_root, "voc", "pascal_sbd_train.json")) or opts.dataset == "coco-voc"
+    if real_data:
         # the real photos: host decode + device-side crop / resample / normalise / target generation (cl4wsis_amd/dataset)
         from .dataset import DeviceLoader, get_dataset
         train_dst, val_dst, test_dst, labels, n_classes = get_dataset(opts)
+        random.seed(opts.random_seed)                                # run.py:68-69
         sampler = DistributedSampler(train_dst, num_replicas=world, rank=rank) if world > 1 else None
         loader = DeviceLoader(train_dst, opts.batch_size, device, sampler=sampler, shuffle=True, num_workers=opts.num_workers,
                               drop_last=True, supervised=supervised)
+        val_loader = DeviceLoader(val_dst, 1, device, shuffle=False, num_workers=opts.num_workers)     # run.py:75-77 (every rank)
+        test_loader = DeviceLoader(test_dst, 1, device, shuffle=False, num_workers=opts.num_workers)   # run.py:162-164
+        logger.info(f"Dataset: {opts.dataset}, Train set: {len(train_dst)}, Val set: {len(val_dst)}, Test set: {len(test_dst)}, "
+                    f"n_classes {n_classes}")
     else:
         n_img = int(os.environ.get("CL4_SYNTH_LEN", "10582"))        # VOC 2012 aug train size
         train_dst = SyntheticVOC(n_img, opts.crop_size, opts.random_seed, supervised=supervised)
         sampler = DistributedSampler(train_dst, num_replicas=world, rank=rank) if world > 1 else None
         loader = data.DataLoader(train_dst, batch_size=opts.batch_size, sampler=sampler, shuffle=sampler is None,
                                  num_workers=opts.num_workers, drop_last=True)
+        n_classes = 21
+        logger.info(f"no dataset under {opts.data_root!r}: synthetic VOC-shaped batches ({n_img} images); validation / test are skipped")
+    logger.info(f"Total batch size is {opts.batch_size * world}")
     opts.max_iters = opts.epochs * len(loader)
-    opts.start_decay = opts.pseudo_ep * len(loader)
-    logger = _Logger(rank)
+    if opts.lr_policy == "warmup":                                   # run.py:82-83
+        opts.start_decay = opts.pseudo_ep * len(loader)
     trainer = Trainer(logger, device, opts)
-    if opts.step > 0 and opts.step_ckpt is not None:
-        trainer.load_step_ckpt(opts.step_ckpt)
-    cur_epoch, best = 0, 0.0
-    if opts.continue_ckpt and os.path.isfile(path):
-        cur_epoch, best = trainer.load_ckpt(path)
-    elif opts.phase == 2 and opts.seg_ckpt is not None:
-        trainer.load_seg_ckpt(opts.seg_ckpt)
-    while cur_epoch < opts.epochs and not opts.test:
+    if opts.step > 0:                                                # run.py:91-98: the previous step's weights are mandatory
+        path = opts.step_ckpt if opts.step_ckpt is not None else f"checkpoints/step/{task_name}/{opts.name}_{opts.step - 1}.pth"
+        if os.environ.get("CL4_ALLOW_RANDOM_INIT") == "1" and not os.path.exists(path):
+            logger.info(f"[!] {path} not found; CL4_ALLOW_RANDOM_INIT=1: old and new model start from the random initialisation")
+        else:
+            trainer.load_step_ckpt(path)                             # FileNotFoundError when missing (train.py:771)
+    if opts.continue_ckpt:                                           # run.py:101-110
+        opts.ckpt = ckpt_path
+    if opts.ckpt is not None:
+        cur_epoch, best_score = trainer.load_ckpt(opts.ckpt)
+    else:
+        if opts.seg_ckpt is not None:
+            trainer.load_seg_ckpt(opts.seg_ckpt)
+        logger.info("[!] Start from epoch 0")
+        cur_epoch, best_score = 0, 0.0
+    TRAIN = not opts.test
+    val_metrics = None
+    if real_data:
+        from .metrics import StreamSegMetrics
+        val_metrics = StreamSegMetrics(n_classes)
+    while cur_epoch < opts.epochs and TRAIN:
         epoch_loss = trainer.train(cur_epoch=cur_epoch, train_loader=loader, print_int=opts.print_interval)
-        logger.info(f"End of Epoch {cur_epoch}/{opts.epochs}, Average Loss={float(epoch_loss[0]) + float(epoch_loss[1])}")
-        if rank == 0 and (cur_epoch + 1) % opts.ckpt_interval == 0:   # the reference writes from every rank (race)
-            save_ckpt(path, trainer, cur_epoch, best)
+        logger.info(f"End of Epoch {cur_epoch}/{opts.epochs}, Average Loss={float(epoch_loss[0]) + float(epoch_loss[1])}, "
+                    f"Class Loss={float(epoch_loss[0])}, Reg Loss={float(epoch_loss[1])}")
+        if rank == 0:                                                # run.py:131 writes from every rank (a race on one file)
+            save_ckpt(ckpt_path, trainer, cur_epoch, 0)
+        if (cur_epoch + 1) % opts.val_interval == 0 and val_loader is not None:      # run.py:133-155
+            if (opts.phase is None or opts.phase == 2) and opts.model == "PanopticDeepLab":
+                logger.info("validate on val set...")
+                val_score = trainer.validate(val_loader, opts)
+                logger.info(val_score)
+            if opts.phase == 1 and opts.weakly:
+                score = trainer.validate_semseg(loader=val_loader, metrics=val_metrics, opts=opts)
+                logger.add_scalar("Val_CAM/MeanIoU", score["Mean IoU"], cur_epoch)
+                logger.info(val_metrics.to_str(score))
+            logger.info(f"End of Validation {cur_epoch}/{opts.epochs}")
         cur_epoch += 1
+    if rank == 0 and TRAIN:                                          # run.py:158-160
+        save_ckpt(ckpt_path, trainer, cur_epoch, best_score)
+        logger.info("[!] Checkpoint saved.")
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
+    results = None
+    if test_loader is not None:                                      # run.py:166-181
+        logger.info("*** Test the model on all seen classes...")
+        if opts.phase == 1:
+            results = trainer.validate_semseg(loader=test_loader, metrics=val_metrics, opts=opts)
+            logger.info(val_metrics.to_str(results))
+        else:
+            results = trainer.validate(test_loader, opts)
+            logger.info("*** End of Test")
+            logger.info(results)
     logger.close()
+    return results
 
 
 if __name__ == "__main__":

@@ -75,3 +75,29 @@ def test_abn_train_two_shards_equal_full_batch(gpu):
         dxs.append(ops.abn_train_backward(xs, dys[r], mean, var, gd, bd, dgamma, dbeta, count, extra_sums=local[1 - r]))
     assert _rel(torch.cat(dxs), dx_ref) < 2e-5
     assert _rel(dgamma, dg_ref) < 2e-5 and _rel(dbeta, db_ref) < 2e-5       # sum over shards = full-batch gradient
+
+
+def test_dropout_masks_of_successive_steps_are_independent(gpu):
+    """The device-resident Dropout seed advances once per launch (graph-replay safe). Successive masks must be independent
+    draws like nn.Dropout's — not the previous mask shifted by one element, which is what a seed advance equal to the
+    per-element counter stride produced."""
+    import torch
+    from cl4wsis_amd import ops
+    seed = torch.tensor([123456789], dtype=torch.int64, device=gpu)
+    shape = (2, 256, 33, 33)
+    m = [ops.dropout_mask_dev(shape, 0.5, seed, 1, gpu).flatten().float() for _ in range(3)]
+    torch.cuda.synchronize()
+    assert int(seed.item()) == 123456789 + 3
+    for a in m:
+        assert abs(a.mean().item() - 0.5) < 5e-3
+    n = m[0].numel()
+    for a, b in ((m[0], m[1]), (m[1], m[2]), (m[0], m[2])):
+        for shift in (0, 1, 2, -1):
+            x = a[max(shift, 0):n + min(shift, 0)]
+            y = b[max(-shift, 0):n + min(-shift, 0)]
+            agree = (x == y).float().mean().item()
+            assert abs(agree - 0.5) < 5e-3, (shift, agree)       # an (anti)shifted copy would agree on 100 % / 0 %
+    # same seed -> same mask (the captured graph and an eager run draw identical masks)
+    s1 = torch.tensor([77], dtype=torch.int64, device=gpu)
+    s2 = torch.tensor([77], dtype=torch.int64, device=gpu)
+    assert torch.equal(ops.dropout_mask_dev(shape, 0.5, s1, 1, gpu), ops.dropout_mask_dev(shape, 0.5, s2, 1, gpu))

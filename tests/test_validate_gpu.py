@@ -150,8 +150,8 @@ def test_eval_after_graph_training_sees_current_weights(gpu):
     x_eval = torch.randn(1, 3, crop, crop, generator=g)
 
     def eval_center():
-        tr.predict_instances(x_eval, (crop, crop), opts)       # the public eval entry (what validate() calls per image)
         tr.model.eval()
+        tr.predict_instances(x_eval, (crop, crop), opts)       # the public eval entry (what validate() calls per image)
         c = tr.model(x_eval.to(gpu))[0]["center"].clone()
         tr.model.train()
         return c
