@@ -102,6 +102,14 @@ def p2_opts(batch):
     return argparser.modify_command_options(argparser.get_argparser().parse_args(args))
 
 
+def _progress(msg):
+    """Progress lines on stderr (stdout carries exactly one JSON line): the host-side legs take minutes."""
+    print(f"[bench.py +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.time()
+
+
 def _host_cores():
     try:
         return len(os.sched_getaffinity(0))      # what this process may actually use (a 1-GPU box gets a share of the host)
@@ -133,12 +141,14 @@ def cpu_baseline(opts, iters):
     b = GLOBAL_BATCH
     images, l1h = synthetic_batch(b, 42, torch.device("cpu"), CROP)
     times, state = [], out["adam_state"]
+    _progress(f"cpu_baseline: warm-up done, {iters} x batch {b} on {cores} threads")
     for i in range(iters):
         t0 = time.time()
         out = ostep.p2_step(new, old, pl, pg, images, l1h, 16, pooling=opts.pooling, lr=opts.lr * opts.lr_head,
                             adam_state=state, step=i + 2)
         state = out["adam_state"]
         times.append(time.time() - t0)
+        _progress(f"cpu_baseline: iteration {i + 1}/{iters} {times[-1]:.1f} s")
     dt = sum(times) / len(times)
     model = ""
     try:
@@ -152,7 +162,7 @@ def cpu_baseline(opts, iters):
                       f"{iters} timed iterations after a batch-2 warm-up, torch threads = {cores}"}
 
 
-def stock_rocm(opts, device, iters=3):
+def stock_rocm(opts, device, iters=2):
     """BASELINE.md §4 second comparator: the same restatement with stock PyTorch-ROCm ops (MIOpen convolutions, ATen
     elementwise kernels) on this GPU, batch 16 — like the reference on a GPU it keeps the label stage on the host
     (OpenCV/numpy loops behind .cpu() copies, modules/utils.py:179-385) — under the reference's own autocast (train.py:252)."""
@@ -173,6 +183,7 @@ def stock_rocm(opts, device, iters=3):
                                 adam_state=state, step=i + 1, autocast=amp)
             state = out["adam_state"]
             torch.cuda.synchronize()
+            _progress(f"stock_rocm[{name}]: iteration {i} {time.time() - t0:.2f} s")
             if i:
                 times.append(time.time() - t0)
         del out, state
@@ -229,6 +240,7 @@ def worker(a):
         debug = info
 
     trainer = Trainer(_Log(), device, opts)
+    trainer.buckets.timing = world > 1         # HIP events around the join with the communication stream (exposed all-reduce)
     images, l1h = synthetic_batch(b, 42 + rank, device, CROP)
     seen = torch.ones(1, device=device)
     if world > 1:
@@ -256,6 +268,8 @@ def worker(a):
         return dt, out
 
     elapsed, out = timed(a.steps, a.warmup)
+    if rank == 0:
+        _progress(f"timed region done: {1e3 * elapsed / a.steps:.2f} ms/step")
     losses = out["losses"].tolist()
     counters_random = trainer.check_label_overflow()          # raises if a device-side label table overflowed
 
@@ -352,7 +366,7 @@ def worker(a):
         }
         if structured is not None:
             res["structured_labels"] = structured
-        if world > 1 and getattr(trainer, "comm_stats", None):
+        if world > 1:
             res["allreduce"] = trainer.comm_stats()
         wgrad_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if ops.WGRAD_PRECISION == 1 else PEAK_FP32_MFMA_TFLOPS
         for kind, pk in (("conv_fwd_bf16x6", PEAK_BF16_MFMA_TFLOPS / 6.0), ("conv_fwd_f32", PEAK_FP32_MFMA_TFLOPS),

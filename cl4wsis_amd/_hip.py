@@ -115,6 +115,14 @@ _decl("cl4_dwconv5_fwd", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_dwconv5_wgrad", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 
 _decl("cl4_cam_smooth", _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P, C.c_size_t, _P)
+_decl("cl4_comm_unique_id", _P)
+_decl("cl4_comm_init", _I, _I, _P)
+_decl("cl4_allreduce_bucket", _P, C.c_size_t, _I, _P)
+_decl("cl4_comm_destroy")
+_decl("cl4_comm_world")
+_decl("cl4_comm_rank")
+_decl("cl4_cam_normalize", _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P, C.c_size_t, _P)
+_decl("cl4_smoothing3x3", _P, _L, _I, _I, _P, _P)
 _decl("cl4_peak_extract", _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_seg_pseudo_gt", _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P)
 _decl("cl4_ccl", _P, _I, _I, _I, _I, _P, _P)
@@ -126,6 +134,7 @@ _decl("cl4_p2_loss", C.POINTER(P2LossIO), _P, C.c_size_t, _P)
 _decl("cl4_adam_step", _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P)
 _decl("cl4_adam_step_dev", _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _I, _P)
 _decl("cl4_fill_zero", _P, C.c_size_t, _P)
+_decl("cl4_peakgen_vjp", _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_peakgen_train_loss", _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_flac_loss", _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_lloc_loss", _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)
@@ -185,6 +194,7 @@ def load():
                    ("cl4_p2_loss_workspace_bytes", [C.c_int] * 6), ("cl4_pamr_workspace_bytes", [C.c_int] * 5),
                    ("cl4_ngwp_workspace_bytes", [C.c_int] * 2), ("cl4_balanced_ce_workspace_bytes", [C.c_int] * 4),
                    ("cl4_bce_ignore_workspace_bytes", []), ("cl4_p1loss_workspace_bytes", [C.c_int] * 4), ("cl4_cam_smooth_workspace_bytes", [C.c_int] * 4),
+                   ("cl4_cam_normalize_workspace_bytes", [C.c_int] * 4),
                    ("cl4_input_workspace_bytes", [C.c_int] * 5), ("cl4_target_generation_workspace_bytes", [C.c_int])):
         getattr(lib, nm).restype = C.c_size_t
         getattr(lib, nm).argtypes = at

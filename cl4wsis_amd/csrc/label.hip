@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void cam_avg_kernel(const float* __restrict__ 
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long pl = i / hw;
     const int p = (int)(i - pl * hw), y = p / w, x = p - y * w;
-    const float d = den[pl];
+    const float d = den ? den[pl] : 1.f;
     float s = 0.f;
     for (int dy = -1; dy <= 1; ++dy)
       for (int dx = -1; dx <= 1; ++dx) {
@@ -534,6 +534,49 @@ extern "C" int cl4_cam_smooth(const float* int_masks, int b, int ctot, int h, in
   hipLaunchKernelGGL(cam_den_kernel, dim3(cnew, b), dim3(256), 0, st, (const float*)ys, hw, cnew, den);
   hipLaunchKernelGGL(cam_avg_kernel, dim3(cl4::stream_grid((long)b * cnew * hw, 256)), dim3(256), 0, st, (const float*)ys, (const float*)den,
                      h, w, (long)b * cnew, cam);
+  return cl4::launch_status();
+}
+
+// PeakGenerator.forward in eval mode without the caller's `smoothing` (wss/modules.py:390-434): the normalised CAM of the
+// new classes, cam [b, cnew, h, w] = relu(conv(PAM(x))) * label / (max_hw + 1e-5). Same kernels and summation order as the
+// large-map path of cl4_cam_smooth; workspace = cl4_cam_smooth_workspace_bytes' large-map size (b*cnew*hw + 2*b*cnew floats).
+extern "C" size_t cl4_cam_normalize_workspace_bytes(int b, int cnew, int h, int w) {
+  if (b <= 0 || cnew <= 0 || h <= 0 || w <= 0) return 0;
+  return ((size_t)b * cnew * h * w + (size_t)2 * b * cnew) * sizeof(float);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void cam_divide_kernel(const float* __restrict__ ys, const float* __restrict__ den, int hw, long total,
+                                                         float* __restrict__ cam) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) cam[i] = ys[i] / den[i / hw];
+}
+}  // namespace
+
+extern "C" int cl4_cam_normalize(const float* int_masks, int b, int ctot, int h, int w, const float* pg_w, const float* pg_b,
+                                 const float* label_new, int cnew, float alpha, float* cam, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  CL4_REQUIRE(int_masks && pg_w && pg_b && label_new && cam && workspace, "cam_normalize: null pointer");
+  CL4_REQUIRE(b > 0 && cnew > 0 && cnew <= ctot && h > 0 && w > 0, "cam_normalize: bad dims");
+  if (workspace_bytes < cl4_cam_normalize_workspace_bytes(b, cnew, h, w)) { cl4::set_error("cam_normalize: workspace too small"); return CL4_ENOSPC; }
+  hipStream_t st = cl4::as_stream(stream);
+  const int hw = h * w;
+  float* ys = (float*)workspace;
+  float* peak = ys + (size_t)b * cnew * hw;
+  float* den = peak + (size_t)b * cnew;
+  hipLaunchKernelGGL(cam_peak_kernel, dim3(cnew, b), dim3(256), 0, st, int_masks, ctot, hw, cnew, peak);
+  hipLaunchKernelGGL(cam_conv_kernel, dim3(cl4::cdiv((long)b * hw, 256)), dim3(256), 0, st, int_masks, ctot, hw, pg_w, pg_b, label_new, cnew,
+                     alpha, (const float*)peak, ys, b);
+  hipLaunchKernelGGL(cam_den_kernel, dim3(cnew, b), dim3(256), 0, st, (const float*)ys, hw, cnew, den);
+  const long total = (long)b * cnew * hw;
+  hipLaunchKernelGGL(cam_divide_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, (const float*)ys, (const float*)den, hw, total, cam);
+  return cl4::launch_status();
+}
+
+// `smoothing` (wss/utils.py:28-32): 3x3 average, stride 1, zero padding, divisor always 9, over `planes` maps of h x w.
+extern "C" int cl4_smoothing3x3(const float* x, long planes, int h, int w, float* out, void* stream) {
+  CL4_REQUIRE(x && out && x != out && planes > 0 && h > 0 && w > 0, "smoothing3x3: bad arguments (not in place)");
+  hipLaunchKernelGGL(cam_avg_kernel, dim3(cl4::stream_grid(planes * h * w, 256)), dim3(256), 0, cl4::as_stream(stream), x,
+                     (const float*)nullptr, h, w, planes, out);
   return cl4::launch_status();
 }
 

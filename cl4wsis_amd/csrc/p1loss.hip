@@ -46,6 +46,7 @@ struct PgArgs {
   float* logit;          // [b, nc]
   float* loss;           // [1]
   float* dx;             // [b, ctot, hw] or null (old-class channels are zero-filled)
+  const float* dlogit;   // [b, nc] upstream gradient of the logits, or null = the built-in mean BCE against `labels`
   float* dw;             // [nc, nc] accumulated
   float* db;             // [nc] accumulated
 };
@@ -104,15 +105,15 @@ __global__ __launch_bounds__(256) void pg_final_kernel(PgArgs a) {  // one workg
   for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const double sxm = a.sums[(long)i * 2], sm = a.sums[(long)i * 2 + 1];
     const double y = sxm / (1.0 + sm);
-    const double t = a.labels[i];
+    const double t = a.labels ? a.labels[i] : 0.0;
     a.logit[i] = (float)y;
     part += fmax(y, 0.0) - y * t + log1p(exp(-fabs(y)));
-    const double g = (1.0 / (1.0 + exp(-y)) - t) * scale;
+    const double g = a.dlogit ? (double)a.dlogit[i] : (1.0 / (1.0 + exp(-y)) - t) * scale;
     a.coef[(long)i * 2] = (float)(g / (1.0 + sm));
     a.coef[(long)i * 2 + 1] = (float)(-g * sxm / ((1.0 + sm) * (1.0 + sm)));
   }
   part = block_sum_d(part);
-  if (threadIdx.x == 0) a.loss[0] = (float)(part * scale);
+  if (threadIdx.x == 0 && a.loss) a.loss[0] = (float)(part * scale);
 }
 
 __global__ __launch_bounds__(256) void pg_grad_kernel(PgArgs a) {   // grid (chunks, b)
@@ -428,7 +429,36 @@ extern "C" int cl4_peakgen_train_loss(const float* x, const float* weight, const
   a.sums = (double*)workspace;
   a.coef = (float*)(a.sums + (size_t)b * nc * 2);
   a.peak = a.coef + (size_t)b * nc * 2;
-  a.logit = logit; a.loss = loss; a.dx = dx; a.dw = dweight; a.db = dbias;
+  a.logit = logit; a.loss = loss; a.dx = dx; a.dw = dweight; a.db = dbias; a.dlogit = nullptr;
+  hipLaunchKernelGGL(pg_peak_kernel, dim3(nc, b), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(pg_sums_kernel, dim3(b), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(pg_final_kernel, dim3(1), dim3(256), 0, st, a);
+  if (dx) hipLaunchKernelGGL(pg_grad_kernel, dim3(cl4::cdiv(a.hw, 256), b), dim3(256), 0, st, a);
+  return cl4::launch_status();
+}
+
+// PeakGenerator.forward in training mode as a differentiable map (wss/modules.py:390-423): logit [b, nc] = nGWP(conv(PAM(x))).
+// dlogit == null: forward only (logit written). dlogit != null: vector-Jacobian product — dx [b, ctot, h, w] written,
+// dweight [nc, nc] / dbias [nc] accumulated — for an arbitrary upstream gradient (the fused cl4_peakgen_train_loss hard-wires the
+// mean BCE of train.py:344-345).
+extern "C" int cl4_peakgen_vjp(const float* x, const float* weight, const float* bias, const float* dlogit, int b, int ctot, int h,
+                               int w, int nc, float alpha, float* logit, float* dx, float* dweight, float* dbias, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  CL4_REQUIRE(x && weight && bias && logit && workspace, "peakgen_vjp: null pointer");
+  CL4_REQUIRE(b > 0 && h > 0 && w > 0 && nc >= 1 && nc <= NC_MAX && nc <= ctot, "peakgen_vjp: bad dims (1 <= nc <= %d)", NC_MAX);
+  CL4_REQUIRE((dlogit == nullptr) == (dx == nullptr) && (dx == nullptr) == (dweight == nullptr) && (dx == nullptr) == (dbias == nullptr),
+              "peakgen_vjp: dlogit / dx / dweight / dbias must come together");
+  if (workspace_bytes < cl4_p1loss_workspace_bytes(b, ctot, h, w)) {
+    cl4::set_error("peakgen_vjp: workspace too small");
+    return CL4_ENOSPC;
+  }
+  hipStream_t st = cl4::as_stream(stream);
+  PgArgs a;
+  a.x = x; a.w = weight; a.bias = bias; a.labels = nullptr; a.b = b; a.ctot = ctot; a.hw = h * w; a.nc = nc; a.alpha = alpha;
+  a.sums = (double*)workspace;
+  a.coef = (float*)(a.sums + (size_t)b * nc * 2);
+  a.peak = a.coef + (size_t)b * nc * 2;
+  a.logit = logit; a.loss = nullptr; a.dx = dx; a.dw = dweight; a.db = dbias; a.dlogit = dlogit;
   hipLaunchKernelGGL(pg_peak_kernel, dim3(nc, b), dim3(256), 0, st, a);
   hipLaunchKernelGGL(pg_sums_kernel, dim3(b), dim3(256), 0, st, a);
   hipLaunchKernelGGL(pg_final_kernel, dim3(1), dim3(256), 0, st, a);

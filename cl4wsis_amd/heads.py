@@ -64,8 +64,9 @@ class DeeplabV3(nn.Module):
                 nn.init.xavier_normal_(m.weight.data, gain)
 
     def forward(self, x):
-        if self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("train-mode DeepLabV3 (step 0 / phase 1) is not built yet; phase 2 freezes it")
+        if self.training:        # batch statistics + global average pooling (modules/deeplab.py:54-76), differentiable
+            from . import autograd as AG
+            return AG.apply(AG.DeeplabRunner(self), [x], list(self.parameters()))
         n, _, h, w = x.shape
         hid = self.hidden
         cat = torch.empty((n, 4 * hid, h, w), dtype=torch.float32, device=x.device)
@@ -90,6 +91,12 @@ class IncrementalClassifier(nn.ModuleList):
     """segmentation_module.py:107-113 — per-step 1x1 classifiers, concatenated on C."""
 
     def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from . import autograd as AG
+            return AG.apply(AG.ClassifierRunner(self), [x], list(self.parameters()))
+        return self._forward(x)
+
+    def _forward(self, x):
         n, _, h, w = x.shape
         tot = sum(m.out_channels for m in self)
         out = torch.empty((n, tot, h, w), dtype=torch.float32, device=x.device)
@@ -170,6 +177,26 @@ class IncrementalPanopticDeepLabDecoder(nn.Module):
             self.instance_decoder = SinglePanopticDeepLabDecoder(
                 in_channels, feature_key, low_level_channels, low_level_key, (64, 32, 16), 128, atrous_rates,
                 aspp_channels=256)
+        self._dropout_keep = None     # test hook: a recorded nn.Dropout keep mask for the next training forward
+
+    def forward(self, features):
+        """modules/panoptic_deeplab.py:413-430 — returns (semantic, instance) decoder features; the semantic decoder does not
+        exist on the CL4WSIS path, so the first item is None. Training mode runs the hand-written forward under
+        torch.autograd (cl4wsis_amd/autograd.py) so that `loss.backward()` of a foreign training loop works
+        (train.py:269-272,537); `detach_instance` cuts the gradient to the backbone features exactly like the reference."""
+        if "ins" not in self.branch:
+            return None, None
+        from . import autograd as AG
+        d = self.instance_decoder
+        branch = InstanceBranch(self, None)
+        if not d.training:
+            return None, branch.decoder_forward_eval(features)
+        keys = [d.feature_key] + list(d.low_level_key)
+        feats = [features[k].detach() if self.detach_instance else features[k] for k in keys]
+        keep, self._dropout_keep = self._dropout_keep, None
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())      # drawn from torch's generator: follows torch.manual_seed
+        runner = AG.DecoderRunner(branch, keys, keep, seed, detach=self.detach_instance)
+        return None, AG.apply(runner, feats, list(d.parameters()))
 
 
 class IncrementalSinglePanopticDeepLabHead(nn.Module):
@@ -186,6 +213,18 @@ class IncrementalSinglePanopticDeepLabHead(nn.Module):
             })
         self.classifier = nn.ModuleDict(classifier)
         self.class_key = list(class_key)
+
+    def forward(self, x):
+        """modules/panoptic_deeplab.py:457-468 — OrderedDict(center [n, sum(classes), h, w], offset [n, 2, h, w])."""
+        from . import autograd as AG
+        branch = InstanceBranch(None, self)
+        if not self.training:
+            return branch._head_eval(x)
+        runner = AG.HeadRunner(branch)
+        outs = AG.apply(runner, [x], list(self.parameters()))
+        if isinstance(outs, dict):
+            return outs
+        return OrderedDict(zip(self.class_key, outs))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -212,7 +251,7 @@ class InstanceBranch:
     """
 
     def __init__(self, decoder, head):
-        self.dec = decoder.instance_decoder
+        self.dec = decoder.instance_decoder if decoder is not None else None     # either half may be driven on its own
         self.head = head
 
     # ------------------------------------------------------------------ eval (frozen old model)
@@ -227,6 +266,10 @@ class InstanceBranch:
 
     @torch.no_grad()
     def forward_eval(self, feats):
+        return self._head_eval(self.decoder_forward_eval(feats))
+
+    @torch.no_grad()
+    def decoder_forward_eval(self, feats):
         d = self.dec
         x = feats[d.feature_key]
         n, _, h, w = x.shape
@@ -249,7 +292,7 @@ class InstanceBranch:
             ops.resize_bilinear(y, (hh, ww), True, out=cat, out_coff=0)
             conv_abn(l, d.project[i][0], d.project[i][1], out=cat, out_coff=cy)
             y = self._dwsep_eval(cat, d.fuse[i])
-        return self._head_eval(y)
+        return y
 
     def _head_eval(self, y):
         pred = OrderedDict()
@@ -279,7 +322,15 @@ class InstanceBranch:
 
     def forward_train(self, feats, dropout_keep=None, seed=0):
         """Forward with batch statistics; returns (pred dict, tape). Inputs are treated as constants
-        (IncrementalPanopticDeepLabDecoder.forward detaches them, modules/panoptic_deeplab.py:422-426)."""
+        (IncrementalPanopticDeepLabDecoder.forward detaches them, modules/panoptic_deeplab.py:422-426).
+        = decoder_forward_train + head_forward_train on one tape (the "fork" record separates the two halves)."""
+        y, tape = self.decoder_forward_train(feats, dropout_keep, seed)
+        pred, htape = self.head_forward_train(y)
+        return pred, tape + htape
+
+    def decoder_forward_train(self, feats, dropout_keep=None, seed=0):
+        """SinglePanopticDeepLabDecoder.forward in training mode (modules/panoptic_deeplab.py:181-193): ASPP + three fusion
+        stages. Returns (decoder features [n,128,h/4,w/4], tape)."""
         d = self.dec
         tape = []
         x = feats[d.feature_key]
@@ -315,9 +366,14 @@ class InstanceBranch:
             _, lm, lv = _bn_train(lz, bn, out=cat, out_coff=cy)
             tape.append(("stage", i, l, lz, lm, lv, cy, cp, y.shape[2:]))
             y = self._dwsep_train(cat, d.fuse[i], tape)
+        return y, tape
+
+    def head_forward_train(self, y):
+        """IncrementalSinglePanopticDeepLabHead.forward in training mode (modules/panoptic_deeplab.py:457-468).
+        Returns (OrderedDict center / offset, tape starting with the "fork" record)."""
         pred = OrderedDict()
         hn, _, hh, hw = y.shape
-        tape.append(("fork", y))
+        tape = [("fork", y)]
         for key in self.head.class_key:
             mod = self.head.classifier[key]
             z = self._dwsep_train(y, mod["fuse"], tape)
@@ -368,16 +424,55 @@ class InstanceBranch:
         ops.dwconv5_wgrad_(G(dw.weight), x, dz0)
         return ops.dwconv5(dz0, dw.weight.detach(), flip=True) if need_dx else None
 
-    def backward(self, tape, dpred, grads=None, on_ready=None, feature_grads=None):
+    def backward(self, tape, dpred, grads=None, on_ready=None, feature_grads=None, stop_before_aspp=False):
         """Back-propagates d(loss)/d(pred[key]) through the recorded forward. Returns {id(param): grad}.
         `feature_grads` (a dict) additionally receives d(loss)/d(feature) for the backbone features the decoder read —
         step 0 trains the body through the instance branch; phases 1 / 2 detach them (modules/panoptic_deeplab.py:422-426).
 
         `grads` may map id(param) -> a pre-zeroed gradient view (the flat DP buffer); `on_ready(param)` is called right
-        after the kernel that finalises a parameter's gradient has been enqueued (bucketed all-reduce hook)."""
+        after the kernel that finalises a parameter's gradient has been enqueued (bucketed all-reduce hook).
+        `stop_before_aspp`: stop after the decoder stages and return the gradient entering the ASPP block instead — the
+        data-parallel graph mode replays everything up to here from a HIP graph and runs `backward_aspp` (90 % of the
+        gradient bytes, the last kernels of the step) eagerly so that its buckets are all-reduced while it is still computing."""
         grads = {} if grads is None else grads
         self._on_ready = on_ready
         self._queue = []
+        fork = max(i for i, r in enumerate(tape) if r[0] == "fork")
+        dy = self._head_backward(tape[fork:], dpred, grads)
+        dy = self._decoder_backward_stages(tape[:fork], dy, grads, feature_grads)
+        if stop_before_aspp:
+            self._flush_ready()
+            return dy
+        self._decoder_backward_aspp(tape[0], dy, grads, feature_grads)
+        self._flush_ready()
+        return grads
+
+    def backward_aspp(self, tape, dy, grads, on_ready=None):
+        """The ASPP part of `backward` on its own (see `stop_before_aspp`)."""
+        self._on_ready = on_ready
+        self._queue = []
+        self._decoder_backward_aspp(tape[0], dy, grads, None)
+        self._flush_ready()
+        return grads
+
+    def aspp_parameters(self):
+        return list(self.dec.aspp.parameters())
+
+    def head_backward(self, tape, dpred, grads=None):
+        """Backward of head_forward_train alone: returns d(loss)/d(decoder features); parameter gradients go to `grads`."""
+        grads = {} if grads is None else grads
+        self._on_ready, self._queue = None, []
+        return self._head_backward(tape, dpred, grads), grads
+
+    def decoder_backward(self, tape, dy, grads=None, feature_grads=None):
+        """Backward of decoder_forward_train alone."""
+        grads = {} if grads is None else grads
+        self._on_ready, self._queue = None, []
+        dy = self._decoder_backward_stages(tape, dy, grads, feature_grads)
+        self._decoder_backward_aspp(tape[0], dy, grads, feature_grads)
+        return grads
+
+    def _head_backward(self, tape, dpred, grads):
         G = lambda p: self._grad(p, grads)
         i = len(tape) - 1
         dfork = None
@@ -401,8 +496,11 @@ class InstanceBranch:
             dx = self._dwsep_bwd(rec, dz, grads)
             dfork = dx if dfork is None else ops.axpy_(dfork, dx)
             i -= 2
-        i -= 1
-        dy = dfork
+        return dfork
+
+    def _decoder_backward_stages(self, tape, dy, grads, feature_grads=None):
+        G = lambda p: self._grad(p, grads)
+        i = len(tape) - 1
         d = self.dec
         # decoder stages, last to first -----------------------------------------------------------------
         while tape[i][0] != "aspp":
@@ -418,8 +516,13 @@ class InstanceBranch:
                 feature_grads[d.low_level_key[si]] = _dx_1x1(dlz, conv)
             dy = ops.resize_bilinear_bwd(dcat, tuple(prev_hw), True, dy_coff=0, c=cy)
             i -= 2
-        # ASPP ------------------------------------------------------------------------------------------
-        _, x, recs, g, gp, cat5, pz, pm, pv, keep, kscale = tape[i]
+        assert i == 0
+        return dy
+
+    def _decoder_backward_aspp(self, rec, dy, grads, feature_grads=None):
+        G = lambda p: self._grad(p, grads)
+        d = self.dec
+        _, x, recs, g, gp, cat5, pz, pm, pv, keep, kscale = rec
         aspp = d.aspp
         pbn = aspp.project[1]
         dpz = ops.bn_train_bwd(pz, dy, pm, pv, pbn.weight.detach(), pbn.bias.detach(), G(pbn.weight), G(pbn.bias), pbn.eps,
@@ -429,7 +532,15 @@ class InstanceBranch:
         dcat5 = _dx_1x1(dpz, pconv0)
         cout = aspp.convs[0][0].out_channels
         dx = None
-        for j in range(4):
+        h, w = x.shape[2:]
+        pconv = aspp.convs[4].aspp_pooling[1]
+        if feature_grads is None:
+            # parameter order in the flat gradient buffer is convs.0 .. convs.4, project: finishing the small pooling branch
+            # first and the four conv branches from the last to the first lets every bucket but the smallest (the 1x1 branch)
+            # be all-reduced under the remaining weight-gradient kernels. The tensors are independent: same values.
+            dgp = ops.relu_bwd(gp, ops.resize_bilinear_bwd(dcat5, (1, 1), True, dy_coff=4 * cout, c=cout))
+            ops.conv2d_wgrad(g, dgp, G(pconv.weight), 1)
+        for j in (range(4) if feature_grads is not None else (3, 2, 1, 0)):
             conv, bn = aspp.convs[j][0], aspp.convs[j][1]
             z, m, v = recs[j]
             dz = ops.bn_train_bwd(z, dcat5, m, v, bn.weight.detach(), bn.bias.detach(), G(bn.weight), G(bn.bias), bn.eps,
@@ -440,16 +551,12 @@ class InstanceBranch:
                 from .body_train import _dgrad_weight
                 part = ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(x.shape[2:]), k, pad=pad, dil=dil)
                 dx = part if dx is None else ops.axpy_(dx, part)
-        h, w = x.shape[2:]
-        dgp = ops.resize_bilinear_bwd(dcat5, (1, 1), True, dy_coff=4 * cout, c=cout)
-        dgp = ops.relu_bwd(gp, dgp)
-        pconv = aspp.convs[4].aspp_pooling[1]
-        ops.conv2d_wgrad(g, dgp, G(pconv.weight), 1)
         if feature_grads is not None:
+            dgp = ops.resize_bilinear_bwd(dcat5, (1, 1), True, dy_coff=4 * cout, c=cout)
+            dgp = ops.relu_bwd(gp, dgp)
+            ops.conv2d_wgrad(g, dgp, G(pconv.weight), 1)
             dg = _dx_1x1(dgp, pconv)
             feature_grads[d.feature_key] = ops.add_per_plane_(dx, dg, 1.0 / (h * w))
-        self._flush_ready()
-        return grads
 
     def trainable_parameters(self):
         return list(self.dec.parameters()) + list(self.head.parameters())

@@ -83,7 +83,7 @@ def deeplab_backward(head, tape, dy, grad_of, group=None):
 # IncrementalClassifier (segmentation_module.py:107-113)
 # ---------------------------------------------------------------------------------------------------------------------
 def cls_forward(cls, x):
-    return cls(x), x
+    return cls._forward(x), x
 
 
 def cls_backward(cls, x, dy, grad_of, need_dx=True):

@@ -523,6 +523,26 @@ def cam_smooth(int_masks, pg_weight, pg_bias, label_new, alpha=0.7):
     return cam
 
 
+def cam_normalize(int_masks, pg_weight, pg_bias, label_new, alpha=0.7):
+    """PeakGenerator eval CAM of the new classes WITHOUT smoothing: [b, cnew, h, w] (see cl4_cam_normalize)."""
+    b, ctot, h, w = int_masks.shape
+    cnew = label_new.shape[1]
+    cam = torch.empty((b, cnew, h, w), dtype=torch.float32, device=int_masks.device)
+    ws = _workspace(int_masks.device, _hip.load().cl4_cam_normalize_workspace_bytes(b, cnew, h, w))
+    call("cl4_cam_normalize", ptr(int_masks), b, ctot, h, w, ptr(pg_weight.reshape(cnew, cnew)), ptr(pg_bias), ptr(label_new),
+         cnew, C.c_float(alpha), ptr(cam), ptr(ws), ws.numel(), stream())
+    return cam
+
+
+def smoothing3x3(x):
+    """`smoothing` of wss/utils.py:28-32 on [b, c, h, w]."""
+    _f32c(x, "smoothing x")
+    b, c, h, w = x.shape
+    out = torch.empty_like(x)
+    call("cl4_smoothing3x3", ptr(x), b * c, h, w, ptr(out), stream())
+    return out
+
+
 def peak_extract(cam, label_new, size, kernel=15, K=25):
     """Upsample-to-`size` + NMS + top-K. Returns device tensors conf f32, ys i32, xs i32 of shape [b, c, K]."""
     b, c, h, w = cam.shape
@@ -804,6 +824,30 @@ def peakgen_train_loss(x, weight, bias, labels_new, alpha=0.7, dweight=None, dbi
     call("cl4_peakgen_train_loss", ptr(x), ptr(wt), ptr(bias), ptr(labels_new), b, ctot, h, w, nc, C.c_float(alpha), ptr(logit),
          ptr(loss), ptr(dx), ptr(dweight) if with_grad else None, ptr(dbias) if with_grad else None, ptr(ws), ws.numel(), stream())
     return loss, logit, dx, dweight, dbias
+
+
+def peakgen_logits(x, weight, bias, nc, alpha=0.7):
+    """PeakGenerator logits of the `nc` new classes (training-mode forward): [b, nc]."""
+    _f32c(x, "peakgen x")
+    b, ctot, h, w = x.shape
+    logit = torch.empty(b, nc, dtype=torch.float32, device=x.device)
+    ws = _p1_ws(x, b, ctot, h, w)
+    call("cl4_peakgen_vjp", ptr(x), ptr(_f32c(weight.reshape(nc, nc), "peakgen weight")), ptr(bias), None, b, ctot, h, w, nc,
+         C.c_float(alpha), ptr(logit), None, None, None, ptr(ws), ws.numel(), stream())
+    return logit
+
+
+def peakgen_vjp(x, weight, bias, dlogit, alpha, dweight, dbias):
+    """d(logits)/d(x, weight, bias) contracted with `dlogit` [b, nc]: returns dx [b, ctot, h, w]; dweight / dbias accumulate."""
+    _f32c(x, "peakgen x"), _f32c(dlogit, "peakgen dlogit")
+    b, ctot, h, w = x.shape
+    nc = dlogit.shape[1]
+    logit = torch.empty(b, nc, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    ws = _p1_ws(x, b, ctot, h, w)
+    call("cl4_peakgen_vjp", ptr(x), ptr(_f32c(weight.reshape(nc, nc), "peakgen weight")), ptr(bias), ptr(dlogit), b, ctot, h, w, nc,
+         C.c_float(alpha), ptr(logit), ptr(dx), ptr(dweight), ptr(dbias), ptr(ws), ws.numel(), stream())
+    return dx
 
 
 def flac_loss(A, bs, old_classes, angle, with_grad=True):

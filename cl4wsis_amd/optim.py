@@ -46,6 +46,10 @@ class FusedAdam(torch.optim.Optimizer):
     def grad_view(self, p):
         return self.grads_fb.views[self.index[id(p)]]
 
+    def flat_params(self):
+        """Parameters in the order of the flat buffers."""
+        return [p for g in self.param_groups for p in g["params"]]
+
     def zero_grad(self, set_to_none=False):
         ops.zero_(self.grads_fb.flat)
 

@@ -85,7 +85,46 @@ class GradBuckets:
         self.is_cuda = flat.flat.is_cuda
         self.native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.comm_stream = torch.cuda.Stream() if (self.is_cuda and self.distributed) else None
+        # The bucket all-reduce goes through the library's own RCCL communicator (cl4_comm_init / cl4_allreduce_bucket,
+        # include/cl4wsis.h) when the job runs on RCCL; torch.distributed then only bootstraps (it carries the 128-byte id).
+        # CL4_COMM=torch keeps torch.distributed's all_reduce on the data path (also the gloo rehearsal path).
+        self.direct = False
+        if self.is_cuda and self.distributed and self.native_avg and process_group is None and os.environ.get("CL4_COMM", "native") != "torch":
+            self.direct = self._init_direct()
+        self.timing = False
+        self._events = []
         self.reset()
+
+    def _init_direct(self):
+        """One RCCL communicator per process, created from an id that rank 0 makes and torch.distributed broadcasts; checked
+        with a sum of ones before it is trusted. Any failure leaves the torch.distributed path in charge."""
+        import ctypes as C
+        from . import _hip
+        try:
+            lib = _hip.load()
+            dev = self.fb.flat.device
+            if lib.cl4_comm_world() != self.world:
+                if lib.cl4_comm_world() != 0:
+                    _hip.call("cl4_comm_destroy")
+                buf = (C.c_char * 128)()
+                if rank() == 0:
+                    _hip.call("cl4_comm_unique_id", buf)
+                t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(dev)
+                dist.broadcast(t, src=0)
+                raw = bytes(t.cpu().numpy().tobytes())
+                with torch.cuda.device(dev):
+                    _hip.call("cl4_comm_init", rank(), self.world, C.c_char_p(raw))
+            probe = torch.ones(8, dtype=torch.float32, device=dev)
+            s = torch.cuda.current_stream(dev)
+            _hip.call("cl4_allreduce_bucket", C.c_void_p(probe.data_ptr()), 8, 0, C.c_void_p(s.cuda_stream))
+            s.synchronize()
+            if not bool((probe == float(self.world)).all()):
+                raise RuntimeError(f"probe all-reduce returned {probe.tolist()} for world size {self.world}")
+            return True
+        except Exception as e:      # noqa: BLE001 - any failure here must degrade to the torch.distributed collectives
+            import warnings
+            warnings.warn(f"cl4wsis_amd: direct RCCL communicator unavailable ({e}); using torch.distributed all_reduce")
+            return False
 
     def reset(self):
         self.pending = [hi - lo for lo, hi in self.bounds]
@@ -100,6 +139,12 @@ class GradBuckets:
             return
         if self.is_cuda:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            if self.direct:
+                import ctypes as C
+                from . import _hip
+                _hip.call("cl4_allreduce_bucket", C.c_void_p(chunk.data_ptr()), chunk.numel(), 1,
+                          C.c_void_p(self.comm_stream.cuda_stream))
+                return
             with torch.cuda.stream(self.comm_stream):
                 if self.native_avg:
                     dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group)      # RCCL
@@ -108,6 +153,15 @@ class GradBuckets:
                     chunk.div_(self.world)
         else:
             self.handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
+
+    def comm_stats(self):
+        """Exposed all-reduce time per step (ms) since `timing` was switched on — needs a device synchronisation first."""
+        if not self._events:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self._events]
+        return {"exposed_ms_per_step": sum(ms) / len(ms), "steps": len(ms), "buckets": len(self.bounds),
+                "bucket_mb": [round(4e-6 * (self.fb.offsets[hi] - self.fb.offsets[lo]), 2) for lo, hi in self.bounds],
+                "path": "cl4_allreduce_bucket (direct RCCL)" if self.direct else "torch.distributed.all_reduce"}
 
     def ready(self, i):
         b = self.bucket_of[i]
@@ -121,7 +175,15 @@ class GradBuckets:
                 self._launch(b)
         if self.distributed:
             if self.is_cuda:
-                torch.cuda.current_stream().wait_stream(self.comm_stream)
+                cur = torch.cuda.current_stream()
+                if self.timing:      # compute stream reaches the join at e0, may proceed at e1: e1 - e0 = exposed communication
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(cur)
+                    cur.wait_stream(self.comm_stream)
+                    e1.record(cur)
+                    self._events.append((e0, e1))
+                else:
+                    cur.wait_stream(self.comm_stream)
             else:
                 for h, chunk in self.handles:
                     h.wait()

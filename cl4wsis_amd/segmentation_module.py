@@ -119,15 +119,40 @@ class IncrementalInstanceSegmentationModule(nn.Module):
             pred = self._upsample_predictions(pred, x.shape[-2:])
         return pred, {"body": x_b, "features": feats}
 
-    @torch.no_grad()
     def forward(self, x, as_feature_extractor=False, interpolate=True, scales=None, do_flip=False):
-        """Full eval forward (segmentation_module.py:360-398): the frozen old model of train.py:253-255 and
-        validation. The trainable phase-2 pass goes through cl4wsis_amd.train.InstanceBranchFunction."""
+        """segmentation_module.py:360-398. Eval mode (the frozen old model of train.py:253-255, validation): fused eval kernels,
+        no autograd. Training mode (`outputs, features = model(images, interpolate=False)`, train.py:274: step 0 and phase 1):
+        every sub-module that is in training mode runs its batch-statistics forward under torch.autograd
+        (cl4wsis_amd/autograd.py), so the reference's loss code + `loss.backward()` work unchanged; sub-modules switched to
+        eval() (train.py:234-240 freezes body / head / cls in phase 2) run the eval kernels and receive no gradient."""
+        if not (self.training and torch.is_grad_enabled()):
+            with torch.no_grad():
+                return self._forward_eval(x, as_feature_extractor, interpolate)
+        from . import autograd as AG
+        if self.body.training:
+            outs = AG.apply(AG.BodyRunner(self.body), [x], list(self.body.parameters()))
+        else:
+            with torch.no_grad():
+                outs = self.body(x)
+        x_b = outs[-1]
+        feats = {f"res{i + 1}": o for i, o in enumerate(outs)}
+        if as_feature_extractor:
+            return {"body": x_b, "features": feats}
+        pred = OrderedDict()
+        instance_l = None
+        if self.decoder is not None:
+            _, instance_l = self.decoder(feats)
+        pred["seg"] = self.cls(self.head(x_b))
+        if "ins" in self.branch:
+            pred.update(self.instance_head(instance_l))
+        if interpolate:
+            pred = OrderedDict((k, AG.apply(AG.ResizeRunner(x.shape[-2:], True), [v], [])) for k, v in pred.items())
+        return pred, {"body": x_b, "features": feats}
+
+    def _forward_eval(self, x, as_feature_extractor=False, interpolate=True):
         x_b, feats = self._features(x)
         if as_feature_extractor:
             return {"body": x_b, "features": feats}
-        if self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("full train-mode forward (step 0) is not built yet")
         pred = OrderedDict(seg=self.cls(self.head(x_b)))
         if "ins" in self.branch:
             pred.update(self.instance_branch().forward_eval(feats))

@@ -134,7 +134,9 @@ class Trainer:
 
     def distribute(self, opts):
         """Replaces the DDP wrappers of train.py:187-196: gradients of the flat buffer are averaged over RCCL."""
-        self.buckets = GradBuckets(self.optimizer.grads_fb, bucket_bytes=16 << 20)
+        # 8 MB buckets: the four ASPP convolutions (8.4 / 18.9 / 18.9 / 18.9 MB of the 63 MB) each close their own bucket, in
+        # the order the backward finishes them (InstanceBranch._decoder_backward_aspp)
+        self.buckets = GradBuckets(self.optimizer.grads_fb, bucket_bytes=8 << 20)
         self._branch = self.model.instance_branch()
         self._p1 = None
         self._cur_epoch = 0
@@ -250,7 +252,8 @@ class Trainer:
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                out = self._forward_backward(self._static["images"], self._static["l1h"], None)
+                out = self._forward_backward(self._static["images"], self._static["l1h"], None,
+                                             split_tail=self.buckets.distributed)
                 if not self.buckets.distributed:
                     opt.step(upload=False)
             self._static["out"] = out
@@ -262,14 +265,21 @@ class Trainer:
         self._graph_active = True
         if not self.buckets.distributed:
             opt.note_replayed_step()
-        else:                                   # gradients are averaged eagerly between the graph and the update
-            for i in range(len(self.buckets.fb.sizes)):
-                self.buckets.ready(i)
+        else:
+            # N > 1: the graph ends where the ASPP block's backward begins. Those last kernels produce 90 % of the gradient
+            # bytes; they run eagerly here so that each bucket's RCCL all-reduce is issued on the communication stream as soon as
+            # its weight-gradient kernel is enqueued and overlaps the remaining ones (RCCL calls stay out of the capture).
+            tape, dy = self._static["out"]["_tail"]
+            aspp = {id(p) for p in self._branch.aspp_parameters()}
+            for p in self.optimizer.flat_params():
+                if id(p) not in aspp:
+                    self.buckets.ready(self.optimizer.index[id(p)])       # finalised inside the graph
+            self._branch.backward_aspp(tape, dy, self._grad_map, on_ready=self._ready)
             self.buckets.finish()
             opt.step()
         return self._static["out"]
 
-    def _forward_backward(self, images, l1h, dropout_keep):
+    def _forward_backward(self, images, l1h, dropout_keep, split_tail=False):
         opts = self.opts
         bs, _, H, W = images.shape
         oc = self.old_classes
@@ -326,10 +336,15 @@ class Trainer:
         losses, dcen, doff = ops.p2_loss(pred["center"], pred["offset"], outputs_old["center"], outputs_old["offset"],
                                          old_w, pseudo, refined, (H, W), self.center_loss_weight, self.offset_loss_weight)
         # train.py:537 — backward of the trainable sub-net; gradient buckets are all-reduced as they complete
+        out = {"losses": losses, "seg_gt": seg_gt, "peaks": peaks, "pseudo": pseudo, "refined": refined,
+               "center": pred["center"], "offset": pred["offset"], "old_w": old_w}
+        if split_tail:       # data-parallel graph capture: stop before the ASPP backward, see _replay
+            dy = self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map, stop_before_aspp=True)
+            out["_tail"] = (tape, dy)
+            return out
         self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map,
                               on_ready=self._ready if (self.buckets.distributed and not torch.cuda.is_current_stream_capturing()) else None)
-        return {"losses": losses, "seg_gt": seg_gt, "peaks": peaks, "pseudo": pseudo, "refined": refined,
-                "center": pred["center"], "offset": pred["offset"], "old_w": old_w}
+        return out
 
     def set_label_override(self, inputs):
         """Benchmark hook (SURVEY.md §8(d) *structured-labels* mode): with random-init networks the label stage only ever sees
@@ -346,6 +361,10 @@ class Trainer:
             CACHE.clear()
             self._graph_active = False
         self._label_acc.zero_()
+
+    def comm_stats(self):
+        """Exposed gradient all-reduce time per step etc. (None unless `self.buckets.timing` was switched on; N > 1 only)."""
+        return self.buckets.comm_stats() if self.buckets.distributed else None
 
     def label_counters(self):
         """Running maxima of the label stage's device-side table counts since construction + the sticky overflow flag

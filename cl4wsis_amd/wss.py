@@ -24,13 +24,19 @@ class PseudoLabeler(nn.Module):
         self.cls = nn.Conv2d(256, num_classes, kernel_size=1, stride=1)
         self.num_classes = num_classes
 
-    @torch.no_grad()
     def forward(self, x):
-        if self.training:
-            raise NotImplementedError("PseudoLabeler training (phase 1, FLAC) is a later §8 row; phase 2 calls .eval()")
-        y = conv_abn(x, self.conv1, self.norm1)
-        y = conv_abn(y, self.conv2, self.norm2)
-        return conv_bias(y, self.cls)
+        """wss/modules.py:335-343. Training mode (phase 1, train.py:311-318): batch statistics over all ranks, differentiable
+        through cl4wsis_amd/autograd.py; eval mode (train.py:304-309, 425-426): fused eval kernels, no autograd."""
+        if self.training and torch.is_grad_enabled():
+            from . import autograd as AG
+            return AG.apply(AG.PseudoLabelerRunner(self), [x], list(self.parameters()))
+        with torch.no_grad():
+            if self.training:
+                from . import heads_train
+                return heads_train.pseudolabeler_forward(self, x.contiguous())[0]
+            y = conv_abn(x, self.conv1, self.norm1)
+            y = conv_abn(y, self.conv2, self.norm2)
+            return conv_bias(y, self.cls)
 
 
 class PeakGenerator(nn.Module):
@@ -55,6 +61,29 @@ class PeakGenerator(nn.Module):
                               self.alpha)
 
     def forward(self, x, label=None, size=None):
+        """wss/modules.py:390-410 — returns (logit [B, num_classes], map): the nGWP logits with zeros for the old classes and,
+        in eval mode, the normalised CAM [B, num_classes, H, W] (old-class channels zero) that the caller smooths and upsamples
+        (train.py:427-431; the step itself uses the fused `cam`). In training mode the second item of the reference is the raw
+        conv map, which train.py:334-336 discards (`peak_logits, _ = ...`): None is returned instead of materialising it.
+        `size` other than the input size is not on the path (cam_normalize is always called with the map's own size)."""
+        B, _, H, W = x.shape
+        if size is not None and tuple(size) != (H, W):
+            raise NotImplementedError("PeakGenerator(size != input size) is never used by train.py")
+        w, b = self.extra_conv4.weight, self.extra_conv4.bias
+        if self.training and torch.is_grad_enabled():
+            from . import autograd as AG
+            new = AG.apply(AG.PeakGeneratorRunner(self), [x], [w, b])
+        else:
+            with torch.no_grad():
+                new = ops.peakgen_logits(x.contiguous(), w.detach(), b.detach(), self.new_classes, self.alpha)
+        logit = torch.cat([new.new_zeros(B, self.old_classes), new], 1) if self.old_classes > 0 else new   # tuple assembly
         if self.training:
-            raise NotImplementedError("PeakGenerator training (phase 1) is a later §8 row; phase 2 calls .eval()")
-        raise RuntimeError("use PeakGenerator.cam(int_masks, label_new): the fused kernel also applies `smoothing`")
+            return logit, None
+        if label is None:
+            raise RuntimeError("PeakGenerator.forward in eval mode needs the image-level labels (wss/modules.py:408)")
+        lab = label[:, -self.new_classes:].to(torch.float32).contiguous()
+        with torch.no_grad():
+            cam_new = ops.cam_normalize(x.contiguous(), w.detach(), b.detach(), lab, self.alpha)
+            cam = x.new_zeros(B, self.num_classes, H, W)
+            ops.copy_channels(cam_new, cam, self.new_classes, out_coff=self.old_classes)
+        return logit, cam

@@ -206,6 +206,14 @@ size_t cl4_cam_smooth_workspace_bytes(int b, int cnew, int h, int w);   /* 0 whe
 int cl4_cam_smooth(const float* int_masks, int b, int ctot, int h, int w, const float* pg_w, const float* pg_b,
                    const float* label_new, int cnew, float alpha, float* cam, void* workspace, size_t workspace_bytes,
                    void* stream);
+/* PeakGenerator.forward in eval mode (wss/modules.py:390-434) WITHOUT the caller's smoothing: cam [b,cnew,h,w] =
+ * relu(conv(PAM(x))) * label / (max_hw + 1e-5) — what `_, cam = peakgenerator(int_masks, l1h)` returns for the new classes
+ * (train.py:427). cl4_smoothing3x3 is `smoothing` (wss/utils.py:28-32; train.py:428): 3x3 mean, zero pad, divisor 9. */
+size_t cl4_cam_normalize_workspace_bytes(int b, int cnew, int h, int w);
+int cl4_cam_normalize(const float* int_masks, int b, int ctot, int h, int w, const float* pg_w, const float* pg_b,
+                      const float* label_new, int cnew, float alpha, float* cam, void* workspace, size_t workspace_bytes,
+                      void* stream);
+int cl4_smoothing3x3(const float* x, long planes, int h, int w, float* out, void* stream);
 /* Bilinear upsample (align_corners=False) to HxW fused with peak_extract (wss/utils.py:3-25): kernel x kernel max-pool
  * NMS + top-K per (b,c). conf/ys/xs: [b,c,K]; slots beyond the positive peaks hold conf=0,y=x=0. Ties: lowest index. */
 size_t cl4_peak_workspace_bytes(int b, int c, int H, int W, int K);
@@ -334,6 +342,12 @@ size_t cl4_p1loss_workspace_bytes(int b, int tot, int h, int w);
 int cl4_peakgen_train_loss(const float* x, const float* weight, const float* bias, const float* labels, int b, int ctot, int h,
                            int w, int nc, float alpha, float* logit, float* loss, float* dx, float* dweight, float* dbias,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* The same generator as a differentiable map for foreign training loops (`peak_logits, _ = peakgenerator(int_masks_raw)`,
+ * train.py:334-336, followed by any loss): dlogit == NULL -> forward only (logit [b,nc]); otherwise the vector-Jacobian
+ * product for the upstream gradient dlogit [b,nc]: dx [b,ctot,h,w] written, dweight / dbias accumulated. */
+int cl4_peakgen_vjp(const float* x, const float* weight, const float* bias, const float* dlogit, int b, int ctot, int h, int w,
+                    int nc, float alpha, float* logit, float* dx, float* dweight, float* dbias, void* workspace,
+                    size_t workspace_bytes, void* stream);
 /* FLAC consistency loss — train.py:314-333. A [3*bs,c,h,h] = PseudoLabeler logits on [x, flip_w(x), rot90(x, angle/90)];
  * angle in {90,180,270}; dA [3*bs,c,h,h] or NULL. */
 int cl4_flac_loss(const float* A, int bs, int c, int old_classes, int h, int w, int angle, float* loss, float* dA, void* workspace,
@@ -442,6 +456,21 @@ size_t cl4_target_generation_workspace_bytes(int b);
 int cl4_target_generation(const long long* seg_map, const uint8_t* mask, int b, int H, int W, int num_classes, int sigma,
                           const float* gauss, float* center, float* offset, float* weight, void* workspace, size_t workspace_bytes,
                           void* stream);
+
+/* --------------------------------------------------------------------------
+ * Data-parallel communication (replaces distributed.init_process_group('nccl') run.py:38 and the DistributedDataParallel
+ * wrappers of train.py:187-196 on the gradient path). One communicator per process, bound to the calling thread's current
+ * HIP device; RCCL is loaded at run time (librccl.so.1). The 128-byte id is created by one rank with cl4_comm_unique_id and
+ * handed to every rank by the caller's own bootstrap channel (TCP store, MPI, torch.distributed ...).
+ * cl4_allreduce_bucket: in-place fp32 all-reduce (sum, or average when `average` != 0) of `count` floats of a caller-owned
+ * buffer, enqueued on `stream` (no host synchronisation; capturable wherever RCCL itself is).
+ * -------------------------------------------------------------------------- */
+int cl4_comm_unique_id(void* id128);
+int cl4_comm_init(int rank, int world, const void* unique_id128);
+int cl4_comm_world(void);
+int cl4_comm_rank(void);
+int cl4_allreduce_bucket(void* buf, size_t count, int average, void* stream);
+int cl4_comm_destroy(void);
 
 #ifdef __cplusplus
 }

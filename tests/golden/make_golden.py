@@ -326,6 +326,64 @@ def label_fixture(R, seed, b, H, W, out_dir=HERE, inp=None, fname=None, top_k=No
           "refined px:", int((refined['weight'] > 0).sum()), "losses:", out["losses"].round(4).tolist())
 
 
+def state_dict_fixture(R):
+    """state_dicts.json.gz — the checkpoint contract as the reference's own modules define it: name, shape
+    and dtype of every state-dict entry of the new / old model for VOC 15-5 (step 0, phase 1 = branch 'none', phase 2),
+    VOC 10-10 step 1 and coco-voc step 1 (WiderResNet-38), of PseudoLabeler and PeakGenerator, plus the two file layouts the
+    loaders read: a `save_ckpt` dictionary as run.py:17-33 writes it from DDP-wrapped modules (`module.` prefixes) and a
+    `<backbone>_iabn_sync.pth.tar`-shaped pretrained file (segmentation_module.py:37-57: {'state_dict': {'module.<body key>':
+    ..., 'classifier.fc.weight/bias': ...}})."""
+    import json
+    ap, sm, wm = R["argparser"], R["segmentation_module"], R["wss_modules"]
+    base = ["--lr_policy", "warmup", "--no_pretrained", "--crop_size", "65"]
+
+    def opts(args):
+        return ap.modify_command_options(ap.get_argparser().parse_args(args + base))
+
+    def desc(sd, prefix=""):
+        return {prefix + k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()}
+
+    out = {}
+    cfgs = {
+        "voc15-5_s0": (["--dataset", "voc", "--task", "15-5", "--step", "0", "--bce", "--optim", "adam"], [16]),
+        "voc15-5_s1_p1": (["--dataset", "voc", "--task", "15-5", "--step", "1", "--weakly", "--phase", "1", "--affinity", "--optim", "sgd"], [16, 5]),
+        "voc15-5_s1_p2": (["--dataset", "voc", "--task", "15-5", "--step", "1", "--weakly", "--phase", "2", "--affinity", "--optim", "adam"], [16, 5]),
+        "voc10-10_s1_p2": (["--dataset", "voc", "--task", "10-10", "--step", "1", "--weakly", "--phase", "2", "--affinity", "--optim", "adam"], [11, 10]),
+        "cocovoc_s1_p2": (["--dataset", "coco-voc", "--task", "voc", "--step", "1", "--weakly", "--phase", "2", "--affinity", "--optim", "adam"], [61, 20]),
+    }
+    for name, (args, classes) in cfgs.items():
+        o = opts(args)
+        torch.manual_seed(0)
+        out[name] = {"classes": classes, "branch": o.branch, "backbone": o.backbone, "model": desc(sm.make_model(o, classes=classes).state_dict())}
+        if len(classes) > 1:
+            out[name]["model_old"] = desc(sm.make_model(o, classes=classes[:-1]).state_dict())
+    o = opts(cfgs["voc15-5_s1_p2"][0])
+    pl = wm.PseudoLabeler(2048, 21, sm.get_norm(o))
+    pg = wm.PeakGenerator(in_channel=21, num_classes=20, old_classes=15)
+    out["pseudolabeler_2048_21"] = desc(pl.state_dict())
+    out["pseudolabeler_4096_81"] = desc(wm.PseudoLabeler(4096, 81, sm.get_norm(o)).state_dict())
+    out["peakgenerator_21_20_15"] = desc(pg.state_dict())
+    # run.py:17-33 on DDP-wrapped modules: every module entry carries the `module.` prefix
+    model = sm.make_model(o, classes=[16, 5])
+    out["save_ckpt_voc15-5_s1_p2"] = {
+        "keys": ["epoch", "model_state", "optimizer_state", "scheduler_state", "scaler", "best_score", "pseudolabeler", "peakgenerator"],
+        "model_state": desc(model.state_dict(), "module."),
+        "pseudolabeler": desc(pl.state_dict(), "module."),
+        "peakgenerator": desc(pg.state_dict(), "module."),
+    }
+    # pretrained body file: the body's own keys under `module.` + the ImageNet classifier that get_body deletes
+    import models
+    body = models.__dict__["net_resnet101"](norm_act=sm.get_norm(o), output_stride=16, keep_outputs=True)
+    pre = desc(body.state_dict(), "module.")
+    pre["classifier.fc.weight"] = [[1000, 2048], "float32"]
+    pre["classifier.fc.bias"] = [[1000], "float32"]
+    out["pretrained_resnet101_iabn_sync"] = {"state_dict": pre}
+    import gzip
+    with gzip.open(os.path.join(HERE, "state_dicts.json.gz"), "wt") as f:
+        json.dump(out, f, sort_keys=True)
+    print("state_dicts.json.gz", {k: (len(v.get("model", v)) if isinstance(v, dict) else 0) for k, v in out.items()})
+
+
 WSS_CASES = [(0, 2, 21, 33, 33), (1, 3, 21, 17, 25), (2, 2, 11, 33, 33)]
 
 
@@ -388,6 +446,7 @@ def wss_fixture(R, seed, b, c, h, w):
 if __name__ == "__main__":
     R = ref_harness.load_reference()
     torch.set_num_threads(8)
+    state_dict_fixture(R)
     model_fixture(R)
     model_p1_fixture(R)
     wrn_fixture(R)
