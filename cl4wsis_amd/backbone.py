@@ -10,7 +10,7 @@ from collections import OrderedDict
 import torch.nn as nn
 
 from . import ops
-from .nn import ABN, conv_abn, packed_weight
+from .nn import ABN, conv_abn, gamma_of, packed_weight
 
 
 class _Holder(nn.Module):
@@ -114,7 +114,7 @@ def _abn_eval(x, bn):
     """Stand-alone InPlaceABN in eval mode (running statistics) — the pre-activation `bn1` of a block reads the SUM of the
     previous block, so it cannot ride in a producing convolution's epilogue."""
     act, slope = bn.act_code()
-    return ops.bn_apply(x, bn.running_mean, bn.running_var, bn.weight.detach(), bn.bias.detach(), eps=bn.eps, act=act, slope=slope)
+    return ops.bn_apply(x, bn.running_mean, bn.running_var, gamma_of(bn), bn.bias.detach(), eps=bn.eps, act=act, slope=slope)
 
 
 class IdentityResidualBlock(nn.Module):

@@ -12,7 +12,7 @@ import torch
 import os
 
 from . import ops
-from .nn import CACHE, packed_weight
+from .nn import CACHE, gamma_grad, gamma_of, packed_weight
 
 # Arithmetic of the convolutions of the step-0 / phase-1 training paths (forward, input and weight gradients): 2 (default) = bf16x6, three bf16 planes per operand and six products — fp32-level
 # accuracy (the gradient parity bar of the tests) at about twice the speed of the fp32 MFMA kernels; 0 = exact fp32 MFMA;
@@ -40,7 +40,7 @@ def conv_abn_train(x, conv, bn, group=None):
     r.x = x
     r.z = ops.conv2d(x, packed_weight(conv, PRECISION), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0])
     act, slope = bn.act_code()
-    r.y, r.mean, r.var, r.count = ops.abn_train_forward(r.z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+    r.y, r.mean, r.var, r.count = ops.abn_train_forward(r.z, gamma_of(bn), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                         bn.momentum, bn.eps, act, slope, group)
     CACHE.touch(bn.running_mean)
     CACHE.touch(bn.running_var)
@@ -49,8 +49,11 @@ def conv_abn_train(x, conv, bn, group=None):
 
 def conv_abn_backward(r, conv, bn, dy, grad_of, need_dx=True, group=None):
     act, slope = bn.act_code()
-    dz = ops.abn_train_backward(r.z, dy, r.mean, r.var, bn.weight.detach(), bn.bias.detach(), grad_of(bn.weight), grad_of(bn.bias),
+    gw, fin = gamma_grad(bn, grad_of)
+    dz = ops.abn_train_backward(r.z, dy, r.mean, r.var, gamma_of(bn), bn.bias.detach(), gw, grad_of(bn.bias),
                                 r.count, bn.eps, act, slope, group)
+    if fin is not None:
+        fin()
     k = conv.kernel_size[0]
     ops.conv2d_wgrad(r.x, dz, grad_of(conv.weight), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], precision=WGRAD_PRECISION)
     if not need_dx:

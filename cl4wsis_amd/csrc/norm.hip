@@ -428,6 +428,28 @@ extern "C" int cl4_random_labels(int* out, long n, uint64_t seed, int modulus, v
 
 __global__ void counter_add_kernel(uint64_t* c, uint64_t inc) { *c += inc; }
 
+__global__ void abs_eps_kernel(const float* __restrict__ w, float* __restrict__ out, int n, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fabsf(w[i]) + eps;
+}
+__global__ void sign_axpy_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ w, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += w[i] > 0.f ? x[i] : -x[i];
+}
+
+// InPlaceABN's effective scale and its chain rule (mapillary/inplace_abn, absent third-party package, believed behaviour:
+// the fused kernels compute with gamma = |weight| + eps and return d(weight) = (weight > 0 ? 1 : -1) * d(gamma)).
+extern "C" int cl4_abs_eps(const float* w, float* out, int n, float eps, void* stream) {
+  CL4_REQUIRE(w && out && n > 0, "abs_eps: bad arguments");
+  hipLaunchKernelGGL(abs_eps_kernel, dim3(cl4::cdiv(n, 256)), dim3(256), 0, cl4::as_stream(stream), w, out, n, eps);
+  return cl4::launch_status();
+}
+extern "C" int cl4_sign_axpy(float* y, const float* x, const float* w, int n, void* stream) {
+  CL4_REQUIRE(y && x && w && n > 0, "sign_axpy: bad arguments");
+  hipLaunchKernelGGL(sign_axpy_kernel, dim3(cl4::cdiv(n, 256)), dim3(256), 0, cl4::as_stream(stream), y, x, w, n);
+  return cl4::launch_status();
+}
+
 extern "C" int cl4_dropout_mask_dev(uint8_t* keep, long n, uint64_t* seed_dev, uint64_t advance, float p, void* stream) {
   CL4_REQUIRE(keep && seed_dev && n > 0 && p >= 0.f && p < 1.f, "dropout_mask_dev: bad arguments");
   hipStream_t st = cl4::as_stream(stream);

@@ -5,12 +5,12 @@ import torch
 from . import ops
 from . import body_train as BT
 from .body_train import _Rec, _dgrad_weight, conv_abn_backward, conv_abn_train
-from .nn import CACHE, packed_weight
+from .nn import CACHE, gamma_grad, gamma_of, packed_weight
 
 
 def _abn_fwd(z, bn, group):
     act, slope = bn.act_code()
-    y, mean, var, count = ops.abn_train_forward(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+    y, mean, var, count = ops.abn_train_forward(z, gamma_of(bn), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                 bn.momentum, bn.eps, act, slope, group)
     CACHE.touch(bn.running_mean)
     CACHE.touch(bn.running_var)
@@ -20,8 +20,12 @@ def _abn_fwd(z, bn, group):
 def _abn_bwd(rec, bn, dy, grad_of, group):
     z, mean, var, count = rec
     act, slope = bn.act_code()
-    return ops.abn_train_backward(z, dy, mean, var, bn.weight.detach(), bn.bias.detach(), grad_of(bn.weight), grad_of(bn.bias), count,
-                                  bn.eps, act, slope, group)
+    gw, fin = gamma_grad(bn, grad_of)
+    dz = ops.abn_train_backward(z, dy, mean, var, gamma_of(bn), bn.bias.detach(), gw, grad_of(bn.bias), count,
+                                bn.eps, act, slope, group)
+    if fin is not None:
+        fin()
+    return dz
 
 
 def _conv1x1_bwd(x, conv, dz, grad_of, need_dx=True):

@@ -4,6 +4,8 @@ The modules keep the reference's attribute names so that ``state_dict()`` keys a
 checkpoint contract of SURVEY.md Appendix B; their ``forward`` never runs a torch compute op —
 it enqueues the HIP kernels of libcl4wsis_hip.so through :mod:`cl4wsis_amd.ops`.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -17,6 +19,7 @@ class ABN(nn.Module):
     (reference: segmentation_module.py:17-29; attribute use in modules/residual.py:52,65,82,92-93,
     modules/deeplab.py:39): weight, bias, running_mean, running_var, .activation, .activation_param.
     Eval mode is folded into the producing conv's epilogue (scale/shift + leaky-ReLU)."""
+    abs_gamma = False           # plain ABN = functional.batch_norm + activation: scales with `weight` itself
 
     def __init__(self, num_features, eps=EPS, momentum=0.1, affine=True, activation="leaky_relu",
                  activation_param=0.01, group=None):
@@ -42,8 +45,33 @@ class ABN(nn.Module):
         raise RuntimeError("ABN is fused into the producing convolution; call the owning block instead")
 
 
-InPlaceABN = ABN
-InPlaceABNSync = ABN
+class InPlaceABN(ABN):
+    """inplace_abn.InPlaceABN: same parameters as ABN, but the fused kernels of the (absent, unpinned) package scale with
+    `|weight| + eps` instead of `weight` and return d(weight) = sign(weight) * d(scale) — believed behaviour of
+    mapillary/inplace_abn (its kernels read `gamma = abs(weight) + eps`). Irrelevant for positive scales up to 1e-5, decisive
+    for a pretrained `*_iabn_sync` checkpoint that holds negative ones. CL4_IABN_PLAIN=1 restores the plain-BN reading."""
+    abs_gamma = os.environ.get("CL4_IABN_PLAIN", "0") != "1"
+
+
+class InPlaceABNSync(InPlaceABN):
+    pass
+
+
+def gamma_of(bn):
+    """The scale the normalisation kernels must use: |weight| + eps for InPlaceABN(Sync), weight otherwise."""
+    if getattr(bn, "abs_gamma", False):
+        return CACHE.get(bn, "absg", (bn.weight,), lambda: ops.abs_eps(bn.weight.detach(), bn.eps))
+    return bn.weight.detach()
+
+
+def gamma_grad(bn, grad_of):
+    """(buffer the backward kernel accumulates d(scale) into, finaliser or None). For InPlaceABN the kernel's result is the
+    gradient of the effective scale; the finaliser folds it into the weight's gradient with the sign rule."""
+    gw = grad_of(bn.weight)
+    if not getattr(bn, "abs_gamma", False):
+        return gw, None
+    tmp = torch.zeros_like(gw)
+    return tmp, (lambda: ops.sign_axpy_(gw, tmp, bn.weight.detach()))
 
 
 class _Cache:
@@ -93,7 +121,7 @@ def folded_bn(bn, lo=0, hi=None):
     ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
 
     def build():
-        return ops.bn_fold(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+        return ops.bn_fold(gamma_of(bn), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
 
     scale, shift = CACHE.get(bn, "bn", ts, build)
     if lo == 0 and hi is None:

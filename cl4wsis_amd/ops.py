@@ -100,6 +100,18 @@ def pack_conv_weight(w, precision=None):
     return PackedWeight(wp, K, cout, 0)
 
 
+def abs_eps(w, eps):
+    out = torch.empty_like(w)
+    call("cl4_abs_eps", ptr(w), ptr(out), w.numel(), C.c_float(eps), stream())
+    return out
+
+
+def sign_axpy_(y, x, w):
+    """y += sign(w) * x with sign(0) = -1 (inplace_abn's convention)."""
+    call("cl4_sign_axpy", ptr(y), ptr(x), ptr(w), y.numel(), stream())
+    return y
+
+
 def bn_fold(gamma, beta, mean, var, eps=1e-5):
     c = mean.numel()
     scale = torch.empty(c, dtype=torch.float32, device=mean.device)

@@ -160,6 +160,24 @@ class IncrementalInstanceSegmentationModule(nn.Module):
             pred = self._upsample_predictions(pred, x.shape[-2:])
         return pred, {"body": x_b, "features": feats}
 
+    def init_new_classifier(self, device):
+        """segmentation_module.py:342-358 (`--init_balanced`): the newest semantic and centre classifiers start from the
+        background / first-channel weights with bias = bias_bkg - log(N_new + 1), and the background bias is lowered by the same
+        amount. The reference's body addresses `self.segmentation_head['seg']['cls']`, an attribute its own constructor never
+        creates with the DeepLabV3 semantic head (the flag therefore raises AttributeError upstream and no script sets it);
+        this is the same arithmetic applied to the classifiers that do exist: `cls` and `instance_head.classifier.center.cls`."""
+        import math
+        groups = [self.cls]
+        if self.instance_head is not None:
+            groups.append(self.instance_head.classifier["center"]["cls"])
+        with torch.no_grad():
+            for all_cls in groups:
+                new, first = all_cls[-1], all_cls[0]
+                new_bias = first.bias[0] - math.log(self.classes[-1] + 1)
+                new.weight.copy_(first.weight[0].expand_as(new.weight))
+                new.bias.fill_(float(new_bias))
+                first.bias[0] = new_bias
+
     def freeze(self):
         for par in self.parameters():
             par.requires_grad = False

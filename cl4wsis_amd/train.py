@@ -532,10 +532,15 @@ class Trainer:
         if self.opts.step_ckpt is not None:
             path = self.opts.step_ckpt
         if not osp.exists(path):
+            if getattr(self.opts, "debug", False):           # train.py:766-768
+                self.logger.info(f"[!] WARNING: Unable to find of step {self.opts.step - 1}! Do you really want to do from scratch?")
+                return
             raise FileNotFoundError(path)
         ck = torch.load(path, map_location="cpu")
         state = self._strip(ck["model_state"])
         self.model.load_state_dict(state, strict=False)
+        if getattr(self.opts, "init_balanced", False):       # train.py:752-754
+            self.model.init_new_classifier(self.device)
         strict = self.opts.branch not in ("none", "seg")
         self.model_old.load_state_dict(state, strict=strict)
         self._realias()
@@ -560,8 +565,9 @@ class Trainer:
         import os.path as osp
         assert osp.isfile(path), f"Error, ckpt not found in {path}"
         ck = torch.load(path, map_location="cpu")
-        state = {k: v for k, v in self._strip(ck["model_state"]).items() if k.startswith(("body.", "head.", "cls."))}
-        self.model.load_state_dict(state, strict=False)
+        # the whole model state, non-strict, exactly like the reference: a phase-1 checkpoint (branch 'none') simply holds no
+        # instance-branch keys, so decoder / instance_head keep the step-0 weights loaded before
+        self.model.load_state_dict(self._strip(ck["model_state"]), strict=False)
         self._realias()
         if "pseudolabeler" in ck and self.pseudolabeler is not None:
             self.pseudolabeler.load_state_dict(self._strip(ck["pseudolabeler"]))

@@ -457,6 +457,12 @@ int cl4_target_generation(const long long* seg_map, const uint8_t* mask, int b, 
                           const float* gauss, float* center, float* offset, float* weight, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* InPlaceABN(Sync) (segmentation_module.py:19-27; mapillary/inplace_abn, not vendored) scales with |weight| + eps, not with
+ * weight: cl4_abs_eps writes that effective scale (out[i] = |w[i]| + eps), cl4_sign_axpy applies its chain rule
+ * (y[i] += w[i] > 0 ? x[i] : -x[i]) to a gradient computed with respect to the effective scale. */
+int cl4_abs_eps(const float* w, float* out, int n, float eps, void* stream);
+int cl4_sign_axpy(float* y, const float* x, const float* w, int n, void* stream);
+
 /* --------------------------------------------------------------------------
  * Data-parallel communication (replaces distributed.init_process_group('nccl') run.py:38 and the DistributedDataParallel
  * wrappers of train.py:187-196 on the gradient path). One communicator per process, bound to the calling thread's current

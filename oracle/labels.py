@@ -159,8 +159,8 @@ def cluster_peaks(offset_map, fg, thresh=2.5, beta=5):
 def group_pixels(ctr, offsets):
     """modules/utils.py:505-542. ctr [K,2] (y,x) long; offsets [2,H,W]. Returns [H,W] ids starting at 1."""
     _, H, W = offsets.shape
-    y = torch.arange(H, dtype=offsets.dtype).repeat(1, W, 1).transpose(1, 2)
-    x = torch.arange(W, dtype=offsets.dtype).repeat(1, H, 1)
+    y = torch.arange(H, dtype=offsets.dtype, device=offsets.device).repeat(1, W, 1).transpose(1, 2)
+    x = torch.arange(W, dtype=offsets.dtype, device=offsets.device).repeat(1, H, 1)
     loc = (torch.cat((y, x), 0) + offsets).reshape(2, H * W).transpose(1, 0)
     dist = torch.norm(ctr.unsqueeze(1) - loc.unsqueeze(0), dim=-1)
     return torch.argmin(dist, dim=0).reshape(H, W) + 1
@@ -172,9 +172,9 @@ def get_instance_segmentation(fg, c_center_map, offsets, threshold, nms_kernel, 
     ctr = find_instance_center(c_center_map, threshold, nms_kernel)
     new_ctr = ctr
     if beta > 0:
-        cl = cluster_peaks(offsets.numpy(), fg.numpy(), beta=beta)
+        cl = cluster_peaks(offsets.cpu().numpy(), fg.cpu().numpy(), beta=beta)       # the reference's own .cpu() copies (:565)
         cl = np.int32([[cy, cx] for cy, cx in cl if c_center_map[cy, cx] > 0.05])
-        cl = torch.from_numpy(cl).long()
+        cl = torch.from_numpy(cl).to(ctr.device).long()
         new_ctr = ctr.clone()
         if cl.size(0) > 0:
             if ctr.size(0) == 0:
@@ -196,23 +196,26 @@ def refine_label_generation(seg_logits, center_map, offset_map, label, gt_seg_ma
     """modules/utils.py:257-385 (top_k=None). seg_logits [B,C+1,H,W]; center_map [B,C,H,W]; offset_map [B,2,H,W];
     label [B,C]; gt_seg_map [B,H,W] long. Returns dict(center [B,C,H,W], offset [B,2,H,W], weight [B,1,H,W]) f32."""
     B, C, H, W = center_map.shape
+    dev = center_map.device      # cpu for the oracle proper; on a GPU (bench.py's stock comparator) the tensor work stays on the
+    # device and only masks / centroids cross to the host — exactly the reference's own split (modules/utils.py:277-325)
     prob = F.softmax(seg_logits, dim=1)
     prob[:, 1:] *= label[:, :, None, None]
-    r_off = torch.zeros((B, 2, H, W))
-    r_w = torch.zeros((B, 1, H, W))
+    r_off = torch.zeros((B, 2, H, W), device=dev)
+    r_w = torch.zeros((B, 1, H, W), device=dev)
     r_ctr = np.zeros((B, C, H, W), dtype=np.float32)
-    yc, xc = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
-    lab = label.numpy()
+    yc, xc = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=dev), torch.arange(W, dtype=torch.float32, device=dev),
+                            indexing="ij")
+    lab = label.cpu().numpy()
     g = gaussian(sigma)
     for b in range(B):
         for cls in np.nonzero(lab[b])[0]:
             fgm = (gt_seg_map[b] == (cls + 1))
-            n, contours, area, cent = connected_components(fgm.numpy().astype(np.uint8), 8)
+            n, contours, area, cent = connected_components(fgm.cpu().numpy().astype(np.uint8), 8)
             for k in range(1, n):
                 if area[k] < MINIMUM_MASK_SIZE:
                     continue
                 cx, cy = int(cent[k][0]), int(cent[k][1])
-                cmask = torch.from_numpy(contours == k)
+                cmask = torch.from_numpy(contours == k).to(dev)
                 c_ctr = center_map[b, cls] * cmask
                 ins = get_instance_segmentation(cmask, c_ctr, offset_map[b], refine_thresh, kernel, beta)
                 n_ins = int(ins.max())
@@ -236,7 +239,7 @@ def refine_label_generation(seg_logits, center_map, offset_map, label, gt_seg_ma
                         r_w[b, 0][idx] = conf
                         r_off[b, 0][idx] = py - yc[idx]
                         r_off[b, 1][idx] = px - xc[idx]
-    return {"center": torch.from_numpy(r_ctr), "offset": r_off, "weight": r_w}
+    return {"center": torch.from_numpy(r_ctr).to(dev), "offset": r_off, "weight": r_w}
 
 
 def weighted_mse(out, target, weight):

@@ -25,9 +25,16 @@ SLOPE = 0.01
 RESNET101 = (3, 4, 23, 3)
 
 
+IABN_ABS_GAMMA = True    # InPlaceABN(Sync) scales with |weight| + eps (believed behaviour of the absent inplace_abn package)
+
+
 def _abn(x, sd, p, act=True, training=False):
-    """InPlaceABN(Sync) — segmentation_module.py:17-29 (third-party; BN + leaky-ReLU 0.01)."""
-    y = F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+    """InPlaceABN(Sync) — segmentation_module.py:17-29 (third-party, not vendored, unpinned): batch norm + leaky-ReLU 0.01 whose
+    fused kernels read the scale as `abs(weight) + eps`; autograd of `abs` gives the package's d(weight) = sign(weight) * d(scale)."""
+    w = sd[p + ".weight"]
+    if IABN_ABS_GAMMA:
+        w = w.abs() + EPS
+    y = F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], w, sd[p + ".bias"],
                      training, 0.1, EPS)
     return F.leaky_relu(y, SLOPE) if act else y
 

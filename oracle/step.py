@@ -49,10 +49,9 @@ def label_and_loss(center_lo, offset_lo, old_center_lo, old_offset_lo, seg2b, l1
     if run_refine:
         l1h_new = l1h.clone()
         l1h_new[:, :old_classes - 1] = 0
-        host = lambda t: t.detach().float().cpu().clone()
-        refined = L.refine_label_generation(host(seg_up), host(center), host(offset), l1h_new.cpu(), seg_gt.cpu().clone(),
+        own = lambda t: t.detach().float().clone()
+        refined = L.refine_label_generation(own(seg_up), own(center), own(offset), l1h_new, seg_gt.clone(),
                                             refine_thresh, kernel, beta, sigma)
-        refined = {k: v.to(dev) for k, v in refined.items()}
         out["refined"] = refined
     old_center = F.interpolate(old_center_lo, size=size, mode="bilinear", align_corners=False)
     old_offset = F.interpolate(old_offset_lo, size=size, mode="bilinear", align_corners=False)

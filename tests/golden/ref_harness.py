@@ -47,8 +47,22 @@ def _install_stubs():
                 return F.elu(y, self.activation_param)
             return y
 
+    class InPlaceABN(ABN):
+        """The in-place variants' fused kernels scale with |weight| + eps (believed behaviour of mapillary/inplace_abn,
+        DESIGN.md §2); the plain ABN above goes through functional.batch_norm with the weight as it is."""
+
+        def forward(self, x):
+            y = F.batch_norm(x, self.running_mean, self.running_var, self.weight.abs() + self.eps, self.bias, self.training,
+                             self.momentum, self.eps)
+            if self.activation == "leaky_relu":
+                return F.leaky_relu(y, self.activation_param)
+            if self.activation == "elu":
+                return F.elu(y, self.activation_param)
+            return y
+
     abn = types.ModuleType("inplace_abn")
-    abn.ABN = abn.InPlaceABN = abn.InPlaceABNSync = ABN
+    abn.ABN = ABN
+    abn.InPlaceABN = abn.InPlaceABNSync = InPlaceABN
     abn.functions = types.ModuleType("inplace_abn.functions")
     sys.modules["inplace_abn"] = abn
     sys.modules["inplace_abn.functions"] = abn.functions

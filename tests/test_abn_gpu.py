@@ -101,3 +101,60 @@ def test_dropout_masks_of_successive_steps_are_independent(gpu):
     s1 = torch.tensor([77], dtype=torch.int64, device=gpu)
     s2 = torch.tensor([77], dtype=torch.int64, device=gpu)
     assert torch.equal(ops.dropout_mask_dev(shape, 0.5, s1, 1, gpu), ops.dropout_mask_dev(shape, 0.5, s2, 1, gpu))
+
+
+def test_inplace_abn_scales_with_abs_gamma_plus_eps(gpu):
+    """InPlaceABN(Sync) — the norm every shipped configuration selects (`--norm_act iabn_sync`) — computes with |weight| + eps
+    and returns d(weight) = sign(weight) * d(scale) (believed behaviour of the absent mapillary/inplace_abn package). A real
+    `*_iabn_sync` checkpoint holds negative weights, so eval folding, train-mode forward and backward are checked with a
+    mixed-sign weight vector against autograd of that formula; plain ABN keeps the signed weight."""
+    import torch.nn as nn
+    from cl4wsis_amd import body_train, nn as N, ops
+    g = torch.Generator().manual_seed(5)
+    c = 40
+    conv = nn.Conv2d(24, c, 3, padding=1, bias=False).to(gpu)
+    x = torch.randn(3, 24, 19, 17, generator=g)
+    dy = torch.randn(3, c, 19, 17, generator=g)
+    w = conv.weight.detach().cpu()
+
+    def make(cls):
+        bn = cls(c, activation="leaky_relu", activation_param=0.01).to(gpu)
+        with torch.no_grad():
+            bn.weight.copy_((torch.rand(c, generator=g) + 0.5) * torch.where(torch.arange(c) % 3 == 0, -1.0, 1.0))
+            bn.bias.copy_(torch.randn(c, generator=g) * 0.2)
+            bn.running_mean.copy_(torch.randn(c, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+        return bn
+
+    for cls, absg in ((N.InPlaceABNSync, True), (N.InPlaceABN, True), (N.ABN, False)):
+        bn = make(cls)
+        assert bn.abs_gamma == absg and (bn.weight < 0).any()
+        gam = lambda t: (t.abs() + bn.eps) if absg else t
+        # eval: folded into the conv epilogue
+        with torch.no_grad():
+            y = N.conv_abn(x.to(gpu), conv, bn)
+        ref = F.leaky_relu(F.batch_norm(F.conv2d(x, w, padding=1), bn.running_mean.cpu(), bn.running_var.cpu(), gam(bn.weight.detach().cpu()),
+                                        bn.bias.detach().cpu(), False, 0.1, bn.eps), 0.01)
+        assert _rel(y, ref) < 2e-5
+        # train: batch statistics, backward with the sign rule
+        gr = bn.weight.detach().cpu().clone().requires_grad_(True)
+        br = bn.bias.detach().cpu().clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        yr = F.leaky_relu(F.batch_norm(F.conv2d(x, wr, padding=1), torch.zeros(c), torch.ones(c), gam(gr), br, True, 0.1, bn.eps), 0.01)
+        yr.backward(dy)
+        saved = body_train.PRECISION, body_train.WGRAD_PRECISION
+        body_train.PRECISION, body_train.WGRAD_PRECISION = 0, 0          # exact fp32 kernels: the comparison is about the formula
+        try:
+            grads = {}
+
+            def grad_of(p):
+                return grads.setdefault(id(p), torch.zeros_like(p))
+
+            yt, rec = body_train.conv_abn_train(x.to(gpu), conv, bn)
+            body_train.conv_abn_backward(rec, conv, bn, dy.to(gpu), grad_of, need_dx=False)
+        finally:
+            body_train.PRECISION, body_train.WGRAD_PRECISION = saved
+        assert _rel(yt, yr.detach()) < 2e-5
+        assert _rel(grads[id(bn.weight)], gr.grad) < 1e-4, cls.__name__
+        assert _rel(grads[id(bn.bias)], br.grad) < 1e-4
+        assert _rel(grads[id(conv.weight)], wr.grad) < 1e-4
