@@ -49,6 +49,12 @@ struct ConvArgs {
   // bf16 kernels (1-D launches): logical tile = tile_base + (workgroup % ntile_l), M index fastest over gx tiles; the split-K
   // slabs cover the pixels [ws_p0, ws_p0 + ws_npix) only ("main + split tail" plans split just the last partial round)
   int gx, ntile_l, tile_base, ws_p0, ws_npix;
+  // Phase stagger (speed only): the two workgroups that share a CU start together and, with equal tiles, stay in lockstep —
+  // both in their K loops (HBM idle), then both in their epilogues (MFMA idle), so the phases ADD instead of overlapping
+  // (tools/probe_epilogue.py: output pass + residual pass + K loop = the measured time). Workgroups 256..511 of a launch — the
+  // second resident workgroup of each CU in dispatch order — sleep `stagger` x 8128 cycles before they start; their successors
+  // inherit the offset because a slot is refilled when its previous tenant retires.
+  int stagger;
 };
 
 
@@ -532,6 +538,8 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
   // fastest: the M tiles that re-read one pixel tile (and neighbouring pixel tiles that share halo rows) meet in one L2.
   const unsigned total = gridDim.x;            // 1-D launch: ntile_l tiles x splits
   const unsigned id = blockIdx.x;
+  if (!PERS && a.stagger > 0 && id >= 256u && id < 512u)
+    for (int s_ = 0; s_ < a.stagger; ++s_) __builtin_amdgcn_s_sleep(127);
   const unsigned q8 = total >> 3, r8 = total & 7, xcd = id & 7;
   const unsigned lid = a.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3) : id;
   const unsigned bz = PERS ? 0u : lid / (unsigned)a.ntile_l;
@@ -1770,6 +1778,7 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
   a.gx = 1; a.ntile_l = 1; a.tile_base = 0; a.ws_p0 = 0; a.ws_npix = a.npix;
   static const int xcd_default = env_int("CL4_XCD_REMAP", 1);
   a.xcd_remap = xcd_default;
+  a.stagger = env_int("CL4_CONV_STAGGER", 0);      // read per call: experiments sweep it inside one process
   a.neg1 = d->act1 == CL4_ACT_NONE ? 1.f : (d->act1 == CL4_ACT_RELU ? 0.f : d->slope1);
   a.neg2 = d->act2 == CL4_ACT_NONE ? 1.f : (d->act2 == CL4_ACT_RELU ? 0.f : d->slope2);
   hipStream_t st = cl4::as_stream(stream);
