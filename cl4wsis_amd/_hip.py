@@ -115,6 +115,7 @@ _decl("cl4_dwconv5_fwd", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_dwconv5_wgrad", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 
 _decl("cl4_cam_smooth", _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P, C.c_size_t, _P)
+_decl("cl4_conv_debug_timeline", _P)
 _decl("cl4_abs_eps", _P, _P, _I, _F, _P)
 _decl("cl4_sign_axpy", _P, _P, _P, _I, _P)
 _decl("cl4_comm_unique_id", _P)

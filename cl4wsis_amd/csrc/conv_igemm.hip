@@ -49,12 +49,10 @@ struct ConvArgs {
   // bf16 kernels (1-D launches): logical tile = tile_base + (workgroup % ntile_l), M index fastest over gx tiles; the split-K
   // slabs cover the pixels [ws_p0, ws_p0 + ws_npix) only ("main + split tail" plans split just the last partial round)
   int gx, ntile_l, tile_base, ws_p0, ws_npix;
-  // Phase stagger (speed only): the two workgroups that share a CU start together and, with equal tiles, stay in lockstep —
-  // both in their K loops (HBM idle), then both in their epilogues (MFMA idle), so the phases ADD instead of overlapping
-  // (tools/probe_epilogue.py: output pass + residual pass + K loop = the measured time). Workgroups 256..511 of a launch — the
-  // second resident workgroup of each CU in dispatch order — sleep `stagger` x 8128 cycles before they start; their successors
-  // inherit the offset because a slot is refilled when its previous tenant retires.
-  int stagger;
+  // Experiments only (tools/probe_timeline.py): when set, every workgroup of a bf16 launch records s_memtime stamps and its
+  // XCC / CU ids into timeline[blockIdx * 8 ..]: [0] start, [1] first K-tile ready, [2] K loop done, [3] accumulators parked,
+  // [4] epilogue done (MFMA wave 0), [5] loader wave 0 done, [6] (xcc << 8) | cu, [7] logical tile.
+  unsigned long long* timeline;
 };
 
 
@@ -538,8 +536,17 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
   // fastest: the M tiles that re-read one pixel tile (and neighbouring pixel tiles that share halo rows) meet in one L2.
   const unsigned total = gridDim.x;            // 1-D launch: ntile_l tiles x splits
   const unsigned id = blockIdx.x;
-  if (!PERS && a.stagger > 0 && id >= 256u && id < 512u)
-    for (int s_ = 0; s_ < a.stagger; ++s_) __builtin_amdgcn_s_sleep(127);
+  unsigned long long* tl = a.timeline ? a.timeline + (size_t)id * 8 : nullptr;
+  auto stamp = [&](int slot) {
+    if (tl && lane == 0 && (wave8 == 0 || (slot == 5 && wave8 == 4))) tl[slot] = __builtin_amdgcn_s_memtime();
+  };
+  if (tl && tid == 0) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    tl[6] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+  }
+  stamp(0);
   const unsigned q8 = total >> 3, r8 = total & 7, xcd = id & 7;
   const unsigned lid = a.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3) : id;
   const unsigned bz = PERS ? 0u : lid / (unsigned)a.ntile_l;
@@ -589,6 +596,7 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
     const float* stage = reinterpret_cast<const float*>(&lds[0][0]);       // [BM][BN] fp32, <= the two K-tile stages
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    stamp(3);
     if (LW > 4 && wave8 >= 8) return;
     constexpr int RPW = BM / 8, PPL = BN / 64, RB = 8;   // rows per batch: 16 measured slower (registers), 4 no better
     long ybase[PPL], rbase[PPL];
@@ -652,6 +660,10 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
         for (int q = 0; q < PPL; ++q)
           if (pv[q]) a.y[ybase[q] + (long)co * HWo] = v[rr][q] > 0.f ? v[rr][q] : v[rr][q] * a.neg2;
       }
+    }
+    if (tl) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(wave8 == 4 ? 5 : 4);
     }
   };
 
@@ -883,6 +895,7 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   __builtin_amdgcn_s_barrier();
+  stamp(1);
   int gk = 0;                                  // K-tiles consumed so far (its parity is the LDS stage)
   for (int ti = 0; ti < (PERS ? cnt : 1); ++ti) {
   if (PERS && ti > 0) {
@@ -940,6 +953,7 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
   if (PERS) fused_epilogue<TM, TN>(a, acc, m0 + wm * WTM, n0 + wn * WTN, lr, lh, HWo);
   }
   for (int e_ = TOT % NS; e_ != 0 && e_ < NS; ++e_) __builtin_amdgcn_s_barrier();   // pairs with the loaders' padded half-iterations
+  stamp(2);
   if (PERS) return;
 
 #pragma unroll
@@ -1190,6 +1204,8 @@ int check_desc(const cl4_conv_desc* d) {
 
 // 16 zero floats the LDS-DMA lanes of the v2 kernel read instead of the convolution's zero padding.
 __device__ __attribute__((aligned(64))) float g_zero_page[16] = {0};
+
+unsigned long long* g_timeline = nullptr;     // experiments only, see ConvArgs::timeline
 
 int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -1778,7 +1794,7 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
   a.gx = 1; a.ntile_l = 1; a.tile_base = 0; a.ws_p0 = 0; a.ws_npix = a.npix;
   static const int xcd_default = env_int("CL4_XCD_REMAP", 1);
   a.xcd_remap = xcd_default;
-  a.stagger = env_int("CL4_CONV_STAGGER", 0);      // read per call: experiments sweep it inside one process
+  a.timeline = g_timeline;
   a.neg1 = d->act1 == CL4_ACT_NONE ? 1.f : (d->act1 == CL4_ACT_RELU ? 0.f : d->slope1);
   a.neg2 = d->act2 == CL4_ACT_NONE ? 1.f : (d->act2 == CL4_ACT_RELU ? 0.f : d->slope2);
   hipStream_t st = cl4::as_stream(stream);
@@ -1787,6 +1803,13 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
     case 3: return launch_fwd<3>(a, st, workspace, workspace_bytes, d->precision);
     default: return launch_fwd<7>(a, st, workspace, workspace_bytes, d->precision);
   }
+}
+
+// Experiments only (not part of the drop-in boundary): device buffer of 8 x uint64 per workgroup that the bf16 forward kernels
+// fill with phase time stamps, or NULL to switch the instrumentation off (the default).
+extern "C" int cl4_conv_debug_timeline(void* buf) {
+  g_timeline = (unsigned long long*)buf;
+  return CL4_OK;
 }
 
 extern "C" int cl4_conv2d_wgrad(const cl4_conv_desc* d, const float* x, const float* dy, float* dw, void* stream) {

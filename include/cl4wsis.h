@@ -460,6 +460,8 @@ int cl4_target_generation(const long long* seg_map, const uint8_t* mask, int b, 
 /* InPlaceABN(Sync) (segmentation_module.py:19-27; mapillary/inplace_abn, not vendored) scales with |weight| + eps, not with
  * weight: cl4_abs_eps writes that effective scale (out[i] = |w[i]| + eps), cl4_sign_axpy applies its chain rule
  * (y[i] += w[i] > 0 ? x[i] : -x[i]) to a gradient computed with respect to the effective scale. */
+/* Experiments only: phase time stamps of the bf16 forward kernels (tools/probe_timeline.py); NULL = off. */
+int cl4_conv_debug_timeline(void* buf);
 int cl4_abs_eps(const float* w, float* out, int n, float eps, void* stream);
 int cl4_sign_axpy(float* y, const float* x, const float* w, int n, void* stream);
 
