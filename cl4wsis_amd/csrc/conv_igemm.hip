@@ -41,7 +41,10 @@ struct ConvArgs {
   int act1, act2;
   float slope1, slope2;
   int K;        // cin*KS*KS
-  int npix;     // n*hout*wout
+  int npix;     // n*hout*wout — or n*hw_pad for the bf16 launches of a "vector gather" plan (see hw_pad)
+  int hw_pad;   // logical pixels per image: pixel p = image p / hw_pad, position p % hw_pad (positions >= hout*wout are padding).
+                // = hout*wout except for 1x1 plans whose activation loader fetches 4 pixels per lane (hw_pad = roundup(hout*wout, 4),
+                // so that a 4-pixel group never straddles two images)
   int xcd_remap;      // 1: XCD-aware logical tile order (bf16x3 kernel)
   float neg1, neg2;   // branch-free activations: act(v) = v > 0 ? v : v * neg  (none: 1, relu: 0, leaky: slope)
   float* ws;    // split-K partial slabs [splits][cout][npix] (v2 kernel only)
@@ -67,8 +70,9 @@ __device__ __forceinline__ void fused_epilogue(const ConvArgs& a, f32x16 (&acc)[
   for (int j = 0; j < TN; ++j) {
     const int p = p_base + j * 32 + lr;
     if (p >= a.npix) continue;
-    const int n = p / HWo;
-    const int hw = p - n * HWo;
+    const int n = p / a.hw_pad;
+    const int hw = p - n * a.hw_pad;
+    if (hw >= HWo) continue;
     const long ybase = ((long)n * a.out_ctot + a.out_coff) * HWo + hw;
     const long rbase = (long)n * a.cout * HWo + hw;
 #pragma unroll
@@ -455,8 +459,9 @@ __global__ void conv_splitk_epilogue(ConvArgs a, int splits) {
   for (; z < splits; ++z) v += w[(long)z * total];
   const int HWo = a.hout * a.wout;
   const int p = a.ws_p0 + i;
-  const int n = p / HWo;
-  const int hw = p - n * HWo;
+  const int n = p / a.hw_pad;
+  const int hw = p - n * a.hw_pad;
+  if (hw >= HWo) return;
   const long r = ((long)n * a.cout + co) * HWo + hw;
   if (a.pre) v += a.pre[r];
   const float sc = a.scale ? a.scale[co] : 1.f;
@@ -486,6 +491,8 @@ __global__ void conv_splitk_epilogue(ConvArgs a, int splits) {
 #define CL4_DBG 0   // experiments only: 1 = loader issues no loads in the loop, 2 = no convert/LDS stores, 4 = no MFMA
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int N>
@@ -508,8 +515,16 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // the loaders' register sets already hold the first K-tiles of the next tile while the MFMA waves drain the accumulators of
 // the previous one — so the pipeline is filled once per workgroup instead of once per tile and no workgroup is re-dispatched
 // per tile (short-K 1x1 layers spent more time on those two than in their eight K-tiles, tools/probe_epilogue.py).
-template <int BM, int BN, int KS, bool SPLIT, bool TAP, int P = 2, int LW = 4, int NS = 2, bool PERS = false>
+// VEC (1x1, stride 1, cin % 32 == 0, unsplit 128x128 launches): the activation loader fetches FOUR CONSECUTIVE PIXELS of one
+// channel per lane and load (buffer_load_dwordx4) instead of one pixel of eight channels with eight dword loads. The CU's
+// vector-memory front end retires a 256-byte dword wave-load in the same ~16 cycles as a 1-KB dwordx4 one, and with 2 x 4
+// loader waves x 20 wave-loads per K-tile it — not L2, HBM or the MFMA pipe — set the K-tile period (tools/probe_timeline.py:
+// 2.1-2.5 us per K-tile and workgroup for 0.64 us of MFMA work). 4 dwordx4 + 4 weight loads per lane and K-tile instead of
+// 16 + 4. The GEMM column order inside a tile is permuted (column = (pixel % 4) * 32 + pixel / 4) so that the loader's
+// ds_writes and the MFMA waves' ds_read_b128 stay bank-conflict free; the wide epilogue undoes it when it streams rows out.
+template <int BM, int BN, int KS, bool SPLIT, bool TAP, int P = 2, int LW = 4, int NS = 2, bool PERS = false, bool VEC = false>
 __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf16x3(ConvArgs a, const float* __restrict__ zero_page) {
+  static_assert(!VEC || (KS == 1 && TAP && P == 2 && BN == 128 && LW == 4 && !SPLIT && !PERS), "vector gather: unsplit 1x1 128-pixel tiles");
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int KHW = KS * KS;
@@ -601,13 +616,17 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
     constexpr int RPW = BM / 8, PPL = BN / 64, RB = 8;   // rows per batch: 16 measured slower (registers), 4 no better
     long ybase[PPL], rbase[PPL];
     bool pv[PPL];
+    int col[PPL];                                  // column of the parked tile that holds this lane's pixel
 #pragma unroll
     for (int q = 0; q < PPL; ++q) {
-      const int p = n0 + lane + 64 * q;
-      pv[q] = p < a.npix;
-      const int pc = pv[q] ? p : 0;
-      const int n = pc / HWo;
-      const int hw = pc - n * HWo;
+      const int pt = lane + 64 * q;                // pixel within the tile
+      col[q] = VEC ? (pt & 3) * 32 + (pt >> 2) : pt;
+      const int p = n0 + pt;
+      const int n_ = p / a.hw_pad;
+      const int hw_ = p - n_ * a.hw_pad;
+      pv[q] = p < a.npix && hw_ < HWo;
+      const int n = pv[q] ? n_ : 0;
+      const int hw = pv[q] ? hw_ : 0;
       ybase[q] = ((long)n * a.out_ctot + a.out_coff) * HWo + hw;
       rbase[q] = (long)n * a.cout * HWo + hw;
     }
@@ -618,7 +637,7 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
 #pragma unroll
       for (int rr = 0; rr < RB; ++rr)
 #pragma unroll
-        for (int q = 0; q < PPL; ++q) v[rr][q] = stage[(row0 + rr) * BN + lane + 64 * q];
+        for (int q = 0; q < PPL; ++q) v[rr][q] = stage[(row0 + rr) * BN + col[q]];
       if (a.pre) {
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr)
@@ -679,17 +698,18 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
     auto set_tile = [&](int ti) {
       tile_ok = ti < cnt;                      // past the last tile: every load goes out of range (zeros, no traffic)
       tile_origin(tile_ok ? ti : 0);
-      const int p = n0 + pl;
-      pvalid = tile_ok && p < a.npix;
-      const int pc = pvalid ? p : 0;
-      const int n = pc / HWo;
-      const int hw = pc - n * HWo;
+      const int p = VEC ? n0 + 4 * (lane & 31) : n0 + pl;          // VEC: first pixel of this lane's 4-pixel group
+      const int n_ = p / a.hw_pad;
+      const int hw_ = p - n_ * a.hw_pad;
+      pvalid = tile_ok && p < a.npix && hw_ < HWo;
+      const int n = pvalid ? n_ : 0;
+      const int hw = pvalid ? hw_ : 0;
       const int oy = hw / a.wout;
       const int ox = hw - oy * a.wout;
       iy0 = oy * a.stride - a.pad;
       ix0 = ox * a.stride - a.pad;
       xptr = a.x + ((long)n * a.in_ctot + a.in_coff) * HWi + (long)iy0 * a.win + ix0;
-      lane_base = (int)((((long)n * a.in_ctot + a.in_coff) * HWi + (long)iy0 * a.win + ix0) * 4);
+      lane_base = (int)((((long)n * a.in_ctot + a.in_coff + (VEC ? 4 * (lane >> 5) : 0)) * HWi + (long)iy0 * a.win + ix0) * 4);
     };
     set_tile(0);
     const bf16x8* wq = reinterpret_cast<const bf16x8*>(a.wp);   // [K/8][2][cout] chunks of 8 bf16
@@ -706,6 +726,22 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
     const unsigned x_bytes = (unsigned)((long)a.n * a.in_ctot * HWi * 4);   // < 2^31, checked on the host for TAP
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, TAP ? x_bytes : 0u, 0x00020000);
     auto gload = [&](float (&xr)[NITEM][8], int kt) {
+      if constexpr (VEC) {
+        // lane = (4-pixel group g = lane % 32, channel half h = lane / 32) of k-group `wave`: channels ci0 + 8*wave + 4*h + j,
+        // j = 0..3, four consecutive pixels each (16 bytes; 4-byte aligned is all a buffer load needs). xr holds [channel j][pixel].
+        const int T = (kbeg >> 5) + kt;                     // wave-uniform K-tile index = 32-channel block
+        const bool ok = pvalid && kt < nk;
+        const unsigned voff = ok ? (unsigned)lane_base : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int soff = __builtin_amdgcn_readfirstlane((T * 32 + wave * 8 + j) * HWi * 4);
+          // (element access on the builtin's result converted to an ext_vector type is miscompiled by this hipcc: bit_cast first)
+          const f32x4v v4 = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xr[(j * 4 + q) >> 3][(j * 4 + q) & 7] = v4[q];
+        }
+        return;
+      }
       if constexpr (TAP) {
         // K order (shared with cl4_pack_conv_weight_bf16x3): k = (cb*KHW + tap)*32 + cil — all KHW taps of a 32-channel
         // block are adjacent K-tiles, so the (shifted) re-reads of those channels hit L1/L2 instead of streaming the whole
@@ -758,6 +794,25 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
     };
     auto cvt_store = [&](const float (&xr)[NITEM][8], int buf) {
       u32x4* Bs = lds[buf] + A_CHUNKS;
+      if constexpr (VEC) {
+        // pixel q of the group lands in column q*32 + g; this lane owns channels 4h..4h+3 of the k-group = bytes 8h..8h+7 of the
+        // 16-byte chunk. Consecutive lanes write consecutive chunks: conflict free.
+        const int g = lane & 31, h = lane >> 5;
+        unsigned long long* B8 = reinterpret_cast<unsigned long long*>(Bs);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bf16x4 hi, lo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = xr[(j * 4 + q) >> 3][(j * 4 + q) & 7];
+            hi[j] = (__bf16)v;
+            lo[j] = (__bf16)(v - (float)hi[j]);
+          }
+          B8[(((wave * P + 0) * BN + q * 32 + g) << 1) + h] = __builtin_bit_cast(unsigned long long, hi);
+          B8[(((wave * P + 1) * BN + q * 32 + g) << 1) + h] = __builtin_bit_cast(unsigned long long, lo);
+        }
+        return;
+      }
 #pragma unroll
       for (int it = 0; it < NITEM; ++it) {
         bf16x8 hi, mid, lo;
@@ -806,7 +861,7 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
         As[(ii / (BM / 64)) * BM + (ii % (BM / 64)) * 64 + lane] = ar[i];
       }
     };
-    constexpr int TILE_LOADS = 8 * NITEM + A_PER_LANE;   // vector-memory instructions per lane and K-tile
+    constexpr int TILE_LOADS = (VEC ? 4 : 8 * NITEM) + A_PER_LANE;   // vector-memory instructions per lane and K-tile
     constexpr int PF_PER_LANE = (BM * (BN / 32) + 64 * LW - 1) / (64 * LW);     // residual-prefetch touches per loader lane
     // One loader half-iteration while the MFMA waves consume tile t: retire the loads of tile t+1 (issued two
     // half-iterations ago; only tile t+2's stay in flight), split / store it into the other LDS stage, refill the register
@@ -830,8 +885,8 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
           const int item = (wave * 64 + lane) * PF_PER_LANE + i;   // (row, segment)
           const int co = min(m0 + min(item / (BN / 32), BM - 1), a.cout - 1);
           const int pp = min(n0 + (item % (BN / 32)) * 32, a.npix - 1);
-          const int pn = pp / HWo;
-          const float* g = r + ((long)pn * a.cout + co) * HWo + (pp - pn * HWo);
+          const int pn = min(pp / a.hw_pad, a.n - 1);
+          const float* g = r + ((long)pn * a.cout + co) * HWo + min(pp - pn * a.hw_pad, HWo - 1);
           asm volatile("global_load_dword %0, %1, off" : "=v"(pf[i]) : "v"(g) : "memory");
         }
       }
@@ -907,6 +962,79 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
+  if constexpr (P == 2 && !PERS && KG == 4) {
+    // Software-pipelined fragment reads. A K-tile is two k-steps of three products each (lo_w*hi_x, hi_w*lo_x, hi_w*hi_x over
+    // the wave's 2x2 accumulator tiles). The straightforward loop read the fragments of a product group right before its MFMAs
+    // and waited: four exposed LDS round trips per K-tile, MFMA pipe 47 % busy even while the CU was full (rocprofv3 PMC:
+    // SQ_VALU_MFMA_BUSY_CYCLES, tools/prof_pmc_conv.sh). Here every read is issued one product group (4-8 MFMAs = 128-256 cycles)
+    // ahead of its use: the second group's fragments (hi_w, lo_x) before the first group's MFMAs, the NEXT k-step's first-group
+    // fragments (lo_w, hi_x) before the second and third groups' MFMAs — across the K-tile boundary too, where they are issued
+    // right after the barrier that publishes the next LDS stage. Ten 16-byte fragments live instead of six (+16 VGPRs).
+    auto rdA = [&](const u32x4* As, int kg, int plane, bf16x8 (&f)[TM]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f[i] = __builtin_bit_cast(bf16x8, As[(kg * P + plane) * BM + i * 32]);
+    };
+    auto rdB = [&](const u32x4* Bs, int kg, int plane, bf16x8 (&f)[TN]) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) f[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + plane) * BN + j * 32]);
+    };
+    auto mm = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fb)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    bf16x8 al0[TM], bh0[TN], ah0[TM], bl0[TN], al1[TM], bh1[TN], ah1[TM], bl1[TN];
+    // The loop is rotated so that its head sits right behind the barrier, where no LDS read is outstanding: the compiler's
+    // s_waitcnt insertion merges the counter states of all predecessors of a loop head pessimistically (it drained to
+    // lgkmcnt(0) in front of the first MFMA group otherwise), inside the straight-line body its counted waits are exact.
+    // The last two product groups of K-tile kt-1 therefore execute at the top of iteration kt (zero fragments for kt = 0).
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ah1[i][e] = (__bf16)0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { bl1[j][e] = (__bf16)0.f; bh1[j][e] = (__bf16)0.f; }
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): scalar loads of the prologue would make the first wait of every iteration a full drain
+    for (int kt = 0; kt < nk; ++kt) {
+      const u32x4* As = lds[kt & 1] + wm * WTM + lr;
+      const u32x4* Bs = lds[kt & 1] + A_CHUNKS + wn * WTN + lr;
+      rdA(As, lh, 1, al0);                       // first product group of this K-tile: issued behind the barrier,
+      rdB(Bs, lh, 0, bh0);                       // covered by the previous K-tile's last eight MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      mm(ah1, bl1);
+      mm(ah1, bh1);
+      __builtin_amdgcn_sched_barrier(0);
+      // k-step 0 (k-groups 0, 1 by lane half)
+      rdA(As, lh, 0, ah0);
+      rdB(Bs, lh, 1, bl0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(al0, bh0);
+      __builtin_amdgcn_sched_barrier(0);
+      rdA(As, 2 + lh, 1, al1);
+      rdB(Bs, 2 + lh, 0, bh1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(ah0, bl0);
+      mm(ah0, bh0);
+      __builtin_amdgcn_sched_barrier(0);
+      // k-step 1 (k-groups 2, 3)
+      rdA(As, 2 + lh, 0, ah1);
+      rdB(Bs, 2 + lh, 1, bl1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(al1, bh1);
+      __builtin_amdgcn_sched_barrier(0);
+      // every read of this stage has been issued: once they have returned the loaders may overwrite it, and the next stage is
+      // complete once they arrive at the same barrier. (The builtin, not inline asm: the compiler's wait-count bookkeeping
+      // sees it and knows that nothing is outstanding at the loop head.)
+      __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+    }
+    mm(ah1, bl1);
+    mm(ah1, bh1);
+    gk = nk;
+  } else
   for (int kt = 0; kt < nk; ++kt, ++gk) {
     const u32x4* As = lds[gk & 1] + wm * WTM + lr;
     const u32x4* Bs = lds[gk & 1] + A_CHUNKS + wn * WTN + lr;
@@ -1309,6 +1437,14 @@ TailGeom tail_geometry(const FwdPlan& pl, int cout, int npix, int precision) {
   return g;
 }
 
+// Does this launch use the 4-pixels-per-lane activation loader (VEC)? 1x1, stride 1, same input and output map, 32-channel
+// K-tiles, bf16x3, 128-pixel tiles. CL4_CONV_VEC=0 switches it off (experiments).
+bool vec_gather_plan(const ConvArgs& a, int ks, int precision, int tile) {
+  static const int enabled = env_int("CL4_CONV_VEC", 1);
+  return enabled && ks == 1 && precision == 1 && tile == 128 && a.stride == 1 && a.pad == 0 && a.cin % 32 == 0 && a.hin == a.hout &&
+         a.win == a.wout && (long)a.n * a.in_ctot * a.hin * a.win * 4 < 0x7FFFFFFFL;
+}
+
 template <int KS>
 int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes, int precision) {
   const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 4 + precision});
@@ -1320,6 +1456,12 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
     if (tapmaj && (long)a.n * a.in_ctot * a.hin * a.win * 4 >= 0x7FFFFFFFL) {
       cl4::set_error("conv2d_fwd(bf16 split): input tensor >= 2 GiB is not addressable by the 32-bit buffer offsets");
       return CL4_EINVAL;
+    }
+    // "vector gather" plans (see the VEC template parameter): logical pixel index space padded per image to a multiple of 4
+    const bool vec = vec_gather_plan(a, KS, precision, pl.tile);
+    if (vec) {
+      a.hw_pad = (a.hout * a.wout + 3) & ~3;
+      a.npix = a.n * a.hw_pad;
     }
     const TailGeom tg = tail_geometry(pl, a.cout, a.npix, precision);
     const bool hybrid = tg.main > 0;
@@ -1350,7 +1492,7 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
           if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
           else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, true, 3>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, false, false, 3>), g, dim3(V2_THREADS), 0, st, a, z); }
         }
-      } else if (!split && persist && ntile > 512) {
+      } else if (!split && persist && ntile > 512 && !vec) {
         // persistent workgroups: 512 resident slots (two per CU) walk ntile / 512 tiles each
         const dim3 gp(512);
         if (tile == 128) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false, 2, 4, 2, true>), gp, dim3(V2_THREADS), 0, st, a, z); }
@@ -1358,6 +1500,7 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
       } else {
         if (tile == 128) {
           if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false>), g, dim3(V2_THREADS), 0, st, a, z); }
+          else if (vec) { if constexpr (KS == 1) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, 1, false, true, 2, 4, 2, false, true>), g, dim3(V2_THREADS), 0, st, a, z); }
           else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false>), g, dim3(V2_THREADS), 0, st, a, z); }
         } else {
           if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, true>), g, dim3(V2_THREADS), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<64, 64, KS, true, false>), g, dim3(V2_THREADS), 0, st, a, z); }
@@ -1744,8 +1887,12 @@ extern "C" int cl4_bn_fold(const float* gamma, const float* beta, const float* m
 extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
   if (!d || d->cout <= 0 || d->n <= 0) return 0;
   const int K = d->cin * d->kh * d->kw;
-  const int npix = d->n * d->hout * d->wout;
+  int npix = d->n * d->hout * d->wout;
   const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin * 4 + d->precision});
+  ConvArgs va;      // the fields vec_gather_plan looks at
+  va.n = d->n; va.cin = d->cin; va.hin = d->hin; va.win = d->win; va.hout = d->hout; va.wout = d->wout; va.stride = d->stride;
+  va.pad = d->pad; va.in_ctot = d->in_ctot;
+  if (pl.impl == 2 && vec_gather_plan(va, d->kh, d->precision, pl.tile)) npix = d->n * ((d->hout * d->wout + 3) & ~3);
   if (d->precision != 0 && pl.impl == 2 && pl.tail > 0) {
     const TailGeom tg = tail_geometry(pl, d->cout, npix, d->precision);
     return (tg.main > 0 && pl.tail > 1) ? (size_t)pl.tail * d->cout * (npix - tg.p0) * sizeof(float) : 0;   // small-tile tail / degenerate: no slabs
@@ -1790,6 +1937,7 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
   a.act1 = d->act1; a.act2 = d->act2; a.slope1 = d->slope1; a.slope2 = d->slope2;
   a.K = d->cin * d->kh * d->kw;
   a.npix = d->n * d->hout * d->wout;
+  a.hw_pad = d->hout * d->wout;
   a.ws = nullptr; a.kchunk = 0;
   a.gx = 1; a.ntile_l = 1; a.tile_base = 0; a.ws_p0 = 0; a.ws_npix = a.npix;
   static const int xcd_default = env_int("CL4_XCD_REMAP", 1);

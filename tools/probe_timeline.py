@@ -31,20 +31,26 @@ def run(name, n, cin, h, cout, k, pad, dil, plan, post):
     torch.cuda.synchronize()
     _hip.call("cl4_conv_debug_timeline", None)
     t = tl.cpu().numpy()[:ntile * 8].reshape(ntile, 8).astype(np.int64)
-    ok = t[:, 4] > 0
+    print("   raw column min/max:", [(int(t[:, i].min()), int(t[:, i].max())) for i in range(8)], "rows with slot0==0:", int((t[:, 0] == 0).sum()))
+    ok = (t[:, 4] > 0) & (t[:, 0] > 0)
     t = t[ok]
-    t0 = t[:, 0].min()
-    span = (t[:, [4, 5]].max() - t0)
-    tick_us = e0.elapsed_time(e1) * 1e3 / span          # us per tick, from the event time of the same launch
-    ph = {"prologue": t[:, 1] - t[:, 0], "kloop": t[:, 2] - t[:, 1], "park": t[:, 3] - t[:, 2], "epilogue": t[:, 4] - t[:, 3],
-          "total": t[:, 4] - t[:, 0]}
-    print(f"== {name}: {ntile} workgroups, launch {e0.elapsed_time(e1) * 1e3:.1f} us, span {span} ticks ({tick_us * 1e3:.3f} ns/tick)")
-    for k_, v in ph.items():
-        print(f"   {k_:9s} mean {v.mean() * tick_us:7.2f} us  p10 {np.percentile(v, 10) * tick_us:7.2f}  p90 {np.percentile(v, 90) * tick_us:7.2f}")
-    # per CU (xcc, hw_id cu/sh/se bits): busy time of the union of its workgroups' [start, end] and resident-workgroup-time
     hw = t[:, 6]
     cu_key = (hw >> 32) * 65536 + ((hw & 0xffffffff) >> 8 & 0xff) * 1 + ((hw & 0xffffffff) >> 12 & 0xf) * 256   # xcc, cu_id, sh/se
     keys = np.unique(cu_key)
+    spans = []
+    for kk in keys:                                     # s_memtime bases differ between CUs: compare within a CU only
+        sel = cu_key == kk
+        t[sel, :6] -= t[sel, 0].min()
+        spans.append(t[sel][:, [4, 5]].max())
+    t0 = 0
+    span = float(np.median(spans))                      # a CU is busy for (almost) the whole launch
+    tick_us = e0.elapsed_time(e1) * 1e3 / span
+    ph = {"prologue": t[:, 1] - t[:, 0], "kloop": t[:, 2] - t[:, 1], "park": t[:, 3] - t[:, 2], "epilogue": t[:, 4] - t[:, 3],
+          "total": t[:, 4] - t[:, 0]}
+    print(f"== {name}: {ntile} workgroups, launch {e0.elapsed_time(e1) * 1e3:.1f} us, median CU span {span:.0f} ticks ({tick_us * 1e3:.3f} ns/tick; "
+          f"CU spans p10 {np.percentile(spans, 10):.0f} p90 {np.percentile(spans, 90):.0f})")
+    for k_, v in ph.items():
+        print(f"   {k_:9s} mean {v.mean() * tick_us:7.2f} us  p10 {np.percentile(v, 10) * tick_us:7.2f}  p90 {np.percentile(v, 90) * tick_us:7.2f}")
     occ, kl, ep = [], [], []
     for kk in keys:
         rows = t[cu_key == kk]
