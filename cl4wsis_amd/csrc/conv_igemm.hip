@@ -962,79 +962,9 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
-  if constexpr (P == 2 && !PERS && KG == 4) {
-    // Software-pipelined fragment reads. A K-tile is two k-steps of three products each (lo_w*hi_x, hi_w*lo_x, hi_w*hi_x over
-    // the wave's 2x2 accumulator tiles). The straightforward loop read the fragments of a product group right before its MFMAs
-    // and waited: four exposed LDS round trips per K-tile, MFMA pipe 47 % busy even while the CU was full (rocprofv3 PMC:
-    // SQ_VALU_MFMA_BUSY_CYCLES, tools/prof_pmc_conv.sh). Here every read is issued one product group (4-8 MFMAs = 128-256 cycles)
-    // ahead of its use: the second group's fragments (hi_w, lo_x) before the first group's MFMAs, the NEXT k-step's first-group
-    // fragments (lo_w, hi_x) before the second and third groups' MFMAs — across the K-tile boundary too, where they are issued
-    // right after the barrier that publishes the next LDS stage. Ten 16-byte fragments live instead of six (+16 VGPRs).
-    auto rdA = [&](const u32x4* As, int kg, int plane, bf16x8 (&f)[TM]) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) f[i] = __builtin_bit_cast(bf16x8, As[(kg * P + plane) * BM + i * 32]);
-    };
-    auto rdB = [&](const u32x4* Bs, int kg, int plane, bf16x8 (&f)[TN]) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) f[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + plane) * BN + j * 32]);
-    };
-    auto mm = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fb)[TN]) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    };
-    bf16x8 al0[TM], bh0[TN], ah0[TM], bl0[TN], al1[TM], bh1[TN], ah1[TM], bl1[TN];
-    // The loop is rotated so that its head sits right behind the barrier, where no LDS read is outstanding: the compiler's
-    // s_waitcnt insertion merges the counter states of all predecessors of a loop head pessimistically (it drained to
-    // lgkmcnt(0) in front of the first MFMA group otherwise), inside the straight-line body its counted waits are exact.
-    // The last two product groups of K-tile kt-1 therefore execute at the top of iteration kt (zero fragments for kt = 0).
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ah1[i][e] = (__bf16)0.f;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { bl1[j][e] = (__bf16)0.f; bh1[j][e] = (__bf16)0.f; }
-    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): scalar loads of the prologue would make the first wait of every iteration a full drain
-    for (int kt = 0; kt < nk; ++kt) {
-      const u32x4* As = lds[kt & 1] + wm * WTM + lr;
-      const u32x4* Bs = lds[kt & 1] + A_CHUNKS + wn * WTN + lr;
-      rdA(As, lh, 1, al0);                       // first product group of this K-tile: issued behind the barrier,
-      rdB(Bs, lh, 0, bh0);                       // covered by the previous K-tile's last eight MFMAs
-      __builtin_amdgcn_sched_barrier(0);
-      mm(ah1, bl1);
-      mm(ah1, bh1);
-      __builtin_amdgcn_sched_barrier(0);
-      // k-step 0 (k-groups 0, 1 by lane half)
-      rdA(As, lh, 0, ah0);
-      rdB(Bs, lh, 1, bl0);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(al0, bh0);
-      __builtin_amdgcn_sched_barrier(0);
-      rdA(As, 2 + lh, 1, al1);
-      rdB(Bs, 2 + lh, 0, bh1);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(ah0, bl0);
-      mm(ah0, bh0);
-      __builtin_amdgcn_sched_barrier(0);
-      // k-step 1 (k-groups 2, 3)
-      rdA(As, 2 + lh, 0, ah1);
-      rdB(Bs, 2 + lh, 1, bl1);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(al1, bh1);
-      __builtin_amdgcn_sched_barrier(0);
-      // every read of this stage has been issued: once they have returned the loaders may overwrite it, and the next stage is
-      // complete once they arrive at the same barrier. (The builtin, not inline asm: the compiler's wait-count bookkeeping
-      // sees it and knows that nothing is outstanding at the loop head.)
-      __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0)
-      __builtin_amdgcn_s_barrier();
-    }
-    mm(ah1, bl1);
-    mm(ah1, bh1);
-    gk = nk;
-  } else
+  // (Measured and dropped, r02: software-pipelining the fragment reads of the MFMA waves — every ds_read_b128 issued one product
+  // group ahead of its MFMAs, rotated loop with exact counted lgkmcnt waits, 120 VGPRs — changed nothing: 125.5 -> 129.5 us on
+  // the res4 conv3 shape, 185 -> 199 us on the 3x3 one. The MFMA waves are not the pacing role; they wait at the barrier.)
   for (int kt = 0; kt < nk; ++kt, ++gk) {
     const u32x4* As = lds[gk & 1] + wm * WTM + lr;
     const u32x4* Bs = lds[gk & 1] + A_CHUNKS + wn * WTN + lr;
