@@ -1,34 +1,72 @@
-"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into HBM-side traffic per launch of the dominant
-kernel (conv_igemm_bf16x3), corrected as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes for gfx950 (FETCH_SIZE
-counts 64 B per 128-B request: doubled; WRITE_SIZE exact; both in KiB). usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>
-Only the dispatches of the LAST step (after the last-but-one Adam launch pair) are counted."""
+"""Aggregate the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh into HBM-side traffic per launch of the
+dominant kernel (conv_igemm_bf16x3, P = 2 launches only — the bf16x6 instantiations are a different kernel in bench.py's
+roofline record). usage: pmc_traffic.py <pmc_dir> <out.json>
+
+Units / corrections (MI355X_MICROARCH.md §HBM): both counters are in KiB; WRITE_SIZE is exact for streaming stores; FETCH_SIZE
+under-reports wide coalesced reads by 2x on gfx950 and is uncalibrated for other widths — so the factor is MEASURED here on
+calibration launches of this very kernel with known minimal traffic (tools/pmc_calib.py; both loader variants) and that factor,
+not an assumed one, scales the bench launches. Only the dispatches of the LAST step (between the last two Adam launch pairs) count."""
 import collections, csv, glob, json, re, sys
 
+root, out_path = sys.argv[1], sys.argv[2]
 
-def last_step(d, counter):
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
-    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
-    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    adam = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
-    sel = rows[adam[-3] + 1: adam[-1] + 1] if len(adam) >= 3 else rows
+
+def rows(d, counter):
+    f = glob.glob(f"{root}/{d}/**/*_counter_collection.csv", recursive=True)[0]
+    r = [x for x in csv.DictReader(open(f)) if x["Counter_Name"] == counter]
+    r.sort(key=lambda x: int(x["Dispatch_Id"]))
+    return r
+
+
+def is_x3(name):
+    m = re.search(r"conv_igemm_bf16x3<([^>]*)>", name)
+    return bool(m) and m.group(1).split(",")[5].strip() == "2"
+
+
+def calib(tag):
+    """FETCH_SIZE / WRITE_SIZE (KiB) of the last calibration conv launch vs its known bytes."""
+    res = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        r = [x for x in rows(f"{tag}_{c}", c) if is_x3(x["Kernel_Name"])]
+        res[c] = float(r[-1]["Counter_Value"]) * 1024
+    known_in = 80 * 1024 * 33 * 33 * 4 + 1024 * 128 * 4
+    known_out = 80 * 128 * 33 * 33 * 4
+    return {"fetch_counter_bytes": res["FETCH_SIZE"], "known_read_bytes": known_in, "fetch_factor": known_in / res["FETCH_SIZE"],
+            "write_counter_bytes": res["WRITE_SIZE"], "known_write_bytes": known_out, "write_factor": known_out / res["WRITE_SIZE"]}
+
+
+def last_step(counter):
+    r = rows(f"bench_{counter}", counter)
+    adam = [i for i, x in enumerate(r) if "adam" in x["Kernel_Name"]]
+    sel = r[adam[-3] + 1: adam[-1] + 1] if len(adam) >= 3 else r
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in sel:
-        n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0]
+    for x in sel:
+        n = re.sub(r"\(anonymous namespace\)::", "", x["Kernel_Name"]).split("(")[0]
         agg[n][0] += 1
-        agg[n][1] += float(r["Counter_Value"])
+        agg[n][1] += float(x["Counter_Value"]) * 1024
     return agg
 
 
-fetch, write = last_step(sys.argv[1], "FETCH_SIZE"), last_step(sys.argv[2], "WRITE_SIZE")
-out = {"note": "last eager step of bench.py (CL4_GRAPH=0 CL4_OVERLAP=0); KiB; FETCH_SIZE doubled (gfx950 correction)", "kernels": {}}
+cal = {"vec_gather_16B_per_lane": calib("calib1"), "dword_gather_4B_per_lane": calib("calib0")}
+fetch, write = last_step("FETCH_SIZE"), last_step("WRITE_SIZE")
+f_fac = cal["vec_gather_16B_per_lane"]["fetch_factor"]      # 1x1 launches use it; the 3x3 / strided ones the dword gather
+f_fac0 = cal["dword_gather_4B_per_lane"]["fetch_factor"]
+out = {"note": "last eager step of bench.py (CL4_GRAPH=0 CL4_OVERLAP=0); bytes; FETCH_SIZE scaled by the factor measured on the "
+               "calibration launch of the same loader variant (1x1 unsplit 128-tile launches: vector gather; all others: dword gather)",
+       "calibration": cal, "kernels": {}}
 tot_l, tot_b = 0, 0.0
 for k in sorted(fetch, key=lambda k: -fetch[k][1]):
     l, f = fetch[k]
     w = write.get(k, [0, 0.0])[1]
-    out["kernels"][k] = {"launches": l, "fetch_kib_x2": 2 * f, "write_kib": w}
-    if "conv_igemm_bf16x3" in k:
+    out["kernels"][k] = {"launches": l, "fetch_counter_bytes": f, "write_counter_bytes": w}
+    if is_x3(k):
+        args = re.search(r"<([^>]*)>", k).group(1).split(",")
+        vec = len(args) > 9 and args[9].strip() == "true"
+        fac = f_fac if vec else f_fac0
+        out["kernels"][k]["fetch_factor_used"] = fac
         tot_l += l
-        tot_b += (2 * f + w) * 1024
+        tot_b += fac * f + cal["vec_gather_16B_per_lane"]["write_factor"] * w
 out["conv_igemm_bf16x3"] = {"launches_per_step": tot_l, "hbm_bytes_per_step": tot_b, "hbm_bytes_per_launch": tot_b / max(tot_l, 1)}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out["conv_igemm_bf16x3"]))
+json.dump(out, open(out_path, "w"), indent=1)
+print(json.dumps({"calibration": {k: {kk: round(vv, 3) if isinstance(vv, float) and vv < 100 else vv for kk, vv in v.items()} for k, v in cal.items()},
+                  "conv_igemm_bf16x3": out["conv_igemm_bf16x3"]}))

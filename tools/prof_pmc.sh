@@ -1,10 +1,17 @@
-# HBM traffic of the dominant kernel: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over eager, non-overlapped
-# bench steps; no tracing options alongside --pmc.
+# HBM traffic of the dominant kernel: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over eager, non-overlapped
+# bench steps, plus calibration launches of the same kernel with known traffic; no tracing options alongside --pmc.
 set -e
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r01k_pmc
+O=$R/gpurun_out/${TAG}_pmc
+mkdir -p $O
 export TMPDIR=/tmp CL4_GRAPH=0 CL4_OVERLAP=0
 cd /tmp
-timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r01k_pmc/fetch -- python3 $R/bench.py --steps 2 --warmup 4 --no-cpu-baseline > $R/gpurun_out/r01k_pmc/fetch.json 2> $R/gpurun_out/r01k_pmc/fetch.err
-timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r01k_pmc/write -- python3 $R/bench.py --steps 2 --warmup 4 --no-cpu-baseline > $R/gpurun_out/r01k_pmc/write.json 2> $R/gpurun_out/r01k_pmc/write.err
-python3 $R/tools/pmc_traffic.py $R/gpurun_out/r01k_pmc/fetch $R/gpurun_out/r01k_pmc/write $R/gpurun_out/r01k_pmc/traffic.json
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $O/bench_$c -- python3 $R/bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-structured > $O/bench_$c.json 2> $O/bench_$c.err
+  echo "pass bench $c done"
+  CL4_CONV_VEC=1 timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $O/calib1_$c -- python3 $R/tools/pmc_calib.py > $O/calib1_$c.log 2>&1
+  CL4_CONV_VEC=0 timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $O/calib0_$c -- python3 $R/tools/pmc_calib.py > $O/calib0_$c.log 2>&1
+  echo "pass calib $c done"
+done
+python3 $R/tools/pmc_traffic.py $O $O/traffic.json
