@@ -39,7 +39,7 @@ def main():
     print(f"wall/step {wall / n:.2f} ms, kernel time/step {tot / n:.2f} ms")
     x3_n = x3_ms = 0
     for k, (c, t) in agg.items():
-        m = re.match(r"conv_igemm_bf16x3<([^>]*)>", k)
+        m = re.search(r"conv_igemm_bf16x3<([^>]*)>", k)
         if m and m.group(1).split(",")[5].strip() == "2":
             x3_n += c
             x3_ms += t
