@@ -46,7 +46,9 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         if self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("train-mode InPlaceABN (step 0 / phase 1) is not built yet; phase 2 freezes the body")
+            # a single block has no stand-alone training entry: the body trains as a whole (batch statistics, tape, backward)
+            raise RuntimeError("train-mode ResidualBlock: call the owning model / body (cl4wsis_amd.body_train.body_forward, or "
+                               "model(images) in training mode, which runs it under torch.autograd)")
         c = self.convs
         r = conv_abn(x, self.proj_conv, self.proj_bn) if hasattr(self, "proj_conv") else x
         y = conv_abn(x, c.conv1, c.bn1)

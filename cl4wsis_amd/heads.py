@@ -9,8 +9,9 @@ State-dict names follow the reference:
 The instance branch has two execution modes:
   * eval (frozen old model): BatchNorm folded into the conv epilogues, one kernel per conv;
   * train (phase-2 trainable sub-net): batch statistics, Dropout(0.5), and a hand-written backward
-    (`InstanceBranch.forward_train` / `.backward`) that accumulates parameter gradients — it is
-    wrapped in one autograd.Function so that ``loss.backward()`` of the reference's Trainer works.
+    (`InstanceBranch.forward_train` / `.backward`) that accumulates parameter gradients. `Trainer.step` drives the
+    tape directly; called the reference's way (`model.decoder(feats)`, `model.instance_head(x)`, train.py:269-272) the
+    two halves run under `cl4wsis_amd.autograd.TapeFunction`, so that ``loss.backward()`` works (train.py:537).
 """
 from collections import OrderedDict
 

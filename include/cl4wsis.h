@@ -39,7 +39,12 @@ int cl4_abi_version(void);
 const char* cl4_last_error(void);
 
 /* ------------------------------------------------------------------------
- * Dense convolution as implicit GEMM on the fp32 MFMA pipe.
+ * Dense convolution as implicit GEMM on the MFMA pipes; `precision` selects the arithmetic of the products:
+ *   0  exact fp32 (v_mfma_f32_32x32x2_f32),
+ *   1  "bf16x3": fp32 operands split hi + lo into bf16, three v_mfma_f32_32x32x16_bf16 products, fp32 accumulation
+ *      (~4e-6 relative per layer) — the default of the frozen networks,
+ *   2  "bf16x6": hi + mid + lo, six products, fp32-level accuracy — the default of every differentiated convolution.
+ * Tensors are fp32 in HBM in every mode.
  *
  * Replaces: nn.Conv2d (+ InPlaceABN eval affine + leaky-ReLU, + residual add)
  *   modules/residual.py:67-97, models/resnet.py:59-63, modules/deeplab.py:54-70,
