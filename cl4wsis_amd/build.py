@@ -66,5 +66,33 @@ def build_library(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, defines, sources=("conv_igemm.hip",)):
+    """Experiments only: libcl4wsis_<name>.so = the product objects with `sources` recompiled under extra -D flags
+    (loaded through CL4_LIB by the probes under tools/)."""
+    hipcc = _hipcc()
+    build_library(verbose=False)
+    vdir = os.path.join(OBJ, name)
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    for s in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")):
+        if s in sources:
+            obj = os.path.join(vdir, s[:-4] + ".o")
+            cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-c", os.path.join(CSRC, s), "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")
+        else:
+            obj = os.path.join(OBJ, s[:-4] + ".o")
+        objs.append(obj)
+    lib = os.path.join(HERE, f"libcl4wsis_{name}.so")
+    r = subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant tl2 CL4_TL2=1 [more defines]
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        print(build_library(force="--force" in sys.argv))

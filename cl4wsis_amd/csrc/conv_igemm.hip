@@ -490,6 +490,9 @@ __global__ void conv_splitk_epilogue(ConvArgs a, int splits) {
 #ifndef CL4_DBG
 #define CL4_DBG 0   // experiments only: 1 = loader issues no loads in the loop, 2 = no convert/LDS stores, 4 = no MFMA
 #endif
+#ifndef CL4_TL2
+#define CL4_TL2 0   // experiments only (tools/probe_phases.py): per-K-tile phase times of loader wave 0 / MFMA wave 0, summed per workgroup
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -902,20 +905,34 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
       loadA(acur, kt_i);
       ++kt_i;
     };
+#if CL4_TL2
+    unsigned long long tl2[5] = {0, 0, 0, 0, 0};   // wait for loads, convert + LDS stores, issue of the next loads, LDS drain, barrier
+#define CL4_T(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tl2[i] += now_ - tprev_; tprev_ = now_; }
+#else
+#define CL4_T(i)
+#endif
     auto half = [&](float (&cur)[NITEM][8], u32x4 (&acur)[A_PER_LANE], int t) {
       const int nb = (t + 1) & 1;
+#if CL4_TL2
+      unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
       wait_vmcnt<(NS - 1) * TILE_LOADS>();
+      CL4_T(0)
 #if !(CL4_DBG & 2)
       cvt_store(cur, nb);
       storeA(acur, nb);
 #endif
+      CL4_T(1)
 #if !(CL4_DBG & 1)
       issue(cur, acur);
 #else
       ++kt_i;
 #endif
+      CL4_T(2)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      CL4_T(3)
       __builtin_amdgcn_s_barrier();
+      CL4_T(4)
     };
 
 #pragma unroll
@@ -936,6 +953,13 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
 #pragma unroll
       for (int i = 0; i < PF_PER_LANE; ++i) asm volatile("" ::"v"(pf[i]));
     }
+#if CL4_TL2
+    if (a.timeline && wave8 == 4 && lane == 0) {
+      unsigned long long* o = a.timeline + (size_t)gridDim.x * 8 + (size_t)id * 16;
+      for (int i = 0; i < 5; ++i) o[i] = tl2[i];
+      o[5] = (unsigned long long)TOT;
+    }
+#endif
     if constexpr (WIDE) wide_epilogue();
     return;
   }
@@ -965,6 +989,13 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
   // (Measured and dropped, r02: software-pipelining the fragment reads of the MFMA waves — every ds_read_b128 issued one product
   // group ahead of its MFMAs, rotated loop with exact counted lgkmcnt waits, 120 VGPRs — changed nothing: 125.5 -> 129.5 us on
   // the res4 conv3 shape, 185 -> 199 us on the 3x3 one. The MFMA waves are not the pacing role; they wait at the barrier.)
+#if CL4_TL2
+  unsigned long long tm2[2] = {0, 0};          // fragment reads + MFMAs, barrier
+  unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#define CL4_TM(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tm2[i] += now_ - tprev_; tprev_ = now_; }
+#else
+#define CL4_TM(i)
+#endif
   for (int kt = 0; kt < nk; ++kt, ++gk) {
     const u32x4* As = lds[gk & 1] + wm * WTM + lr;
     const u32x4* Bs = lds[gk & 1] + A_CHUNKS + wn * WTN + lr;
@@ -1004,8 +1035,16 @@ __global__ __launch_bounds__(256 + 64 * LW, LW == 4 ? 4 : 3) void conv_igemm_bf1
     }
     // all of this wave's LDS reads of the stage have returned before the loaders are told it may be overwritten
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CL4_TM(0)
     __builtin_amdgcn_s_barrier();
+    CL4_TM(1)
   }
+#if CL4_TL2
+  if (a.timeline && wave8 == 0 && lane == 0) {
+    unsigned long long* o = a.timeline + (size_t)gridDim.x * 8 + (size_t)id * 16 + 8;
+    o[0] = tm2[0]; o[1] = tm2[1];
+  }
+#endif
   // persistent: drain this tile while the loaders (blocked at their next barrier, their register sets already filled with
   // the next tile's first K-tiles) wait
   if (PERS) fused_epilogue<TM, TN>(a, acc, m0 + wm * WTM, n0 + wn * WTN, lr, lh, HWo);

@@ -155,6 +155,27 @@ __global__ void resize_bwd_kernel(const float* __restrict__ dy, float* __restric
     if (a.sx == 0.f) { ox_lo = 0; ox_hi = a.wout - 1; }
     const float* dyp = dy + ((long)n * a.out_ctot + a.out_coff + c) * a.hout * a.wout;
     float acc = 0.f;
+    constexpr int WXN = 12;                      // column weights once per input pixel, not once per candidate row (the decoder's
+    const int nx = ox_hi - ox_lo + 1;            // x2 upsamplings have <= 9 candidates per axis; larger factors take the plain loop)
+    if (nx <= WXN) {
+      float wxs[WXN];
+#pragma unroll
+      for (int t = 0; t < WXN; ++t) {
+        int x0, x1; float lx;
+        src_index(min(ox_lo + t, a.wout - 1), a.sx, a.align, a.win, x0, x1, lx);
+        wxs[t] = t < nx ? (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f) : 0.f;
+      }
+      for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        int y0, y1; float ly;
+        src_index(oy, a.sy, a.align, a.hin, y0, y1, ly);
+        const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+        if (wy == 0.f) continue;
+        const float* row = dyp + oy * a.wout + ox_lo;
+#pragma unroll
+        for (int t = 0; t < WXN; ++t)            // same products in the same order as the plain loop (zero weights were skipped there)
+          if (wxs[t] != 0.f) acc += wy * wxs[t] * row[t];
+      }
+    } else
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
       int y0, y1; float ly;
       src_index(oy, a.sy, a.align, a.hin, y0, y1, ly);
