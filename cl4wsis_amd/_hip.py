@@ -201,6 +201,8 @@ def load():
                    ("cl4_input_workspace_bytes", [C.c_int] * 5), ("cl4_target_generation_workspace_bytes", [C.c_int])):
         getattr(lib, nm).restype = C.c_size_t
         getattr(lib, nm).argtypes = at
+    lib.cl4_conv_debug_u_launches.restype = C.c_long
+    lib.cl4_conv_debug_u_launches.argtypes = []
     lib.cl4_input_ksize.restype = C.c_int
     lib.cl4_input_ksize.argtypes = [C.c_int, C.c_int]
     for name, args in PROTOTYPES.items():

@@ -92,7 +92,11 @@ def build_variant(name, defines, sources=("conv_igemm.hip",)):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant tl2 CL4_TL2=1 [more defines]
-        print(build_variant(sys.argv[2], sys.argv[3:]))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # build.py --variant tl2 [--src conv_u.hip] CL4_TL2=1 [more defines]
+        rest = sys.argv[3:]
+        srcs = ("conv_igemm.hip",)
+        if rest and rest[0] == "--src":
+            srcs, rest = tuple(rest[1].split(",")), rest[2:]
+        print(build_variant(sys.argv[2], rest, srcs))
     else:
         print(build_library(force="--force" in sys.argv))

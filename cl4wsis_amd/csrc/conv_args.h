@@ -1,0 +1,41 @@
+// Launch arguments shared by the forward convolution kernels (conv_igemm.hip, conv_u.hip).
+#pragma once
+#include "common.h"
+
+namespace cl4 {
+
+struct ConvArgs {
+  const float* x;
+  const float* wp;
+  const float* scale;
+  const float* shift;
+  const float* pre;
+  const float* post;
+  float* y;
+  int n, cin, hin, win, cout, stride, pad, dil, hout, wout;
+  int in_ctot, in_coff, out_ctot, out_coff;
+  int act1, act2;
+  float slope1, slope2;
+  int K;        // cin*KS*KS
+  int npix;     // n*hout*wout — or n*hw_pad for the bf16 launches of a "vector gather" plan (see hw_pad)
+  int hw_pad;   // logical pixels per image: pixel p = image p / hw_pad, position p % hw_pad (positions >= hout*wout are padding).
+                // = hout*wout except for 1x1 plans whose activation loader fetches 4 pixels per lane (hw_pad = roundup(hout*wout, 4),
+                // so that a 4-pixel group never straddles two images)
+  int xcd_remap;      // 1: XCD-aware logical tile order (bf16x3 kernel)
+  float neg1, neg2;   // branch-free activations: act(v) = v > 0 ? v : v * neg  (none: 1, relu: 0, leaky: slope)
+  float* ws;    // split-K partial slabs [splits][cout][npix] (v2 kernel only)
+  int kchunk;   // k range per split (multiple of 32)
+  // bf16 kernels (1-D launches): logical tile = tile_base + (workgroup % ntile_l), M index fastest over gx tiles; the split-K
+  // slabs cover the pixels [ws_p0, ws_p0 + ws_npix) only ("main + split tail" plans split just the last partial round)
+  int gx, ntile_l, tile_base, ws_p0, ws_npix;
+  // Experiments only (tools/probe_timeline.py): when set, every workgroup of a bf16 launch records s_memtime stamps and its
+  // XCC / CU ids into timeline[blockIdx * 8 ..]: [0] start, [1] first K-tile ready, [2] K loop done, [3] accumulators parked,
+  // [4] epilogue done (MFMA wave 0), [5] loader wave 0 done, [6] (xcc << 8) | cu, [7] logical tile.
+  unsigned long long* timeline;
+};
+
+// conv_u.hip: the unified-wave bf16x3 kernel (every wave loads, splits and multiplies). One launch of `grid` workgroups of 256
+// threads; ks = 1 | 3, split = K-split slabs (a.ws) instead of the fused epilogue.
+int launch_conv_u(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st);
+
+}  // namespace cl4

@@ -20,6 +20,7 @@
 #include <tuple>
 #include <type_traits>
 #include "common.h"
+#include "conv_args.h"
 
 namespace {
 
@@ -28,35 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;       // K-tile of the forward kernel
 constexpr int NTHREADS = 256;
 
-struct ConvArgs {
-  const float* x;
-  const float* wp;
-  const float* scale;
-  const float* shift;
-  const float* pre;
-  const float* post;
-  float* y;
-  int n, cin, hin, win, cout, stride, pad, dil, hout, wout;
-  int in_ctot, in_coff, out_ctot, out_coff;
-  int act1, act2;
-  float slope1, slope2;
-  int K;        // cin*KS*KS
-  int npix;     // n*hout*wout — or n*hw_pad for the bf16 launches of a "vector gather" plan (see hw_pad)
-  int hw_pad;   // logical pixels per image: pixel p = image p / hw_pad, position p % hw_pad (positions >= hout*wout are padding).
-                // = hout*wout except for 1x1 plans whose activation loader fetches 4 pixels per lane (hw_pad = roundup(hout*wout, 4),
-                // so that a 4-pixel group never straddles two images)
-  int xcd_remap;      // 1: XCD-aware logical tile order (bf16x3 kernel)
-  float neg1, neg2;   // branch-free activations: act(v) = v > 0 ? v : v * neg  (none: 1, relu: 0, leaky: slope)
-  float* ws;    // split-K partial slabs [splits][cout][npix] (v2 kernel only)
-  int kchunk;   // k range per split (multiple of 32)
-  // bf16 kernels (1-D launches): logical tile = tile_base + (workgroup % ntile_l), M index fastest over gx tiles; the split-K
-  // slabs cover the pixels [ws_p0, ws_p0 + ws_npix) only ("main + split tail" plans split just the last partial round)
-  int gx, ntile_l, tile_base, ws_p0, ws_npix;
-  // Experiments only (tools/probe_timeline.py): when set, every workgroup of a bf16 launch records s_memtime stamps and its
-  // XCC / CU ids into timeline[blockIdx * 8 ..]: [0] start, [1] first K-tile ready, [2] K loop done, [3] accumulators parked,
-  // [4] epilogue done (MFMA wave 0), [5] loader wave 0 done, [6] (xcc << 8) | cu, [7] logical tile.
-  unsigned long long* timeline;
-};
+using cl4::ConvArgs;
 
 
 // Fused epilogue shared by the forward kernels: y = act2( act1( (acc + pre) * scale[co] + shift[co] ) + post ).
@@ -1414,6 +1387,14 @@ bool vec_gather_plan(const ConvArgs& a, int ks, int precision, int tile) {
          a.win == a.wout && (long)a.n * a.in_ctot * a.hin * a.win * 4 < 0x7FFFFFFFL;
 }
 
+// Does this launch run on the unified-wave kernel (conv_u.hip)? bf16x3, 128x128 plan, 1x1 / 3x3 stride-1 "same" convolution with
+// 32-channel K-tiles. Like the VEC plans it walks a pixel index space padded per image to a multiple of 4. CL4_CONV_U=0: off.
+bool u_plan(const ConvArgs& a, int ks, int precision, int tile) {
+  static const int enabled = env_int("CL4_CONV_U", 1);
+  return enabled && precision == 1 && tile == 128 && (ks == 1 || ks == 3) && a.stride == 1 && a.pad == a.dil * (ks / 2) &&
+         a.cin % 32 == 0 && a.hin == a.hout && a.win == a.wout && (long)a.n * a.in_ctot * a.hin * a.win * 4 < 0x7FFFFFFFL;
+}
+
 template <int KS>
 int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes, int precision) {
   const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 4 + precision});
@@ -1427,8 +1408,9 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
       return CL4_EINVAL;
     }
     // "vector gather" plans (see the VEC template parameter): logical pixel index space padded per image to a multiple of 4
-    const bool vec = vec_gather_plan(a, KS, precision, pl.tile);
-    if (vec) {
+    const bool upl = u_plan(a, KS, precision, pl.tile);
+    const bool vec = !upl && vec_gather_plan(a, KS, precision, pl.tile);
+    if (vec || upl) {
       a.hw_pad = (a.hout * a.wout + 3) & ~3;
       a.npix = a.n * a.hw_pad;
     }
@@ -1453,7 +1435,9 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
       a.gx = cl4::cdiv(a.cout, tile);
       const dim3 g((unsigned)ntile * (unsigned)(sp > 1 ? sp : 1));
       const bool split = sp > 1;
-      if (precision == 2) {
+      if (upl && tile == 128) {
+        if (cl4::launch_conv_u(a, KS, split, g.x, st) != CL4_OK) return;
+      } else if (precision == 2) {
         if (tile == 128) {
           if (split) { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, true, 3, 8, 4>), g, dim3(768), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, true, false, 3, 8, 4>), g, dim3(768), 0, st, a, z); }
           else { if (tapmaj) hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, true, 3, 8, 4>), g, dim3(768), 0, st, a, z); else hipLaunchKernelGGL((conv_igemm_bf16x3<128, 128, KS, false, false, 3, 8, 4>), g, dim3(768), 0, st, a, z); }
@@ -1860,8 +1844,9 @@ extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
   const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin * 4 + d->precision});
   ConvArgs va;      // the fields vec_gather_plan looks at
   va.n = d->n; va.cin = d->cin; va.hin = d->hin; va.win = d->win; va.hout = d->hout; va.wout = d->wout; va.stride = d->stride;
-  va.pad = d->pad; va.in_ctot = d->in_ctot;
-  if (pl.impl == 2 && vec_gather_plan(va, d->kh, d->precision, pl.tile)) npix = d->n * ((d->hout * d->wout + 3) & ~3);
+  va.pad = d->pad; va.in_ctot = d->in_ctot; va.dil = d->dil;
+  if (pl.impl == 2 && (vec_gather_plan(va, d->kh, d->precision, pl.tile) || u_plan(va, d->kh, d->precision, pl.tile)))
+    npix = d->n * ((d->hout * d->wout + 3) & ~3);
   if (d->precision != 0 && pl.impl == 2 && pl.tail > 0) {
     const TailGeom tg = tail_geometry(pl, d->cout, npix, d->precision);
     return (tg.main > 0 && pl.tail > 1) ? (size_t)pl.tail * d->cout * (npix - tg.p0) * sizeof(float) : 0;   // small-tile tail / degenerate: no slabs

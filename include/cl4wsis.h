@@ -467,6 +467,8 @@ int cl4_target_generation(const long long* seg_map, const uint8_t* mask, int b, 
  * (y[i] += w[i] > 0 ? x[i] : -x[i]) to a gradient computed with respect to the effective scale. */
 /* Experiments only: phase time stamps of the bf16 forward kernels (tools/probe_timeline.py); NULL = off. */
 int cl4_conv_debug_timeline(void* buf);
+/* Experiments / tests only: number of launches this process has sent to the unified-wave bf16x3 kernel (csrc/conv_u.hip). */
+long cl4_conv_debug_u_launches(void);
 int cl4_abs_eps(const float* w, float* out, int n, float eps, void* stream);
 int cl4_sign_axpy(float* y, const float* x, const float* w, int n, void* stream);
 
