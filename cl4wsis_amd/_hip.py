@@ -116,6 +116,9 @@ _decl("cl4_dwconv5_wgrad", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 
 _decl("cl4_cam_smooth", _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P, C.c_size_t, _P)
 _decl("cl4_conv_debug_timeline", _P)
+_decl("cl4_to_planes", _P, _P, _I, _I, _I, _I, _I, _P)
+_decl("cl4_from_planes", _P, _P, _I, _I, _I, _I, _I, _P)
+_decl("cl4_conv2d_fwd_planes", C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_abs_eps", _P, _P, _I, _F, _P)
 _decl("cl4_sign_axpy", _P, _P, _P, _I, _P)
 _decl("cl4_comm_unique_id", _P)
@@ -201,8 +204,9 @@ def load():
                    ("cl4_input_workspace_bytes", [C.c_int] * 5), ("cl4_target_generation_workspace_bytes", [C.c_int])):
         getattr(lib, nm).restype = C.c_size_t
         getattr(lib, nm).argtypes = at
-    lib.cl4_conv_debug_u_launches.restype = C.c_long
-    lib.cl4_conv_debug_u_launches.argtypes = []
+    for nm in ("cl4_conv_debug_u_launches", "cl4_conv_debug_s_launches"):
+        getattr(lib, nm).restype = C.c_long
+        getattr(lib, nm).argtypes = []
     lib.cl4_input_ksize.restype = C.c_int
     lib.cl4_input_ksize.argtypes = [C.c_int, C.c_int]
     for name, args in PROTOTYPES.items():

@@ -32,10 +32,21 @@ struct ConvArgs {
   // XCC / CU ids into timeline[blockIdx * 8 ..]: [0] start, [1] first K-tile ready, [2] K loop done, [3] accumulators parked,
   // [4] epilogue done (MFMA wave 0), [5] loader wave 0 done, [6] (xcc << 8) | cu, [7] logical tile.
   unsigned long long* timeline;
+  // "Planes" operands (conv_s.hip): a tensor stored as pre-split bf16 planes, [n][c/8][plane: hi, lo][h*w][8 x bf16] — one 16-byte
+  // chunk = 8 consecutive channels of one pixel of one plane = one MFMA operand fragment row. xs: the input in that format (x is
+  // then unused), ys: an additional / alternative output in that format (y may be null), post_s: the residual operand in that
+  // format (instead of post). Channel slices use in_ctot / in_coff / out_ctot / out_coff in units of channels (multiples of 8).
+  const void* xs;
+  void* ys;
+  const void* post_s;
 };
 
 // conv_u.hip: the unified-wave bf16x3 kernel (every wave loads, splits and multiplies). One launch of `grid` workgroups of 256
 // threads; ks = 1 | 3, split = K-split slabs (a.ws) instead of the fused epilogue.
 int launch_conv_u(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st);
+
+// conv_s.hip: the planes-input bf16x3 kernel (activations arrive pre-split: no conversion in the K loop). Any stride / pad / dilation,
+// ks = 1 | 3, cin % 32 == 0. Same launch conventions as launch_conv_u.
+int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st);
 
 }  // namespace cl4

@@ -1311,14 +1311,14 @@ FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision
   FwdPlan p{1, 128, 1, 0, 0};
   if (impl != 2 || cout % 4 != 0 || cout < 64) return p;
   p.impl = 2;
-  p.tile = (tile == 128 && cout >= 128) ? 128 : 64;
+  p.tile = ((tile == 128 && cout >= 128) || precision == 3) ? 128 : 64;      // planes-input kernel (precision code 3): 128x128 only
   const int ktiles = cl4::cdiv(K, BK2);
   int s = splits < 0 ? -splits : (splits < 1 ? 1 : splits);
   if (s > ktiles) s = ktiles;
   const int per = cl4::cdiv(ktiles, s);
   p.kchunk = per * BK2;
   const int actual = cl4::cdiv(K, p.kchunk);
-  if (splits == -1 && precision != 0 && p.tile == 128) { p.tail = 1; p.splits = 1; }     // main + SMALL-TILE tail (64x64, unsplit)
+  if (splits == -1 && precision != 0 && precision != 3 && p.tile == 128) { p.tail = 1; p.splits = 1; }     // main + SMALL-TILE tail (64x64, unsplit)
   else if (splits < 0 && precision != 0 && actual > 1) { p.tail = actual; p.splits = 1; }
   else p.splits = actual;
   return p;
@@ -1343,7 +1343,8 @@ FwdPlan plan_fwd(const PlanKey& key) {
   double best = 1e30;
   FwdPlan bestp = make_plan(2, 64, 1, cout, K, precision);
   for (int tile = 64; tile <= 128; tile += 64) {
-    if (tile == 128 && (cout < 128 || (precision == 2 && ktiles < 64))) continue;   // bf16x6 at 128x128: 96 KB LDS, one WG per CU — long K only
+    if (precision == 3 && tile != 128) continue;
+    if (tile == 128 && precision != 3 && (cout < 128 || (precision == 2 && ktiles < 64))) continue;   // bf16x6 at 128x128: 96 KB LDS, one WG per CU — long K only
     const long wgs = (long)cl4::cdiv(cout, tile) * cl4::cdiv(npix, tile);
     const double t_tile = tile == 128 ? 2.4 : 0.65;   // us per K-tile of one workgroup at ~70 % MFMA issue
     const double t_fixed = tile == 128 ? 5.0 : 2.5;   // prologue + epilogue
@@ -1387,6 +1388,110 @@ bool vec_gather_plan(const ConvArgs& a, int ks, int precision, int tile) {
          a.win == a.wout && (long)a.n * a.in_ctot * a.hin * a.win * 4 < 0x7FFFFFFFL;
 }
 
+// Split-K second pass of the planes-input kernel: like conv_splitk_epilogue, but one thread owns 8 consecutive output channels of one
+// pixel, so that it can emit the planes chunks (a.ys) and read a planes residual (a.post_s); fp32 rows (a.y) are written as well when
+// requested. grid = (pixel chunks of 256, ceil(cout / 8)).
+__global__ void conv_splitk_epilogue_s(ConvArgs a, int splits) {
+  const int co0 = blockIdx.y * 8;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.ws_npix) return;
+  const long total = (long)a.cout * a.ws_npix;
+  float v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float* w = a.ws + (long)min(co0 + r, a.cout - 1) * a.ws_npix + i;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += w[(long)z * total];     // fixed order: reproducible
+    v[r] = s;
+  }
+  const int HWo = a.hout * a.wout;
+  const int p = a.ws_p0 + i;
+  const int n = p / HWo;
+  const int hw = p - n * HWo;
+  const long rbase = (long)n * a.cout * HWo + hw;
+  float t[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int cc = min(co0 + r, a.cout - 1);
+    if (a.pre) v[r] += a.pre[rbase + (long)cc * HWo];
+    const float u = v[r] * (a.scale ? a.scale[cc] : 1.f) + (a.shift ? a.shift[cc] : 0.f);
+    v[r] = u > 0.f ? u : u * a.neg1;
+    t[r] = a.post ? a.post[rbase + (long)cc * HWo] : 0.f;
+  }
+  if (a.post_s) {
+    const u32x4* ps = reinterpret_cast<const u32x4*>(a.post_s) + (((long)n * (a.cout >> 3) + (co0 >> 3)) * 2) * HWo + hw;
+    const u32x4 hi = ps[0], lo = ps[HWo];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      t[2 * q] = __builtin_bit_cast(float, hi[q] << 16) + __builtin_bit_cast(float, lo[q] << 16);
+      t[2 * q + 1] = __builtin_bit_cast(float, hi[q] & 0xFFFF0000u) + __builtin_bit_cast(float, lo[q] & 0xFFFF0000u);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    v[r] += t[r];
+    v[r] = v[r] > 0.f ? v[r] : v[r] * a.neg2;
+  }
+  if (a.y) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (co0 + r < a.cout) a.y[((long)n * a.out_ctot + a.out_coff + co0 + r) * HWo + hw] = v[r];
+  }
+  if (a.ys) {
+    u32x4 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                          // the same split as conv_s.hip::split8 (round to nearest even twice)
+      const float x0 = v[2 * q], x1 = v[2 * q + 1];
+      const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+      const __bf16 l0 = (__bf16)(x0 - (float)h0), l1 = (__bf16)(x1 - (float)h1);
+      hi[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+      lo[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+    u32x4* ys = reinterpret_cast<u32x4*>(a.ys) + (((long)n * (a.out_ctot >> 3) + ((a.out_coff + co0) >> 3)) * 2) * HWo + hw;
+    ys[0] = hi;
+    ys[HWo] = lo;
+  }
+}
+
+// Planes-input launch (precision code 3, conv_s.hip): same plan machinery as the bf16 launches — unsplit, K-split, or whole rounds
+// unsplit + split tail — on 128x128 tiles only.
+template <int KS>
+int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes) {
+  if constexpr (KS == 7) {
+    cl4::set_error("conv2d_fwd_planes: 7x7 kernels are not built for planes input");
+    return CL4_EINVAL;
+  } else {
+    const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 4 + 3});
+    if (pl.impl != 2 || pl.tile != 128) { cl4::set_error("conv2d_fwd_planes: no 128x128 plan for this shape"); return CL4_EINVAL; }
+    const TailGeom tg = tail_geometry(pl, a.cout, a.npix, 3);
+    const bool hybrid = tg.main > 0 && pl.tail > 1;
+    const int nsplit = hybrid ? pl.tail : pl.splits;
+    a.gx = tg.gx;
+    a.kchunk = pl.kchunk;
+    a.ws = nullptr;
+    a.ws_p0 = hybrid ? tg.p0 : 0;
+    a.ws_npix = a.npix - a.ws_p0;
+    if (nsplit > 1) {
+      const size_t need = (size_t)nsplit * a.cout * a.ws_npix * sizeof(float);
+      if (!workspace || workspace_bytes < need) { cl4::set_error("conv2d_fwd_planes: workspace too small for split-K"); return CL4_ENOSPC; }
+      a.ws = (float*)workspace;
+    }
+    auto go = [&](int base, int ntile, int sp) {
+      a.tile_base = base;
+      a.ntile_l = ntile;
+      return cl4::launch_conv_s(a, KS, sp > 1, (unsigned)ntile * (unsigned)(sp > 1 ? sp : 1), st);
+    };
+    int rc;
+    if (hybrid) {
+      if ((rc = go(0, tg.main, 1)) != CL4_OK) return rc;
+      if ((rc = go(tg.main, tg.ntiles - tg.main, nsplit)) != CL4_OK) return rc;
+    } else if ((rc = go(0, tg.ntiles, nsplit)) != CL4_OK) return rc;
+    if (nsplit > 1)
+      hipLaunchKernelGGL(conv_splitk_epilogue_s, dim3(cl4::cdiv(a.ws_npix, 256), cl4::cdiv(a.cout, 8)), dim3(256), 0, st, a, nsplit);
+    return cl4::launch_status();
+  }
+}
+
 // Does this launch run on the unified-wave kernel (conv_u.hip)? bf16x3, 128x128 plan, 1x1 / 3x3 stride-1 "same" convolution with
 // 32-channel K-tiles. Like the VEC plans it walks a pixel index space padded per image to a multiple of 4. CL4_CONV_U=0: off.
 bool u_plan(const ConvArgs& a, int ks, int precision, int tile) {
@@ -1397,6 +1502,7 @@ bool u_plan(const ConvArgs& a, int ks, int precision, int tile) {
 
 template <int KS>
 int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes, int precision) {
+  if (precision == 3) return launch_planes<KS>(a, st, workspace, workspace_bytes);
   const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 4 + precision});
   if (precision == 1 || precision == 2) {
     static float* zp3 = nullptr;
@@ -1847,6 +1953,7 @@ extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
   va.pad = d->pad; va.in_ctot = d->in_ctot; va.dil = d->dil;
   if (pl.impl == 2 && (vec_gather_plan(va, d->kh, d->precision, pl.tile) || u_plan(va, d->kh, d->precision, pl.tile)))
     npix = d->n * ((d->hout * d->wout + 3) & ~3);
+  if (d->precision == 3 && (pl.impl != 2 || pl.tile != 128)) return 0;
   if (d->precision != 0 && pl.impl == 2 && pl.tail > 0) {
     const TailGeom tg = tail_geometry(pl, d->cout, npix, d->precision);
     return (tg.main > 0 && pl.tail > 1) ? (size_t)pl.tail * d->cout * (npix - tg.p0) * sizeof(float) : 0;   // small-tile tail / degenerate: no slabs
@@ -1875,14 +1982,9 @@ extern "C" int cl4_conv2d_fwd_clear_plans(void) {
   return CL4_OK;
 }
 
-extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const float* wp, const float* scale,
-                              const float* shift, const float* pre, const float* post, float* y, void* workspace,
-                              size_t workspace_bytes, void* stream) {
-  int rc = check_desc(d);
-  if (rc) return rc;
-  CL4_REQUIRE(x && wp && y, "conv2d_fwd: null tensor");
-  CL4_REQUIRE(d->precision >= 0 && d->precision <= 2, "conv2d_fwd: precision %d unknown (0 fp32, 1 bf16x3, 2 bf16x6)", d->precision);
-  CL4_REQUIRE(d->precision == 0 || (d->cout % 4 == 0 && d->cout >= 64), "conv2d_fwd: bf16x3 / bf16x6 need cout %% 4 == 0 and cout >= 64");
+static int conv2d_fwd_common(const cl4_conv_desc* d, const float* x, const void* xs, const float* wp, const float* scale,
+                             const float* shift, const float* pre, const float* post, const void* post_s, float* y, void* ys,
+                             void* workspace, size_t workspace_bytes, void* stream) {
   ConvArgs a;
   a.x = x; a.wp = wp; a.scale = scale; a.shift = shift; a.pre = pre; a.post = post; a.y = y;
   a.n = d->n; a.cin = d->cin; a.hin = d->hin; a.win = d->win; a.cout = d->cout;
@@ -1897,6 +1999,7 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
   static const int xcd_default = env_int("CL4_XCD_REMAP", 1);
   a.xcd_remap = xcd_default;
   a.timeline = g_timeline;
+  a.xs = xs; a.ys = ys; a.post_s = post_s;
   a.neg1 = d->act1 == CL4_ACT_NONE ? 1.f : (d->act1 == CL4_ACT_RELU ? 0.f : d->slope1);
   a.neg2 = d->act2 == CL4_ACT_NONE ? 1.f : (d->act2 == CL4_ACT_RELU ? 0.f : d->slope2);
   hipStream_t st = cl4::as_stream(stream);
@@ -1905,6 +2008,34 @@ extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const floa
     case 3: return launch_fwd<3>(a, st, workspace, workspace_bytes, d->precision);
     default: return launch_fwd<7>(a, st, workspace, workspace_bytes, d->precision);
   }
+}
+
+extern "C" int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const float* wp, const float* scale,
+                              const float* shift, const float* pre, const float* post, float* y, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CL4_REQUIRE(x && wp && y, "conv2d_fwd: null tensor");
+  CL4_REQUIRE(d->precision >= 0 && d->precision <= 2, "conv2d_fwd: precision %d unknown (0 fp32, 1 bf16x3, 2 bf16x6)", d->precision);
+  CL4_REQUIRE(d->precision == 0 || (d->cout % 4 == 0 && d->cout >= 64), "conv2d_fwd: bf16x3 / bf16x6 need cout %% 4 == 0 and cout >= 64");
+  return conv2d_fwd_common(d, x, nullptr, wp, scale, shift, pre, post, nullptr, y, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cl4_conv2d_fwd_planes(const cl4_conv_desc* d, const void* xs, const float* wp, const float* scale, const float* shift,
+                                     const float* pre, const float* post, const void* post_s, float* y, void* ys, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CL4_REQUIRE(xs && wp && (y || ys), "conv2d_fwd_planes: null tensor");
+  CL4_REQUIRE(d->precision == 3, "conv2d_fwd_planes: the descriptor's precision must be 3 (bf16x3 on a planes input)");
+  CL4_REQUIRE(d->kh == 1 || d->kh == 3, "conv2d_fwd_planes: 1x1 and 3x3 kernels only");
+  CL4_REQUIRE(d->cin % 32 == 0 && d->in_ctot % 8 == 0 && d->in_coff % 8 == 0, "conv2d_fwd_planes: cin %% 32 == 0 and 8-aligned input channel slices");
+  CL4_REQUIRE(d->cout % 4 == 0 && d->cout >= 64, "conv2d_fwd_planes: cout %% 4 == 0 and cout >= 64");
+  CL4_REQUIRE(!ys || (d->cout % 8 == 0 && d->out_ctot % 8 == 0 && d->out_coff % 8 == 0), "conv2d_fwd_planes: a planes output needs 8-aligned output channels");
+  CL4_REQUIRE(!post_s || d->cout % 8 == 0, "conv2d_fwd_planes: a planes residual needs cout %% 8 == 0");
+  CL4_REQUIRE(!(post && post_s), "conv2d_fwd_planes: one residual operand (post or post_s)");
+  CL4_REQUIRE((long)d->n * d->in_ctot * d->hin * d->win * 4 < 0x7FFFFFFFL, "conv2d_fwd_planes: input >= 2 GiB is not addressable by the 32-bit buffer offsets");
+  return conv2d_fwd_common(d, nullptr, xs, wp, scale, shift, pre, post, post_s, y, ys, workspace, workspace_bytes, stream);
 }
 
 // Experiments only (not part of the drop-in boundary): device buffer of 8 x uint64 per workgroup that the bf16 forward kernels

@@ -1,0 +1,462 @@
+// Planes-input bf16x3 forward convolution ("S" kernel). Same arithmetic as conv_igemm_bf16x3 / conv_u_bf16x3 (three
+// v_mfma bf16 products per fp32-equivalent MAC, fp32 accumulation, fused epilogue), but the activations arrive ALREADY split:
+//
+//   planes format of a tensor [n][c][h][w] (c % 8 == 0):   [n][c/8][plane: hi, lo][h*w][8 x bf16]
+//   hi = bf16(x), lo = bf16(x - hi); one 16-byte chunk = 8 consecutive channels of one pixel of one plane.
+//
+// tools/probe_clock.py on the unified-wave kernel (profiles/r02c_u_clock.txt) showed what bounds a bf16x3 K-tile once loads are wide and
+// every wave does everything: with the MFMAs REMOVED the loop still takes ~2200 cycles per K-tile — its ~95 VALU instructions per
+// wave (three per activation element for the split, masks, addresses) plus LDS stores, against 1412 cycles for the MFMAs alone, and the
+// shader clock falls from 2.34 to 1.8-1.9 GHz when both run together. A chunk of the planes format is exactly what one lane hands to
+// ds_write_b128 / what an MFMA B-fragment row is, for ANY tap of ANY stride / dilation (a tap is a per-lane pixel offset; padding is an
+// out-of-range buffer offset): the K loop of this kernel has no conversion, no masking and ~15 address VALU per K-tile. The split is
+// paid once per activation by the PRODUCING kernel's epilogue (ys output below, or cl4_to_planes for tensors that other kernels
+// write) instead of once per (M-tile x tap) by every consumer: 18 times less often for a 3x3 256 -> 256 layer.
+//
+// Structure (as conv_u.hip): 256-thread workgroups (4 waves, 64x64 each of a 128x128 tile, two workgroups per CU), 32-deep K-tiles =
+// one tap x 32 channels, two LDS stages, two register sets per operand (tile t+3 requested while tile t is multiplied), one barrier per
+// K-tile, XCD-aware tile order, K-split slabs, accumulators parked in LDS for a row-streaming fused epilogue that can emit fp32 NCHW
+// and / or planes. MF selects the MFMA shape: 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16.
+#include "conv_args.h"
+
+namespace {
+
+using cl4::ConvArgs;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#ifndef CL4_S_DBG
+#define CL4_S_DBG 0   // experiments only: 1 = no loads in the loop, 2 = no LDS stores, 4 = no MFMA
+#endif
+
+constexpr int BM = 128, BN = 128, BKS = 32, P = 2, KG = 4;
+constexpr int A_CHUNKS = KG * P * BM;
+constexpr int B_CHUNKS = KG * P * BN;
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {   // {bf16(lo), bf16(hi)} in one dword (round to nearest even)
+  f32x2v t = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+}
+__device__ __forceinline__ float sub_f32(float a, float b) {          // one v_sub_f32 (keeps hipcc's SLP pass from forming v_pk_add_f32)
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// split 8 fp32 values into the hi / lo chunks of the planes format
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
+    lo[i] = pack_bf16(sub_f32(v[2 * i], __builtin_bit_cast(float, hi[i] << 16)), sub_f32(v[2 * i + 1], __builtin_bit_cast(float, hi[i] & 0xFFFF0000u)));
+  }
+}
+__device__ __forceinline__ void join8(const u32x4& hi, const u32x4& lo, float (&v)[8]) {     // hi + lo, exact in fp32
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __builtin_bit_cast(float, hi[i] << 16) + __builtin_bit_cast(float, lo[i] << 16);
+    v[2 * i + 1] = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u) + __builtin_bit_cast(float, lo[i] & 0xFFFF0000u);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int KS, bool SPLIT, int MF>
+__global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
+  static_assert(MF == 32 || MF == 16, "MFMA shape");
+  constexpr int WTM = 64, WTN = 64;
+  constexpr int KHW = KS * KS;
+  constexpr int NB = MF == 32 ? 2 : 4;                     // MFMA blocks per wave-tile side
+  constexpr int ACCV = MF == 32 ? 16 : 4;                  // accumulator registers per block
+  __shared__ u32x4 lds[2][A_CHUNKS + B_CHUNKS];            // 64 KB: two K-tile stages; reused as the parked [128][128] fp32 tile
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const unsigned total = gridDim.x, id = blockIdx.x;
+  unsigned long long* tl = a.timeline ? a.timeline + (size_t)id * 8 : nullptr;
+  auto stamp = [&](int slot) {
+    if (tl && tid == 0) tl[slot] = __builtin_amdgcn_s_memtime();
+  };
+  if (tl && tid == 0) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    tl[6] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+    tl[7] = __builtin_amdgcn_s_memrealtime();
+  }
+  stamp(0);
+  const unsigned q8 = total >> 3, r8 = total & 7, xcd = id & 7;
+  const unsigned lid = a.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3) : id;
+  const unsigned bz = lid / (unsigned)a.ntile_l;
+  const unsigned tile_ = (unsigned)a.tile_base + (lid - bz * (unsigned)a.ntile_l);
+  const unsigned by_ = tile_ / (unsigned)a.gx, bx_ = tile_ - by_ * (unsigned)a.gx;
+  const int m0 = bx_ * BM, n0 = by_ * BN;
+  const int HWo = a.hout * a.wout, HWi = a.hin * a.win;
+  const int kbeg = SPLIT ? bz * a.kchunk : 0;
+  const int kend = SPLIT ? min(a.K, kbeg + a.kchunk) : a.K;
+  const int nk = (kend - kbeg + BKS - 1) / BKS;
+  const int T0 = kbeg >> 5;
+
+  // ---- staging roles: thread = (GEMM row / column tid & 127, plane tid >> 7); per K-tile it moves the 4 k-group chunks of that
+  // plane for its weight row AND for its pixel: 8 x 16 bytes in, 8 x ds_write_b128 out -------------------------------------------------
+  const int col = tid & 127, plane = wave >> 1;            // plane is wave-uniform
+  const int p = n0 + col;
+  const bool pvalid = p < a.npix;
+  const int pn = pvalid ? p / HWo : 0;
+  const int phw = pvalid ? p - pn * HWo : 0;
+  const int oy = phw / a.wout, ox = phw - oy * a.wout;
+  const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+  const int c8tot = a.in_ctot >> 3;
+  // chunk index of (image, first channel group of the slice, plane, pixel 0) — the tap's pixel and the K-tile's channel groups are added per tile
+  const unsigned cbase = (unsigned)((((long)pn * c8tot + (a.in_coff >> 3)) * 2 + plane) * HWi);
+  const unsigned x_bytes = (unsigned)((long)a.n * a.in_ctot * HWi * 4);       // planes: 4 bytes per element too; < 2^31 checked on the host
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, x_bytes, 0x00020000);
+  const int KGtot = a.K / 8;
+  const unsigned w_bytes = (unsigned)((long)KGtot * P * a.cout * 16);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, w_bytes, 0x00020000);
+  const unsigned a_voff = (m0 + col) < a.cout ? (unsigned)(m0 + col) * 16u : OOB;
+  const unsigned pkeep = (unsigned)(-(int)pvalid);
+
+  auto loadB = [&](u32x4 (&br)[4], int kt) {
+    const int T = T0 + kt;                                 // wave-uniform
+    int cg0;                                               // first channel group (of 8) of this K-tile
+    unsigned pix;
+    unsigned keep = pkeep & (unsigned)(-(int)(kt < nk));
+    if (KS == 1) {
+      cg0 = T * 4;
+      const int iy = iy0, ix = ix0;                        // pad == 0 for every 1x1 layer of the networks; general for safety
+      keep &= (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
+      pix = (unsigned)(iy * a.win + ix);
+    } else {
+      const int cb = T / KHW, tap = T - cb * KHW;
+      cg0 = cb * 4;
+      const int ky = tap / KS, kx = tap - ky * KS;
+      const int iy = iy0 + ky * a.dil, ix = ix0 + kx * a.dil;
+      keep &= (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
+      pix = (unsigned)(iy * a.win + ix);
+    }
+    const unsigned vo = (cbase + pix) * 16u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned co = (unsigned)__builtin_amdgcn_readfirstlane((cg0 + i) * 2 * HWi * 16);
+      const unsigned voff = ((vo + co) & keep) | (OOB & ~keep);   // whole address in the bounds-checked offset
+      br[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
+    }
+  };
+  auto loadA = [&](u32x4 (&ar)[4], int kt) {
+    const unsigned kkeep = (unsigned)(-(int)(kt < nk));
+    const unsigned voff = (a_voff & kkeep) | (OOB & ~kkeep);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kgg = (kbeg >> 3) + kt * 4 + i;
+      const int soff = __builtin_amdgcn_readfirstlane((kgg * P + plane) * a.cout * 16);
+      ar[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, soff, 0);
+    }
+  };
+  auto storeAB = [&](const u32x4 (&ar)[4], const u32x4 (&br)[4], int stage) {
+    u32x4* As = lds[stage];
+    u32x4* Bs = lds[stage] + A_CHUNKS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) As[(2 * i + plane) * BM + col] = ar[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Bs[(2 * i + plane) * BN + col] = br[i];
+  };
+
+  typedef float accv_t __attribute__((ext_vector_type(ACCV)));
+  accv_t acc[NB][NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < ACCV; ++r) acc[i][j][r] = 0.f;
+
+  // one half (MF = 32: 16 of the 32 k) / one plane pairing step of a K-tile
+  auto mfma_half = [&](int stage, int s2) {
+    if constexpr (MF == 32) {
+      const int lr = lane & 31, lh = lane >> 5;
+      const u32x4* As = lds[stage] + wm * WTM + lr;
+      const u32x4* Bs = lds[stage] + A_CHUNKS + wn * WTN + lr;
+      const int kg = 2 * s2 + lh;
+      bf16x8 ah[NB], al[NB], bh[NB], bl[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        ah[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 0) * BM + i * 32]);
+        al[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 1) * BM + i * 32]);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        bh[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 0) * BN + j * 32]);
+        bl[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 1) * BN + j * 32]);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+#if CL4_S_DBG & 4
+          acc[i][j][0] += (float)al[i][0] * (float)bh[j][0] + (float)ah[i][1] * (float)bl[j][1];
+#else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#endif
+        }
+    } else {
+      // 16x16x32: lane l holds row / column l & 15 and k-group l >> 4 — one fragment spans the whole 32-deep K-tile. Half s2 = the row
+      // blocks 2*s2, 2*s2+1 against all four column blocks (the B fragments are read by both halves: 24 reads per K-tile instead of 16,
+      // in exchange for 8 fewer live registers... keep it simple: half 0 reads everything it needs, half 1 re-reads B).
+      const int l15 = lane & 15, kg = lane >> 4;
+      const u32x4* As = lds[stage] + wm * WTM + l15;
+      const u32x4* Bs = lds[stage] + A_CHUNKS + wn * WTN + l15;
+      bf16x8 ah[2], al[2], bh[NB], bl[NB];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 0) * BM + (2 * s2 + i) * 16]);
+        al[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 1) * BM + (2 * s2 + i) * 16]);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        bh[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 0) * BN + j * 16]);
+        bl[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 1) * BN + j * 16]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          accv_t& c = acc[2 * s2 + i][j];
+#if CL4_S_DBG & 4
+          c[0] += (float)al[i][0] * (float)bh[j][0] + (float)ah[i][1] * (float)bl[j][1];
+#else
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], c, 0, 0, 0);
+#endif
+        }
+    }
+  };
+
+  u32x4 ar[2][4], br[2][4];
+  loadA(ar[0], 0); loadB(br[0], 0);
+  loadA(ar[1], 1); loadB(br[1], 1);
+  wait_vmcnt<8>();
+  storeAB(ar[0], br[0], 0);
+  loadA(ar[0], 2); loadB(br[0], 2);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  stamp(1);
+
+  // one K-tile: multiply tile t out of `stage` while tile t+1 (register set a1 / b1) goes into the other stage and tile t+3 is requested
+  auto step = [&](u32x4 (&a1)[4], u32x4 (&b1)[4], int t, int stage) {
+    wait_vmcnt<8>();                                       // tile t+1 has landed (requested a whole K-tile ago); tile t+2's 8 loads stay in flight
+    mfma_half(stage, 0);
+#if !(CL4_S_DBG & 2)
+    storeAB(a1, b1, stage ^ 1);
+#endif
+#if !(CL4_S_DBG & 1)
+    loadA(a1, t + 3);
+    loadB(b1, t + 3);
+#endif
+    mfma_half(stage, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int t = 0; t < nk; t += 2) {
+    step(ar[1], br[1], t, 0);
+    step(ar[0], br[0], t + 1, 1);
+  }
+  stamp(2);
+
+  // ---- park the accumulators: stage[row][col] fp32 ----------------------------------------------------------------------------------
+  wait_vmcnt<0>();
+  float* stage = reinterpret_cast<float*>(&lds[0][0]);
+  if constexpr (MF == 32) {
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * WTN + j * 32 + lr] = acc[i][j][r];
+  } else {
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          stage[(wm * WTM + i * 16 + l4 * 4 + r) * BN + wn * WTN + j * 16 + l15] = acc[i][j][r];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  stamp(3);
+
+  if (SPLIT) {                                             // raw partial sums into this split's slab, channel rows, lane = pixel
+    constexpr int RPW = BM / 4;
+    float* wsb = a.ws + ((long)bz * a.cout) * a.ws_npix - a.ws_p0 + n0;
+#pragma unroll 4
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int co = m0 + wave * RPW + rr;
+      if (co >= a.cout) break;                             // wave-uniform
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (n0 + lane + 64 * q < a.npix) wsb[(long)co * a.ws_npix + lane + 64 * q] = stage[(wave * RPW + rr) * BN + lane + 64 * q];
+    }
+    return;
+  }
+
+  // ---- fused epilogue, 8-channel groups: thread = (pixel `col`, group parity `plane`), groups plane, plane + 2, ... of the tile's 16.
+  // y = act2( act1( (acc + pre) * scale + shift ) + post ); written as fp32 NCHW rows (a.y) and / or as planes chunks (a.ys) ------------
+  {
+    const long ybase = ((long)pn * a.out_ctot + a.out_coff) * HWo + phw;
+    const long rbase = (long)pn * a.cout * HWo + phw;
+    const int oc8tot = a.out_ctot >> 3;
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+      const int g8 = plane + 2 * it;                       // wave-uniform
+      const int co0 = m0 + g8 * 8;
+      if (co0 >= a.cout) break;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = stage[(g8 * 8 + r) * BN + col];
+      if (!pvalid) continue;
+      float t[8];
+      if (a.pre) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t[r] = a.pre[rbase + (long)min(co0 + r, a.cout - 1) * HWo];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += t[r];
+      }
+      u32x4 ph, pl_;
+      if (a.post_s) {                                      // residual in planes format: the same channel group of the same pixel
+        const u32x4* ps = reinterpret_cast<const u32x4*>(a.post_s) + (((long)pn * (a.cout >> 3) + (co0 >> 3)) * 2) * HWo + phw;
+        ph = ps[0];
+        pl_ = ps[HWo];
+      } else if (a.post) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t[r] = a.post[rbase + (long)min(co0 + r, a.cout - 1) * HWo];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int cc = min(co0 + r, a.cout - 1);
+        const float sc = a.scale ? a.scale[cc] : 1.f;
+        const float sh = a.shift ? a.shift[cc] : 0.f;
+        const float u = v[r] * sc + sh;
+        v[r] = u > 0.f ? u : u * a.neg1;
+      }
+      if (a.post_s) join8(ph, pl_, t);
+      if (a.post_s || a.post) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += t[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.neg2;
+      if (a.y) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (co0 + r < a.cout) a.y[ybase + (long)(co0 + r) * HWo] = v[r];
+      }
+      if (a.ys) {                                          // cout % 8 == 0 whenever ys is requested (checked on the host)
+        u32x4 hi, lo;
+        split8(v, hi, lo);
+        u32x4* ys = reinterpret_cast<u32x4*>(a.ys) + (((long)pn * oc8tot + ((a.out_coff + co0) >> 3)) * 2) * HWo + phw;
+        ys[0] = hi;
+        ys[HWo] = lo;
+      }
+    }
+  }
+  if (tl) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(4);
+    if (tid == 0) tl[5] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+// fp32 NCHW (channel slice) -> planes. One thread per (image, channel group, pixel): 8 strided dword loads (coalesced along pixels),
+// two 16-byte stores.
+__global__ void to_planes_kernel(const float* __restrict__ x, u32x4* __restrict__ xs, int n, int ctot, int coff, int c, int hw) {
+  const int c8 = c >> 3;
+  const long total = (long)n * c8 * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % hw);
+    const long r = i / hw;
+    const int g = (int)(r % c8), im = (int)(r / c8);
+    const float* src = x + ((long)im * ctot + coff + g * 8) * hw + px;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(long)j * hw];
+    u32x4 hi, lo;
+    split8(v, hi, lo);
+    u32x4* dst = xs + (((long)im * c8 + g) * 2) * hw + px;
+    dst[0] = hi;
+    dst[hw] = lo;
+  }
+}
+
+// planes -> fp32 NCHW (channel slice of the destination): hi + lo (exact in fp32)
+__global__ void from_planes_kernel(const u32x4* __restrict__ xs, float* __restrict__ y, int n, int c, int hw, int out_ctot, int out_coff) {
+  const int c8 = c >> 3;
+  const long total = (long)n * c8 * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % hw);
+    const long r = i / hw;
+    const int g = (int)(r % c8), im = (int)(r / c8);
+    const u32x4* src = xs + (((long)im * c8 + g) * 2) * hw + px;
+    float v[8];
+    join8(src[0], src[hw], v);
+    float* dst = y + ((long)im * out_ctot + out_coff + g * 8) * hw + px;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[(long)j * hw] = v[j];
+  }
+}
+
+}  // namespace
+
+static long g_s_launches = 0;
+extern "C" long cl4_conv_debug_s_launches(void) { return g_s_launches; }
+
+extern "C" int cl4_to_planes(const float* x, void* xs, int n, int ctot, int coff, int c, int hw, void* stream) {
+  CL4_REQUIRE(x && xs, "to_planes: null tensor");
+  CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0 && coff >= 0 && coff + c <= ctot, "to_planes: bad channel slice (c %% 8 == 0 required)");
+  const long total = (long)n * (c >> 3) * hw;
+  hipLaunchKernelGGL(to_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, (u32x4*)xs, n, ctot, coff, c, hw);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_from_planes(const void* xs, float* y, int n, int c, int hw, int out_ctot, int out_coff, void* stream) {
+  CL4_REQUIRE(xs && y, "from_planes: null tensor");
+  CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0 && out_coff >= 0 && out_coff + c <= out_ctot, "from_planes: bad channel slice");
+  const long total = (long)n * (c >> 3) * hw;
+  hipLaunchKernelGGL(from_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), (const u32x4*)xs, y, n, c, hw, out_ctot, out_coff);
+  return cl4::launch_status();
+}
+
+namespace cl4 {
+
+int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st) {
+  static const int mf = [] { const char* e = getenv("CL4_CONV_S_MFMA"); return e ? atoi(e) : 32; }();
+  const dim3 g(grid), b(256);
+  ++g_s_launches;
+#define CL4_S_GO(KS_, SP_)                                                                                   \
+  do {                                                                                                       \
+    if (mf == 16) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16>), g, b, 0, st, a);                          \
+    else hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 32>), g, b, 0, st, a);                                   \
+  } while (0)
+  if (ks == 1) { if (split) CL4_S_GO(1, true); else CL4_S_GO(1, false); }
+  else if (ks == 3) { if (split) CL4_S_GO(3, true); else CL4_S_GO(3, false); }
+  else { set_error("conv_s: kernel size %d not built", ks); return CL4_EINVAL; }
+#undef CL4_S_GO
+  return launch_status();
+}
+
+}  // namespace cl4

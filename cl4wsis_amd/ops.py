@@ -183,6 +183,41 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
     _tuned[key] = (best, best_ms)
 
 
+def _autotune_planes(d, args, reps=6):
+    """_autotune_conv for the planes-input entry point (128x128 tiles only: unsplit, K-split, or main + split tail)."""
+    dev = torch.cuda.current_device()
+    key = (d.n, d.cin, d.hin, d.win, d.cout, d.kh, d.stride, d.pad, d.dil, d.precision, dev)
+    if key in _tuned:
+        return
+    lib = _hip.load()
+    K = d.cin * d.kh * d.kw
+    best, best_ms = None, float("inf")
+    seen = set()
+    for impl, tile, splits in _CANDIDATES:
+        if impl != 2 or tile != 128 or splits == -1 or abs(splits) > max(1, K // 64):
+            continue
+        call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, tile, splits)
+        need = lib.cl4_conv2d_fwd_workspace_bytes(C.byref(d))
+        sig = (need, splits < 0)
+        if sig in seen or need > (1 << 30):
+            continue
+        seen.add(sig)
+        ws = _conv_workspace(torch.device("cuda", dev), need) if need else None
+        run = lambda: call("cl4_conv2d_fwd_planes", C.byref(d), *args, ptr(ws), need, stream())
+        run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        if ms < best_ms:
+            best, best_ms = (impl, tile, splits), ms
+    call("cl4_conv2d_fwd_set_plan", C.byref(d), *best)
+    _tuned[key] = (best, best_ms)
+
+
 def _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, act1, slope1, act2, slope2, precision=0):
     n, in_ctot, hin, win = x.shape
     d = ConvDesc()
@@ -244,6 +279,102 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     if TIMER is not None:
         e1.record()
     return out
+
+
+class Planes:
+    """An activation tensor [n, c, h, w] kept as pre-split bf16 planes — [n][c/8][hi, lo][h*w][8 x bf16], 4 bytes per element
+    (include/cl4wsis.h, "Planes" activations): what conv2d_planes reads and can write."""
+    __slots__ = ("data", "n", "c", "h", "w")
+
+    def __init__(self, n, c, h, w, device, data=None):
+        if c % 8:
+            raise RuntimeError(f"Planes: channel count {c} is not a multiple of 8")
+        self.n, self.c, self.h, self.w = n, c, h, w
+        self.data = torch.empty(n * c * h * w, dtype=torch.int32, device=device) if data is None else data
+
+    @property
+    def shape(self):
+        return (self.n, self.c, self.h, self.w)
+
+
+def to_planes(x, in_coff=0, c=None, out=None):
+    _f32(x, "to_planes")
+    n, ctot, h, w = x.shape
+    c = ctot - in_coff if c is None else c
+    ps = Planes(n, c, h, w, x.device) if out is None else out
+    call("cl4_to_planes", ptr(x), ptr(ps.data), n, ctot, in_coff, c, h * w, stream())
+    return ps
+
+
+def from_planes(ps, out=None, out_coff=0):
+    if out is None:
+        out = torch.empty(ps.shape, dtype=torch.float32, device=ps.data.device)
+        out_coff = 0
+    call("cl4_from_planes", ptr(ps.data), ptr(out), ps.n, ps.c, ps.h * ps.w, out.shape[1], out_coff, stream())
+    return out
+
+
+def conv2d_planes(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, post=None,
+                  act1=ACT_NONE, slope1=0.01, act2=ACT_NONE, slope2=0.01, in_coff=0, cin=None,
+                  out=None, out_coff=0, want_fp32=True, out_planes=None, want_planes=False):
+    """conv2d on a Planes input (csrc/conv_s.hip). `post` may be an fp32 tensor or a Planes tensor. Returns (y, ys): the fp32 NCHW
+    output (None unless want_fp32 / out) and the Planes output (None unless want_planes / out_planes). `out` / `out_coff` /
+    `out_planes` write channel slices of wider tensors (both outputs use the same slice offsets)."""
+    if not isinstance(xs, Planes):
+        raise RuntimeError("conv2d_planes: the input must be a Planes tensor (ops.to_planes)")
+    n, in_ctot, hin, win = xs.shape
+    if cin is None:
+        cin = in_ctot - in_coff
+    if not isinstance(wp, PackedWeight) or wp.precision != 1:
+        raise RuntimeError("conv2d_planes: bf16x3 packed weights (pack_conv_weight(w, 1)) expected")
+    K, cout = wp.K, wp.cout
+    if K != cin * k * k:
+        raise RuntimeError(f"conv2d_planes: packed weight K={K} does not match cin*k*k={cin * k * k}")
+    hout = conv_out_size(hin, k, stride, pad, dil)
+    wout = conv_out_size(win, k, stride, pad, dil)
+    dev = xs.data.device
+    if out is None and want_fp32:
+        out = torch.empty((n, cout, hout, wout), dtype=torch.float32, device=dev)
+        out_coff = 0
+    if out_planes is None and want_planes:
+        out_planes = Planes(n, cout if out is None else out.shape[1], hout, wout, dev)
+    out_ctot = out.shape[1] if out is not None else out_planes.c
+    for t in (out, out_planes):
+        if t is not None and (tuple(t.shape[2:]) != (hout, wout) or t.shape[0] != n or t.shape[1] != out_ctot):
+            raise RuntimeError(f"conv2d_planes: output shape {tuple(t.shape)} incompatible with {(n, out_ctot, hout, wout)}")
+    post_f = post if (post is not None and not isinstance(post, Planes)) else None
+    post_s = post if isinstance(post, Planes) else None
+    for t, nm in ((pre, "pre"), (post, "post")):
+        if t is not None and tuple(t.shape) != (n, cout, hout, wout):
+            raise RuntimeError(f"conv2d_planes: {nm} shape {tuple(t.shape)} != {(n, cout, hout, wout)}")
+    d = ConvDescFor(n, cin, hin, win, in_ctot, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, act1, slope1, act2, slope2, 3)
+    if TIMER is not None:
+        e0, e1 = TIMER.span("conv_fwd_bf16x3", 2.0 * n * hout * wout * cout * K, (n, cin, hin, cout, k, stride, dil))
+        e0.record()
+    args = (ptr(xs.data), ptr(wp.data), ptr(scale), ptr(shift), ptr(pre), ptr(post_f), ptr(post_s.data) if post_s is not None else None,
+            ptr(out), ptr(out_planes.data) if out_planes is not None else None)
+    if AUTOTUNE:
+        _autotune_planes(d, args)
+    need = _hip.load().cl4_conv2d_fwd_workspace_bytes(C.byref(d))
+    ws = _conv_workspace(dev, need) if need else None
+    call("cl4_conv2d_fwd_planes", C.byref(d), *args, ptr(ws), need, stream())
+    if TIMER is not None:
+        e1.record()
+    return out, out_planes
+
+
+def ConvDescFor(n, cin, hin, win, in_ctot, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, act1, slope1, act2, slope2, precision):
+    d = ConvDesc()
+    d.n, d.cin, d.hin, d.win = n, cin, hin, win
+    d.cout, d.kh, d.kw = cout, k, k
+    d.stride, d.pad, d.dil = stride, pad, dil
+    d.hout = conv_out_size(hin, k, stride, pad, dil)
+    d.wout = conv_out_size(win, k, stride, pad, dil)
+    d.in_ctot, d.in_coff = in_ctot, in_coff
+    d.out_ctot, d.out_coff = out_ctot, out_coff
+    d.act1, d.slope1, d.act2, d.slope2 = act1, slope1, act2, slope2
+    d.precision = precision
+    return d
 
 
 # Arithmetic of the weight gradients: 1 = bf16x3 split products (phase 2's trainable branch: ~4e-6 relative, 1.4x faster),

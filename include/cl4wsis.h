@@ -467,8 +467,27 @@ int cl4_target_generation(const long long* seg_map, const uint8_t* mask, int b, 
  * (y[i] += w[i] > 0 ? x[i] : -x[i]) to a gradient computed with respect to the effective scale. */
 /* Experiments only: phase time stamps of the bf16 forward kernels (tools/probe_timeline.py); NULL = off. */
 int cl4_conv_debug_timeline(void* buf);
-/* Experiments / tests only: number of launches this process has sent to the unified-wave bf16x3 kernel (csrc/conv_u.hip). */
+/* Experiments / tests only: number of launches this process has sent to the unified-wave bf16x3 kernel (csrc/conv_u.hip) and to
+ * the planes-input kernel (csrc/conv_s.hip). */
 long cl4_conv_debug_u_launches(void);
+long cl4_conv_debug_s_launches(void);
+
+/* "Planes" activations (csrc/conv_s.hip). The dense convolutions of the frozen networks (modules/residual.py:84-97,
+ * modules/deeplab.py:54-70, every nn.Conv2d + InPlaceABN + residual add of the eval-mode forward passes at train.py:253-263) multiply
+ * bf16 hi / lo splits of their fp32 operands. A tensor [n][c][h][w] (c % 8 == 0) can be kept pre-split between two such layers:
+ *     planes layout   [n][c/8][plane: hi, lo][h*w][8 x bf16],   hi = bf16(x), lo = bf16(x - hi)     (4 bytes per element, like fp32)
+ * so that the consuming convolution does no conversion work in its K loop. cl4_to_planes / cl4_from_planes convert a channel slice
+ * of an fp32 NCHW tensor to / from that layout (from_planes returns hi + lo: x rounded to 16-17 significant bits — exactly what
+ * cl4_conv2d_fwd's bf16x3 arithmetic sees of x anyway).
+ * cl4_conv2d_fwd_planes = cl4_conv2d_fwd for a planes INPUT `xs` (descriptor precision 3; 1x1 / 3x3, any stride / pad / dilation,
+ * cin % 32 == 0, 8-aligned channel slices, cout % 4 == 0 and >= 64; the packed weights are cl4_pack_conv_weight_bf16x3's). Outputs:
+ * `y` (fp32 NCHW, channel slice out_coff of out_ctot) and / or `ys` (planes, the same slice; needs cout % 8 == 0) — at least one.
+ * The residual operand is `post` (fp32, [n][cout][hout][wout]) or `post_s` (planes, same shape), not both. */
+int cl4_to_planes(const float* x, void* xs, int n, int ctot, int coff, int c, int hw, void* stream);
+int cl4_from_planes(const void* xs, float* y, int n, int c, int hw, int out_ctot, int out_coff, void* stream);
+int cl4_conv2d_fwd_planes(const cl4_conv_desc* d, const void* xs, const float* wp, const float* scale, const float* shift,
+                          const float* pre, const float* post, const void* post_s, float* y, void* ys, void* workspace,
+                          size_t workspace_bytes, void* stream);
 int cl4_abs_eps(const float* w, float* out, int n, float eps, void* stream);
 int cl4_sign_axpy(float* y, const float* x, const float* w, int n, void* stream);
 

@@ -1,0 +1,139 @@
+"""GPU parity of the planes format and of the planes-input bf16x3 convolution (csrc/conv_s.hip, cl4_conv2d_fwd_planes) against
+float64 CPU convolutions. The planes format stores x as bf16 hi + bf16 lo, i.e. x rounded to 16-17 significant bits — the same
+operand the bf16x3 arithmetic of cl4_conv2d_fwd forms on the fly — so the tolerance is that arithmetic's 5e-5 relative to the
+output scale (north-star 1e-3). to_planes / from_planes themselves are checked BIT-EXACTLY against a torch restatement of the split."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 5e-5
+
+
+def _rel_err(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _split_ref(x):
+    hi = x.to(torch.bfloat16).float()
+    lo = (x - hi).to(torch.bfloat16).float()
+    return hi, lo
+
+
+def test_planes_round_trip_is_the_bf16_split(gpu):
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 40, 9, 7, generator=g) * torch.logspace(-6, 6, 40)[None, :, None, None]
+    x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1.0, -3.5])
+    ps = ops.to_planes(x.to(gpu), in_coff=8, c=24)
+    hi, lo = _split_ref(x[:, 8:32])
+    back = ops.from_planes(ps).cpu()
+    assert torch.equal(back, hi + lo)
+    raw = ps.data.cpu().view(torch.int16).view(3, 3, 2, 63, 8)          # [n][c/8][plane][hw][8]
+    want_hi = hi.view(3, 3, 8, 63).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).view(torch.int16)
+    want_lo = lo.view(3, 3, 8, 63).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16).view(torch.int16)
+    assert torch.equal(raw[:, :, 0], want_hi) and torch.equal(raw[:, :, 1], want_lo)
+    out = torch.full((3, 40, 9, 7), 5.0, device=gpu)
+    ops.from_planes(ps, out=out, out_coff=16)
+    assert torch.equal(out[:, 16:40].cpu(), hi + lo) and (out[:, :16] == 5).all()
+    assert ((back - x[:, 8:32]).abs() <= x[:, 8:32].abs() * 2.0 ** -16).all()
+
+
+def _run(gpu, n, cin, h, w, cout, k, stride, pad, dil, plan, seed, epilogue=False, planes_post=False, in_ctot=None, in_coff=0,
+         out_ctot=None, out_coff=0):
+    from cl4wsis_amd import _hip, ops
+    g = torch.Generator().manual_seed(seed)
+    in_ctot = in_ctot or cin
+    out_ctot = out_ctot or cout
+    x = torch.randn(n, in_ctot, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    ref = F.conv2d(x[:, in_coff:in_coff + cin].double(), wt.double(), stride=stride, padding=pad, dilation=dil).float()
+    ho, wo = ref.shape[2:]
+    kw = {}
+    if epilogue:
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        pre, post = torch.randn(n, cout, ho, wo, generator=g), torch.randn(n, cout, ho, wo, generator=g)
+        ref = F.relu(F.leaky_relu((ref + pre) * scale[None, :, None, None] + shift[None, :, None, None], 0.01) + post)
+        postd = ops.to_planes(post.to(gpu)) if planes_post else post.to(gpu)
+        kw = dict(scale=scale.to(gpu), shift=shift.to(gpu), pre=pre.to(gpu), post=postd, act1=ops.ACT_LEAKY, slope1=0.01, act2=ops.ACT_RELU)
+    xs = ops.to_planes(x.to(gpu))
+    wp = ops.pack_conv_weight(wt.to(gpu), 1)
+    out = torch.full((n, out_ctot, ho, wo), 7.0, device=gpu)
+    outp = ops.Planes(n, out_ctot, ho, wo, gpu) if out_ctot % 8 == 0 and out_coff % 8 == 0 and cout % 8 == 0 else None
+    if outp is not None:
+        outp.data.fill_(0)
+    d = ops.ConvDescFor(n, cin, h, w, in_ctot, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, 0, 0.0, 0, 0.0, 3)
+    _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), *plan)
+    before = _hip.load().cl4_conv_debug_s_launches()
+    try:
+        ops.conv2d_planes(xs, wp, k, stride=stride, pad=pad, dil=dil, in_coff=in_coff, cin=cin, out=out, out_coff=out_coff,
+                          out_planes=outp, **kw)
+        torch.cuda.synchronize()
+    finally:
+        _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 0, 64, 1)
+    assert _hip.load().cl4_conv_debug_s_launches() > before
+    y = out[:, out_coff:out_coff + cout].cpu()
+    assert _rel_err(y, ref) < TOL, (_rel_err(y, ref), (n, cin, h, w, cout, k, stride, pad, dil, plan))
+    if out_ctot != cout:
+        assert (out[:, :out_coff] == 7).all() and (out[:, out_coff + cout:] == 7).all()
+    if outp is not None:                                   # the planes output is the bf16 split of the fp32 output, bit for bit
+        hi, lo = _split_ref(y)
+        yp = ops.from_planes(outp).cpu()
+        assert torch.equal(yp[:, out_coff:out_coff + cout], hi + lo)
+        if out_ctot != cout:
+            assert (yp[:, :out_coff] == 0).all() and (yp[:, out_coff + cout:] == 0).all()
+
+
+# (n, cin, h, w, cout, k, stride, pad, dil)
+SHAPES = [
+    (2, 64, 17, 17, 256, 1, 1, 0, 1),
+    (3, 32, 10, 10, 128, 1, 1, 0, 1),       # one K-tile
+    (1, 96, 33, 33, 160, 3, 1, 6, 6),       # ragged cout, odd K-tile count, dilation 6
+    (2, 64, 33, 33, 136, 3, 1, 18, 18),     # most taps outside the image
+    (2, 160, 21, 19, 192, 3, 1, 2, 2),
+    (2, 128, 33, 33, 128, 3, 2, 1, 1),      # strided 3x3 (res3 / res4 entry blocks)
+    (2, 256, 33, 31, 512, 1, 2, 0, 1),      # strided 1x1 (downsample branch)
+    (1, 128, 9, 7, 144, 3, 1, 1, 1),        # 63 pixels
+    (5, 64, 65, 67, 256, 3, 1, 1, 1),       # more tiles than resident workgroups
+    (1, 64, 12, 12, 64, 3, 1, 0, 1),        # no padding ("valid"), cout = 64 on a 128-row tile
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_planes_plain(gpu, shape):
+    _run(gpu, *shape, plan=(2, 128, 1), seed=sum(shape))
+
+
+@pytest.mark.parametrize("planes_post", [False, True])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_planes_fused_epilogue(gpu, shape, planes_post):
+    _run(gpu, *shape, plan=(2, 128, 1), seed=1 + sum(shape), epilogue=True, planes_post=planes_post)
+
+
+@pytest.mark.parametrize("plan", [(2, 128, 2), (2, 128, 5), (2, 128, -8)])
+@pytest.mark.parametrize("shape", [(5, 64, 65, 67, 256, 3, 1, 1, 1), (2, 160, 21, 19, 192, 3, 1, 2, 2), (4, 256, 33, 33, 256, 1, 1, 0, 1)])
+def test_conv_planes_split_plans(gpu, shape, plan):
+    _run(gpu, *shape, plan=plan, seed=2 + sum(shape), epilogue=True, planes_post=True)
+
+
+def test_conv_planes_channel_slices(gpu):
+    _run(gpu, 2, 64, 15, 15, 128, 3, 1, 2, 2, plan=(2, 128, 1), seed=5, in_ctot=104, in_coff=24, out_ctot=200, out_coff=24)
+    _run(gpu, 2, 32, 15, 15, 160, 1, 1, 0, 1, plan=(2, 128, 1), seed=6, in_ctot=40, in_coff=8, out_ctot=176, out_coff=8, epilogue=True)
+    _run(gpu, 2, 32, 15, 15, 132, 1, 1, 0, 1, plan=(2, 128, 1), seed=7, out_ctot=133, out_coff=1)      # fp32 output only (cout % 8 != 0)
+
+
+def test_conv_planes_both_mfma_shapes_agree_with_the_fp32_input_kernel(gpu):
+    """The planes kernel and cl4_conv2d_fwd's bf16x3 kernels form the same three products from the same hi / lo operands: their
+    results differ only through the summation order inside the MFMA pipe (a few ulps)."""
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 256, 33, 33, generator=g).to(gpu)
+    wt = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(gpu)
+    wp = ops.pack_conv_weight(wt, 1)
+    y0 = ops.conv2d(x, wp, 3, pad=1)
+    y1, _ = ops.conv2d_planes(ops.to_planes(x), wp, 3, pad=1)
+    torch.cuda.synchronize()
+    assert _rel_err(y1.cpu(), y0.cpu()) < 2e-6
