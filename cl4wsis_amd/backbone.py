@@ -10,7 +10,7 @@ from collections import OrderedDict
 import torch.nn as nn
 
 from . import ops
-from .nn import ABN, conv_abn, gamma_of, packed_weight
+from .nn import ABN, conv_abn, conv_abn_planes, gamma_of, packed_weight, planes_of, planes_ok
 
 
 class _Holder(nn.Module):
@@ -56,6 +56,27 @@ class ResidualBlock(nn.Module):
         act, slope = c.bn1.act_code()
         return conv_abn(y, c.conv3, c.bn3, post=r, act2=act, slope2=slope)
 
+    def planes_capable(self):
+        c = self.convs
+        return all(planes_ok(m) for m in (c.conv1, c.conv2, c.conv3)) and (not hasattr(self, "proj_conv") or planes_ok(self.proj_conv))
+
+    def forward_planes(self, x, xp, want_fp32):
+        """Eval forward with planes activations (frozen networks only). `x`: fp32 input or None, `xp`: its planes twin or None (at
+        least one). Returns (fp32 output or None, planes output). With a planes input the four convolutions stay in planes; a block
+        that only has an fp32 input (the first eligible block after the 64-channel stage) runs its first convolutions on the fp32
+        kernels and splits the 3x3 output once for conv3."""
+        c = self.convs
+        act, slope = c.bn1.act_code()
+        if xp is not None:
+            rp = conv_abn_planes(xp, self.proj_conv, self.proj_bn)[1] if hasattr(self, "proj_conv") else xp
+            y = conv_abn_planes(xp, c.conv1, c.bn1)[1]
+            y = conv_abn_planes(y, c.conv2, c.bn2)[1]
+            return conv_abn_planes(y, c.conv3, c.bn3, post=rp, act2=act, slope2=slope, want_fp32=want_fp32)
+        r = conv_abn(x, self.proj_conv, self.proj_bn) if hasattr(self, "proj_conv") else x
+        y = conv_abn(x, c.conv1, c.bn1)
+        y = conv_abn(y, c.conv2, c.bn2)
+        return conv_abn_planes(ops.to_planes(y), c.conv3, c.bn3, post=r, act2=act, slope2=slope, want_fp32=want_fp32)
+
 
 class ResNet(nn.Module):
     def __init__(self, structure, norm_act=ABN, output_stride=16, keep_outputs=False):
@@ -86,10 +107,17 @@ class ResNet(nn.Module):
     def forward(self, x):
         y = conv_abn(x, self.mod1.conv1, self.mod1.bn1)
         outs = [ops.maxpool3x3s2(y)]
+        frozen = not (self.training and any(p.requires_grad for p in self.parameters()))
+        yp = None                                              # planes twin of y (nn.CONV_PLANES), carried across blocks and stages
         for m in (self.mod2, self.mod3, self.mod4, self.mod5):
             y = outs[-1]
-            for blk in m:
-                y = blk(y)
+            for i, blk in enumerate(m):
+                if frozen and blk.planes_capable():
+                    y, yp = blk.forward_planes(y, yp, want_fp32=(i == len(m) - 1))     # fp32 only where a stage output is handed out
+                else:
+                    y, yp = blk(y if y is not None else ops.from_planes(yp)), None
+            if yp is not None:
+                y._cl4_planes = yp                             # consumers that can read planes (DeeplabV3) pick it up
             outs.append(y)
         return outs if self.keep_outputs else outs[-1]
 

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .nn import ABN, CACHE, conv_abn, conv_bias, packed_weight
+from .nn import ABN, CACHE, conv_abn, conv_abn_planes, conv_bias, packed_weight, planes_of, planes_ok
 
 EPS = 1e-5
 # Arithmetic of the trainable sub-net's convolutions. Gradients through batch-statistics BN + ReLU amplify operand noise
@@ -70,9 +70,16 @@ class DeeplabV3(nn.Module):
             return AG.apply(AG.DeeplabRunner(self), [x], list(self.parameters()))
         n, _, h, w = x.shape
         hid = self.hidden
-        cat = torch.empty((n, 4 * hid, h, w), dtype=torch.float32, device=x.device)
-        for i, conv in enumerate(self.map_convs):  # each branch writes its slice, map_bn folded per slice
-            conv_abn(x, conv, self.map_bn, out=cat, out_coff=i * hid, bn_lo=i * hid, bn_hi=(i + 1) * hid)
+        xp = planes_of(x)
+        use_planes = xp is not None and all(planes_ok(m) for m in self.map_convs) and planes_ok(self.red_conv) and hid % 8 == 0
+        if use_planes:                            # the body handed its output out pre-split: the branches and red_conv stay in planes
+            cat = ops.Planes(n, 4 * hid, h, w, x.device)
+            for i, conv in enumerate(self.map_convs):
+                conv_abn_planes(xp, conv, self.map_bn, bn_lo=i * hid, bn_hi=(i + 1) * hid, out_planes=cat, out_coff=i * hid)
+        else:
+            cat = torch.empty((n, 4 * hid, h, w), dtype=torch.float32, device=x.device)
+            for i, conv in enumerate(self.map_convs):  # each branch writes its slice, map_bn folded per slice
+                conv_abn(x, conv, self.map_bn, out=cat, out_coff=i * hid, bn_lo=i * hid, bn_hi=(i + 1) * hid)
         # eval-mode image pooling (deeplab.py:78-88): box average, stride 1, then replicate pad. The two 1x1
         # convs + ABN are pointwise, so they commute exactly with the replicate pad: run them on the
         # (h-k+1)x(w-k+1) map and pad afterwards.
@@ -85,6 +92,8 @@ class DeeplabV3(nn.Module):
         pr = pl if kw % 2 == 1 else pl + 1
         pb = pt if kh % 2 == 1 else pt + 1
         pool = ops.replicate_pad(pool, pl, pr, pt, pb)
+        if use_planes:
+            return conv_abn_planes(cat, self.red_conv, self.red_bn, pre=pool, want_fp32=True, want_planes=False)[0]
         return conv_abn(cat, self.red_conv, self.red_bn, pre=pool)
 
 

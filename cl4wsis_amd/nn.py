@@ -140,6 +140,35 @@ def conv_abn(x, conv, bn, post=None, act2=ops.ACT_NONE, slope2=0.01, out=None, o
                       out=out, out_coff=out_coff)
 
 
+# "Planes" activations between the dense convolutions of the frozen networks (include/cl4wsis.h; csrc/conv_s.hip): the producing
+# convolution's epilogue emits the bf16 hi / lo split its consumers multiply, instead of every consumer re-splitting fp32 values in
+# its K loop. CL4_CONV_PLANES=0 keeps every activation fp32 NCHW (A/B measurements).
+CONV_PLANES = os.environ.get("CL4_CONV_PLANES", "1") != "0"
+
+
+def planes_ok(conv):
+    """Can this convolution READ a planes input (cl4_conv2d_fwd_planes)? bf16x3 arithmetic, 1x1 / 3x3, 32-channel K-tiles, at
+    least one full 128-row M tile."""
+    return (CONV_PLANES and ops.CONV_PRECISION == 1 and conv.kernel_size[0] in (1, 3) and conv.kernel_size[0] == conv.kernel_size[1]
+            and conv.in_channels % 32 == 0 and conv.out_channels >= 128 and conv.out_channels % 8 == 0 and conv.groups == 1)
+
+
+def conv_abn_planes(xs, conv, bn, post=None, act2=ops.ACT_NONE, slope2=0.01, pre=None, bn_lo=0, bn_hi=None, want_fp32=False,
+                    want_planes=True, out=None, out_planes=None, out_coff=0):
+    """conv_abn on a planes input; `post` may be fp32 or planes. Returns (fp32 output or None, planes output or None)."""
+    scale, shift = folded_bn(bn, bn_lo, bn_hi)
+    act1, slope1 = bn.act_code() if isinstance(bn, ABN) else (ops.ACT_RELU, 0.0)
+    return ops.conv2d_planes(xs, packed_weight(conv, 1), conv.kernel_size[0], stride=conv.stride[0], pad=conv.padding[0],
+                             dil=conv.dilation[0], scale=scale, shift=shift, pre=pre, post=post, act1=act1, slope1=slope1,
+                             act2=act2, slope2=slope2, out=out, out_coff=out_coff, want_fp32=want_fp32, out_planes=out_planes,
+                             want_planes=want_planes)
+
+
+def planes_of(t):
+    """The planes twin a producing layer attached to an fp32 activation (same values, pre-split), or None."""
+    return getattr(t, "_cl4_planes", None)
+
+
 def conv_bias(x, conv, out=None, out_coff=0, act=ops.ACT_NONE):
     """conv (+bias) with no normalisation (classifier heads)."""
     k = conv.kernel_size[0]
