@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < ACCV; ++r) acc[i][j][r] = 0.f;
 
-  // one half (MF = 32: 16 of the 32 k) / one plane pairing step of a K-tile
+  bf16x8 bh16[NB], bl16[NB];                               // MF = 16: the B fragments of the current K-tile (read by half 0, reused by half 1)
+  // one half of a K-tile's MFMAs (MF = 32: 16 of the 32 k; MF = 16: two of the four row blocks)
   auto mfma_half = [&](int stage, int s2) {
     if constexpr (MF == 32) {
       const int lr = lane & 31, lh = lane >> 5;
@@ -212,21 +213,23 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
         }
     } else {
       // 16x16x32: lane l holds row / column l & 15 and k-group l >> 4 — one fragment spans the whole 32-deep K-tile. Half s2 = the row
-      // blocks 2*s2, 2*s2+1 against all four column blocks (the B fragments are read by both halves: 24 reads per K-tile instead of 16,
-      // in exchange for 8 fewer live registers... keep it simple: half 0 reads everything it needs, half 1 re-reads B).
+      // blocks 2*s2, 2*s2+1 against all four column blocks; the eight B fragments are read by half 0 and stay in registers for half 1
+      // (16 fragment reads per K-tile, like the 32x32x16 path).
       const int l15 = lane & 15, kg = lane >> 4;
       const u32x4* As = lds[stage] + wm * WTM + l15;
       const u32x4* Bs = lds[stage] + A_CHUNKS + wn * WTN + l15;
-      bf16x8 ah[2], al[2], bh[NB], bl[NB];
+      bf16x8 ah[2], al[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         ah[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 0) * BM + (2 * s2 + i) * 16]);
         al[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 1) * BM + (2 * s2 + i) * 16]);
       }
+      if (s2 == 0) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        bh[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 0) * BN + j * 16]);
-        bl[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 1) * BN + j * 16]);
+        for (int j = 0; j < NB; ++j) {
+          bh16[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 0) * BN + j * 16]);
+          bl16[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 1) * BN + j * 16]);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -234,16 +237,19 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
         for (int j = 0; j < NB; ++j) {
           accv_t& c = acc[2 * s2 + i][j];
 #if CL4_S_DBG & 4
-          c[0] += (float)al[i][0] * (float)bh[j][0] + (float)ah[i][1] * (float)bl[j][1];
+          c[0] += (float)al[i][0] * (float)bh16[j][0] + (float)ah[i][1] * (float)bl16[j][1];
 #else
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh16[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl16[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh16[j], c, 0, 0, 0);
 #endif
         }
     }
   };
 
+  // (Measured and dropped: touching the residual tile's lines at the start of the K loop, as conv_igemm_bf16x3 does. On the short-K
+  // residual layers — 256 -> 1024 at 33x33 — it moved 6,000 cycles from the epilogue into the prologue and nothing else: those
+  // launches stream their residual and output at the HBM rate either way. profiles/r02d_planes_prefetch.txt)
   u32x4 ar[2][4], br[2][4];
   loadA(ar[0], 0); loadB(br[0], 0);
   loadA(ar[1], 1); loadB(br[1], 1);
@@ -444,7 +450,7 @@ extern "C" int cl4_from_planes(const void* xs, float* y, int n, int c, int hw, i
 namespace cl4 {
 
 int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st) {
-  static const int mf = [] { const char* e = getenv("CL4_CONV_S_MFMA"); return e ? atoi(e) : 32; }();
+  static const int mf = [] { const char* e = getenv("CL4_CONV_S_MFMA"); return e ? atoi(e) : 16; }();   // 16x16x32: 3-6 % faster on the long-K layers (higher sustained clock), equal elsewhere
   const dim3 g(grid), b(256);
   ++g_s_launches;
 #define CL4_S_GO(KS_, SP_)                                                                                   \
