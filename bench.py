@@ -334,7 +334,7 @@ def worker(a):
             with open(pmcs[-1]) as f:
                 t = json.load(f)["conv_igemm_bf16x3"]
             traffic = t["hbm_bytes_per_launch"]
-            traffic_note = ("bytes per launch, average over the %d conv_igemm_bf16x3 (P = 2) launches of one step; rocprofv3 --pmc "
+            traffic_note = ("bytes per launch, average over the %d bf16x3 forward launches of one step; rocprofv3 --pmc "
                             "FETCH_SIZE + WRITE_SIZE in separate passes, corrected as calibrated in %s"
                             % (t["launches_per_step"], os.path.relpath(pmcs[-1], ROOT)))
         # algorithmic operand bytes of the same launches: input + output activations (fp32) + split weights (4 B / weight);
@@ -358,7 +358,8 @@ def worker(a):
                        "arithmetic": "fp32 tensors; convolutions as split-bf16 MFMA products with fp32 accumulation (bf16x3 frozen networks, "
                                      "bf16x6 = fp32-level for the differentiated convs, bf16x3 weight gradients)"},
             "label_counters": counters_random,
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_bf16x3 (cl4_conv2d_fwd precision 1): all its launches of 2 "
+            "roofline": {"bound": "mfma", "kernel": "bf16x3 forward convolution (cl4_conv2d_fwd precision 1 + cl4_conv2d_fwd_planes: kernels "
+                                                    "conv_igemm_bf16x3 / conv_u_bf16x3 / conv_s_bf16x3): all its launches of 2 "
                                                     "eager steps run right after the timed region (graph replay and two-stream "
                                                     "overlap off), HIP events on the launch stream around every launch",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,

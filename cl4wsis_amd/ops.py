@@ -136,7 +136,8 @@ def _conv_workspace(device, nbytes):
 
 AUTOTUNE = False      # set True during warm-up (Trainer / bench): time the launch plans of every new conv shape once
 _tuned = {}
-_CANDIDATES = [(1, 128, 1)] + [(2, t, s) for t in (128, 64) for s in (1, 2, 3, 4, 6, 8, 12, 16, 24, -1, -4, -8, -16)]   # s < 0: main + split tail (-1: small-tile tail)
+_SPLITS = [int(v) for v in os.environ.get("CL4_TUNE_SPLITS", "1,2,3,4,6,8,12,16,24,-1,-4,-8,-16").split(",")]   # experiments: restrict the K splits tried
+_CANDIDATES = [(1, 128, 1)] + [(2, t, s) for t in (128, 64) for s in _SPLITS]   # s < 0: main + split tail (-1: small-tile tail)
 
 
 def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):

@@ -1,6 +1,6 @@
 """Aggregate the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh into HBM-side traffic per launch of the
-dominant kernel (conv_igemm_bf16x3, P = 2 launches only — the bf16x6 instantiations are a different kernel in bench.py's
-roofline record). usage: pmc_traffic.py <pmc_dir> <out.json>
+dominant kernel family (the bf16x3 forward kernels: conv_igemm_bf16x3 with two planes, conv_u_bf16x3, conv_s_bf16x3 — the bf16x6
+instantiations are a different entry of bench.py's record). usage: pmc_traffic.py <pmc_dir> <out.json>
 
 Units / corrections (MI355X_MICROARCH.md §HBM): both counters are in KiB; WRITE_SIZE is exact for streaming stores; FETCH_SIZE
 under-reports wide coalesced reads by 2x on gfx950 and is uncalibrated for other widths — so the factor is MEASURED here on
@@ -19,6 +19,8 @@ def rows(d, counter):
 
 
 def is_x3(name):
+    if "conv_u_bf16x3" in name or "conv_s_bf16x3" in name:
+        return True
     m = re.search(r"conv_igemm_bf16x3<([^>]*)>", name)
     return bool(m) and m.group(1).split(",")[5].strip() == "2"
 
@@ -61,7 +63,7 @@ for k in sorted(fetch, key=lambda k: -fetch[k][1]):
     out["kernels"][k] = {"launches": l, "fetch_counter_bytes": f, "write_counter_bytes": w}
     if is_x3(k):
         args = re.search(r"<([^>]*)>", k).group(1).split(",")
-        vec = len(args) > 9 and args[9].strip() == "true"
+        vec = "conv_u_bf16x3" in k or "conv_s_bf16x3" in k or (len(args) > 9 and args[9].strip() == "true")   # 16-byte-per-lane activation loads
         fac = f_fac if vec else f_fac0
         out["kernels"][k]["fetch_factor_used"] = fac
         tot_l += l

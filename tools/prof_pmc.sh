@@ -11,7 +11,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $O/bench_$c -- python3 $R/bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-structured > $O/bench_$c.json 2> $O/bench_$c.err
   echo "pass bench $c done"
   CL4_CONV_VEC=1 timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $O/calib1_$c -- python3 $R/tools/pmc_calib.py > $O/calib1_$c.log 2>&1
-  CL4_CONV_VEC=0 timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $O/calib0_$c -- python3 $R/tools/pmc_calib.py > $O/calib0_$c.log 2>&1
+  CL4_CONV_VEC=0 CL4_CONV_U=0 timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $O/calib0_$c -- python3 $R/tools/pmc_calib.py > $O/calib0_$c.log 2>&1
   echo "pass calib $c done"
 done
 python3 $R/tools/pmc_traffic.py $O $O/traffic.json

@@ -8,13 +8,22 @@ replay and the structured-labels leg; Adam launches delimit steps (two `adam_dev
 eager pair as the first two steps whose kernels were NOT launched from a graph... rocprofv3 does not tag graph launches, so
 the steps are identified by position instead: warm-up (W eager/captured) + K replays come first, then exactly the two eager
 steps, then the structured-labels leg (2 + K steps). Pass --index to choose the step numbers explicitly.
-Prints per-kernel totals of the selected steps and the conv_igemm_bf16x3 (P = 2, non bf16x6) average launch duration.
+Prints per-kernel totals of the selected steps and the average launch duration of the bf16x3 forward family (is_x3 below).
 """
 import collections
 import csv
 import glob
 import re
 import sys
+
+
+def is_x3(name):
+    """The bf16x3 forward kernels behind cl4_conv2d_fwd (precision 1) / cl4_conv2d_fwd_planes: the role-split kernel's two-plane
+    instantiations, the unified-wave kernel and the planes-input kernel."""
+    if "conv_u_bf16x3" in name or "conv_s_bf16x3" in name:
+        return True
+    m = re.search(r"conv_igemm_bf16x3<([^>]*)>", name)
+    return bool(m) and m.group(1).split(",")[5].strip() == "2"
 
 
 def main():
@@ -39,11 +48,11 @@ def main():
     print(f"wall/step {wall / n:.2f} ms, kernel time/step {tot / n:.2f} ms")
     x3_n = x3_ms = 0
     for k, (c, t) in agg.items():
-        m = re.search(r"conv_igemm_bf16x3<([^>]*)>", k)
-        if m and m.group(1).split(",")[5].strip() == "2":
+        if is_x3(k):
             x3_n += c
             x3_ms += t
-    print(f"conv_igemm_bf16x3 (P=2): {x3_n / n:.1f} launches/step, {x3_ms / n:.3f} ms/step, avg launch {x3_ms / max(x3_n, 1):.5f} ms")
+    print(f"bf16x3 forward family (conv_igemm_bf16x3 P=2, conv_u_bf16x3, conv_s_bf16x3): {x3_n / n:.1f} launches/step, {x3_ms / n:.3f} ms/step, "
+          f"avg launch {x3_ms / max(x3_n, 1):.5f} ms")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"{k[:80]:80s} calls/step {c / n:7.1f}  ms/step {t / n:8.3f}  {100 * t / tot:5.1f}%")
 
