@@ -156,6 +156,7 @@ _decl("cl4_maxpool3x3s2_bwd", _P, _P, _P, _L, _I, _I, _I, _I, _P)
 _decl("cl4_add_act", _P, _P, _P, _L, _I, _F, _P)
 _decl("cl4_act_bwd", _P, _P, _P, _L, _I, _F, _P)
 _decl("cl4_add_per_plane", _P, _P, _L, _I, _F, _P)
+_decl("cl4_dropout2d", _P, _P, _P, _L, _I, _F, _P)
 _decl("cl4_rot90", _P, _P, _L, _I, _I, _I, _P)
 _decl("cl4_channel_affine", _P, _P, _I, _I, _I, _P, _P, _P)
 _decl("cl4_randrop_loss", _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)

@@ -67,6 +67,8 @@ class ResidualBlock(nn.Module):
         kernels and splits the 3x3 output once for conv3."""
         c = self.convs
         act, slope = c.bn1.act_code()
+        if xp is None and x.shape[1] <= 64:                    # a thin fp32 input (the pooled stem output): split it once, stay in planes
+            xp = ops.to_planes(x)
         if xp is not None:
             rp = conv_abn_planes(xp, self.proj_conv, self.proj_bn)[1] if hasattr(self, "proj_conv") else xp
             y = conv_abn_planes(xp, c.conv1, c.bn1)[1]
@@ -171,7 +173,8 @@ class IdentityResidualBlock(nn.Module):
 
     def forward(self, x, ret_prev=False):
         if self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("train-mode WiderResNet blocks are not built (coco-voc phase 2 freezes the body)")
+            raise RuntimeError("train-mode IdentityResidualBlock: call the owning model / body (cl4wsis_amd.body_train.body_forward, or "
+                               "model(images) in training mode, which runs it under torch.autograd)")
         c = self.convs
         a = _abn_eval(x, self.bn1)
         if hasattr(self, "proj_conv"):

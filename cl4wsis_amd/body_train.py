@@ -25,6 +25,9 @@ PRECISION = int(os.environ.get("CL4_TRAIN_PRECISION", "2"))
 WGRAD_PRECISION = 0 if PRECISION == 0 else 1
 
 
+_wrn_calls = 0
+
+
 class _Rec:
     __slots__ = ("x", "z", "mean", "var", "count", "y")
 
@@ -90,8 +93,13 @@ def block_backward(blk, rec, dout, grad_of, group=None):
     return ops.axpy_(dx, dsum)
 
 
-def body_forward(body, x, group=None):
-    """ResNet.forward (keep_outputs) with batch statistics. Returns (list of the 5 module outputs, tape)."""
+def body_forward(body, x, group=None, seed=None):
+    """Train-mode forward of the body with batch statistics: ResNet (models/resnet.py) or WiderResNet-38 A2 (models/wide_resnet.py;
+    `seed` feeds its Dropout2d masks, default: a per-call counter). Returns (list of the 5 outputs, tape)."""
+    if hasattr(body, "bn_out"):
+        global _wrn_calls
+        _wrn_calls += 1
+        return wrn_body_forward(body, x, group, seed=_wrn_calls * 0x9E3779B1 if seed is None else seed)
     y, r0 = conv_abn_train(x, body.mod1.conv1, body.mod1.bn1, group)
     outs = [ops.maxpool3x3s2(y)]
     tape = [("stem", r0)]
@@ -108,6 +116,8 @@ def body_forward(body, x, group=None):
 def body_backward(body, tape, douts, grad_of, group=None):
     """douts: {index of a module output (0..4): gradient or None}. Accumulates the parameter gradients; the input image
     needs no gradient (the stem's input gradient is skipped)."""
+    if hasattr(body, "bn_out"):
+        return wrn_body_backward(body, tape, douts, grad_of, group)
     dy = None
     for item in reversed(tape):
         if item[0] == "out":
@@ -126,3 +136,149 @@ def body_backward(body, tape, douts, grad_of, group=None):
             r0 = item[1]
             dpool = ops.maxpool3x3s2_bwd(r0.y, dy)
             conv_abn_backward(r0, body.mod1.conv1, body.mod1.bn1, dpool, grad_of, need_dx=False, group=group)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# WiderResNet-38 A2 in training mode (coco-voc step 0 / phase 1: models/wide_resnet.py:82-207, modules/residual.py:101-181).
+# Pre-activation identity blocks: bn1 (ABN with batch statistics) on the block input, convolutions WITHOUT a following ABN at the
+# end of the residual branch and on the projection shortcut, Dropout2d(0.3 / 0.5) in mod6 / mod7, max-pooling in front of mod2 and
+# mod3, a final ABN (bn_out). The same tape discipline as the ResNet body above.
+# ---------------------------------------------------------------------------------------------------------------------
+def _abn_train(x, bn, group=None):
+    """Stand-alone train-mode ABN on x (the pre-activation bn1 / bn_out). Returns (y, record)."""
+    r = _Rec()
+    r.x = r.z = x
+    act, slope = bn.act_code()
+    r.y, r.mean, r.var, r.count = ops.abn_train_forward(x, gamma_of(bn), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                        bn.momentum, bn.eps, act, slope, group)
+    CACHE.touch(bn.running_mean)
+    CACHE.touch(bn.running_var)
+    return r.y, r
+
+
+def _abn_backward(r, bn, dy, grad_of, group=None):
+    act, slope = bn.act_code()
+    gw, fin = gamma_grad(bn, grad_of)
+    dx = ops.abn_train_backward(r.z, dy, r.mean, r.var, gamma_of(bn), bn.bias.detach(), gw, grad_of(bn.bias), r.count, bn.eps,
+                                act, slope, group)
+    if fin is not None:
+        fin()
+    return dx
+
+
+def _conv_train(x, conv):
+    k = conv.kernel_size[0]
+    return ops.conv2d(x, packed_weight(conv, PRECISION), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0])
+
+
+def _conv_backward(x, conv, dz, grad_of, need_dx=True):
+    k = conv.kernel_size[0]
+    ops.conv2d_wgrad(x, dz, grad_of(conv.weight), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], precision=WGRAD_PRECISION)
+    if not need_dx:
+        return None
+    return ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(x.shape[2:]), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0])
+
+
+def identity_block_forward(blk, x, group=None, drop_p=None, keep=None, seed=0):
+    """IdentityResidualBlock.forward in training mode. `drop_p`: the Dropout2d rate of the block's module (None: no dropout);
+    `keep`: an injected uint8 [n, c] mask (tests), otherwise drawn on the device from `seed`. Returns (out, bn1 output, record)."""
+    c = blk.convs
+    a, ra = _abn_train(x, blk.bn1, group)
+    three = hasattr(c, "conv3")
+    z1 = _conv_train(a, c.conv1)
+    y1, r2 = _abn_train(z1, c.bn2, group)
+    r3 = z2 = y2 = None
+    if three:
+        z2 = _conv_train(y1, c.conv2)
+        y2, r3 = _abn_train(z2, c.bn3, group)
+        last_in, last = y2, c.conv3
+    else:
+        last_in, last = y1, c.conv2
+    dropped = last_in
+    if drop_p is not None:
+        if keep is None:
+            keep = ops.dropout_mask((last_in.shape[0], last_in.shape[1]), drop_p, seed, last_in.device)
+        dropped = ops.dropout2d(last_in, keep, drop_p)
+    out = _conv_train(dropped, last)
+    if hasattr(blk, "proj_conv"):
+        ops.axpy_(out, _conv_train(a, blk.proj_conv))
+    else:
+        ops.axpy_(out, x)
+    return out, a, (x, ra, a, z1, r2, y1, z2, r3, y2, dropped, keep, drop_p)
+
+
+def identity_block_backward(blk, rec, dout, grad_of, da_extra=None, group=None):
+    """dout: gradient of the block output (None: no gradient reaches it); da_extra: gradient that reaches the block's bn1 output from
+    outside (the first blocks of mod4..mod7 hand it out as a feature, models/wide_resnet.py:168-197). Returns the gradient of the
+    block input (None when nothing reaches the block)."""
+    x, ra, a, z1, r2, y1, z2, r3, y2, dropped, keep, drop_p = rec
+    c = blk.convs
+    da = None
+    if dout is not None:
+        three = r3 is not None
+        last = c.conv3 if three else c.conv2
+        d = _conv_backward(dropped, last, dout, grad_of)
+        if drop_p is not None:
+            d = ops.dropout2d(d, keep, drop_p)
+        if three:
+            d = _abn_backward(r3, c.bn3, d, grad_of, group)
+            d = _conv_backward(y1, c.conv2, d, grad_of)
+        d = _abn_backward(r2, c.bn2, d, grad_of, group)
+        da = _conv_backward(a, c.conv1, d, grad_of)
+        if hasattr(blk, "proj_conv"):
+            ops.axpy_(da, _conv_backward(a, blk.proj_conv, dout, grad_of))
+    if da_extra is not None:
+        da = da_extra.clone() if da is None else ops.axpy_(da, da_extra)
+    if da is None:
+        return None
+    dx = _abn_backward(ra, blk.bn1, da, grad_of, group)
+    if dout is not None and not hasattr(blk, "proj_conv"):
+        ops.axpy_(dx, dout)
+    return dx
+
+
+_WRN_DROP = {"mod6": 0.3, "mod7": 0.5}
+
+
+def wrn_body_forward(body, x, group=None, keeps=None, seed=0):
+    """WiderResNetA2.forward (keep_outputs) with batch statistics. Returns ([out3, out4, out5, out6, out7], tape). `keeps`: optional
+    {block name: uint8 [n, c]} Dropout2d masks (tests); otherwise they are drawn on the device from `seed`."""
+    out = _conv_train(x, body.mod1.conv1)
+    tape = [("stem", x)]
+    prevs = []
+    for name in ("mod2", "mod3", "mod4", "mod5", "mod6", "mod7"):
+        if name in ("mod2", "mod3"):
+            tape.append(("pool", out))
+            out = ops.maxpool3x3s2(out)
+        for i, blk in enumerate(getattr(body, name)):
+            key = f"{name}.block{i + 1}"
+            out, a, rec = identity_block_forward(blk, out, group, _WRN_DROP.get(name), None if keeps is None else keeps.get(key),
+                                                 seed + 7919 * len(tape))
+            hand_out = i == 0 and name in ("mod4", "mod5", "mod6", "mod7")
+            if hand_out:
+                prevs.append(a)
+            tape.append(("block", blk, rec, len(prevs) - 1 if hand_out else None))
+    out7, r7 = _abn_train(out, body.bn_out, group)
+    tape.append(("bn_out", r7))
+    return prevs + [out7], tape
+
+
+def wrn_body_backward(body, tape, douts, grad_of, group=None):
+    """douts: {index into [out3, out4, out5, out6, out7]: gradient or None}. The input image needs no gradient."""
+    dy = None
+    for item in reversed(tape):
+        if item[0] == "bn_out":
+            g = douts.get(4)
+            if g is None:
+                continue
+            dy = _abn_backward(item[1], body.bn_out, g, grad_of, group)
+        elif item[0] == "block":
+            _, blk, rec, prev_idx = item
+            extra = douts.get(prev_idx) if prev_idx is not None else None
+            dy = identity_block_backward(blk, rec, dy, grad_of, extra, group)
+        elif item[0] == "pool":
+            if dy is not None:
+                dy = ops.maxpool3x3s2_bwd(item[1], dy)
+        else:  # stem conv: weight gradient only
+            if dy is not None:
+                _conv_backward(item[1], body.mod1.conv1, dy, grad_of, need_dx=False)

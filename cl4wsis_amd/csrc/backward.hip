@@ -91,6 +91,15 @@ __global__ void add_per_plane_kernel(float* __restrict__ y, const float* __restr
     y[i] += scale * v[i / hw];
 }
 
+// nn.Dropout2d (models/wide_resnet.py:150-155, train mode of mod6 / mod7): a whole (image, channel) plane is dropped or scaled by
+// 1 / (1 - p); `keep` is one byte per plane. The backward is the same operation on the gradient.
+__global__ void dropout2d_kernel(const float* __restrict__ x, const unsigned char* __restrict__ keep, float* __restrict__ y, long planes, int hw,
+                                 float scale) {
+  const long total = planes * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    y[i] = keep[i / hw] ? x[i] * scale : 0.f;
+}
+
 // torch.rot90(x, k, dims=(-2,-1)) on square planes: out[i][j] = x[j][h-1-i] (k=1), x[h-1-i][h-1-j] (k=2), x[h-1-j][i] (k=3).
 __global__ void rot90_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int h, int k) {
   const long hw = (long)h * h, total = planes * hw;
@@ -166,6 +175,13 @@ extern "C" int cl4_add_per_plane(float* y, const float* v, long planes, int hw, 
   CL4_REQUIRE(y && v && planes > 0 && hw > 0, "add_per_plane: bad arguments");
   hipLaunchKernelGGL(add_per_plane_kernel, dim3(cl4::stream_grid(planes * hw, 256)), dim3(256), 0, cl4::as_stream(stream), y, v,
                      planes, hw, scale);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_dropout2d(const float* x, const unsigned char* keep, float* y, long planes, int hw, float p, void* stream) {
+  CL4_REQUIRE(x && keep && y && planes > 0 && hw > 0 && p >= 0.f && p < 1.f, "dropout2d: bad arguments");
+  hipLaunchKernelGGL(dropout2d_kernel, dim3(cl4::stream_grid(planes * hw, 256)), dim3(256), 0, cl4::as_stream(stream), x, keep, y, planes, hw,
+                     1.f / (1.f - p));
   return cl4::launch_status();
 }
 

@@ -140,6 +140,17 @@ _SPLITS = [int(v) for v in os.environ.get("CL4_TUNE_SPLITS", "1,2,3,4,6,8,12,16,
 _CANDIDATES = [(1, 128, 1)] + [(2, t, s) for t in (128, 64) for s in _SPLITS]   # s < 0: main + split tail (-1: small-tile tail)
 
 
+def _fills_the_chip(d):
+    """A launch with at least one 128x128 tile per CU. The tuner times candidates ALONE, but the step runs two streams side by
+    side (frozen old model || new model): there, what counts is the CU-time a plan consumes, not its latency in isolation, and a
+    whole-launch K split (more prologues, slab traffic, a second pass) consumes more. Measured on the bench step: with the full
+    splits tried everywhere the eager conv time is lowest (33.2 ms) but the overlapped step is slower (47.1 vs 46.8 ms) than with
+    whole-launch splits reserved for the launches that cannot fill the chip (small batches, thin layers). Tail plans (splits < 0:
+    only the last partial round is split) stay available everywhere."""
+    tiles = -(-d.cout // 128) * -(-(d.n * d.hout * d.wout) // 128)
+    return d.precision != 0 and tiles >= 256
+
+
 def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
     """Measure-don't-guess: run each candidate plan of this shape a few times (HIP events on the launch stream) and pin
     the fastest through cl4_conv2d_fwd_set_plan. The output is simply rewritten, so tuning is side-effect free."""
@@ -160,6 +171,8 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
         if splits == -1 and tile != 128:
             continue
         if splits < 0 and d.precision == 0:
+            continue
+        if splits > 1 and _fills_the_chip(d):
             continue
         call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, tile, splits)
         need = lib.cl4_conv2d_fwd_workspace_bytes(C.byref(d))
@@ -196,6 +209,8 @@ def _autotune_planes(d, args, reps=6):
     seen = set()
     for impl, tile, splits in _CANDIDATES:
         if impl != 2 or tile != 128 or splits == -1 or abs(splits) > max(1, K // 64):
+            continue
+        if splits > 1 and _fills_the_chip(d):
             continue
         call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, tile, splits)
         need = lib.cl4_conv2d_fwd_workspace_bytes(C.byref(d))
@@ -1087,6 +1102,16 @@ def add_per_plane_(y, v, scale=1.0):
     if v.numel() != n * c:
         raise RuntimeError("add_per_plane_: v must hold one value per (n, c) plane")
     call("cl4_add_per_plane", ptr(y), ptr(v), n * c, h * w, C.c_float(scale), stream())
+    return y
+
+
+def dropout2d(x, keep, p):
+    """nn.Dropout2d forward / backward: planes with keep == 0 are zeroed, the others scaled by 1 / (1 - p). keep: uint8 [n, c]."""
+    n, c, h, w = x.shape
+    if keep.numel() != n * c or keep.dtype != torch.uint8:
+        raise RuntimeError("dropout2d: keep must hold one byte per (n, c) plane")
+    y = torch.empty_like(x)
+    call("cl4_dropout2d", ptr(x), ptr(keep), ptr(y), n * c, h * w, C.c_float(p), stream())
     return y
 
 

@@ -393,6 +393,10 @@ int cl4_act_bwd(const float* y, const float* dy, float* dx, long n, int act, flo
 /* y[plane][:] += scale * v[plane] — broadcast add of DeepLabV3's image-pooling branch in training mode
  * (modules/deeplab.py:64-67) and, with scale = 1/hw, the backward of the global mean. */
 int cl4_add_per_plane(float* y, const float* v, long planes, int hw, float scale, void* stream);
+/* nn.Dropout2d in training mode (models/wide_resnet.py:150-155: p = 0.3 in mod6, 0.5 in mod7 of WiderResNet-38): y = keep[plane] ?
+ * x / (1 - p) : 0 for every (image, channel) plane; `keep` holds one byte per plane (cl4_dropout_mask draws it). The backward pass is
+ * the same call on the gradient. */
+int cl4_dropout2d(const float* x, const unsigned char* keep, float* y, long planes, int hw, float p, void* stream);
 /* torch.rot90(x, k, dims=(-2,-1)) on square planes = torchvision `rotate` by k*90 degrees (train.py:317,324,330; FLAC). */
 int cl4_rot90(const float* x, float* y, long planes, int h, int w, int k, void* stream);
 /* y[n,c,:] = x[n,c,:] * scale[c] + shift[c] — `denorm` (utils/utils.py:23-40, train.py:376). */

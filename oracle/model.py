@@ -83,35 +83,48 @@ WRN_CHANNELS = [(128, 128), (256, 256), (512, 512), (512, 1024), (512, 1024, 204
 WRN38 = (3, 3, 6, 3, 1, 1)
 
 
-def identity_block(x, sd, p, channels, stride, dil):
-    """IdentityResidualBlock.forward (eval) — modules/residual.py:168-181. Returns (out, bn1)."""
-    a = _abn(x, sd, p + ".bn1")
+def identity_block(x, sd, p, channels, stride, dil, training=False, drop_p=None, keep=None):
+    """IdentityResidualBlock.forward — modules/residual.py:168-181. Returns (out, bn1). training=True: batch statistics and, in the
+    modules that have one (models/wide_resnet.py:150-155), Dropout2d(drop_p) in front of the last convolution with the [n, c] keep
+    mask `keep` (the reference draws it from torch's generator; tests inject it on both sides)."""
+    a = _abn(x, sd, p + ".bn1", training=training)
     shortcut = F.conv2d(a, sd[p + ".proj_conv.weight"], stride=stride) if (p + ".proj_conv.weight") in sd else x
+
+    def drop(y):
+        if not training or drop_p is None:
+            return y
+        return y * keep.to(y.dtype)[:, :, None, None] / (1.0 - drop_p)
+
     if len(channels) == 2:
-        y = _abn(F.conv2d(a, sd[p + ".convs.conv1.weight"], stride=stride, padding=dil, dilation=dil), sd, p + ".convs.bn2")
-        y = F.conv2d(y, sd[p + ".convs.conv2.weight"], padding=dil, dilation=dil)
+        y = _abn(F.conv2d(a, sd[p + ".convs.conv1.weight"], stride=stride, padding=dil, dilation=dil), sd, p + ".convs.bn2", training=training)
+        y = F.conv2d(drop(y), sd[p + ".convs.conv2.weight"], padding=dil, dilation=dil)
     else:
-        y = _abn(F.conv2d(a, sd[p + ".convs.conv1.weight"], stride=stride), sd, p + ".convs.bn2")
-        y = _abn(F.conv2d(y, sd[p + ".convs.conv2.weight"], padding=dil, dilation=dil), sd, p + ".convs.bn3")
-        y = F.conv2d(y, sd[p + ".convs.conv3.weight"])
+        y = _abn(F.conv2d(a, sd[p + ".convs.conv1.weight"], stride=stride), sd, p + ".convs.bn2", training=training)
+        y = _abn(F.conv2d(y, sd[p + ".convs.conv2.weight"], padding=dil, dilation=dil), sd, p + ".convs.bn3", training=training)
+        y = F.conv2d(drop(y), sd[p + ".convs.conv3.weight"])
     return y + shortcut, a
 
 
-def wider_resnet_a2_body(x, sd, p="body", structure=WRN38):
-    """WiderResNetA2.forward with keep_outputs, dilation=True (output stride 8) — models/wide_resnet.py:122-207."""
+WRN_DROPOUT = {4: 0.3, 5: 0.5}       # mod6, mod7 (models/wide_resnet.py:150-155)
+
+
+def wider_resnet_a2_body(x, sd, p="body", structure=WRN38, training=False, keeps=None):
+    """WiderResNetA2.forward with keep_outputs, dilation=True (output stride 8) — models/wide_resnet.py:122-207. training=True: batch
+    statistics, Dropout2d masks from `keeps` ({"mod6.block1": uint8 [n, c], ...})."""
     out = F.conv2d(x, sd[p + ".mod1.conv1.weight"], padding=1)
     prevs = []
-    in_ch = 64
     for mod_id, num in enumerate(structure):
         if mod_id < 2:
             out = F.max_pool2d(out, 3, stride=2, padding=1)
         for b in range(num):
             dil = 2 if mod_id == 3 else (4 if mod_id > 3 else 1)
             stride = 2 if b == 0 and mod_id == 2 else 1
-            out, a = identity_block(out, sd, f"{p}.mod{mod_id + 2}.block{b + 1}", WRN_CHANNELS[mod_id], stride, dil)
+            key = f"mod{mod_id + 2}.block{b + 1}"
+            out, a = identity_block(out, sd, f"{p}.{key}", WRN_CHANNELS[mod_id], stride, dil, training=training,
+                                    drop_p=WRN_DROPOUT.get(mod_id), keep=None if keeps is None else keeps.get(key))
             if b == 0 and mod_id >= 2:
                 prevs.append(a)
-    return prevs + [_abn(out, sd, p + ".bn_out")]
+    return prevs + [_abn(out, sd, p + ".bn_out", training=training)]
 
 
 def deeplab_head(x, sd, p="head", pooling=32, training=False, output_stride=16):
