@@ -26,6 +26,7 @@ WGRAD_PRECISION = 0 if PRECISION == 0 else 1
 
 
 _wrn_calls = 0
+WRN_KEEPS = None      # tests: {block name: uint8 [n, c]} Dropout2d masks used instead of drawn ones (the reference's draws cannot be reproduced)
 
 
 class _Rec:
@@ -99,7 +100,7 @@ def body_forward(body, x, group=None, seed=None):
     if hasattr(body, "bn_out"):
         global _wrn_calls
         _wrn_calls += 1
-        return wrn_body_forward(body, x, group, seed=_wrn_calls * 0x9E3779B1 if seed is None else seed)
+        return wrn_body_forward(body, x, group, keeps=WRN_KEEPS, seed=_wrn_calls * 0x9E3779B1 if seed is None else seed)
     y, r0 = conv_abn_train(x, body.mod1.conv1, body.mod1.bn1, group)
     outs = [ops.maxpool3x3s2(y)]
     tape = [("stem", r0)]

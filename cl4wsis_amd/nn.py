@@ -144,13 +144,12 @@ def conv_abn(x, conv, bn, post=None, act2=ops.ACT_NONE, slope2=0.01, out=None, o
 # convolution's epilogue emits the bf16 hi / lo split its consumers multiply, instead of every consumer re-splitting fp32 values in
 # its K loop. CL4_CONV_PLANES=0 keeps every activation fp32 NCHW (A/B measurements).
 CONV_PLANES = os.environ.get("CL4_CONV_PLANES", "1") != "0"
-PLANES_MIN_COUT = int(os.environ.get("CL4_PLANES_MIN_COUT", "64"))
+PLANES_MIN_COUT = int(os.environ.get("CL4_PLANES_MIN_COUT", "128"))   # 64 (res2 on the planes path too) measured neutral: 345.5 vs 345.3 images/s
 
 
 def planes_ok(conv):
     """Can this convolution READ a planes input (cl4_conv2d_fwd_planes)? bf16x3 arithmetic, 1x1 / 3x3, 32-channel K-tiles, at
-    least half a 128-row M tile (the 64-channel layers of res2 are HBM-bound: idle MFMA rows cost them nothing, the conversion-free
-    loop and the 16-byte output stores help)."""
+    least PLANES_MIN_COUT output channels (one full 128-row M tile by default)."""
     return (CONV_PLANES and ops.CONV_PRECISION == 1 and conv.kernel_size[0] in (1, 3) and conv.kernel_size[0] == conv.kernel_size[1]
             and conv.in_channels % 32 == 0 and conv.out_channels >= PLANES_MIN_COUT and conv.out_channels % 8 == 0 and conv.groups == 1)
 

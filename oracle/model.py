@@ -214,6 +214,13 @@ def _body(x, sd):
     return resnet_body(x, sd), 16
 
 
+def body_any(x, sd, structure=None, training=False, keeps=None):
+    """(outputs, output stride) of whichever body the state dict holds, in eval or training mode (oracle/step.py)."""
+    if any(k.startswith("body.mod7.") for k in sd):
+        return wider_resnet_a2_body(x, sd, structure=structure or WRN38, training=training, keeps=keeps), 8
+    return resnet_body(x, sd, structure=structure or RESNET101, training=training), 16
+
+
 def forward_seg(x, sd, pooling=32, training=False):
     """IncrementalInstanceSegmentationModule.forward_seg(interpolate=False) — segmentation_module.py:400-426."""
     outs, os_ = _body(x, sd)

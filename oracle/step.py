@@ -151,7 +151,7 @@ def p1_param_groups(sd_new, sd_pl, sd_pg, lr, lr_head, lr_pseudo, weight_decay):
 
 def p1_step(sd_new, sd_old, sd_pl, sd_pg, images, l1h, old_classes, cur_epoch=0, pseudo_epoch=5, flac_angle=90,
             randrop_neg=None, lr=1e-3, lr_head=10.0, lr_pseudo=0.01, weight_decay=1e-4, loss_de=1.0, alpha=0.5,
-            l_seg_weight=1.0, icarl_bkg=-1.0, momentum_state=None, pooling=32, structure=M.RESNET101):
+            l_seg_weight=1.0, icarl_bkg=-1.0, momentum_state=None, pooling=32, structure=None, wrn_keeps=None):
     """One phase-1 iteration on the CPU. Applies torch.optim.SGD(momentum 0.9, nesterov) arithmetic in place to the three
     state dicts and returns the loss terms, the gradients and the momentum buffers."""
     from . import wss as W
@@ -162,12 +162,12 @@ def p1_step(sd_new, sd_old, sd_pl, sd_pg, images, l1h, old_classes, cur_epoch=0,
         d[k].requires_grad_(True)
         d[k].grad = None
     with torch.no_grad():
-        outs_old = M.resnet_body(images, sd_old, structure=structure)
-        old_seg = M.incremental_classifier(M.deeplab_head(outs_old[-1], sd_old, pooling=pooling), sd_old)
+        outs_old, os_ = M.body_any(images, sd_old, structure=structure)      # ResNet-101, or WiderResNet-38 for the coco-voc task
+        old_seg = M.incremental_classifier(M.deeplab_head(outs_old[-1], sd_old, pooling=pooling, output_stride=os_), sd_old)
         res5_old = outs_old[-1]
-    outs = M.resnet_body(images, sd_new, structure=structure, training=True)
+    outs, os_ = M.body_any(images, sd_new, structure=structure, training=True, keeps=wrn_keeps)
     res5 = outs[-1]
-    seg = M.incremental_classifier(M.deeplab_head(res5, sd_new, pooling=pooling, training=True), sd_new)
+    seg = M.incremental_classifier(M.deeplab_head(res5, sd_new, pooling=pooling, training=True, output_stride=os_), sd_new)
     with torch.no_grad():
         int_masks = M.pseudolabeler(res5, sd_pl)                              # eval mode, detached (train.py:304-311)
     feat3 = torch.cat([res5, res5.flip(-1), W.rot90k(res5, flac_angle)], 0)   # train.py:314-317

@@ -83,3 +83,83 @@ def test_dropout2d_matches_torch(gpu):
     assert torch.allclose(y, torch.where(keep.bool()[:, :, None, None], x * (1.0 / (1.0 - 0.3)), torch.zeros(())), rtol=1e-6, atol=0)
     drawn = ops.dropout_mask((64, 512), 0.5, 1234, gpu)
     assert 0.45 < drawn.float().mean().item() < 0.55
+
+
+class _Log:
+    def info(self, *a, **k):
+        pass
+    debug = info
+
+
+def _wrn_p1_opts(crop):
+    from cl4wsis_amd import argparser
+    args = ["--dataset", "coco-voc", "--task", "voc", "--step", "1", "--weakly", "--phase", "1", "--alpha", "0.9", "--loss_de", "1",
+            "--lr_policy", "warmup", "--affinity", "--optim", "sgd", "--lr", "0.001", "--epochs", "40", "--batch_size", "32",
+            "--no_pretrained"]
+    opts = argparser.modify_command_options(argparser.get_argparser().parse_args(args))
+    assert opts.backbone == "wider_resnet38_a2" and opts.output_stride == 8
+    opts.crop_size, opts.pooling = crop, crop // 8
+    return opts
+
+
+@pytest.mark.parametrize("cur_epoch", [0, 5])
+def test_trainer_phase1_step_with_wrn_body_matches_oracle(gpu, monkeypatch, cur_epoch):
+    """The coco-voc task's phase-1 iteration (WiderResNet-38 A2 body in training mode, DeepLabV3 at output stride 8, 61 + 20 classes,
+    PseudoLabeler / PeakGenerator, SGD-Nesterov) through Trainer.step's phase-1 path against oracle.step.p1_step on identical weights,
+    inputs, FLAC angle, RandDrop draws and Dropout2d masks: every loss term within 1e-3, and the update of the trainable tensors no
+    further from the float64 update than a few times the CPU-fp32 oracle is (the statistical bar of tests/test_phase1_gpu.py)."""
+    from cl4wsis_amd import body_train
+    from cl4wsis_amd.train import Trainer
+    from oracle import step as ostep, weights
+    monkeypatch.setattr(body_train, "PRECISION", 0)
+    monkeypatch.setattr(body_train, "WGRAD_PRECISION", 0)
+    crop = 49
+    opts = _wrn_p1_opts(crop)
+    opts.max_iters, opts.start_decay = 1000, 1000
+    torch.manual_seed(0)
+    tr = Trainer(_Log(), gpu, opts)
+    sds = []
+    for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
+        sd = weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=31 + i)
+        m.load_state_dict(sd)
+        sds.append({k: v.clone() for k, v in sd.items()})
+    tr._realias()
+    new, old, pl, pg = sds
+    g = torch.Generator().manual_seed(5)
+    n = 2
+    x = torch.randn(n, 3, crop, crop, generator=g)
+    l1h = torch.zeros(n, 80); l1h[0, 63] = 1; l1h[1, 71] = 1; l1h[1, 79] = 1      # 60 COCO-only + 20 VOC foreground classes
+    hs = (crop + 7) // 8
+    neg = torch.randint(0, 61, (n, hs, hs), generator=g)
+    keeps = {"mod6.block1": (torch.rand(n, 1024, generator=g) > 0.3).to(torch.uint8),
+             "mod7.block1": (torch.rand(n, 2048, generator=g) > 0.5).to(torch.uint8)}
+    monkeypatch.setattr(body_train, "WRN_KEEPS", {k: v.to(gpu) for k, v in keeps.items()})
+    before = [{k: v.clone() for k, v in d.items()} for d in (new, pl, pg)]
+    kw = dict(cur_epoch=cur_epoch, pseudo_epoch=opts.pseudo_ep, flac_angle=180, randrop_neg=neg, lr=opts.lr, lr_head=opts.lr_head,
+              lr_pseudo=opts.lr_pseudo, weight_decay=opts.weight_decay, loss_de=opts.loss_de, alpha=opts.alpha,
+              l_seg_weight=opts.l_seg, icarl_bkg=opts.icarl_bkg, pooling=opts.pooling, wrn_keeps=keeps)
+    to64 = lambda d: {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in d.items()}
+    new64, old64, pl64, pg64 = to64(new), to64(old), to64(pl), to64(pg)
+    ostep.p1_step(new64, old64, pl64, pg64, x.double(), l1h.double(), 61, **kw)
+    ref = ostep.p1_step(new, old, pl, pg, x, l1h, 61, **kw)
+    out = tr._step_phase1((x, l1h), cur_epoch=cur_epoch, flac_angle=180, randrop_neg=neg.to(torch.int32).to(gpu))
+    torch.cuda.synchronize()
+    names = ["l_cam_new", "l_loc", "flac", "l_peak", "lde"] + (["l_seg", "l_cls", "l_rand"] if cur_epoch >= opts.pseudo_ep else [])
+    for k in names:
+        v, r = float(out["losses"][k]), float(ref[k])
+        assert abs(v - r) <= 1e-3 * max(abs(r), 1e-3), (k, v, r)
+    ratios, worst = [], 0.0
+    for mod, after32, after64, sd_before in ((tr.model, new, new64, before[0]), (tr.pseudolabeler, pl, pl64, before[1]),
+                                             (tr.peakgenerator, pg, pg64, before[2])):
+        for k, p in mod.named_parameters():
+            d64 = after64[k] - sd_before[k].double()
+            if d64.norm() == 0:
+                continue
+            ours = ((p.detach().cpu().double() - sd_before[k].double() - d64).norm() / d64.norm()).item()
+            cpu32 = ((after32[k].double() - sd_before[k].double() - d64).norm() / d64.norm()).item()
+            ratios.append(ours / (cpu32 + 1e-5))
+            worst = max(worst, ours)
+    ratios = torch.tensor(ratios)
+    print("WRN P1STAT epoch", cur_epoch, "tensors", len(ratios), "median ratio", ratios.median().item(), "frac>3", (ratios > 3).float().mean().item(), "worst", worst)
+    assert len(ratios) > 100
+    assert ratios.median() < 2.5 and (ratios > 3).float().mean() < 0.05 and worst < 0.3, (ratios.median(), (ratios > 3).float().mean(), worst)
