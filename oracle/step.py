@@ -227,7 +227,7 @@ def p1_step(sd_new, sd_old, sd_pl, sd_pg, images, l1h, old_classes, cur_epoch=0,
 # Step 0 (supervised: train.py:241-300 with --step 0 --bce, Adam; BASELINE config 1)
 # ---------------------------------------------------------------------------------------------------------------------
 def s0_step(sd, images, seg_maps, center_maps, offset_maps, weights, dropout_mask=None, lr=5e-5, pooling=32,
-            structure=M.RESNET101, adam_state=None, step=1, betas=(0.9, 0.999), eps=1e-8):
+            structure=None, adam_state=None, step=1, betas=(0.9, 0.999), eps=1e-8, wrn_keeps=None):
     """One supervised iteration: the whole network (body, DeepLabV3, classifier, instance decoder + heads) in training mode,
     loss = BCE-with-ignore(seg) + 200 * Weighted_MSE(center) + 0.01 * Weighted_L1(offset) on the upsampled outputs
     (train.py:279-300, utils/loss.py:62-85,228-275), torch.optim.Adam arithmetic (lr_head = 1 at step 0, argparser.py:32)."""
@@ -237,9 +237,9 @@ def s0_step(sd, images, seg_maps, center_maps, offset_maps, weights, dropout_mas
     for k in names:
         sd[k].requires_grad_(True)
         sd[k].grad = None
-    outs = M.resnet_body(images, sd, structure=structure, training=True)
+    outs, os_ = M.body_any(images, sd, structure=structure, training=True, keeps=wrn_keeps)
     feats = {f"res{i + 1}": o for i, o in enumerate(outs)}
-    seg = M.incremental_classifier(M.deeplab_head(outs[-1], sd, pooling=pooling, training=True), sd)
+    seg = M.incremental_classifier(M.deeplab_head(outs[-1], sd, pooling=pooling, training=True, output_stride=os_), sd)
     ins = M.instance_decoder(feats, sd, training=True, dropout_mask=dropout_mask)
     pred = M.instance_head(ins, sd, training=True)
     up = lambda t: F.interpolate(t, size=size, mode="bilinear", align_corners=False)

@@ -163,3 +163,64 @@ def test_trainer_phase1_step_with_wrn_body_matches_oracle(gpu, monkeypatch, cur_
     print("WRN P1STAT epoch", cur_epoch, "tensors", len(ratios), "median ratio", ratios.median().item(), "frac>3", (ratios > 3).float().mean().item(), "worst", worst)
     assert len(ratios) > 100
     assert ratios.median() < 2.5 and (ratios > 3).float().mean() < 0.05 and worst < 0.3, (ratios.median(), (ratios > 3).float().mean(), worst)
+
+
+def test_trainer_step0_with_wrn_body_matches_oracle(gpu, monkeypatch):
+    """coco-voc step 0 (scripts/coco.sh: supervised, Adam): the whole network with the WiderResNet-38 body in training mode — semantic
+    head, classifier, instance decoder and heads back-propagating into the body's features — against oracle.step.s0_step: the three
+    loss terms within 1e-3 and every gradient no further from float64 than a few times the CPU-fp32 oracle is."""
+    from cl4wsis_amd import argparser, body_train, heads
+    from cl4wsis_amd.train import Trainer
+    from oracle import step as ostep, weights
+    monkeypatch.setattr(body_train, "PRECISION", 0)
+    monkeypatch.setattr(body_train, "WGRAD_PRECISION", 0)
+    monkeypatch.setattr(heads, "TRAIN_PRECISION", 0)
+    crop = 49
+    args = ["--dataset", "coco-voc", "--task", "voc", "--step", "0", "--bce", "--lr", "5e-5", "--epochs", "100", "--optim", "adam",
+            "--weight_decay", "0", "--batch_size", "32", "--no_pretrained"]
+    opts = argparser.modify_command_options(argparser.get_argparser().parse_args(args))
+    assert opts.backbone == "wider_resnet38_a2" and opts.output_stride == 8
+    opts.crop_size, opts.pooling = crop, crop // 8
+    opts.max_iters, opts.start_decay = 1000, 1000
+    torch.manual_seed(0)
+    tr = Trainer(_Log(), gpu, opts)
+    assert tr.model_old is None and tr.model.decoder is not None
+    sd = weights.fill_({k: v.cpu().clone() for k, v in tr.model.state_dict().items()}, seed=43)
+    tr.model.load_state_dict(sd)
+    tr._realias()
+    g = torch.Generator().manual_seed(8)
+    b = 3
+    ncls = tr.model.tot_classes                                # background + 60 COCO-only classes
+    x = torch.randn(b, 3, crop, crop, generator=g)
+    seg_maps = torch.randint(0, ncls, (b, crop, crop), generator=g)
+    seg_maps[torch.rand(b, crop, crop, generator=g) < 0.1] = 255
+    center_maps = torch.rand(b, ncls - 1, crop, crop, generator=g)
+    offset_maps = torch.randn(b, 2, crop, crop, generator=g) * 5
+    wts = (torch.rand(b, 1, crop, crop, generator=g) < 0.4).float() * torch.rand(b, 1, crop, crop, generator=g)
+    hs = (crop + 7) // 8
+    keep = torch.rand(b, 256, hs, hs, generator=g) >= 0.5
+    keeps = {"mod6.block1": (torch.rand(b, 1024, generator=g) > 0.3).to(torch.uint8),
+             "mod7.block1": (torch.rand(b, 2048, generator=g) > 0.5).to(torch.uint8)}
+    monkeypatch.setattr(body_train, "WRN_KEEPS", {k: v.to(gpu) for k, v in keeps.items()})
+    kw = dict(dropout_mask=keep.float(), lr=opts.lr, pooling=opts.pooling, wrn_keeps=keeps)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    ref64 = ostep.s0_step(sd64, x.double(), seg_maps, center_maps.double(), offset_maps.double(), wts.double(),
+                          **{**kw, "dropout_mask": keep.double()})
+    ref = ostep.s0_step({k: v.clone() for k, v in sd.items()}, x, seg_maps, center_maps, offset_maps, wts, **kw)
+    out = tr.step((x, seg_maps, center_maps, offset_maps, wts, torch.zeros(b, ncls - 1)), dropout_keep=keep.to(torch.uint8).to(gpu))
+    torch.cuda.synchronize()
+    for k in ("seg_loss", "center_loss", "offset_loss"):
+        v, r = float(out["losses"][k]), float(ref[k])
+        assert abs(v - r) <= 1e-3 * max(abs(r), 1e-3), (k, v, r)
+    ratios = []
+    for k, p in tr.model.named_parameters():
+        g64 = ref64["grads"][k]
+        if g64.norm() == 0:
+            continue
+        ours = ((tr._grad_map[id(p)].double().cpu() - g64).norm() / g64.norm()).item()
+        cpu32 = ((ref["grads"][k].double() - g64).norm() / g64.norm()).item()
+        ratios.append(ours / (cpu32 + 1e-5))
+    ratios = torch.tensor(ratios)
+    print("WRN S0STAT tensors", len(ratios), "median ratio", ratios.median().item(), "frac>3", (ratios > 3).float().mean().item())
+    assert len(ratios) > 150
+    assert ratios.median() < 2 and (ratios > 3).float().mean() < 0.05, (ratios.median(), (ratios > 3).float().mean())
