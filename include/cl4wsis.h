@@ -44,7 +44,8 @@ const char* cl4_last_error(void);
  *   1  "bf16x3": fp32 operands split hi + lo into bf16, three v_mfma_f32_32x32x16_bf16 products, fp32 accumulation
  *      (~4e-6 relative per layer) — the default of the frozen networks,
  *   2  "bf16x6": hi + mid + lo, six products, fp32-level accuracy — the default of every differentiated convolution.
- * Tensors are fp32 in HBM in every mode.
+ * Tensors are fp32 in HBM in every mode of cl4_conv2d_fwd; cl4_conv2d_fwd_planes (further down, descriptor precision 3) is the
+ * bf16x3 arithmetic on activations that are kept pre-split ("planes") between two such layers.
  *
  * Replaces: nn.Conv2d (+ InPlaceABN eval affine + leaky-ReLU, + residual add)
  *   modules/residual.py:67-97, models/resnet.py:59-63, modules/deeplab.py:54-70,
@@ -74,7 +75,8 @@ typedef struct cl4_conv_desc {
   int32_t act2;
   float   slope2;
   int32_t precision; /* 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 1: bf16x3; 2: bf16x6 (three bf16 planes, six products:
-                      * fp32-level accuracy on the bf16 MFMA pipe) */
+                      * fp32-level accuracy on the bf16 MFMA pipe); 3: bf16x3 on a planes input (cl4_conv2d_fwd_planes only; also the
+                      * key under which cl4_conv2d_fwd_set_plan / _workspace_bytes keep that entry point's launch plans) */
 } cl4_conv_desc;
 
 /* w: [cout, cin, kh, kw] (PyTorch layout) -> wp: [cin*kh*kw, cout]. */
