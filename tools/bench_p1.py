@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 from util import p1_opts
 from cl4wsis_amd.train import Trainer
-from bench import synthetic_batch
+from cl4wsis_amd.synthetic import synthetic_batch
 
 class _Log:
     def info(self, *a, **k): pass
