@@ -93,6 +93,17 @@ class Trainer:
         self._side_stream = torch.cuda.Stream(device=self.device) if os.environ.get("CL4_OVERLAP", "1") != "0" else None
         self._use_graph = os.environ.get("CL4_GRAPH", "1") != "0"
         self._graph, self._static, self._graph_active = None, None, False
+        # Software pipelining across iterations (single-GPU graph mode): the frozen old model's forward of batch t+1 is replayed on
+        # its own stream while batch t's step runs (it depends on nothing the optimizer touches). CL4_PIPELINE=0 switches it off.
+        self._pipeline = os.environ.get("CL4_PIPELINE", "1") != "0"
+        self._pipe = None
+        # per-GPU batches below this stay on the one-graph path: measured +4.8 % at b = 16, +1-2 % at 8 / 4, -1.8 % at 2 (where the chip
+        # is far from full and the old model is better placed beside the new model's forward)
+        self._pipe_min_b = int(os.environ.get("CL4_PIPELINE_MIN_BATCH", "4"))
+        # where the next batch's old-model forward forks off: after the new model's body ("body") or head ("seg"). Measured (images/s):
+        # body 362-364, head 361-362, after mod4 361-363, after mod3 349 = no pipelining: what pays is the overlap with the trainable
+        # branch / backward, not with the new model's own convolutions.
+        self._pipe_fork = os.environ.get("CL4_PIPE_FORK", "body")
         self._label_override = None
         self._label_acc = torch.zeros(5, dtype=torch.int32, device=self.device)   # sticky label-stage counters, see check_label_overflow
         self._seed_dev = torch.tensor([opts.random_seed * 1000003 + 7919 * (dist.get_rank() if dist.is_initialized() else 0)],
@@ -153,10 +164,12 @@ class Trainer:
             self.model.head.eval()
             self.model.cls.eval()
 
-    def step(self, batch, dropout_keep=None):
+    def step(self, batch, dropout_keep=None, next_batch=None):
         """One training iteration = the body of train.py:241-566 for phase 2. `batch` is the loader tuple
         (images, seg_maps, center_maps, offset_maps, weights, l1h) or just (images, l1h): the weakly-supervised branch
         only consumes images and l1h (the other four are uploaded but unused by the reference, train.py:243-248).
+        `next_batch` (optional, phase 2): the batch the NEXT call will be given — its frozen old-model forward (train.py:253-255)
+        is then enqueued now, on a separate stream, and overlaps this iteration; the results are those of the unpipelined step.
         Returns a dict of device scalars (no host synchronisation)."""
         opts = self.opts
         if self.weakly and opts.phase == 1:
@@ -171,8 +184,11 @@ class Trainer:
         l1h = l1h.to(self.device, dtype=torch.float32).contiguous()
         self._set_phase2_modes()
         use_graph = (self._use_graph and dropout_keep is None and self._iter >= 1 and ops.TIMER is None
-                     and (self._static is None or tuple(images.shape) == tuple(self._static["images"].shape)))
+                     and (self._static is None or tuple(images.shape) == tuple(self._static["images"].shape))
+                     and (self._pipe is None or tuple(images.shape) == tuple(self._pipe["x"][0].shape)))
         if not use_graph:
+            if self._pipe is not None:
+                self._pipe["have_old"] = [False, False]      # an eager step consumes its batch itself: drop any announced prefetch
             if self._graph_active:
                 from .nn import CACHE
                 CACHE.clear()            # packed weights cached by the captured run are one step stale for eager code
@@ -185,6 +201,9 @@ class Trainer:
                 ops.AUTOTUNE = False
             self.buckets.finish()
             self.optimizer.step()
+        elif (self._pipeline and images.shape[0] >= self._pipe_min_b and
+              (next_batch is not None or (self._pipe is not None and self._pipe["have_old"][self._pipe["cur"]]))):
+            out = self._replay_pipelined(images, l1h, next_batch if next_batch is not None else (images, l1h))
         else:
             out = self._replay(images, l1h)
         if self.scheduler is not None:
@@ -266,20 +285,84 @@ class Trainer:
         if not self.buckets.distributed:
             opt.note_replayed_step()
         else:
-            # N > 1: the graph ends where the ASPP block's backward begins. Those last kernels produce 90 % of the gradient
-            # bytes; they run eagerly here so that each bucket's RCCL all-reduce is issued on the communication stream as soon as
-            # its weight-gradient kernel is enqueued and overlaps the remaining ones (RCCL calls stay out of the capture).
-            tape, dy = self._static["out"]["_tail"]
-            aspp = {id(p) for p in self._branch.aspp_parameters()}
-            for p in self.optimizer.flat_params():
-                if id(p) not in aspp:
-                    self.buckets.ready(self.optimizer.index[id(p)])       # finalised inside the graph
-            self._branch.backward_aspp(tape, dy, self._grad_map, on_ready=self._ready)
-            self.buckets.finish()
-            opt.step()
+            self._distributed_tail(self._static["out"])
         return self._static["out"]
 
-    def _forward_backward(self, images, l1h, dropout_keep, split_tail=False):
+    def _distributed_tail(self, out):
+        # N > 1: the graph ends where the ASPP block's backward begins. Those last kernels produce 90 % of the gradient
+        # bytes; they run eagerly here so that each bucket's RCCL all-reduce is issued on the communication stream as soon as
+        # its weight-gradient kernel is enqueued and overlaps the remaining ones (RCCL calls stay out of the capture).
+        tape, dy = out["_tail"]
+        aspp = {id(p) for p in self._branch.aspp_parameters()}
+        for p in self.optimizer.flat_params():
+            if id(p) not in aspp:
+                self.buckets.ready(self.optimizer.index[id(p)])       # finalised inside the graph
+        self._branch.backward_aspp(tape, dy, self._grad_map, on_ready=self._ready)
+        self.buckets.finish()
+        self.optimizer.step()
+
+    # Pipelined graph path (single GPU, used when the caller announces the next batch). Two parities p = iteration % 2 with their
+    # own static inputs X[p], L[p] and old-model outputs OLD[p]. Graph G[p] = the step on X[p] reading OLD[p], PLUS, forked off
+    # after the new model's forward, the frozen old model's forward of X[1-p] into OLD[1-p] (joined at the end). The old model
+    # of the next batch thus runs beside this step's trainable branch / label stage / backward / Adam — mostly memory-bound
+    # kernels — instead of beside the new model's forward, which is the same kind of work. (Two separate graphs on two streams do
+    # not overlap on this ROCm: their replays serialise — measured 49.2 vs 45.7 ms — so the fork has to live inside one graph.)
+    def _replay_pipelined(self, images, l1h, next_batch):
+        opt = self.optimizer
+        if self._pipe is None:
+            opt.upload_lr()
+            with torch.no_grad():
+                o, _ = self.model_old(images, interpolate=False)         # shapes of the two maps the step reads from the old model
+            P = {"x": [images.clone(), images.clone()], "l": [l1h.clone(), l1h.clone()],
+                 "old": [{k: torch.empty_like(o[k]) for k in ("center", "offset")} for _ in range(2)],
+                 "g": [], "out": [], "have_old": [False, False], "cur": 0}
+            del o
+            torch.cuda.synchronize()
+            pool = torch.cuda.graph_pool_handle()
+            from .nn import CACHE
+            for q in range(2):
+                # every graph must re-derive (pack / fold) what it reads from the trainable weights ITSELF: a derived tensor cached
+                # by the other parity's capture would only be refreshed when that other graph replays
+                CACHE.clear()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    out = self._forward_backward(P["x"][q], P["l"][q], None, split_tail=self.buckets.distributed,
+                                                 old_outputs=P["old"][q], prefetch_old=(P["x"][1 - q], P["old"][1 - q]))
+                    if not self.buckets.distributed:
+                        opt.step(upload=False)
+                if not self.buckets.distributed:
+                    opt._step -= 1                        # capture only recorded the kernels
+                P["g"].append(g)
+                P["out"].append(out)
+            CACHE.clear()                                 # nothing eager may read a derived tensor that only one of the graphs refreshes
+            self._pipe = P
+        P = self._pipe
+        p = P["cur"]
+        P["x"][p].copy_(images)
+        P["l"][p].copy_(l1h)
+        if not P["have_old"][p]:                         # not announced by the previous call: the old model runs now, up front
+            with torch.no_grad():
+                o, _ = self.model_old(P["x"][p], interpolate=False)
+            for k in ("center", "offset"):
+                P["old"][p][k].copy_(o[k])
+        nx, nl = next_batch[0], next_batch[-1]
+        P["x"][1 - p].copy_(nx.to(self.device, dtype=torch.float32))
+        P["l"][1 - p].copy_(nl.to(self.device, dtype=torch.float32))
+        opt.upload_lr()
+        P["g"][p].replay()
+        P["have_old"][p] = False
+        P["have_old"][1 - p] = True
+        P["cur"] = 1 - p
+        self._graph_active = True
+        if not self.buckets.distributed:
+            opt.note_replayed_step()
+        else:
+            from .nn import CACHE
+            CACHE.clear()                                 # the eager ASPP tail derives its operands from the current weights itself
+            self._distributed_tail(P["out"][p])
+        return P["out"][p]
+
+    def _forward_backward(self, images, l1h, dropout_keep, split_tail=False, old_outputs=None, prefetch_old=None):
         opts = self.opts
         bs, _, H, W = images.shape
         oc = self.old_classes
@@ -288,7 +371,9 @@ class Trainer:
         # forward below, so it runs on a side stream: the two kernel sequences interleave on the device and fill each
         # other's workgroup-quantisation tails (33x33 layers at b=16 are only ~1 workgroup per CU).
         main = torch.cuda.current_stream()
-        if self._side_stream is not None:
+        if old_outputs is not None:
+            outputs_old = old_outputs                    # pipelined replay: computed by its own graph (see _replay_pipelined)
+        elif self._side_stream is not None:
             self._side_stream.wait_stream(main)
             with torch.cuda.stream(self._side_stream):
                 outputs_old, _ = self.model_old(images, interpolate=False)
@@ -301,7 +386,24 @@ class Trainer:
         x2 = torch.empty((2 * bs, 3, H, W), dtype=torch.float32, device=self.device)
         x2[:bs].copy_(images)
         ops.flip_w(images, out=x2[bs:])
-        outputs, features = self.model.forward_seg(x2, interpolate=False)
+        def fork_old():                          # pipelined replay: the NEXT batch's old-model forward starts here, on the side stream
+            x_next, old_next = prefetch_old
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                o_next, _ = self.model_old(x_next, interpolate=False)
+                for k in ("center", "offset"):
+                    old_next[k].copy_(o_next[k])
+
+        if prefetch_old is not None and self._pipe_fork == "body":
+            # fork between the new model's body and its DeepLabV3 head (forward_seg = body -> head -> cls, segmentation_module.py:400-426)
+            feats_all = self.model.forward_seg(x2, as_feature_extractor=True)
+            fork_old()
+            outputs = {"seg": self.model.cls(self.model.head(feats_all["body"]))}
+            features = feats_all
+        else:
+            outputs, features = self.model.forward_seg(x2, interpolate=False)
+            if prefetch_old is not None:
+                fork_old()
         feats = {k: v[:bs] for k, v in features["features"].items()}   # first half = un-flipped images (contiguous views)
         # train.py:265-272 — trainable instance decoder + heads on the detached features
         if dropout_keep is None:
@@ -330,7 +432,7 @@ class Trainer:
             pseudo_thresh=opts.pseudo_thresh, refine_thresh=opts.refine_thresh, nms_kernel=opts.kernel, beta=opts.beta,
             run_refine=opts.run_refine)
         ops.label_counters_accumulate_(self._label_acc, bs, H, W)
-        if self._side_stream is not None:
+        if self._side_stream is not None and old_outputs is None:
             main.wait_stream(self._side_stream)      # the old model's centre / offset maps are consumed from here on
         # train.py:503-522 — blended targets + four weighted losses (+ gradient w.r.t. the low-resolution maps)
         losses, dcen, doff = ops.p2_loss(pred["center"], pred["offset"], outputs_old["center"], outputs_old["offset"],
@@ -341,9 +443,13 @@ class Trainer:
         if split_tail:       # data-parallel graph capture: stop before the ASPP backward, see _replay
             dy = self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map, stop_before_aspp=True)
             out["_tail"] = (tape, dy)
+            if prefetch_old is not None:
+                main.wait_stream(self._side_stream)
             return out
         self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map,
                               on_ready=self._ready if (self.buckets.distributed and not torch.cuda.is_current_stream_capturing()) else None)
+        if prefetch_old is not None:
+            main.wait_stream(self._side_stream)      # join the next batch's old-model forward before the step (and its graph) ends
         return out
 
     def set_label_override(self, inputs):
@@ -355,7 +461,7 @@ class Trainer:
         if inputs is not None:
             inputs = {k: inputs[k].to(self.device, dtype=torch.float32).contiguous() for k in ("seg2b", "int_masks", "center_lo", "offset_lo")}
         self._label_override = inputs
-        self._graph, self._static = None, None
+        self._graph, self._static, self._pipe = None, None, None
         if self._graph_active:
             from .nn import CACHE
             CACHE.clear()
@@ -395,8 +501,14 @@ class Trainer:
         interval = torch.zeros_like(total)
         n = 0
         self._cur_epoch = cur_epoch
-        for cur_step, batch in enumerate(train_loader):
-            out = self.step(batch)
+        it = iter(train_loader)
+        batch = next(it, None)
+        cur_step = -1
+        while batch is not None:
+            cur_step += 1
+            nxt = next(it, None)                 # one batch of lookahead: Trainer.step overlaps its frozen old-model forward
+            out = self.step(batch, next_batch=nxt) if (self.weakly and self.opts.phase == 2) else self.step(batch)
+            batch = nxt
             l = out["losses"]                   # phase 2: l_center + l_offset (the zeroed terms of train.py:524-529 vanish)
             loss = torch.stack([v.reshape(()) for v in l.values()]).sum() if isinstance(l, dict) else l.sum()
             total += loss

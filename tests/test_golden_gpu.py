@@ -198,7 +198,7 @@ def test_graph_replay_matches_eager(gpu, monkeypatch):
         for x, l in batches:
             losses.append(tr.step((x, l))["losses"].clone())
         torch.cuda.synchronize()
-        assert (tr._graph is not None) == graph
+        assert (tr._graph is not None or tr._pipe is not None) == graph
         w = torch.cat([p.detach().flatten() for p in tr._branch.trainable_parameters()]).cpu()
         assert torch.isfinite(w).all() and not torch.equal(w, w0)
         return torch.stack(losses).cpu(), w, tr.optimizer.param_groups[0]["lr"]
@@ -262,7 +262,7 @@ def test_collective_path_over_rccl_single_rank(gpu, monkeypatch):
     batches = [(torch.randn(2, 3, crop, crop, generator=g), torch.eye(20)[[16 + i % 4, 15]].clone()) for i in range(3)]
     LR = 5e-6
 
-    def run():
+    def run(lookahead=False):
         opts = p2_opts(crop)
         opts.lr = LR / 10
         opts.max_iters, opts.start_decay = 50, 1
@@ -271,7 +271,8 @@ def test_collective_path_over_rccl_single_rank(gpu, monkeypatch):
         for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
             m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=31 + i))
         tr._realias()
-        losses = [tr.step((x, l))["losses"].clone() for x, l in batches]
+        losses = [tr.step(b, next_batch=batches[i + 1] if lookahead and i + 1 < len(batches) else None)["losses"].clone()
+                  for i, b in enumerate(batches)]
         torch.cuda.synchronize()
         w = torch.cat([p.detach().flatten() for p in tr._branch.trainable_parameters()]).cpu()
         return torch.stack(losses).cpu(), w, tr
@@ -280,12 +281,62 @@ def test_collective_path_over_rccl_single_rank(gpu, monkeypatch):
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29577")
     monkeypatch.setenv("CL4_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("CL4_PIPELINE_MIN_BATCH", "1")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
     try:
         ld, wd, tr = run()
         assert tr.buckets.distributed and tr.buckets.native_avg and tr._graph is not None
+        lp, wp_, trp = run(lookahead=True)               # the same with the next batch announced: pipelined graphs + eager ASPP tail
+        assert trp.buckets.distributed and trp._pipe is not None
     finally:
         dist.destroy_process_group()
-    assert torch.allclose(ls, ld, rtol=2e-3, atol=1e-6), (ls, ld)
-    d = (ws - wd).abs()
-    assert d.max() < 3.2 * LR and (d > 0.4 * LR).float().mean() < 1e-5 and d.mean() < 0.02 * LR
+    for l_, w_ in ((ld, wd), (lp, wp_)):
+        assert torch.allclose(ls, l_, rtol=2e-3, atol=1e-6), (ls, l_)
+        d = (ws - w_).abs()
+        assert d.max() < 3.2 * LR and (d > 0.4 * LR).float().mean() < 1e-5 and d.mean() < 0.02 * LR
+
+
+def test_pipelined_replay_matches_plain_graph_replay(gpu, monkeypatch):
+    """Trainer.step(batch, next_batch=...) replays the frozen old model of the NEXT batch beside the current step's trainable branch
+    and backward (two parities of static buffers, one graph each, the fork inside the graph). Two alternating batches, six steps: the losses of every step and the final weights equal those
+    of the unpipelined graph path (same kernels; only the fp32 atomics of the split-K weight gradients may reorder)."""
+    import copy
+    from cl4wsis_amd.train import Trainer
+    from util import p2_opts
+    opts = p2_opts(65)
+    opts.max_iters, opts.start_decay = 1000, 1000
+    g = torch.Generator().manual_seed(12)
+    batches = []
+    for i in range(2):
+        x = torch.randn(2, 3, 65, 65, generator=g)
+        l1h = torch.zeros(2, 20); l1h[0, 15 + i] = 1; l1h[1, 18 + i] = 1
+        batches.append((x.to(gpu), l1h.to(gpu)))
+
+    class _L:
+        def info(self, *a, **k):
+            pass
+        debug = info
+
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CL4_PIPELINE", mode)
+        monkeypatch.setenv("CL4_PIPELINE_MIN_BATCH", "1")       # the default keeps batches below 4 per GPU on the one-graph path
+        torch.manual_seed(0)
+        tr = Trainer(_L(), gpu, copy.deepcopy(opts))
+        assert tr._pipeline == (mode == "1")
+        losses = []
+        for t in range(6):
+            b, nb = batches[t % 2], batches[(t + 1) % 2]
+            out = tr.step(b, next_batch=nb if t < 5 else None)
+            losses.append(out["losses"].clone())
+        torch.cuda.synchronize()
+        assert (tr._pipe is not None) == (mode == "1") and (tr._graph is not None) == (mode == "0")
+        results[mode] = (torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()})
+    l0, w0 = results["0"]
+    l1, w1 = results["1"]
+    assert torch.isfinite(l1).all()
+    assert torch.allclose(l0, l1, rtol=2e-3, atol=1e-6), (l0, l1)
+    lr = opts.lr * opts.lr_head
+    for k in w0:
+        if w0[k].is_floating_point():                      # Adam: up to +-lr per step where a gradient is numerically zero
+            assert (w0[k] - w1[k]).abs().max() <= 3.2 * lr * 6 + 1e-6 * w0[k].abs().max(), k
