@@ -30,6 +30,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+#ifndef CL4_S_NO_AFFINE_LDS
+#define CL4_S_NO_AFFINE_LDS 0   // experiments only: 1 = read scale / shift from global memory inside the epilogue loop (the r02e kernel)
+#endif
 #ifndef CL4_S_DBG
 #define CL4_S_DBG 0   // experiments only: 1 = no loads in the loop, 2 = no LDS stores, 4 = no MFMA
 #endif
@@ -75,6 +78,9 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   constexpr int NB = MF == 32 ? 2 : 4;                     // MFMA blocks per wave-tile side
   constexpr int ACCV = MF == 32 ? 16 : 4;                  // accumulator registers per block
   __shared__ u32x4 lds[2][A_CHUNKS + B_CHUNKS];            // 64 KB: two K-tile stages; reused as the parked [128][128] fp32 tile
+#if !CL4_S_NO_AFFINE_LDS
+  __shared__ float affine[2 * BM];                         // scale / shift of the tile's 128 output channels, fetched once at the start
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -105,6 +111,16 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   const int kend = SPLIT ? min(a.K, kbeg + a.kchunk) : a.K;
   const int nk = (kend - kbeg + BKS - 1) / BKS;
   const int T0 = kbeg >> 5;
+#if !CL4_S_NO_AFFINE_LDS
+  // The epilogue multiplies every output by its channel's folded-ABN scale / shift. Read from global memory inside the epilogue loop
+  // they were 16 dependent vector loads per 8-channel group (hipcc cannot use scalar loads: the pointers may alias the output);
+  // one load per thread here, hidden under the whole K loop.
+  if (!SPLIT) {
+    const int ch = min(m0 + (tid & 127), a.cout - 1);
+    const float* src = tid < 128 ? a.scale : a.shift;
+    affine[tid] = src ? src[ch] : (tid < 128 ? 1.f : 0.f);
+  }
+#endif
 
   // ---- staging roles: thread = (GEMM row / column tid & 127, plane tid >> 7); per K-tile it moves the 4 k-group chunks of that
   // plane for its weight row AND for its pixel: 8 x 16 bytes in, 8 x ds_write_b128 out -------------------------------------------------
@@ -343,27 +359,39 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += t[r];
       }
-      u32x4 ph, pl_;
+      auto affine_act1 = [&]() {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#if !CL4_S_NO_AFFINE_LDS
+          const float sc = affine[g8 * 8 + r], sh = affine[BM + g8 * 8 + r];
+#else
+          const int cc = min(co0 + r, a.cout - 1);
+          const float sc = a.scale ? a.scale[cc] : 1.f;
+          const float sh = a.shift ? a.shift[cc] : 0.f;
+#endif
+          const float u = v[r] * sc + sh;
+          v[r] = u > 0.f ? u : u * a.neg1;
+        }
+      };
+      // three separate straight-line variants (residual in planes / fp32 / none): with one merged body hipcc shared registers between
+      // the two residual forms and the fp32 one came out wrong on a few lanes once the scale / shift loads had moved to LDS
       if (a.post_s) {                                      // residual in planes format: the same channel group of the same pixel
         const u32x4* ps = reinterpret_cast<const u32x4*>(a.post_s) + (((long)pn * (a.cout >> 3) + (co0 >> 3)) * 2) * HWo + phw;
-        ph = ps[0];
-        pl_ = ps[HWo];
+        const u32x4 ph = ps[0], pl_ = ps[HWo];
+        affine_act1();
+        float tq[8];
+        join8(ph, pl_, tq);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += tq[r];
       } else if (a.post) {
+        float tq[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) t[r] = a.post[rbase + (long)min(co0 + r, a.cout - 1) * HWo];
-      }
+        for (int r = 0; r < 8; ++r) tq[r] = a.post[rbase + (long)min(co0 + r, a.cout - 1) * HWo];
+        affine_act1();
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int cc = min(co0 + r, a.cout - 1);
-        const float sc = a.scale ? a.scale[cc] : 1.f;
-        const float sh = a.shift ? a.shift[cc] : 0.f;
-        const float u = v[r] * sc + sh;
-        v[r] = u > 0.f ? u : u * a.neg1;
-      }
-      if (a.post_s) join8(ph, pl_, t);
-      if (a.post_s || a.post) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += t[r];
+        for (int r = 0; r < 8; ++r) v[r] += tq[r];
+      } else {
+        affine_act1();
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.neg2;
