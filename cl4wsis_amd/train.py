@@ -92,6 +92,13 @@ class Trainer:
         self._iter = 0
         self._side_stream = torch.cuda.Stream(device=self.device) if os.environ.get("CL4_OVERLAP", "1") != "0" else None
         self._use_graph = os.environ.get("CL4_GRAPH", "1") != "0"
+        if self._side_stream is None and self._use_graph:
+            # OPEN ISSUE (r02g): graph replay of the single-stream step (CL4_OVERLAP=0 is a measurement switch; tools/prof_pmc.sh uses it
+            # with CL4_GRAPH=0) faulted sporadically on the GPU ("write access to a read-only page", 4 of 9 runs of 30 steps) once the
+            # planes kernels and autotuned split-tail plans were in; eager single-stream steps and every two-stream configuration (the
+            # default, ~60 bench runs and the whole GPU suite) never did. Not root-caused: the combination is disabled rather than
+            # left armed ("Open issue").
+            self._use_graph = False
         self._graph, self._static, self._graph_active = None, None, False
         # Software pipelining across iterations (single-GPU graph mode): the frozen old model's forward of batch t+1 is replayed on
         # its own stream while batch t's step runs (it depends on nothing the optimizer touches). CL4_PIPELINE=0 switches it off.
@@ -320,10 +327,17 @@ class Trainer:
             torch.cuda.synchronize()
             pool = torch.cuda.graph_pool_handle()
             from .nn import CACHE
+
+            def stale_trainable():
+                # every graph must re-derive (pack / fold) what it reads from the TRAINABLE weights itself — a derived tensor cached by
+                # the other parity's capture would only be refreshed when that other graph replays. The frozen networks' derived
+                # tensors (made by the eager first iteration, outside any graph pool) stay valid and are not rebuilt per replay.
+                for grp in opt.param_groups:
+                    for prm in grp["params"]:
+                        CACHE.touch(prm)
+
             for q in range(2):
-                # every graph must re-derive (pack / fold) what it reads from the trainable weights ITSELF: a derived tensor cached
-                # by the other parity's capture would only be refreshed when that other graph replays
-                CACHE.clear()
+                stale_trainable()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
                     out = self._forward_backward(P["x"][q], P["l"][q], None, split_tail=self.buckets.distributed,
@@ -334,7 +348,7 @@ class Trainer:
                     opt._step -= 1                        # capture only recorded the kernels
                 P["g"].append(g)
                 P["out"].append(out)
-            CACHE.clear()                                 # nothing eager may read a derived tensor that only one of the graphs refreshes
+            stale_trainable()                             # nothing eager may read a derived tensor that only one of the graphs refreshes
             self._pipe = P
         P = self._pipe
         p = P["cur"]
@@ -358,7 +372,8 @@ class Trainer:
             opt.note_replayed_step()
         else:
             from .nn import CACHE
-            CACHE.clear()                                 # the eager ASPP tail derives its operands from the current weights itself
+            for prm in self._branch.aspp_parameters():    # the eager ASPP tail derives its operands from the current weights itself
+                CACHE.touch(prm)
             self._distributed_tail(P["out"][p])
         return P["out"][p]
 
