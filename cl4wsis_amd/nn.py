@@ -105,6 +105,20 @@ class _Cache:
     def clear(self):
         self._epoch += 1
 
+    def snapshot(self, roots):
+        """Strong references to every derived tensor currently cached under `roots` (modules). A captured HIP graph holds the
+        ADDRESSES of the derived tensors of frozen weights it read (they are made eagerly, before the capture); whoever owns the
+        graph keeps this list so that a later clear() + eager rebuild cannot hand that memory to another tensor under the graph."""
+        keep = []
+        for root in roots:
+            if root is None:
+                continue
+            for m in root.modules():
+                store = m.__dict__.get("_cl4_cache")
+                if store:
+                    keep.extend(v for _, v in store.values())
+        return keep
+
 
 CACHE = _Cache()
 

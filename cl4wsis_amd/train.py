@@ -283,6 +283,7 @@ class Trainer:
                 if not self.buckets.distributed:
                     opt.step(upload=False)
             self._static["out"] = out
+            self._static["keep"] = self._derived_snapshot()
             opt._step -= 1 if not self.buckets.distributed else 0   # capture only recorded the kernels
         self._static["images"].copy_(images)
         self._static["l1h"].copy_(l1h)
@@ -294,6 +295,13 @@ class Trainer:
         else:
             self._distributed_tail(self._static["out"])
         return self._static["out"]
+
+    def _derived_snapshot(self):
+        # The captured kernels read the frozen networks' packed weights / folded BN at fixed addresses; those tensors were cached by
+        # the eager first iteration and would be freed (and their memory reused) by the first eager rebuild after a CACHE.clear()
+        # — validation between epochs, an eager fallback step. Holding them for the life of the graph keeps the addresses valid.
+        from .nn import CACHE
+        return CACHE.snapshot([self.model, self.model_old, getattr(self, "pseudolabeler", None), getattr(self, "peakgenerator", None)])
 
     def _distributed_tail(self, out):
         # N > 1: the graph ends where the ASPP block's backward begins. Those last kernels produce 90 % of the gradient
@@ -349,6 +357,7 @@ class Trainer:
                 P["g"].append(g)
                 P["out"].append(out)
             stale_trainable()                             # nothing eager may read a derived tensor that only one of the graphs refreshes
+            P["keep"] = self._derived_snapshot()
             self._pipe = P
         P = self._pipe
         p = P["cur"]
