@@ -215,6 +215,16 @@ def test_graph_steps_unchanged_by_an_eval_pass_in_between(gpu, lookahead):
         assert (tr._pipe is not None) if lookahead else (tr._graph is not None)
         return torch.stack(losses).cpu()
 
-    a, b = run(False), run(True)
+    import os
+    if os.environ.get("CL4_TEST_NO_PIN"):                 # one-off check that this test has teeth: drop the pin, expect a failure
+        Trainer._derived_snapshot = lambda self: []
+    a, a2, b = run(False), run(False), run(True)
     assert torch.isfinite(a).all()
-    assert torch.allclose(a, b, rtol=2e-3, atol=1e-6), (a, b)      # not bit-equal: the weight gradients accumulate with fp32 atomics
+    # not bit-equal run to run: the weight gradients accumulate with fp32 atomics and the label stage is discrete, so the bar is
+    # what two UNPERTURBED runs differ by (a corrupted operand shows as a gross change of the losses, not as a drift)
+    noise = ((a - a2).abs() / a.abs().clamp_min(1e-6)).max().item()
+    dev = ((a - b).abs() / a.abs().clamp_min(1e-6)).max().item()
+    torch.set_printoptions(profile="full")
+    print("run-to-run noise %.3e, deviation with the eval pass %.3e" % (noise, dev))
+    assert torch.equal(a[:4], b[:4]) or torch.allclose(a[:4], b[:4], rtol=max(2e-3, 3 * noise)), (a, b)     # before the eval pass
+    assert dev <= max(2e-3, 3 * noise), (noise, dev, a, a2, b)
