@@ -251,7 +251,7 @@ def worker(a):
         debug = info
 
     trainer = Trainer(_Log(), device, opts)
-    trainer.buckets.timing = world > 1         # HIP events around the join with the communication stream (exposed all-reduce)
+    trainer.buckets.timing = trainer.buckets.distributed         # HIP events around the join with the communication stream (exposed all-reduce)
     images, l1h = synthetic_batch(b, 42 + rank, device, CROP)
     seen = torch.ones(1, device=device)
     if world > 1:
@@ -382,7 +382,7 @@ def worker(a):
         }
         if structured is not None:
             res["structured_labels"] = structured
-        if world > 1:
+        if trainer.buckets.distributed:
             res["allreduce"] = trainer.comm_stats()
         wgrad_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if ops.WGRAD_PRECISION == 1 else PEAK_FP32_MFMA_TFLOPS
         for kind, pk in (("conv_fwd_bf16x6", PEAK_BF16_MFMA_TFLOPS / 6.0), ("conv_fwd_f32", PEAK_FP32_MFMA_TFLOPS),

@@ -17,7 +17,8 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    solo = os.environ.get("CL4_FORCE_COLLECTIVES") == "1"     # world-size-1 rehearsal of the N > 1 path (see BucketedAllReduce.solo)
+    if (world > 1 or solo) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
