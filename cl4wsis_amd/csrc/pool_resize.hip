@@ -2,6 +2,7 @@
 // replicate pad, bilinear resize (forward + deterministic gather backward), W-flip, axpy.
 // All tensors NCHW fp32; "planes" = n*c. One lane per output element with the fastest index
 // on the lane (coalesced), grid-stride loops sized by cl4::stream_grid.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -194,6 +195,102 @@ __global__ void resize_bwd_kernel(const float* __restrict__ dy, float* __restric
   }
 }
 
+// The same gather for UPSAMPLING (hout >= hin, wout >= win), restructured so that the gradient is read coalesced and once (plus the
+// overlap of neighbouring row bands). resize_bwd_kernel's thread = input pixel walks a (2/s + 3)^2 window of dy with a lane stride of
+// 1/s floats: 81 dword loads per thread at 129 -> 513, each wave-load spread over 1 KB — 0.6-0.7 ms for the 320 centre-map planes of
+// the bench step, ten times their HBM time (profiles/r02g_kernel_stats_bench.csv). Here a workgroup = (plane, band of RBR input
+// rows) makes two separable passes: (1) vertical: thread = output column, walks the band's candidate output rows top to bottom
+// (lanes read consecutive floats of one row); the forward's first source row y0(oy) never decreases and steps by at most 1 when
+// upsampling, so two running sums (rows y0 and y0 + 1) are enough and each finished row is stored once into an LDS image
+// t[row][ox]; (2) horizontal: thread = input pixel of the band sums its candidate columns of t. Every candidate re-derives the
+// forward's own (i0, i1, l1), like the plain kernel, so forward and backward cannot disagree; only the order of the fp32 sums differs.
+// The workgroup has one thread per output column (whole waves, at most 1024): 513 columns on 256 threads would walk the band three
+// times, the third time for a single column.
+constexpr int RBR = 16;
+__global__ __launch_bounds__(1024) void resize_bwd_rows_kernel(const float* __restrict__ dy, float* __restrict__ dx, ResizeArgs a,
+                                                              int accumulate) {
+  extern __shared__ float tbuf[];                // [RBR][wout]
+  const int plane = blockIdx.x;
+  const int n = plane / a.c, c = plane - n * a.c;
+  const int iy_a = blockIdx.y * RBR, iy_b = min(a.hin, iy_a + RBR);
+  const int rows = iy_b - iy_a;
+  const float ry = 1.f / a.sy, rx = 1.f / a.sx;  // the launcher routes sy, sx > 0 here
+  int oy_lo = max(0, (int)floorf(((float)iy_a - 1.f) * ry) - 1), oy_hi = min(a.hout - 1, (int)ceilf(((float)(iy_b - 1) + 1.5f) * ry) + 1);
+  if (iy_b == a.hin) oy_hi = a.hout - 1;
+  if (iy_a == 0) oy_lo = 0;
+  const float* dyp = dy + ((long)n * a.out_ctot + a.out_coff + c) * a.hout * a.wout;
+  for (int i = threadIdx.x; i < rows * a.wout; i += blockDim.x) tbuf[i] = 0.f;
+  __syncthreads();
+  // Map sizes are 2^k + 1 (33, 65, 129, 513): a wave for the one column past the last multiple of 64 would walk the band for a
+  // single lane. Up to 15 such columns are left to pass 1b below (thread = (band row, left-over column), a plain vertical gather).
+  const int rem = a.wout & 63;
+  const int wmain = (rem && rem < 16 && a.wout >= 64) ? a.wout - rem : a.wout;     // the launcher sizes the workgroup for wmain
+  for (int ox = threadIdx.x; ox < wmain; ox += blockDim.x) {
+    const float* col = dyp + ox;
+    int cur = -2;                                // y0 of the rows being summed: acc0 belongs to input row cur, acc1 to cur + 1
+    float acc0 = 0.f, acc1 = 0.f;
+    auto put = [&](int row, float v) {
+      if (row >= iy_a && row < iy_b) tbuf[(row - iy_a) * a.wout + ox] = v;
+    };
+    constexpr int UN = 8;                        // rows requested together: the walk is a chain of dependent sums, the loads are not
+    for (int oyb = oy_lo; oyb <= oy_hi; oyb += UN) {
+      float gv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) gv[u] = col[(long)min(oyb + u, oy_hi) * a.wout];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int oy = oyb + u;
+        if (oy > oy_hi) break;                   // uniform
+        int y0, y1; float ly;
+        src_index(oy, a.sy, a.align, a.hin, y0, y1, ly);
+        const float g = gv[u];
+        if (y0 != cur) {                         // uniform: oy is
+          if (y0 == cur + 1) { put(cur, acc0); acc0 = acc1; }
+          else { put(cur, acc0); put(cur + 1, acc1); acc0 = 0.f; }   // first row of the walk (or a jump: not when upsampling)
+          acc1 = 0.f;
+          cur = y0;
+        }
+        acc0 += (1.f - ly) * g;
+        if (y1 != y0) acc1 += ly * g; else acc0 += ly * g;             // clamped last row: both taps are row y0
+      }
+    }
+    put(cur, acc0);
+    put(cur + 1, acc1);
+  }
+  for (int i = threadIdx.x; i < rows * (a.wout - wmain); i += blockDim.x) {
+    const int r = i / (a.wout - wmain), ox = wmain + (i - r * (a.wout - wmain));
+    const int iy = iy_a + r;
+    int lo = max(0, (int)floorf(((float)iy - 1.f) * ry) - 1), hi = min(a.hout - 1, (int)ceilf(((float)iy + 1.5f) * ry) + 1);
+    if (iy == a.hin - 1) hi = a.hout - 1;
+    if (iy == 0) lo = 0;
+    float acc = 0.f;
+    for (int oy = lo; oy <= hi; ++oy) {
+      int y0, y1; float ly;
+      src_index(oy, a.sy, a.align, a.hin, y0, y1, ly);
+      const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+      if (wy != 0.f) acc += wy * dyp[(long)oy * a.wout + ox];
+    }
+    tbuf[r * a.wout + ox] = acc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < rows * a.win; i += blockDim.x) {
+    const int r = i / a.win, ix = i - r * a.win;
+    int ox_lo = max(0, (int)floorf(((float)ix - 1.f) * rx) - 1), ox_hi = min(a.wout - 1, (int)ceilf(((float)ix + 1.5f) * rx) + 1);
+    if (ix == a.win - 1) ox_hi = a.wout - 1;
+    if (ix == 0) ox_lo = 0;
+    const float* t = tbuf + r * a.wout;
+    float acc = 0.f;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      int x0, x1; float lx;
+      src_index(ox, a.sx, a.align, a.win, x0, x1, lx);
+      const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+      acc += wx * t[ox];
+    }
+    const long o = (((long)n * a.in_ctot + a.in_coff + c) * a.hin + iy_a + r) * a.win + ix;
+    dx[o] = accumulate ? dx[o] + acc : acc;
+  }
+}
+
 // y[r][w-1-x] = x[r][x] (torch.flip(-1), train.py:261).
 __global__ void flip_w_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int w) {
   long total = rows * w;
@@ -286,6 +383,15 @@ extern "C" int cl4_resize_bilinear_bwd(const float* dy, float* dx, int n, int c,
   int rc = fill_resize(a, n, c, hin, win, hout, wout, align_corners, in_ctot, in_coff, out_ctot, out_coff);
   if (rc) return rc;
   long total = (long)n * c * hin * win;
+  static const int rows_kernel = [] { const char* v = getenv("CL4_RESIZE_BWD_ROWS"); return v ? atoi(v) : 1; }();   // 0: the plain gather (experiments)
+  if (rows_kernel && a.hout >= a.hin && a.wout >= a.win && a.sy > 0.f && a.sx > 0.f && a.sy <= 1.f && a.sx <= 1.f && (size_t)RBR * a.wout * 4 <= (48u << 10)) {
+    const int rem = a.wout & 63;
+    const int wmain = (rem && rem < 16 && a.wout >= 64) ? a.wout - rem : a.wout;       // see the kernel: left-over columns take pass 1b
+    const int threads = wmain >= 1024 ? 1024 : 64 * cl4::cdiv(wmain, 64);
+    hipLaunchKernelGGL(resize_bwd_rows_kernel, dim3(a.n * a.c, cl4::cdiv(a.hin, RBR)), dim3(threads), (size_t)RBR * a.wout * sizeof(float),
+                       cl4::as_stream(stream), dy, dx, a, accumulate);
+    return cl4::launch_status();
+  }
   hipLaunchKernelGGL(resize_bwd_kernel, dim3(a.n * a.c, cl4::cdiv((long)a.hin * a.win, 1024) < 64 ? cl4::cdiv((long)a.hin * a.win, 1024) : 64), dim3(256), 0, cl4::as_stream(stream), dy, dx, a,
                      accumulate);
   return cl4::launch_status();

@@ -140,6 +140,9 @@ _SPLITS = [int(v) for v in os.environ.get("CL4_TUNE_SPLITS", "1,2,3,4,6,8,12,16,
 _CANDIDATES = [(1, 128, 1)] + [(2, t, s) for t in (128, 64) for s in _SPLITS]   # s < 0: main + split tail (-1: small-tile tail)
 
 
+_FULL_SPLITS_MIN_N = int(os.environ.get("CL4_TUNE_FULL_SPLITS_MIN_N", "1000000"))   # experiment: launches of at least this many images may use whole-launch K splits
+
+
 def _fills_the_chip(d):
     """A launch with at least one 128x128 tile per CU. The tuner times candidates ALONE, but the step runs two streams side by
     side (frozen old model || new model): there, what counts is the CU-time a plan consumes, not its latency in isolation, and a
@@ -148,6 +151,8 @@ def _fills_the_chip(d):
     whole-launch splits reserved for the launches that cannot fill the chip (small batches, thin layers). Tail plans (splits < 0:
     only the last partial round is split) stay available everywhere."""
     tiles = -(-d.cout // 128) * -(-(d.n * d.hout * d.wout) // 128)
+    if d.n >= _FULL_SPLITS_MIN_N:
+        return False
     return d.precision != 0 and tiles >= 256
 
 

@@ -77,6 +77,10 @@ def test_add_act_and_derivative(gpu):
     (65, 65, 129, 129, True),
     (3, 5, 5, 9, True),
     (7, 9, 33, 21, True),
+    (129, 129, 513, 513, True),  # the centre / offset maps of the phase-2 step (row-band kernel, three column passes, 9 bands)
+    (129, 129, 513, 513, False),
+    (17, 40, 35, 300, True),     # bands and column passes that do not divide
+    (16, 16, 17, 16, False),     # one axis unchanged
     (17, 13, 9, 7, False),       # downsampling
     (4, 4, 4, 4, False),         # identity
 ])
