@@ -1105,6 +1105,7 @@ struct WgradArgs {
   int npix;     // n*hout*wout
   int chunk;    // pixels per grid.z slice (multiple of BKP)
   int precision;  // 0: exact fp32 MFMA, 1: bf16x3 split products
+  int hw_pad;   // VEC kernels: hout*wout rounded up to a multiple of 4; their K axis is the pixel space padded per image, n*hw_pad long
 };
 
 template <int BM, int BN, int KS>
@@ -1634,7 +1635,17 @@ int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_by
 // load has a whole phase to land — while waves 4-7 only read LDS fragments and issue MFMAs; one workgroup barrier per
 // K-tile. (The earlier single-role kernel waited the full L2/HBM latency every K-tile: 75-120 TFLOP/s.) All loads are
 // unconditional (out-of-range offsets past the end), which keeps the compiler's vmcnt accounting exact.
-template <int BM, int BN, int KS, int P>
+// VEC (stride-1 "same" convolutions, 1x1 / 3x3): the loader waves were bound by the CU's vector-memory front end — one wave-load
+// per ~16 cycles whatever its width, 32 dword loads per thread and K-tile = ~2,000 cycles against 770 cycles of MFMA work (the r02g
+// roofline leg: 144 TFLOP/s, 0.17 of the bf16x3 ceiling). K = pixels are contiguous in both operands (dy rows; x rows shifted by
+// the tap, because win == wout makes the flattened pixel index linear across row ends), so a lane now fetches FOUR consecutive
+// pixels of one row with one buffer_load_dwordx4: 4 + 4 loads per thread and K-tile. The K axis becomes the pixel space padded per
+// image to a multiple of 4 (no group straddles two images); elements past the image's last pixel and taps outside the image are
+// zeroed in registers from per-pixel tap masks; a group whose first element lies in front of the tensor (image 0, channel 0, the
+// taps above / left of the first pixels) would be bounds-checked away as a whole, so its offset is clamped to 0 and the elements are
+// shifted back in registers. Lanes hold 4 consecutive k of one row: bf16 pairs are packed without the DPP neighbour exchange and
+// stored with ds_write_b64 into the same swizzled LDS image; the MFMA waves are unchanged.
+template <int BM, int BN, int KS, int P, bool VEC = false>
 __global__ __launch_bounds__(2 * NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -1656,11 +1667,141 @@ __global__ __launch_bounds__(2 * NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
   const int m0 = blockIdx.x * BM;
   const int j0 = blockIdx.y * BN;
   const int pbeg = blockIdx.z * a.chunk;
-  const int pend = min(a.npix, pbeg + a.chunk);
+  const int pend = min(VEC ? a.n * a.hw_pad : a.npix, pbeg + a.chunk);
   if (pbeg >= pend) return;
 
   const int HWo = a.hout * a.wout;
   const int HWi = a.hin * a.win;
+  if constexpr (VEC) {
+    if (wave8 < 4) {
+      static_assert(KS == 1 || KS == 3, "VEC loader: 1x1 / 3x3");
+      constexpr int RV = BM * 8 / NTHREADS, RW = BN * 8 / NTHREADS;      // x4 loads per thread and K-tile (A rows, B rows)
+      constexpr unsigned OOBV = 0x80000000u;
+      const int wv = wave8, kq = lane & 7, rl = lane >> 3;
+      const int row0 = wv * 8 + rl;                                     // rows of this thread: row0 + 32 r
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)((long)a.n * a.in_ctot * HWi * 4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (unsigned)((long)a.n * a.out_ctot * HWo * 4), 0x00020000);
+      int b_off[RW], b_tap[RW];                  // per B row (ci, tap): element offset relative to the pixel's own position, tap index (or 31: row out of range)
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int j = j0 + row0 + 32 * r;
+        const bool ok = j < a.Nj;
+        const int jc = ok ? j : 0;
+        const int ci = jc / KHW, t = jc - ci * KHW, ky = t / KS, kx = t - ky * KS;
+        b_off[r] = (a.in_coff + ci) * HWi + (ky * a.dil - a.pad) * a.win + (kx * a.dil - a.pad);
+        b_tap[r] = ok ? t : 31;
+      }
+      const int lds_idx = row0 * BKP + (((kq >> 1) ^ ((row0 >> 2) & 3)) << 3) + ((kq & 1) << 2);   // (row0 + 32 r) >> 2 & 3 == row0 >> 2 & 3
+      typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+      typedef float f32x2w __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+      auto pk2 = [](float lo, float hi) { f32x2w f = {lo, hi}; return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2v)); };
+      auto load_tile = [&](int kt, f32x4v (&ra)[RV], f32x4v (&rb)[RW], unsigned (&em)[5]) {
+        const int p0 = pbeg + kt * BKP + kq * 4;
+        const bool gv = p0 < pend;               // pend is a multiple of 4
+        const int pc = gv ? p0 : 0;
+        const int img = pc / a.hw_pad, hw0 = pc - img * a.hw_pad;
+        const int oy0 = hw0 / a.wout, ox0 = hw0 - oy0 * a.wout;
+        // per element: tap mask (bit t: tap t of that pixel reads inside the image; 0 for the padding pixels of the image)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int ox = ox0 + e, oy = oy0;
+          if (ox >= a.wout) { ox -= a.wout; oy += 1; }     // wout >= 4 is required by the launcher: one wrap at most
+          unsigned m = 0;
+          if (KS == 1) m = 1u;
+          else {
+            unsigned cols = 0, rows = 0;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+              cols |= ((unsigned)(ox - a.pad + k * a.dil) < (unsigned)a.win ? 1u : 0u) << k;
+              rows |= ((unsigned)(oy - a.pad + k * a.dil) < (unsigned)a.hin ? 1u : 0u) << k;
+            }
+#pragma unroll
+            for (int k = 0; k < KS; ++k) m |= ((rows >> k) & 1u) ? cols << (k * KS) : 0u;
+          }
+          em[e] = (gv && hw0 + e < HWo) ? m : 0u;
+        }
+        const unsigned gm = 0u - (unsigned)gv;
+        const unsigned a_v = (unsigned)(((img * a.out_ctot + a.out_coff + m0 + row0) * HWo + hw0) * 4);
+#pragma unroll
+        for (int r = 0; r < RV; ++r) {
+          const unsigned m = gm & (0u - (unsigned)(m0 + row0 + 32 * r < a.cout));
+          ra[r] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rdy, (a_v & m) | (OOBV & ~m), r * 32 * HWo * 4, 0));
+        }
+        const int xb = img * a.in_ctot * HWi + hw0;
+        unsigned shp = 0;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          const int off = xb + b_off[r];         // element index of the group's first source pixel; negative only in front of the tensor
+          const int offc = max(off, 0);
+          const unsigned m = gm & (0u - (unsigned)(b_tap[r] != 31));
+          rb[r] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rx, ((unsigned)(offc * 4) & m) | (OOBV & ~m), 0, 0));
+          shp |= (unsigned)min(offc - off, 3) << (2 * r);   // 0, or how many leading elements lie in front of the tensor (undone at store time; those elements are masked)
+        }
+        em[4] = shp;
+      };
+      auto store_tile = [&](int buf, f32x4v (&ra)[RV], f32x4v (&rb)[RW], const unsigned (&em)[5]) {
+        auto put = [&](unsigned short* base, int rows_total, int idx, const float (&f)[4]) {
+          const unsigned h0 = pk2(f[0], f[1]), h1 = pk2(f[2], f[3]);
+          const float r0 = f[0] - __builtin_bit_cast(float, h0 << 16), r1 = f[1] - __builtin_bit_cast(float, h0 & 0xFFFF0000u);
+          const float r2 = f[2] - __builtin_bit_cast(float, h1 << 16), r3 = f[3] - __builtin_bit_cast(float, h1 & 0xFFFF0000u);
+          *reinterpret_cast<u32x2w*>(base + idx) = u32x2w{h0, h1};
+          if (P == 2) {
+            *reinterpret_cast<u32x2w*>(base + (P - 1) * rows_total * BKP + idx) = u32x2w{pk2(r0, r1), pk2(r2, r3)};
+          } else {
+            const unsigned q0 = pk2(r0, r1), q1 = pk2(r2, r3);
+            *reinterpret_cast<u32x2w*>(base + rows_total * BKP + idx) = u32x2w{q0, q1};
+            const float s0 = r0 - __builtin_bit_cast(float, q0 << 16), s1 = r1 - __builtin_bit_cast(float, q0 & 0xFFFF0000u);
+            const float s2 = r2 - __builtin_bit_cast(float, q1 << 16), s3 = r3 - __builtin_bit_cast(float, q1 & 0xFFFF0000u);
+            *reinterpret_cast<u32x2w*>(base + 2 * rows_total * BKP + idx) = u32x2w{pk2(s0, s1), pk2(s2, s3)};
+          }
+        };
+        // hipcc narrows some of these b128 loads to their first dword although all four elements are read (DESIGN.md finding 15; here:
+        // every load of register set 0). An empty asm that "modifies" the whole vector at its point of use keeps all elements demanded
+        // without forcing a wait where the load is issued.
+#pragma unroll
+        for (int r = 0; r < RV; ++r) asm volatile("" : "+v"(ra[r]));
+#pragma unroll
+        for (int r = 0; r < RW; ++r) asm volatile("" : "+v"(rb[r]));
+#pragma unroll
+        for (int r = 0; r < RV; ++r) {
+          float f[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = em[e] ? ra[r][e] : 0.f;   // "the pixel exists" = any tap bit (the centre tap always reads inside)
+          put(&Ash[buf][0][0], BM, lds_idx + 32 * r * BKP, f);
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          f32x4v v = rb[r];
+          const unsigned sh = (em[4] >> (2 * r)) & 3u;
+          v[3] = sh == 0 ? v[3] : sh == 1 ? v[2] : sh == 2 ? v[1] : v[0];
+          v[2] = sh == 0 ? v[2] : sh == 1 ? v[1] : v[0];
+          v[1] = sh == 0 ? v[1] : v[0];
+          float f[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = ((em[e] >> (b_tap[r] & 31)) & 1u) ? v[e] : 0.f;
+          put(&Bsh[buf][0][0], BN, lds_idx + 32 * r * BKP, f);
+        }
+      };
+      const int nk = (pend - pbeg + BKP - 1) / BKP;
+      f32x4v ra0[RV], rb0[RW], ra1[RV], rb1[RW];     // float vectors: element access on an unsigned-vector view of the b128 builtin's result read element 0 four times (hipcc, ROCm 7.2)
+      unsigned em0[5], em1[5];
+      load_tile(0, ra0, rb0, em0);
+      load_tile(1, ra1, rb1, em1);
+      store_tile(0, ra0, rb0, em0);
+      __syncthreads();
+      for (int kt = 0; kt < nk; kt += 2) {        // tile kt is in LDS stage 0, tile kt+1 in register set 1
+        load_tile(kt + 2, ra0, rb0, em0);
+        store_tile(1, ra1, rb1, em1);
+        __syncthreads();
+        load_tile(kt + 3, ra1, rb1, em1);
+        store_tile(0, ra0, rb0, em0);
+        __syncthreads();
+      }
+      return;
+    }
+  }
   const int pl = lane & 31;      // pixel within the K tile
   const int rsub = lane >> 5;    // which of the two rows this half-wave stages
 
@@ -1870,7 +2011,16 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   // Split K (pixels) so that the grid fills the chip in whole rounds: `slots` workgroups are resident at once (2 per CU for
   // the 64 KB kernels, 1 per CU for the 96 KB bf16x6 tile); among the split counts near 1024 / (gm*gn) pick the one whose last
   // round is fullest (fewest splits on ties: every split adds one atomic pass over dW). Each slice is a multiple of BKP.
-  const int tiles = cl4::cdiv(a.npix, BKP);
+  // bf16x3 MFMA path: 32-bit buffer offsets, so both tensors must stay below 2 GiB (always true on the phase-2 path)
+  const long lim = (1L << 31) - 4096;
+  // bf16x6 (precision 2) pays off for k >= 3 (114 vs 88 TFLOP/s on the ASPP 3x3); for 1x1 the exact fp32 kernel is as fast
+  const bool split3 = (a.precision == 1 || (a.precision == 2 && KS > 1)) && (long)a.n * a.in_ctot * a.hin * a.win * 4 < lim && (long)a.n * a.out_ctot * a.hout * a.wout * 4 < lim;
+  static const int vec_enabled = env_int("CL4_WGRAD_VEC", 1);
+  a.hw_pad = (a.hout * a.wout + 3) & ~3;
+  const bool vec = vec_enabled && split3 && (KS == 1 || KS == 3) && a.stride == 1 && a.hin == a.hout && a.win == a.wout && a.wout >= 4 &&
+                   a.pad == a.dil * (KS / 2);
+  const int kpix = vec ? a.n * a.hw_pad : a.npix;
+  const int tiles = cl4::cdiv(kpix, BKP);
   const int slots = (a.precision == 2 && KS > 1 && !small_m) ? 256 : 512;
   int want = cl4::cdiv(1024, gm * gn);
   if (want < 1) want = 1;
@@ -1886,12 +2036,17 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   }
   const int tiles_per = cl4::cdiv(tiles, best_s);
   a.chunk = tiles_per * BKP;
-  const int gz = cl4::cdiv(a.npix, a.chunk);
+  const int gz = cl4::cdiv(kpix, a.chunk);
   dim3 g(gm, gn, gz);
-  // bf16x3 MFMA path: 32-bit buffer offsets, so both tensors must stay below 2 GiB (always true on the phase-2 path)
-  const long lim = (1L << 31) - 4096;
-  // bf16x6 (precision 2) pays off for k >= 3 (114 vs 88 TFLOP/s on the ASPP 3x3); for 1x1 the exact fp32 kernel is as fast
-  const bool split3 = (a.precision == 1 || (a.precision == 2 && KS > 1)) && (long)a.n * a.in_ctot * a.hin * a.win * 4 < lim && (long)a.n * a.out_ctot * a.hout * a.wout * 4 < lim;
+  if constexpr (KS == 1 || KS == 3) {
+    if (vec) {
+      if (a.precision == 2 && small_m) hipLaunchKernelGGL((conv_wgrad_bf16<64, 128, KS, 3, true>), g, dim3(2 * NTHREADS), 0, st, a);
+      else if (a.precision == 2) hipLaunchKernelGGL((conv_wgrad_bf16<128, 128, KS, 3, true>), g, dim3(2 * NTHREADS), 0, st, a);
+      else if (small_m) hipLaunchKernelGGL((conv_wgrad_bf16<64, 128, KS, 2, true>), g, dim3(2 * NTHREADS), 0, st, a);
+      else hipLaunchKernelGGL((conv_wgrad_bf16<128, 128, KS, 2, true>), g, dim3(2 * NTHREADS), 0, st, a);
+      return cl4::launch_status();
+    }
+  }
   if (split3 && a.precision == 2 && small_m)
     hipLaunchKernelGGL((conv_wgrad_bf16<64, 128, KS, 3>), g, dim3(2 * NTHREADS), 0, st, a);
   else if (split3 && a.precision == 2)

@@ -252,3 +252,23 @@ def test_bad_arguments_raise(gpu):
     wp = torch.zeros(4 * 25, 8, device=gpu)
     with pytest.raises(RuntimeError):
         ops.conv2d(x, wp, 5, pad=2)  # 5x5 dense conv is not part of the path
+
+
+@pytest.mark.parametrize("k,d", [(1, 1), (3, 1), (3, 2), (3, 6)])
+@pytest.mark.parametrize("precision", [1, 2])
+def test_conv_wgrad_channel_slices_vector_loader(gpu, k, d, precision):
+    """The stride-1 "same" weight gradients run on the 16-byte loader (K = the per-image padded pixel space): channel slices of both
+    operands, map sizes whose pixel count is not a multiple of 4, widths of 4 and 5 (every 4-pixel group wraps a row), against autograd;
+    CL4_WGRAD_VEC=0 (the dword loader) must give the same numbers."""
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(100 + k * 10 + d)
+    for n, h, w in ((2, 9, 13), (3, 6, 4), (1, 7, 5), (2, 33, 33)):
+        x = torch.randn(n, 40, h, w, generator=g, dtype=torch.float64)
+        dy = torch.randn(n, 72, h, w, generator=g, dtype=torch.float64)
+        wt = torch.zeros(48, 24, k, k, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x[:, 8:32], wt, padding=d * (k // 2), dilation=d).backward(dy[:, 16:64])
+        dw = torch.zeros(48, 24, k, k, device=gpu)
+        ops.conv2d_wgrad(x.float().to(gpu), dy.float().to(gpu), dw, k, pad=d * (k // 2), dil=d, in_coff=8, cin=24, dy_coff=16, cout=48,
+                         precision=precision)
+        tol = 2e-6 if precision == 2 and k > 1 else 1e-5
+        assert _rel_err(dw.cpu(), wt.grad.float()) < tol, (n, h, w)
