@@ -33,6 +33,42 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
+// The same pooling with two wave-loads per output row instead of nine (DESIGN.md finding 22: a CU retires one wave-load per ~16 cycles
+// whatever its width, and thread-per-output issues 9 stride-2 dword loads). Workgroup = (plane, band of MPB output rows), thread =
+// output column: per input row ONE unaligned 16-byte buffer load fetches columns 2ox-1 .. 2ox+2 (neighbouring lanes overlap by half;
+// the lines are in L1), its horizontal max is kept, and the vertical window slides: output row oy = max(rows 2oy-1, 2oy, 2oy+1), the
+// last of which is the first of row oy+1. Column 0 has no left neighbour: it loads from column 0 and shifts.
+constexpr int MPB = 16, MPK = 4;
+__global__ __launch_bounds__(1024) void maxpool3x3s2_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long planes,
+                                                                 int hin, int win, int hout, int wout) {
+  typedef float f32x4p __attribute__((ext_vector_type(4)));
+  const long pl = blockIdx.x;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)(planes * hin * win * 4), 0x00020000);
+  // a workgroup takes MPK bands at once, (band, column) flattened over its lanes: map widths are 2^k + 1, and one band per
+  // workgroup would spend a whole wave on the last column
+  for (int idx = threadIdx.x; idx < MPK * wout; idx += blockDim.x) {
+    const int bk = idx / wout, ox = idx - bk * wout;
+    const int oy_a = (blockIdx.y * MPK + bk) * MPB, oy_b = min(hout, oy_a + MPB);
+    if (oy_a >= hout) continue;
+    const int c0 = 2 * ox - 1;                   // first column of the window
+    const int cl = max(c0, 0);                   // first column loaded
+    const bool v0 = c0 >= 0, v1 = c0 + 1 < win, v2 = c0 + 2 < win;
+    auto rowmax = [&](int iy) {
+      if ((unsigned)iy >= (unsigned)hin) return -INFINITY;          // uniform
+      const f32x4p v = __builtin_bit_cast(f32x4p, __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)((pl * hin + iy) * (long)win + cl) * 4u, 0, 0));
+      const float e0 = v0 ? v[0] : -INFINITY;                      // column c0 (absent for ox = 0)
+      const float e1 = v0 ? v[1] : v[0], e2 = v0 ? v[2] : v[1];    // columns c0+1, c0+2
+      return fmaxf(e0, fmaxf(v1 ? e1 : -INFINITY, v2 ? e2 : -INFINITY));
+    };
+    float top = rowmax(2 * oy_a - 1);
+    for (int oy = oy_a; oy < oy_b; ++oy) {
+      const float mid = rowmax(2 * oy), bot = rowmax(2 * oy + 1);
+      y[(pl * hout + oy) * (long)wout + ox] = fmaxf(top, fmaxf(mid, bot));
+      top = bot;
+    }
+  }
+}
+
 // modules/deeplab.py:87 avg_pool2d(x, (kh,kw), stride=1): one workgroup per plane, the plane is staged
 // in LDS once and every output window is summed from LDS (planes here are <= 65x65).
 __global__ void avgpool_s1_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int kh, int kw) {
@@ -291,6 +327,27 @@ __global__ __launch_bounds__(1024) void resize_bwd_rows_kernel(const float* __re
   }
 }
 
+// Upsampling FROM a 1x1 map (ASPP image pooling, panoptic_deeplab.py:80-98: the pooled vector is broadcast back over the map): every
+// output pixel reads the one input pixel with weight 1, so its gradient is the plane's sum. The gather above gave this to ONE thread
+// per plane (0.29 ms for 4096 planes of 33x33); here a workgroup reduces the plane.
+__global__ void resize_bwd_1x1_kernel(const float* __restrict__ dy, float* __restrict__ dx, ResizeArgs a, int accumulate) {
+  __shared__ float part[4];
+  const int plane = blockIdx.x;
+  const int n = plane / a.c, c = plane - n * a.c;
+  const int hw = a.hout * a.wout;
+  const float* dyp = dy + ((long)n * a.out_ctot + a.out_coff + c) * hw;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) s += dyp[i];
+  s = cl4::wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = part[0] + part[1] + part[2] + part[3];
+    const long o = (long)n * a.in_ctot + a.in_coff + c;
+    dx[o] = accumulate ? dx[o] + t : t;
+  }
+}
+
 // y[r][w-1-x] = x[r][x] (torch.flip(-1), train.py:261).
 __global__ void flip_w_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int w) {
   long total = rows * w;
@@ -324,6 +381,13 @@ __global__ void copy_channels_kernel(const float* __restrict__ x, float* __restr
 extern "C" int cl4_maxpool3x3s2(const float* x, float* y, long planes, int hin, int win, int hout, int wout, void* stream) {
   CL4_REQUIRE(x && y && planes > 0, "maxpool: bad arguments");
   CL4_REQUIRE(hout == (hin + 2 - 3) / 2 + 1 && wout == (win + 2 - 3) / 2 + 1, "maxpool: output size mismatch");
+  static const int rows_kernel = [] { const char* v = getenv("CL4_MAXPOOL_ROWS"); return v ? atoi(v) : 1; }();   // 0: thread per output (experiments)
+  if (rows_kernel && planes * hin * win * 4 < (1L << 31) && planes <= 0x7fffffffL) {      // 32-bit buffer offsets
+    const int threads = MPK * wout >= 1024 ? 1024 : 64 * cl4::cdiv(MPK * wout, 64);
+    hipLaunchKernelGGL(maxpool3x3s2_rows_kernel, dim3((unsigned)planes, cl4::cdiv(hout, MPB * MPK)), dim3(threads), 0, cl4::as_stream(stream),
+                       x, y, planes, hin, win, hout, wout);
+    return cl4::launch_status();
+  }
   const int chunks = cl4::cdiv((long)hout * wout, 1024) < 64 ? cl4::cdiv((long)hout * wout, 1024) : 64;
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)planes, chunks), dim3(256), 0, cl4::as_stream(stream), x, y,
                      planes, hin, win, hout, wout);
@@ -384,6 +448,10 @@ extern "C" int cl4_resize_bilinear_bwd(const float* dy, float* dx, int n, int c,
   if (rc) return rc;
   long total = (long)n * c * hin * win;
   static const int rows_kernel = [] { const char* v = getenv("CL4_RESIZE_BWD_ROWS"); return v ? atoi(v) : 1; }();   // 0: the plain gather (experiments)
+  if (rows_kernel && a.hin == 1 && a.win == 1) {
+    hipLaunchKernelGGL(resize_bwd_1x1_kernel, dim3(a.n * a.c), dim3(256), 0, cl4::as_stream(stream), dy, dx, a, accumulate);
+    return cl4::launch_status();
+  }
   if (rows_kernel && a.hout >= a.hin && a.wout >= a.win && a.sy > 0.f && a.sx > 0.f && a.sy <= 1.f && a.sx <= 1.f && (size_t)RBR * a.wout * 4 <= (48u << 10)) {
     const int rem = a.wout & 63;
     const int wmain = (rem && rem < 16 && a.wout >= 64) ? a.wout - rem : a.wout;       // see the kernel: left-over columns take pass 1b

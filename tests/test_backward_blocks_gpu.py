@@ -40,6 +40,19 @@ def test_conv_input_gradient(gpu, case):
     assert _rel(dx, x.grad.float()) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 257, 257), (1, 5, 7, 9), (3, 2, 8, 6), (1, 1, 2, 2), (2, 4, 65, 33), (1, 2, 130, 300)])
+def test_maxpool_forward(gpu, shape):
+    """nn.MaxPool2d(3, stride=2, padding=1) (models/resnet.py:63) on odd / even sizes, widths beyond one workgroup pass, all-negative
+    inputs (the implicit padding is -inf, not 0); bit-exact."""
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g) - 3.0
+    ref = F.max_pool2d(x, 3, stride=2, padding=1)
+    out = ops.maxpool3x3s2(x.to(gpu))
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert torch.equal(out.cpu(), ref)
+
+
 def test_maxpool_backward_with_ties(gpu):
     from cl4wsis_amd import ops
     g = torch.Generator().manual_seed(3)
@@ -81,6 +94,8 @@ def test_add_act_and_derivative(gpu):
     (129, 129, 513, 513, False),
     (17, 40, 35, 300, True),     # bands and column passes that do not divide
     (16, 16, 17, 16, False),     # one axis unchanged
+    (1, 1, 33, 33, True),        # ASPP image pooling broadcast back over the map (plane-sum kernel)
+    (1, 1, 7, 5, False),
     (17, 13, 9, 7, False),       # downsampling
     (4, 4, 4, 4, False),         # identity
 ])
