@@ -93,3 +93,40 @@ def test_gaussian_table_matches_definition():
     g = gaussian(6)
     assert g.shape == (39, 39) and g[19, 19] == 1.0
     assert abs(g[19, 25] - np.exp(-36 / 72)) < 1e-15
+
+
+def test_derived_tensor_cache_invalidation_and_snapshot():
+    """nn.CACHE: entries are rebuilt when the source tensor changes (version bump, external-write touch, clear) and `snapshot` holds
+    the tensors a captured graph reads, so that a rebuild cannot free them (Trainer._derived_snapshot)."""
+    import gc
+    import weakref
+    from cl4wsis_amd.nn import _Cache
+    cache = _Cache()
+    m = torch.nn.Conv2d(2, 2, 1)
+    builds = []
+
+    def build():
+        builds.append(1)
+        return m.weight.detach().clone()
+
+    a = cache.get(m, "k", (m.weight,), build)
+    assert cache.get(m, "k", (m.weight,), build) is a and len(builds) == 1          # hit
+    cache.touch(m.weight)                                                          # a kernel wrote the weight behind torch's back
+    b = cache.get(m, "k", (m.weight,), build)
+    assert b is not a and len(builds) == 2
+    with torch.no_grad():
+        m.weight.add_(1.0)                                                         # in-place torch op: _version
+    c = cache.get(m, "k", (m.weight,), build)
+    assert c is not b and len(builds) == 3
+    keep = cache.snapshot([torch.nn.Sequential(m), None])
+    assert len(keep) == 1 and keep[0] is c
+    ref = weakref.ref(c)
+    del a, b, c
+    cache.clear()
+    d = cache.get(m, "k", (m.weight,), build)                                      # rebuilt: the store now holds d
+    assert len(builds) == 4 and d is not keep[0]
+    gc.collect()
+    assert ref() is keep[0]                                                        # still alive: the snapshot pins what the graph captured
+    del keep
+    gc.collect()
+    assert ref() is None
