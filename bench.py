@@ -11,8 +11,8 @@ Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N 
 One "step" = one `Trainer.step` (cl4wsis_amd.train) on a synthetic VOC-shaped batch: global batch 16 split over the N
 ranks (run.py:66 semantics, strong scaling), 513x513, VOC 15-5 step 1 phase 2, fp32 tensors, inputs resident in HBM.
 Every timed step announces the next batch to `Trainer.step` (one batch of loader lookahead, as `Trainer.train` does), so that the
-frozen old model's forward of batch t+1 overlaps step t; the last warm-up and the last timed step announce nothing, i.e. exactly K
-old-model forwards run inside the timed region of K steps.
+frozen old model's forward of batch t+1 overlaps step t; every warm-up and timed step does (steady state), i.e. exactly K old-model
+forwards are enqueued and finish inside the timed region of K steps.
 Rank 0 prints ONE JSON line with
   * the throughput of the timed region (e2e-random mode: the label stage consumes the random-init networks' own outputs),
   * `structured_labels`: the same step with the label stage fed by the structured synthetic maps of SURVEY.md §8(d),
@@ -259,18 +259,21 @@ def worker(a):
 
     def timed(steps, warmup):
         # `next_batch` announces the following iteration's batch (as Trainer.train does with one batch of loader lookahead), so
-        # that its frozen old-model forward overlaps the current step. The LAST warm-up step and the LAST timed step announce
-        # nothing: every one of the K old-model forwards of the K timed steps is enqueued — and finishes — inside the timed region.
+        # that its frozen old-model forward overlaps the current step. Steady state: every replayed step contains exactly one
+        # old-model forward (the next batch's), so the K timed steps enqueue — and finish — K old-model forwards inside the timed
+        # region: the one the first timed step consumes was made by the last warm-up step, the one the last timed step makes is for
+        # the step after it. (An unannounced step would add an eager old-model forward to the following call: Trainer.step does that
+        # at the start of an epoch.)
         batch = (images, l1h)
         for i in range(warmup):
-            trainer.step(batch, next_batch=batch if i + 1 < warmup else None)
+            trainer.step(batch, next_batch=batch)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            out = trainer.step(batch, next_batch=batch if i + 1 < steps else None)
+            out = trainer.step(batch, next_batch=batch)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -210,7 +210,7 @@ class Trainer:
             self.optimizer.step()
         elif (self._pipeline and images.shape[0] >= self._pipe_min_b and
               (next_batch is not None or (self._pipe is not None and self._pipe["have_old"][self._pipe["cur"]]))):
-            out = self._replay_pipelined(images, l1h, next_batch if next_batch is not None else (images, l1h))
+            out = self._replay_pipelined(images, l1h, next_batch)
         else:
             out = self._replay(images, l1h)
         if self.scheduler is not None:
@@ -368,13 +368,20 @@ class Trainer:
                 o, _ = self.model_old(P["x"][p], interpolate=False)
             for k in ("center", "offset"):
                 P["old"][p][k].copy_(o[k])
-        nx, nl = next_batch[0], next_batch[-1]
-        P["x"][1 - p].copy_(nx.to(self.device, dtype=torch.float32))
-        P["l"][1 - p].copy_(nl.to(self.device, dtype=torch.float32))
+        # The graph always runs the old model on X[1-p]; its result counts only if the caller announced that batch and it has the
+        # captured shape (a last, smaller batch of an epoch takes the eager path of step()). Nothing announced — the last step of an
+        # epoch, a caller that stops looking ahead — leaves OLD[1-p] marked invalid, and the next call runs the old model itself.
+        announced = False
+        if next_batch is not None:
+            nx, nl = next_batch[0], next_batch[-1]
+            if tuple(nx.shape) == tuple(P["x"][1 - p].shape):
+                P["x"][1 - p].copy_(nx.to(self.device, dtype=torch.float32))
+                P["l"][1 - p].copy_(nl.to(self.device, dtype=torch.float32))
+                announced = True
         opt.upload_lr()
         P["g"][p].replay()
         P["have_old"][p] = False
-        P["have_old"][1 - p] = True
+        P["have_old"][1 - p] = announced
         P["cur"] = 1 - p
         self._graph_active = True
         if not self.buckets.distributed:

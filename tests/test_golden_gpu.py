@@ -298,7 +298,7 @@ def test_collective_path_over_rccl_single_rank(gpu, monkeypatch):
 
 def test_pipelined_replay_matches_plain_graph_replay(gpu, monkeypatch):
     """Trainer.step(batch, next_batch=...) replays the frozen old model of the NEXT batch beside the current step's trainable branch
-    and backward (two parities of static buffers, one graph each, the fork inside the graph). Two alternating batches, six steps: the losses of every step and the final weights equal those
+    and backward (two parities of static buffers, one graph each, the fork inside the graph). Two alternating batches, eight steps (one of them without an announcement in mid-sequence): the losses of every step and the final weights equal those
     of the unpipelined graph path (same kernels; only the fp32 atomics of the split-K weight gradients may reorder)."""
     import copy
     from cl4wsis_amd.train import Trainer
@@ -325,9 +325,11 @@ def test_pipelined_replay_matches_plain_graph_replay(gpu, monkeypatch):
         tr = Trainer(_L(), gpu, copy.deepcopy(opts))
         assert tr._pipeline == (mode == "1")
         losses = []
-        for t in range(6):
+        for t in range(8):
+            # step 2 announces nothing (the end of an epoch) and step 3 brings a DIFFERENT batch than the one last seen: the old-model
+            # maps prefetched by step 2 must not be taken for it
             b, nb = batches[t % 2], batches[(t + 1) % 2]
-            out = tr.step(b, next_batch=nb if t < 5 else None)
+            out = tr.step(b, next_batch=None if t in (2, 7) else nb)
             losses.append(out["losses"].clone())
         torch.cuda.synchronize()
         assert (tr._pipe is not None) == (mode == "1") and (tr._graph is not None) == (mode == "0")
@@ -335,8 +337,11 @@ def test_pipelined_replay_matches_plain_graph_replay(gpu, monkeypatch):
     l0, w0 = results["0"]
     l1, w1 = results["1"]
     assert torch.isfinite(l1).all()
-    assert torch.allclose(l0, l1, rtol=2e-3, atol=1e-6), (l0, l1)
+    dev = ((l0 - l1).abs() / l0.abs().clamp_min(1e-6)).max(1).values      # per step
+    # the reordered fp32 atomics of the weight gradients grow through the discrete label stage step by step (measured: 0, 0, 1e-7,
+    # 4e-7, 2e-5, 8e-4, 2e-3, 4e-3); a wrong old-model map at step 3 would show there, as a deviation of order one
+    assert torch.allclose(l0[:6], l1[:6], rtol=2e-3, atol=1e-6) and (dev[6:] < 3e-2).all(), (dev, l0, l1)
     lr = opts.lr * opts.lr_head
     for k in w0:
         if w0[k].is_floating_point():                      # Adam: up to +-lr per step where a gradient is numerically zero
-            assert (w0[k] - w1[k]).abs().max() <= 3.2 * lr * 6 + 1e-6 * w0[k].abs().max(), k
+            assert (w0[k] - w1[k]).abs().max() <= 3.2 * lr * 8 + 1e-6 * w0[k].abs().max(), k
