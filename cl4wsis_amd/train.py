@@ -210,7 +210,7 @@ class Trainer:
             self.optimizer.step()
         elif (self._pipeline and images.shape[0] >= self._pipe_min_b and
               (next_batch is not None or (self._pipe is not None and self._pipe["have_old"][self._pipe["cur"]]))):
-            out = self._replay_pipelined(images, l1h, next_batch)
+            out = self._replay_pipelined(images, l1h, next_batch, batch)
         else:
             out = self._replay(images, l1h)
         if self.scheduler is not None:
@@ -322,7 +322,7 @@ class Trainer:
     # of the next batch thus runs beside this step's trainable branch / label stage / backward / Adam — mostly memory-bound
     # kernels — instead of beside the new model's forward, which is the same kind of work. (Two separate graphs on two streams do
     # not overlap on this ROCm: their replays serialise — measured 49.2 vs 45.7 ms — so the fork has to live inside one graph.)
-    def _replay_pipelined(self, images, l1h, next_batch):
+    def _replay_pipelined(self, images, l1h, next_batch, batch=None):
         opt = self.optimizer
         if self._pipe is None:
             opt.upload_lr()
@@ -361,6 +361,8 @@ class Trainer:
             self._pipe = P
         P = self._pipe
         p = P["cur"]
+        if P["have_old"][p] and P.get("announced") is not batch:
+            P["have_old"][p] = False                     # the caller came with another batch object than it announced: prefetch void
         P["x"][p].copy_(images)
         P["l"][p].copy_(l1h)
         if not P["have_old"][p]:                         # not announced by the previous call: the old model runs now, up front
@@ -378,6 +380,7 @@ class Trainer:
                 P["x"][1 - p].copy_(nx.to(self.device, dtype=torch.float32))
                 P["l"][1 - p].copy_(nl.to(self.device, dtype=torch.float32))
                 announced = True
+        P["announced"] = next_batch if announced else None       # identity of the promise (held, so that its id cannot be reused)
         opt.upload_lr()
         P["g"][p].replay()
         P["have_old"][p] = False
