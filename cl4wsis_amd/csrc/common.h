@@ -24,6 +24,10 @@ static inline int launch_status() {
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// memset(p, value, bytes) as a kernel launch of this library (api.hip). Every fill of the step path goes through it instead of
+// hipMemsetAsync, so that a captured step consists of kernel nodes only (CL4_MEMSET_KERNEL=0 restores hipMemsetAsync: experiments).
+hipError_t fill_bytes_async(void* p, int value, size_t bytes, hipStream_t st);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Grid size for a grid-stride elementwise / streaming kernel: enough workgroups to

@@ -324,9 +324,9 @@ extern "C" int cl4_target_generation(const long long* seg_map, const uint8_t* ma
   hipStream_t st = cl4::as_stream(stream);
   const long hw = (long)H * W;
   InstStat* stat = (InstStat*)workspace;
-  hipError_t e = hipMemsetAsync(center, 0, (size_t)b * num_classes * hw * sizeof(float), st);
-  if (e == hipSuccess) e = hipMemsetAsync(offset, 0, (size_t)b * 2 * hw * sizeof(float), st);
-  if (e == hipSuccess) e = hipMemsetAsync(weight, 0, (size_t)b * hw * sizeof(float), st);
+  hipError_t e = cl4::fill_bytes_async(center, 0, (size_t)b * num_classes * hw * sizeof(float), st);
+  if (e == hipSuccess) e = cl4::fill_bytes_async(offset, 0, (size_t)b * 2 * hw * sizeof(float), st);
+  if (e == hipSuccess) e = cl4::fill_bytes_async(weight, 0, (size_t)b * hw * sizeof(float), st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(inst_init_kernel, dim3(cl4::cdiv((long)b * 256, 256)), dim3(256), 0, st, stat, b * 256);
   const int g = cl4::cdiv(hw, 256 * 4);

@@ -287,12 +287,20 @@ __global__ __launch_bounds__(256) void peak_topk_kernel(PeakCand* __restrict__ c
 // ---------------------------------------------------------------------------------------------
 constexpr int SEG_ROWS = 16;   // output rows per workgroup (halved until the low-resolution band fits LDS)
 constexpr int SEG_MAXC = 96;   // 21 on VOC, 81 on coco-voc
+constexpr int SEG_REGC = 24;   // class counts up to this keep the per-pixel logits in registers (VOC); beyond: recomputed per pass
 
+// No per-thread arrays with run-time indices here. The r02 kernel kept `float v[SEG_MAXC], mask[SEG_MAXC]` per thread = 784 bytes of
+// scratch (private segment) per lane, ~410 MB for a full chip of waves: above the runtime's per-dispatch scratch limit, so the
+// memory is mapped for one dispatch and reclaimed after it. A captured single-stream step replays a pre-built dispatch packet and
+// the kernel then wrote its private arrays through a stale mapping ("write access to a read-only page"). REGC > 0:
+// fully unrolled loops over REGC classes with compile-time indices (registers); REGC == 0: the logits are re-sampled from LDS in each
+// of the three passes (max, sum of exponentials, arg-max) — the same expressions in the same order, so the same bits.
+template <int REGC>
 __global__ __launch_bounds__(256) void seg_pseudo_gt_kernel(const float* __restrict__ seg2b, const float* __restrict__ l1h,
                                                             int bs, int C, int h, int w, int H, int W, int old_classes,
                                                             int no_mask, int band, int seg_rows, uint8_t* __restrict__ seg_gt,
                                                             float* __restrict__ old_w, float* __restrict__ prob_win) {
-  extern __shared__ float lds[];  // [C][band][w] flip-TTA mean of the logits
+  extern __shared__ float lds[];  // [C][band][w] flip-TTA mean of the logits, then [C] class mask
   const int b = blockIdx.y;
   const int Y0 = blockIdx.x * seg_rows;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
@@ -308,33 +316,48 @@ __global__ __launch_bounds__(256) void seg_pseudo_gt_kernel(const float* __restr
     float f = seg2b[((long)(bs + b) * C + c) * plane + y * w + (w - 1 - x)];
     lds[i] = (a + f) / 2.f;
   }
-  __syncthreads();
-  float mask[SEG_MAXC];
-  for (int c = 0; c < C; ++c) {
+  float* mask = lds + C * band * w;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float m = 1.f;
     if (no_mask) { if (c >= 1) m = l1h[b * (C - 1) + c - 1]; }
     else if (c >= old_classes) m = l1h[b * (C - 1) + c - 1];
     mask[c] = m;
   }
+  __syncthreads();
   const int rows = min(seg_rows, H - Y0);
   for (int i = threadIdx.x; i < rows * W; i += blockDim.x) {
     int yy = i / W, X = i - yy * W;
     int Y = Y0 + yy;
     Bilin by = bilin_half_pixel(Y, sy, h), bx = bilin_half_pixel(X, sx, w);
     by.i0 -= ylo; by.i1 -= ylo;  // band-relative rows
-    float v[SEG_MAXC];
     float mx = -INFINITY;
-    for (int c = 0; c < C; ++c) {
-      v[c] = bilin_sample(lds + c * band * w, w, by, bx);
-      mx = fmaxf(mx, v[c]);
-    }
     float sum = 0.f;
-    for (int c = 0; c < C; ++c) { v[c] = expf(v[c] - mx); sum += v[c]; }
     int arg = 0;
     float best = -INFINITY;
-    for (int c = 0; c < C; ++c) {
-      float p = (v[c] / sum) * mask[c];
-      if (p > best) { best = p; arg = c; }
+    if constexpr (REGC > 0) {
+      float v[REGC];
+#pragma unroll
+      for (int c = 0; c < REGC; ++c)
+        if (c < C) {
+          v[c] = bilin_sample(lds + c * band * w, w, by, bx);
+          mx = fmaxf(mx, v[c]);
+        }
+#pragma unroll
+      for (int c = 0; c < REGC; ++c)
+        if (c < C) { v[c] = expf(v[c] - mx); sum += v[c]; }
+#pragma unroll
+      for (int c = 0; c < REGC; ++c)
+        if (c < C) {
+          float p = (v[c] / sum) * mask[c];
+          if (p > best) { best = p; arg = c; }
+        }
+    } else {
+      for (int c = 0; c < C; ++c) mx = fmaxf(mx, bilin_sample(lds + c * band * w, w, by, bx));
+      for (int c = 0; c < C; ++c) sum += expf(bilin_sample(lds + c * band * w, w, by, bx) - mx);
+      for (int c = 0; c < C; ++c) {
+        float p = (expf(bilin_sample(lds + c * band * w, w, by, bx) - mx) / sum) * mask[c];
+        if (p > best) { best = p; arg = c; }
+      }
     }
     long o = ((long)b * H + Y) * W + X;
     old_w[o] = (arg < old_classes && arg != 0) ? 1.f : 0.f;
@@ -612,14 +635,18 @@ extern "C" int cl4_seg_pseudo_gt(const float* seg2b, const float* l1h, int bs, i
   for (;;) {
     band = (int)((float)rows * (float)h / (float)H) + 3;
     if (band > h) band = h;
-    lds = (size_t)C * band * w * sizeof(float);
+    lds = ((size_t)C * band * w + C) * sizeof(float);
     if (lds <= 64 * 1024 || rows == 1) break;
     rows /= 2;
   }
   CL4_REQUIRE(lds <= 64 * 1024, "seg_pseudo_gt: low-res band does not fit LDS");
   dim3 g(cl4::cdiv(H, rows), bs);
-  hipLaunchKernelGGL(seg_pseudo_gt_kernel, g, dim3(256), lds, cl4::as_stream(stream), seg2b, l1h, bs, C, h, w, H, W,
-                     old_classes, no_mask, band, rows, seg_gt, old_w, prob_win);
+  if (C <= SEG_REGC)
+    hipLaunchKernelGGL(seg_pseudo_gt_kernel<SEG_REGC>, g, dim3(256), lds, cl4::as_stream(stream), seg2b, l1h, bs, C, h, w, H, W,
+                       old_classes, no_mask, band, rows, seg_gt, old_w, prob_win);
+  else
+    hipLaunchKernelGGL(seg_pseudo_gt_kernel<0>, g, dim3(256), lds, cl4::as_stream(stream), seg2b, l1h, bs, C, h, w, H, W,
+                       old_classes, no_mask, band, rows, seg_gt, old_w, prob_win);
   return cl4::launch_status();
 }
 
@@ -641,9 +668,9 @@ extern "C" int cl4_cc_stats(const int* labels, int b, int H, int W, unsigned* ar
   CL4_REQUIRE(labels && area && sumx && sumy && b > 0 && H > 0 && W > 0, "cc_stats: bad arguments");
   hipStream_t st = cl4::as_stream(stream);
   size_t bytes = (size_t)b * H * W * sizeof(unsigned);
-  hipMemsetAsync(area, 0, bytes, st);
-  hipMemsetAsync(sumx, 0, bytes, st);
-  hipMemsetAsync(sumy, 0, bytes, st);
+  cl4::fill_bytes_async(area, 0, bytes, st);
+  cl4::fill_bytes_async(sumx, 0, bytes, st);
+  cl4::fill_bytes_async(sumy, 0, bytes, st);
   int rpr = cl4::cdiv(W, RUN);
   long runs = (long)b * H * rpr;
   hipLaunchKernelGGL(cc_stats_kernel, dim3(cl4::stream_grid(runs, 256)), dim3(256), 0, st, labels, H, W, runs, rpr, area, sumx, sumy);

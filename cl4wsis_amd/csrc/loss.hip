@@ -188,7 +188,7 @@ extern "C" int cl4_p2_loss(const cl4_p2_loss_io* d, void* workspace, size_t work
   const int ctot = d->cold + d->cnew;
   a.g_center = with_grad ? (float*)((char*)workspace + 256) : nullptr;
   a.g_offset = with_grad ? a.g_center + (size_t)d->b * ctot * d->H * d->W : nullptr;
-  hipMemsetAsync(a.acc, 0, 64, st);
+  cl4::fill_bytes_async(a.acc, 0, 64, st);
   const int g = cl4::stream_grid(N, 256);
   hipLaunchKernelGGL(loss_count_kernel, dim3(g), dim3(256), 0, st, a);
   hipLaunchKernelGGL(loss_main_kernel, dim3(g), dim3(256), 0, st, a);
@@ -277,6 +277,6 @@ extern "C" int cl4_sgd_step(float* p, const float* g, float* buf, long n, float 
 
 extern "C" int cl4_fill_zero(void* p, size_t bytes, void* stream) {
   CL4_REQUIRE(p && bytes > 0, "fill_zero: bad arguments");
-  hipError_t e = hipMemsetAsync(p, 0, bytes, cl4::as_stream(stream));
+  hipError_t e = cl4::fill_bytes_async(p, 0, bytes, cl4::as_stream(stream));
   return e == hipSuccess ? CL4_OK : (int)e;
 }

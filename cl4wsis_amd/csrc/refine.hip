@@ -545,10 +545,10 @@ extern "C" int cl4_label_generation(const cl4_label_io* d, void* workspace, size
   hipStream_t st = cl4::as_stream(stream);
   const int g = cl4::stream_grid(N, 256);
   const size_t cmap = (size_t)d->b * d->cnew * d->H * d->W * sizeof(float);
-  hipMemsetAsync(ws.cnt, 0, sizeof(Counters), st);
-  hipMemsetAsync(ws.pcnt, 0, N * 4, st);
-  hipMemsetAsync(ws.cid_map, 0xFF, N * 4, st);
-  hipMemsetAsync(io.p_center, 0, cmap, st);
+  cl4::fill_bytes_async(ws.cnt, 0, sizeof(Counters), st);
+  cl4::fill_bytes_async(ws.pcnt, 0, N * 4, st);
+  cl4::fill_bytes_async(ws.cid_map, 0xFF, N * 4, st);
+  cl4::fill_bytes_async(io.p_center, 0, cmap, st);
   int rc = cl4_ccl(io.seg_gt, d->b, d->H, d->W, 8, ws.L8, stream);
   if (rc) return rc;
   rc = cl4_cc_stats(ws.L8, d->b, d->H, d->W, ws.area, ws.sumx, ws.sumy, stream);
@@ -558,10 +558,10 @@ extern "C" int cl4_label_generation(const cl4_label_io* d, void* workspace, size
   hipLaunchKernelGGL(pseudo_splat_kernel, dim3(512), dim3(256), 0, st, io, ws);
   if (!d->run_refine) return cl4::launch_status();
 
-  hipMemsetAsync(io.r_center, 0, cmap, st);
-  hipMemsetAsync(ws.mark, 0, N, st);
-  hipMemsetAsync(ws.ins_id, 0, N, st);
-  hipMemsetAsync(ws.inst, 0, sizeof(Inst) * (size_t)CT_CAP * (MAX_INST + 1), st);
+  cl4::fill_bytes_async(io.r_center, 0, cmap, st);
+  cl4::fill_bytes_async(ws.mark, 0, N, st);
+  cl4::fill_bytes_async(ws.ins_id, 0, N, st);
+  cl4::fill_bytes_async(ws.inst, 0, sizeof(Inst) * (size_t)CT_CAP * (MAX_INST + 1), st);
   hipLaunchKernelGGL(weak_map_kernel, dim3(g), dim3(256), 0, st, io, ws);
   rc = cl4_ccl(ws.weak, d->b, d->H, d->W, 4, ws.L4, stream);
   if (rc) return rc;
@@ -631,18 +631,18 @@ extern "C" int cl4_instance_map(const cl4_insmap_io* d, void* workspace, size_t 
 
   hipStream_t st = cl4::as_stream(stream);
   const int g = cl4::stream_grid(N, 256);
-  hipMemsetAsync(ws.cnt, 0, sizeof(Counters), st);
-  hipMemsetAsync(ws.pcnt, 0, N * 4, st);
-  hipMemsetAsync(ws.cid_map, 0xFF, N * 4, st);
-  hipMemsetAsync(d->ins_map, 0xFF, N * 4, st);
+  cl4::fill_bytes_async(ws.cnt, 0, sizeof(Counters), st);
+  cl4::fill_bytes_async(ws.pcnt, 0, N * 4, st);
+  cl4::fill_bytes_async(ws.cid_map, 0xFF, N * 4, st);
+  cl4::fill_bytes_async(d->ins_map, 0xFF, N * 4, st);
   int rc = cl4_ccl(io.seg_gt, 1, d->H, d->W, 8, ws.L8, stream);
   if (rc) return rc;
   rc = cl4_cc_stats(ws.L8, 1, d->H, d->W, ws.area, ws.sumx, ws.sumy, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(pseudo_paint_kernel, dim3(g), dim3(256), 0, st, io, ws);      // registers the contours
-  hipMemsetAsync(ws.mark, 0, N, st);
-  hipMemsetAsync(ws.ins_id, 0, N, st);
-  hipMemsetAsync(ws.inst, 0, sizeof(Inst) * (size_t)CT_CAP * (MAX_INST + 1), st);
+  cl4::fill_bytes_async(ws.mark, 0, N, st);
+  cl4::fill_bytes_async(ws.ins_id, 0, N, st);
+  cl4::fill_bytes_async(ws.inst, 0, sizeof(Inst) * (size_t)CT_CAP * (MAX_INST + 1), st);
   hipLaunchKernelGGL(weak_map_kernel, dim3(g), dim3(256), 0, st, io, ws);
   rc = cl4_ccl(ws.weak, 1, d->H, d->W, 4, ws.L4, stream);
   if (rc) return rc;

@@ -120,18 +120,66 @@ def bn_fold(gamma, beta, mean, var, eps=1e-5):
     return scale, shift
 
 
-_conv_ws = {}
+class _Scratch:
+    """Scratch buffers that kernels address by raw pointer — and that captured HIP graphs therefore keep addressing on every
+    replay. Rules (r03; the r02 caches replaced a buffer on growth and so freed memory a live graph still wrote to):
+
+    * one buffer per (device, stream) key: kernels of different streams run concurrently and must not share scratch;
+    * a buffer that has to grow is RETIRED, never freed: the old tensor moves to `retired` and stays alive, so an address baked
+      into a captured kernel remains this module's memory for the life of the process (growth is geometric, so the retired
+      buffers of a key sum to less than the live one; `release_retired()` frees them once the caller knows no graph is alive);
+    * a key seen for the first time (the capture stream of torch.cuda.graph is one) starts at the largest size any stream of the
+      device has needed so far, so a capture that follows an eager warm-up step never grows a buffer inside the capture."""
+
+    def __init__(self, min_bytes):
+        self.min_bytes = min_bytes
+        self.cur = {}
+        self.retired = []
+        self.peak = {}          # device index -> largest request so far
+        self.events = []        # (stream key, bytes, allocated while capturing, address of the buffer it retired or 0): diagnostics
+
+    def get(self, device, nbytes, per_stream=True):
+        idx = device.index if device.type == "cuda" else -1
+        key = (device.type, idx, torch.cuda.current_stream().cuda_stream if (per_stream and device.type == "cuda") else 0)
+        nbytes = int(nbytes)
+        peak = self.peak[idx] = max(self.peak.get(idx, 0), nbytes)
+        ws = self.cur.get(key)
+        if ws is None or ws.numel() < nbytes:
+            size = max(peak, self.min_bytes)
+            if ws is not None:
+                self.retired.append(ws)
+                size = max(size, ws.numel() + ws.numel() // 2)
+            old = ws.data_ptr() if ws is not None else 0
+            ws = torch.empty(size, dtype=torch.uint8, device=device)
+            self.cur[key] = ws
+            self.events.append((key[2], size, device.type == "cuda" and torch.cuda.is_current_stream_capturing(), old))
+        return ws
+
+    def live(self):
+        return list(self.cur.values()) + list(self.retired)
+
+    def release_retired(self):
+        self.retired.clear()
+
+
+_conv_scratch = _Scratch(64 << 20)
 
 
 def _conv_workspace(device, nbytes):
-    """Split-K scratch of the forward conv — one buffer PER STREAM (kernels of different streams run concurrently and
-    must not share scratch); it never aliases the BN / loss workspaces."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
-    ws = _conv_ws.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _conv_ws[key] = ws
-    return ws
+    """Split-K scratch of the forward conv — one buffer PER STREAM; it never aliases the BN / loss workspaces."""
+    return _conv_scratch.get(device, nbytes)
+
+
+def workspace_snapshot():
+    """Strong references to every scratch buffer of this module (live and retired). The owner of a captured graph may hold the
+    list next to the graph; with the retire-on-growth rule of `_Scratch` it is a second lock on the same door."""
+    return _conv_scratch.live() + _misc_scratch.live() + _input_scratch.live() + list(_label_ws.values())
+
+
+def release_retired_workspaces():
+    """Free the buffers that growth has retired. Only safe when no captured graph of this process is alive."""
+    for s in (_conv_scratch, _misc_scratch, _input_scratch):
+        s.release_retired()
 
 
 AUTOTUNE = False      # set True during warm-up (Trainer / bench): time the launch plans of every new conv shape once
@@ -514,16 +562,11 @@ def copy_channels(x, out, c, in_coff=0, out_coff=0):
 # ---------------------------------------------------------------------------------------------
 # train-mode BatchNorm / dropout / depthwise conv
 # ---------------------------------------------------------------------------------------------
-_ws_cache = {}
+_misc_scratch = _Scratch(1 << 20)
 
 
 def _workspace(device, nbytes):
-    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
-    return ws
+    return _misc_scratch.get(device, nbytes)
 
 
 def bn_workspace_bytes(c):
@@ -777,10 +820,12 @@ def label_generation(seg_gt, prob_win, label_new, peaks, center_lo, offset_lo, g
     if run_refine:
         d.r_center, d.r_offset, d.r_weight = pv(refined["center"]), pv(refined["offset"]), pv(refined["weight"])
     nbytes = _hip.load().cl4_label_workspace_bytes(b, H, W)
+    # one buffer per (device, size), kept for the life of the process: the label kernels keep their counters in it between
+    # launches, and a captured step addresses it on every replay — an eager call at another batch size (the short last batch of
+    # an epoch) used to clear this table and free the buffer under the graph (r02)
     key = (dev.index, nbytes)
     ws = _label_ws.get(key)
     if ws is None:
-        _label_ws.clear()
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _label_ws[key] = ws
     call("cl4_label_generation", C.byref(d), ptr(ws), ws.numel(), stream())
@@ -1244,16 +1289,7 @@ def instance_map(seg_map, prob_win, center, offset, thresh=0.1, nms_kernel=41, b
 # ---------------------------------------------------------------------------------------------------------------------
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
-_input_ws = {}
-
-
-def _ws_u8(cache, device, nbytes):
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
-    ws = cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        cache[key] = ws
-    return ws
+_input_scratch = _Scratch(1 << 20)
 
 
 def input_batch(images, descs, out_hw, labels=None, lut=None, want_mask=True, mean=IMAGENET_MEAN, std=IMAGENET_STD):
@@ -1280,7 +1316,7 @@ def input_batch(images, descs, out_hw, labels=None, lut=None, want_mask=True, me
     seg = torch.empty((b, oh, ow), dtype=torch.int64, device=dev) if labels is not None else None
     mask = torch.empty((b, oh, ow), dtype=torch.uint8, device=dev) if labels is not None and want_mask else None
     need = lib.cl4_input_workspace_bytes(b, oh, ow, max(max_ch, 1), max(ks, 1))
-    ws = _ws_u8(_input_ws, dev, need)
+    ws = _input_scratch.get(dev, need)
     m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
     call("cl4_input_batch", ptr(images), images.numel(), ptr(labels), labels.numel() if labels is not None else 0, arr, b, oh, ow,
          m3, s3, ptr(lut), ptr(img), ptr(seg), ptr(mask), ptr(ws), ws.numel(), stream())

@@ -92,17 +92,10 @@ class Trainer:
         self._iter = 0
         self._side_stream = torch.cuda.Stream(device=self.device) if os.environ.get("CL4_OVERLAP", "1") != "0" else None
         self._use_graph = os.environ.get("CL4_GRAPH", "1") != "0"
-        if self._side_stream is None and self._use_graph:
-            # OPEN ISSUE (r02g): graph replay of the single-stream step (CL4_OVERLAP=0 is a measurement switch; tools/prof_pmc.sh uses it
-            # with CL4_GRAPH=0) faulted sporadically on the GPU ("write access to a read-only page", 4 of 9 runs of 30 steps) once the
-            # planes kernels and autotuned split-tail plans were in; eager single-stream steps and every two-stream configuration (the
-            # default, ~60 bench runs and the whole GPU suite) never did. Not root-caused: the combination is disabled rather than
-            # left armed ("Open issue").
-            self._use_graph = False
         self._graph, self._static, self._graph_active = None, None, False
         # Software pipelining across iterations (single-GPU graph mode): the frozen old model's forward of batch t+1 is replayed on
         # its own stream while batch t's step runs (it depends on nothing the optimizer touches). CL4_PIPELINE=0 switches it off.
-        self._pipeline = os.environ.get("CL4_PIPELINE", "1") != "0"
+        self._pipeline = os.environ.get("CL4_PIPELINE", "1") != "0" and self._side_stream is not None   # the fork needs a second stream
         self._pipe = None
         # per-GPU batches below this stay on the one-graph path: measured +4.8 % at b = 16, +1-2 % at 8 / 4, -1.8 % at 2 (where the chip
         # is far from full and the old model is better placed beside the new model's forward)
@@ -300,8 +293,11 @@ class Trainer:
         # The captured kernels read the frozen networks' packed weights / folded BN at fixed addresses; those tensors were cached by
         # the eager first iteration and would be freed (and their memory reused) by the first eager rebuild after a CACHE.clear()
         # — validation between epochs, an eager fallback step. Holding them for the life of the graph keeps the addresses valid.
+        # The scratch buffers the captured kernels address (split-K slabs, BN / loss / label workspaces) ride along: ops._Scratch
+        # never frees a buffer it has handed out, this list is the graph owner's own reference to the same memory.
         from .nn import CACHE
-        return CACHE.snapshot([self.model, self.model_old, getattr(self, "pseudolabeler", None), getattr(self, "peakgenerator", None)])
+        return (CACHE.snapshot([self.model, self.model_old, getattr(self, "pseudolabeler", None), getattr(self, "peakgenerator", None)])
+                + ops.workspace_snapshot())
 
     def _distributed_tail(self, out):
         # N > 1: the graph ends where the ASPP block's backward begins. Those last kernels produce 90 % of the gradient
