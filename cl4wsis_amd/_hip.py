@@ -96,6 +96,8 @@ _decl("cl4_conv2d_wgrad", C.POINTER(ConvDesc), _P, _P, _P, _P)
 _decl("cl4_bn_fold", _P, _P, _P, _P, _F, _P, _P, _I, _P)
 
 _decl("cl4_maxpool3x3s2", _P, _P, _L, _I, _I, _I, _I, _P)
+_decl("cl4_pack_stem_weight", _P, _P, _P)
+_decl("cl4_stem_fused", _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P)
 _decl("cl4_avgpool_s1", _P, _P, _L, _I, _I, _I, _I, _P)
 _decl("cl4_replicate_pad", _P, _P, _L, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_global_mean", _P, _P, _L, _I, _P)
@@ -208,6 +210,8 @@ def load():
     for nm in ("cl4_conv_debug_u_launches", "cl4_conv_debug_s_launches"):
         getattr(lib, nm).restype = C.c_long
         getattr(lib, nm).argtypes = []
+    lib.cl4_stem_weight_bytes.restype = C.c_size_t
+    lib.cl4_stem_weight_bytes.argtypes = []
     lib.cl4_input_ksize.restype = C.c_int
     lib.cl4_input_ksize.argtypes = [C.c_int, C.c_int]
     for name, args in PROTOTYPES.items():

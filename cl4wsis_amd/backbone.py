@@ -13,6 +13,11 @@ from . import ops
 from .nn import ABN, conv_abn, conv_abn_planes, gamma_of, packed_weight, planes_of, planes_ok
 
 
+import os
+
+STEM_FUSED = os.environ.get("CL4_STEM_FUSED", "1") != "0"      # 0: conv + ABN launch followed by a max-pool launch (the r02 path)
+
+
 class _Holder(nn.Module):
     """A named container of sub-modules (keeps state_dict prefixes; has no forward of its own)."""
 
@@ -107,10 +112,21 @@ class ResNet(nn.Module):
         self.out_channels = in_ch
 
     def forward(self, x):
-        y = conv_abn(x, self.mod1.conv1, self.mod1.bn1)
-        outs = [ops.maxpool3x3s2(y)]
         frozen = not (self.training and any(p.requires_grad for p in self.parameters()))
         yp = None                                              # planes twin of y (nn.CONV_PLANES), carried across blocks and stages
+        c1, b1 = self.mod1.conv1, self.mod1.bn1
+        if (frozen and STEM_FUSED and ops.CONV_PRECISION == 1 and isinstance(b1, ABN) and b1.activation == "leaky_relu"
+                and x.is_contiguous()):
+            # conv 7x7/2 + ABN + max-pool in one kernel (csrc/stem.hip): the 257 x 257 x 64 map is never written
+            from .nn import CACHE, CONV_PLANES, folded_bn
+            wq = CACHE.get(c1, "stemq", (c1.weight,), lambda: ops.pack_stem_weight(c1.weight.detach()))
+            scale, shift = folded_bn(b1)
+            y0, yp = ops.stem_fused(x, wq, scale, shift, slope=float(b1.activation_param),
+                                    want_planes=CONV_PLANES and self.mod2[0].planes_capable())
+            outs = [y0]
+        else:
+            y = conv_abn(x, c1, b1)
+            outs = [ops.maxpool3x3s2(y)]
         for m in (self.mod2, self.mod3, self.mod4, self.mod5):
             y = outs[-1]
             for i, blk in enumerate(m):

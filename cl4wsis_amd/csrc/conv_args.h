@@ -47,6 +47,7 @@ int launch_conv_u(const ConvArgs& a, int ks, bool split, unsigned grid, hipStrea
 
 // conv_s.hip: the planes-input bf16x3 kernel (activations arrive pre-split: no conversion in the K loop). Any stride / pad / dilation,
 // ks = 1 | 3, cin % 32 == 0. Same launch conventions as launch_conv_u.
-int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st);
+// bn = pixels per tile: 128, or 144 (one round of the 33 x 33 maps, see conv_s.hip).
+int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st, int bn = 128);
 
 }  // namespace cl4

@@ -1296,6 +1296,8 @@ struct FwdPlan {
                // last partial round is split `tail` ways (kchunk is then the tail's K range); 1 = "main + small-tile tail": the
                // last partial round of a 128x128 plan runs as 64x64 tiles (4x the workgroups, a quarter of the work each — for
                // short-K layers where splitting K further is pointless); 0 = plain
+  int bn = 0;  // pixels per tile where they differ from `tile` (planes-input kernel: 144, see conv_s.hip); 0 = same as `tile`
+  int pix() const { return bn ? bn : tile; }
 };
 
 // Measured plans (cl4_conv2d_fwd_set_plan, filled by the host-side autotuner during warm-up) override the heuristic.
@@ -1312,7 +1314,8 @@ FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision
   FwdPlan p{1, 128, 1, 0, 0};
   if (impl != 2 || cout % 4 != 0 || cout < 64) return p;
   p.impl = 2;
-  p.tile = ((tile == 128 && cout >= 128) || precision == 3) ? 128 : 64;      // planes-input kernel (precision code 3): 128x128 only
+  p.tile = ((tile == 128 && cout >= 128) || precision == 3) ? 128 : 64;      // planes-input kernel (precision code 3): 128 output channels per tile
+  if (precision == 3 && tile == 144) p.bn = 144;                             // ... x 128 or 144 pixels
   const int ktiles = cl4::cdiv(K, BK2);
   int s = splits < 0 ? -splits : (splits < 1 ? 1 : splits);
   if (s > ktiles) s = ktiles;
@@ -1368,7 +1371,7 @@ struct TailGeom { int gx, ntiles, main, p0; };
 TailGeom tail_geometry(const FwdPlan& pl, int cout, int npix, int precision) {
   TailGeom g;
   g.gx = cl4::cdiv(cout, pl.tile);
-  g.ntiles = g.gx * cl4::cdiv(npix, pl.tile);
+  g.ntiles = g.gx * cl4::cdiv(npix, pl.pix());
   g.main = 0;
   g.p0 = 0;
   if (pl.tail > 0) {
@@ -1376,7 +1379,7 @@ TailGeom tail_geometry(const FwdPlan& pl, int cout, int npix, int precision) {
     if (g.ntiles < slots + slots / 16) slots = 256;
     int m = (g.ntiles / slots) * slots;
     m -= m % g.gx;
-    if (m > 0 && m < g.ntiles) { g.main = m; g.p0 = (m / g.gx) * pl.tile; }
+    if (m > 0 && m < g.ntiles) { g.main = m; g.p0 = (m / g.gx) * pl.pix(); }
   }
   return g;
 }
@@ -1480,7 +1483,7 @@ int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace
     auto go = [&](int base, int ntile, int sp) {
       a.tile_base = base;
       a.ntile_l = ntile;
-      return cl4::launch_conv_s(a, KS, sp > 1, (unsigned)ntile * (unsigned)(sp > 1 ? sp : 1), st);
+      return cl4::launch_conv_s(a, KS, sp > 1, (unsigned)ntile * (unsigned)(sp > 1 ? sp : 1), st, pl.pix());
     };
     int rc;
     if (hybrid) {
@@ -2126,7 +2129,7 @@ extern "C" int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int til
   std::lock_guard<std::mutex> g(plan_mutex());
   if (impl == 0) { plan_table().erase(key); return CL4_OK; }
   CL4_REQUIRE(impl == 1 || impl == 2, "set_plan: impl must be 0, 1 or 2");
-  CL4_REQUIRE(tile == 64 || tile == 128, "set_plan: tile must be 64 or 128");
+  CL4_REQUIRE(tile == 64 || tile == 128 || (tile == 144 && d->precision == 3), "set_plan: tile must be 64 or 128 (144: planes-input launches only)");
   plan_table()[key] = make_plan(impl, tile, splits, d->cout, K, d->precision);
   return CL4_OK;
 }

@@ -37,9 +37,8 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define CL4_S_DBG 0   // experiments only: 1 = no loads in the loop, 2 = no LDS stores, 4 = no MFMA
 #endif
 
-constexpr int BM = 128, BN = 128, BKS = 32, P = 2, KG = 4;
+constexpr int BM = 128, BKS = 32, P = 2, KG = 4;
 constexpr int A_CHUNKS = KG * P * BM;
-constexpr int B_CHUNKS = KG * P * BN;
 constexpr unsigned OOB = 0x80000000u;
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {   // {bf16(lo), bf16(hi)} in one dword (round to nearest even)
@@ -70,14 +69,122 @@ __device__ __forceinline__ void join8(const u32x4& hi, const u32x4& lo, float (&
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int KS, bool SPLIT, int MF>
+// ---- fused epilogue of one thread, r03: NG 8-channel groups g0, g0 + gstep, ... of the tile's 16, for ONE pixel column of the tile.
+// y = act2( act1( (acc + pre) * scale + shift ) + post ); written as fp32 NCHW rows (a.y) and / or as planes chunks (a.ys).
+// Two halves, called on either side of the accumulator parking: `issue` requests EVERY residual operand of the thread (16 x 16 bytes
+// for a planes residual, 64 dwords for an fp32 one) in one burst — one memory round trip per tile instead of one per group, and it
+// runs under the parking and the barrier; `finish` is straight-line code (no loop-carried wait): LDS reads, arithmetic and the 16 / 64
+// stores of the thread stream out with counted waits on the loads only. The r02 loop (one group per iteration: load, wait, store)
+// made every iteration's load wait behind the previous iteration's stores (vmcnt is in order): res4 conv3 at n = 32 112.8 -> 103.5 us,
+// with fp32 output 125 -> 108 us (profiles/r03_conv_s_epilogue.txt).
+// RES: 0 no residual, 1 fp32 (a.post), 2 planes (a.post_s). Separate instantiations on purpose: a merged body (r02e) came out wrong.
+template <int RES, int NG, int BNT>
+struct SEpilogue {
+  u32x4 rh[NG], rl[NG];      // RES == 2
+  float rf[NG][8];           // RES == 1
+  __device__ __forceinline__ void issue(const ConvArgs& a, int m0, int g0, int gstep, bool pvalid, int pn, int phw, int HWo) {
+    if constexpr (RES == 2) {
+#pragma unroll
+      for (int it = 0; it < NG; ++it) {
+        const int co0 = m0 + (g0 + gstep * it) * 8;
+        if (pvalid && co0 < a.cout) {
+          const u32x4* ps = reinterpret_cast<const u32x4*>(a.post_s) + (((long)pn * (a.cout >> 3) + (co0 >> 3)) * 2) * HWo + phw;
+          rh[it] = ps[0];
+          rl[it] = ps[HWo];
+        }
+      }
+    } else if constexpr (RES == 1) {
+      const long rbase = (long)pn * a.cout * HWo + phw;
+#pragma unroll
+      for (int it = 0; it < NG; ++it) {
+        const int co0 = m0 + (g0 + gstep * it) * 8;
+        if (pvalid && co0 < a.cout) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) rf[it][r] = a.post[rbase + (long)min(co0 + r, a.cout - 1) * HWo];
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void finish(const ConvArgs& a, const float* stage, const float* affine, int m0, int col, int g0, int gstep,
+                                         bool pvalid, int pn, int phw, int HWo) {
+    const long ybase = ((long)pn * a.out_ctot + a.out_coff) * HWo + phw;
+    const long rbase = (long)pn * a.cout * HWo + phw;
+    const int oc8tot = a.out_ctot >> 3;
+#pragma unroll
+    for (int it = 0; it < NG; ++it) {
+      const int g8 = g0 + gstep * it;
+      const int co0 = m0 + g8 * 8;
+      if (co0 < a.cout && pvalid) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = stage[(g8 * 8 + r) * BNT + col];
+        if (a.pre) {
+          float t[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) t[r] = a.pre[rbase + (long)min(co0 + r, a.cout - 1) * HWo];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += t[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#if !CL4_S_NO_AFFINE_LDS
+          const float sc = affine[g8 * 8 + r], sh = affine[BM + g8 * 8 + r];
+#else
+          const int cc = min(co0 + r, a.cout - 1);
+          const float sc = a.scale ? a.scale[cc] : 1.f;
+          const float sh = a.shift ? a.shift[cc] : 0.f;
+#endif
+          const float u = v[r] * sc + sh;
+          v[r] = u > 0.f ? u : u * a.neg1;
+        }
+        if constexpr (RES == 2) {
+          float tq[8];
+          join8(rh[it], rl[it], tq);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += tq[r];
+        } else if constexpr (RES == 1) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += rf[it][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.neg2;
+        if (a.y) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r)
+            if (co0 + r < a.cout) a.y[ybase + (long)(co0 + r) * HWo] = v[r];
+        }
+        if (a.ys) {                                        // cout % 8 == 0 whenever ys is requested (checked on the host)
+          u32x4 hi, lo;
+          split8(v, hi, lo);
+          u32x4* ys = reinterpret_cast<u32x4*>(a.ys) + (((long)pn * oc8tot + ((a.out_coff + co0) >> 3)) * 2) * HWo + phw;
+          ys[0] = hi;
+          ys[HWo] = lo;
+        }
+      }
+    }
+  }
+};
+
+// BNT = pixels per tile: 128, or 144 (MF = 16 only, r03). Why 144: the 33 x 33 maps of res4 / res5 / DeepLabV3 give 273 tiles of 128
+// pixels per 32 images and 137 per 16 — 1.07 and 0.54 rounds of the 512 resident workgroups for a 256-channel layer, i.e. a second
+// round (or a second workgroup on 18 of the 256 CUs) for 7 % of the work. With 144 pixels there are 242 and 121 pixel tiles: one round
+// at two workgroups per CU (n = 32), or one workgroup per CU / a whole-launch K split that fills both slots (n = 16).
+// Wave layout for 144: two row halves x two column parts of 80 and 64 pixels (5 and 4 blocks of 16).
+template <int KS, bool SPLIT, int MF, int BNT>
 __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   static_assert(MF == 32 || MF == 16, "MFMA shape");
-  constexpr int WTM = 64, WTN = 64;
+  static_assert(BNT == 128 || (BNT == 144 && MF == 16), "tile width");
+  constexpr bool WIDE = BNT == 144;
+  constexpr int WTM = 64;
   constexpr int KHW = KS * KS;
-  constexpr int NB = MF == 32 ? 2 : 4;                     // MFMA blocks per wave-tile side
+  constexpr int NB = MF == 32 ? 2 : 4;                     // MFMA row blocks per wave
+  constexpr int NBJ = MF == 32 ? 2 : (WIDE ? 5 : 4);       // MFMA column blocks per wave (the second column part of a wide tile has 4)
   constexpr int ACCV = MF == 32 ? 16 : 4;                  // accumulator registers per block
-  __shared__ u32x4 lds[2][A_CHUNKS + B_CHUNKS];            // 64 KB: two K-tile stages; reused as the parked [128][128] fp32 tile
+  constexpr int BCH = KG * P * BNT;                        // B chunks per stage
+  constexpr int STG = A_CHUNKS + BCH;                      // chunks per stage
+  constexpr int LDSC = (2 * STG * 16 > BM * BNT * 4) ? 2 * STG : BM * BNT / 4;
+  constexpr int LPT = WIDE ? 9 : 8;                        // vector-memory loads per thread and K-tile
+  __shared__ u32x4 lds[LDSC];                              // two K-tile stages; reused as the parked [128][BNT] fp32 tile (64 / 72 KB)
 #if !CL4_S_NO_AFFINE_LDS
   __shared__ float affine[2 * BM];                         // scale / shift of the tile's 128 output channels, fetched once at the start
 #endif
@@ -86,6 +193,8 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  const int cb0 = WIDE ? wn * 80 : wn * 64;                // first pixel column of this wave's part
+  const int nbj = (WIDE && wn == 1) ? 4 : NBJ;             // wave-uniform
 
   const unsigned total = gridDim.x, id = blockIdx.x;
   unsigned long long* tl = a.timeline ? a.timeline + (size_t)id * 8 : nullptr;
@@ -105,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   const unsigned bz = lid / (unsigned)a.ntile_l;
   const unsigned tile_ = (unsigned)a.tile_base + (lid - bz * (unsigned)a.ntile_l);
   const unsigned by_ = tile_ / (unsigned)a.gx, bx_ = tile_ - by_ * (unsigned)a.gx;
-  const int m0 = bx_ * BM, n0 = by_ * BN;
+  const int m0 = bx_ * BM, n0 = by_ * BNT;
   const int HWo = a.hout * a.wout, HWi = a.hin * a.win;
   const int kbeg = SPLIT ? bz * a.kchunk : 0;
   const int kend = SPLIT ? min(a.K, kbeg + a.kchunk) : a.K;
@@ -123,15 +232,26 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
 #endif
 
   // ---- staging roles: thread = (GEMM row / column tid & 127, plane tid >> 7); per K-tile it moves the 4 k-group chunks of that
-  // plane for its weight row AND for its pixel: 8 x 16 bytes in, 8 x ds_write_b128 out -------------------------------------------------
+  // plane for its weight row AND for its pixel: 8 x 16 bytes in, 8 x ds_write_b128 out. A wide tile has 16 more pixel columns = 128 more
+  // chunks per K-tile: threads 0..127 move one each (column 128 + (tid & 15), chunk row tid >> 4 = 2 * k-group + plane); the other
+  // half issues the same load out of range, so that every wave counts 9 loads per K-tile ------------------------------------------------
   const int col = tid & 127, plane = wave >> 1;            // plane is wave-uniform
-  const int p = n0 + col;
-  const bool pvalid = p < a.npix;
-  const int pn = pvalid ? p / HWo : 0;
-  const int phw = pvalid ? p - pn * HWo : 0;
-  const int oy = phw / a.wout, ox = phw - oy * a.wout;
-  const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
   const int c8tot = a.in_ctot >> 3;
+  struct Pix { bool valid; int pn, phw, iy0, ix0; };
+  auto decode = [&](int pcol) {
+    Pix q;
+    const int p = n0 + pcol;
+    q.valid = p < a.npix;
+    q.pn = q.valid ? p / HWo : 0;
+    q.phw = q.valid ? p - q.pn * HWo : 0;
+    const int oy = q.phw / a.wout, ox = q.phw - oy * a.wout;
+    q.iy0 = oy * a.stride - a.pad;
+    q.ix0 = ox * a.stride - a.pad;
+    return q;
+  };
+  const Pix px = decode(col);
+  const bool pvalid = px.valid;
+  const int pn = px.pn, phw = px.phw, iy0 = px.iy0, ix0 = px.ix0;
   // chunk index of (image, first channel group of the slice, plane, pixel 0) — the tap's pixel and the K-tile's channel groups are added per tile
   const unsigned cbase = (unsigned)((((long)pn * c8tot + (a.in_coff >> 3)) * 2 + plane) * HWi);
   const unsigned x_bytes = (unsigned)((long)a.n * a.in_ctot * HWi * 4);       // planes: 4 bytes per element too; < 2^31 checked on the host
@@ -141,32 +261,46 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, w_bytes, 0x00020000);
   const unsigned a_voff = (m0 + col) < a.cout ? (unsigned)(m0 + col) * 16u : OOB;
   const unsigned pkeep = (unsigned)(-(int)pvalid);
+  // the 16 extra columns of a wide tile (also this thread's extra epilogue item: column ecol, 8-channel group tid >> 4)
+  const int ecol = 128 + (tid & 15), erow = tid >> 4;      // erow: chunk row 2 * k-group + plane (staging, tid < 128) / channel group (epilogue)
+  Pix ex = px;
+  unsigned ebase = 0, ekeep = 0;
+  if constexpr (WIDE) {
+    ex = decode(ecol);
+    ebase = (unsigned)((((long)ex.pn * c8tot + (a.in_coff >> 3)) * 2 + (erow & 1)) * HWi);
+    ekeep = (unsigned)(-(int)(ex.valid && tid < 128));
+  }
 
-  auto loadB = [&](u32x4 (&br)[4], int kt) {
-    const int T = T0 + kt;                                 // wave-uniform
-    int cg0;                                               // first channel group (of 8) of this K-tile
-    unsigned pix;
-    unsigned keep = pkeep & (unsigned)(-(int)(kt < nk));
-    if (KS == 1) {
-      cg0 = T * 4;
-      const int iy = iy0, ix = ix0;                        // pad == 0 for every 1x1 layer of the networks; general for safety
-      keep &= (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
-      pix = (unsigned)(iy * a.win + ix);
-    } else {
+  auto tap_of = [&](int kt, int& cg0, int& dy, int& dx) {  // wave-uniform: first channel group and tap offset of K-tile kt
+    const int T = T0 + kt;
+    if (KS == 1) { cg0 = T * 4; dy = 0; dx = 0; }
+    else {
       const int cb = T / KHW, tap = T - cb * KHW;
       cg0 = cb * 4;
       const int ky = tap / KS, kx = tap - ky * KS;
-      const int iy = iy0 + ky * a.dil, ix = ix0 + kx * a.dil;
-      keep &= (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
-      pix = (unsigned)(iy * a.win + ix);
+      dy = ky * a.dil; dx = kx * a.dil;
     }
-    const unsigned vo = (cbase + pix) * 16u;
+  };
+  auto loadB = [&](u32x4 (&br)[4], int kt) {
+    int cg0, dy, dx;
+    tap_of(kt, cg0, dy, dx);
+    const int iy = iy0 + dy, ix = ix0 + dx;                // pad == 0 for every 1x1 layer of the networks; general for safety
+    const unsigned keep = pkeep & (unsigned)(-(int)(kt < nk)) & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
+    const unsigned vo = (cbase + (unsigned)(iy * a.win + ix)) * 16u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned co = (unsigned)__builtin_amdgcn_readfirstlane((cg0 + i) * 2 * HWi * 16);
       const unsigned voff = ((vo + co) & keep) | (OOB & ~keep);   // whole address in the bounds-checked offset
       br[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
     }
+  };
+  auto loadX = [&](u32x4& bx, int kt) {                    // wide tiles: this thread's extra pixel chunk (k-group erow >> 1, plane erow & 1)
+    int cg0, dy, dx;
+    tap_of(kt, cg0, dy, dx);
+    const int iy = ex.iy0 + dy, ix = ex.ix0 + dx;
+    const unsigned keep = ekeep & (unsigned)(-(int)(kt < nk)) & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
+    const unsigned vo = (ebase + (unsigned)(iy * a.win + ix)) * 16u + (unsigned)((cg0 + (erow >> 1)) * 2 * HWi * 16);
+    bx = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (vo & keep) | (OOB & ~keep), 0, 0);
   };
   auto loadA = [&](u32x4 (&ar)[4], int kt) {
     const unsigned kkeep = (unsigned)(-(int)(kt < nk));
@@ -178,47 +312,49 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
       ar[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, soff, 0);
     }
   };
-  auto storeAB = [&](const u32x4 (&ar)[4], const u32x4 (&br)[4], int stage) {
-    u32x4* As = lds[stage];
-    u32x4* Bs = lds[stage] + A_CHUNKS;
+  auto storeAB = [&](const u32x4 (&ar)[4], const u32x4 (&br)[4], const u32x4& bx, int stage) {
+    u32x4* As = lds + stage * STG;
+    u32x4* Bs = As + A_CHUNKS;
 #pragma unroll
     for (int i = 0; i < 4; ++i) As[(2 * i + plane) * BM + col] = ar[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Bs[(2 * i + plane) * BN + col] = br[i];
+    for (int i = 0; i < 4; ++i) Bs[(2 * i + plane) * BNT + col] = br[i];
+    if constexpr (WIDE)
+      if (wave < 2) Bs[erow * BNT + ecol] = bx;
   };
 
   typedef float accv_t __attribute__((ext_vector_type(ACCV)));
-  accv_t acc[NB][NB];
+  accv_t acc[NB][NBJ];
 #pragma unroll
   for (int i = 0; i < NB; ++i)
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
+    for (int j = 0; j < NBJ; ++j)
 #pragma unroll
       for (int r = 0; r < ACCV; ++r) acc[i][j][r] = 0.f;
 
-  bf16x8 bh16[NB], bl16[NB];                               // MF = 16: the B fragments of the current K-tile (read by half 0, reused by half 1)
+  bf16x8 bh16[NBJ], bl16[NBJ];                             // MF = 16: the B fragments of the current K-tile (read by half 0, reused by half 1)
   // one half of a K-tile's MFMAs (MF = 32: 16 of the 32 k; MF = 16: two of the four row blocks)
   auto mfma_half = [&](int stage, int s2) {
     if constexpr (MF == 32) {
       const int lr = lane & 31, lh = lane >> 5;
-      const u32x4* As = lds[stage] + wm * WTM + lr;
-      const u32x4* Bs = lds[stage] + A_CHUNKS + wn * WTN + lr;
+      const u32x4* As = lds + stage * STG + wm * WTM + lr;
+      const u32x4* Bs = lds + stage * STG + A_CHUNKS + cb0 + lr;
       const int kg = 2 * s2 + lh;
-      bf16x8 ah[NB], al[NB], bh[NB], bl[NB];
+      bf16x8 ah[NB], al[NB], bh[NBJ], bl[NBJ];
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         ah[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 0) * BM + i * 32]);
         al[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 1) * BM + i * 32]);
       }
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        bh[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 0) * BN + j * 32]);
-        bl[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 1) * BN + j * 32]);
+      for (int j = 0; j < NBJ; ++j) {
+        bh[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 0) * BNT + j * 32]);
+        bl[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 1) * BNT + j * 32]);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
+        for (int j = 0; j < NBJ; ++j) {
 #if CL4_S_DBG & 4
           acc[i][j][0] += (float)al[i][0] * (float)bh[j][0] + (float)ah[i][1] * (float)bl[j][1];
 #else
@@ -229,11 +365,11 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
         }
     } else {
       // 16x16x32: lane l holds row / column l & 15 and k-group l >> 4 — one fragment spans the whole 32-deep K-tile. Half s2 = the row
-      // blocks 2*s2, 2*s2+1 against all four column blocks; the eight B fragments are read by half 0 and stay in registers for half 1
-      // (16 fragment reads per K-tile, like the 32x32x16 path).
+      // blocks 2*s2, 2*s2+1 against all column blocks of the wave; the B fragments are read by half 0 and stay in registers for half 1
+      // (16 fragment reads per K-tile, like the 32x32x16 path; 18 / 16 for the two column parts of a wide tile).
       const int l15 = lane & 15, kg = lane >> 4;
-      const u32x4* As = lds[stage] + wm * WTM + l15;
-      const u32x4* Bs = lds[stage] + A_CHUNKS + wn * WTN + l15;
+      const u32x4* As = lds + stage * STG + wm * WTM + l15;
+      const u32x4* Bs = lds + stage * STG + A_CHUNKS + cb0 + l15;
       bf16x8 ah[2], al[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -242,82 +378,100 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
       }
       if (s2 == 0) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          bh16[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 0) * BN + j * 16]);
-          bl16[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 1) * BN + j * 16]);
-        }
+        for (int j = 0; j < NBJ; ++j)
+          if (j < nbj) {
+            bh16[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 0) * BNT + j * 16]);
+            bl16[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 1) * BNT + j * 16]);
+          }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          accv_t& c = acc[2 * s2 + i][j];
+        for (int j = 0; j < NBJ; ++j)
+          if (j < nbj) {
+            accv_t& c = acc[2 * s2 + i][j];
 #if CL4_S_DBG & 4
-          c[0] += (float)al[i][0] * (float)bh16[j][0] + (float)ah[i][1] * (float)bl16[j][1];
+            c[0] += (float)al[i][0] * (float)bh16[j][0] + (float)ah[i][1] * (float)bl16[j][1];
 #else
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh16[j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl16[j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh16[j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh16[j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl16[j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh16[j], c, 0, 0, 0);
 #endif
-        }
+          }
     }
   };
 
   // (Measured and dropped: touching the residual tile's lines at the start of the K loop, as conv_igemm_bf16x3 does. On the short-K
   // residual layers — 256 -> 1024 at 33x33 — it moved 6,000 cycles from the epilogue into the prologue and nothing else: those
   // launches stream their residual and output at the HBM rate either way. profiles/r02d_planes_prefetch.txt)
-  u32x4 ar[2][4], br[2][4];
-  loadA(ar[0], 0); loadB(br[0], 0);
-  loadA(ar[1], 1); loadB(br[1], 1);
-  wait_vmcnt<8>();
-  storeAB(ar[0], br[0], 0);
-  loadA(ar[0], 2); loadB(br[0], 2);
+  u32x4 ar[2][4], br[2][4], bx[2];
+  bx[0] = bx[1] = u32x4{0, 0, 0, 0};
+  loadA(ar[0], 0); loadB(br[0], 0); if constexpr (WIDE) loadX(bx[0], 0);
+  loadA(ar[1], 1); loadB(br[1], 1); if constexpr (WIDE) loadX(bx[1], 1);
+  wait_vmcnt<LPT>();
+  storeAB(ar[0], br[0], bx[0], 0);
+  loadA(ar[0], 2); loadB(br[0], 2); if constexpr (WIDE) loadX(bx[0], 2);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   stamp(1);
 
   // one K-tile: multiply tile t out of `stage` while tile t+1 (register set a1 / b1) goes into the other stage and tile t+3 is requested
-  auto step = [&](u32x4 (&a1)[4], u32x4 (&b1)[4], int t, int stage) {
-    wait_vmcnt<8>();                                       // tile t+1 has landed (requested a whole K-tile ago); tile t+2's 8 loads stay in flight
+  auto step = [&](u32x4 (&a1)[4], u32x4 (&b1)[4], u32x4& x1, int t, int stage) {
+    wait_vmcnt<LPT>();                                     // tile t+1 has landed (requested a whole K-tile ago); tile t+2's loads stay in flight
     mfma_half(stage, 0);
 #if !(CL4_S_DBG & 2)
-    storeAB(a1, b1, stage ^ 1);
+    storeAB(a1, b1, x1, stage ^ 1);
 #endif
 #if !(CL4_S_DBG & 1)
     loadA(a1, t + 3);
     loadB(b1, t + 3);
+    if constexpr (WIDE) loadX(x1, t + 3);
 #endif
     mfma_half(stage, 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
   for (int t = 0; t < nk; t += 2) {
-    step(ar[1], br[1], t, 0);
-    step(ar[0], br[0], t + 1, 1);
+    step(ar[1], br[1], bx[1], t, 0);
+    step(ar[0], br[0], bx[0], t + 1, 1);
   }
   stamp(2);
 
-  // ---- park the accumulators: stage[row][col] fp32 ----------------------------------------------------------------------------------
+  // ---- residual operands requested (everything this thread will add, one burst), then the accumulators are parked: stage[row][col] fp32 ----
   wait_vmcnt<0>();
-  float* stage = reinterpret_cast<float*>(&lds[0][0]);
+  SEpilogue<2, 8, BNT> ep2;
+  SEpilogue<1, 8, BNT> ep1;
+  SEpilogue<2, 1, BNT> ex2;                                // the extra (column, group) item of a wide tile
+  SEpilogue<1, 1, BNT> ex1;
+  const int res_kind = SPLIT ? 0 : (a.post_s ? 2 : (a.post ? 1 : 0));     // wave-uniform (kernel argument)
+  if (res_kind == 2) {
+    ep2.issue(a, m0, plane, 2, pvalid, pn, phw, HWo);
+    if constexpr (WIDE) ex2.issue(a, m0, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+  } else if (res_kind == 1) {
+    ep1.issue(a, m0, plane, 2, pvalid, pn, phw, HWo);
+    if constexpr (WIDE) ex1.issue(a, m0, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+  }
+  float* stage = reinterpret_cast<float*>(&lds[0]);
   if constexpr (MF == 32) {
     const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
+      for (int j = 0; j < NBJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          stage[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * WTN + j * 32 + lr] = acc[i][j][r];
+          stage[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BNT + cb0 + j * 32 + lr] = acc[i][j][r];
   } else {
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
+      for (int j = 0; j < NBJ; ++j)
+        if (j < nbj) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          stage[(wm * WTM + i * 16 + l4 * 4 + r) * BN + wn * WTN + j * 16 + l15] = acc[i][j][r];
+          for (int r = 0; r < 4; ++r)
+            stage[(wm * WTM + i * 16 + l4 * 4 + r) * BNT + cb0 + j * 16 + l15] = acc[i][j][r];
+        }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -331,82 +485,28 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
       const int co = m0 + wave * RPW + rr;
       if (co >= a.cout) break;                             // wave-uniform
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-        if (n0 + lane + 64 * q < a.npix) wsb[(long)co * a.ws_npix + lane + 64 * q] = stage[(wave * RPW + rr) * BN + lane + 64 * q];
+      for (int q = 0; q < (BNT + 63) / 64; ++q)
+        if (lane + 64 * q < BNT && n0 + lane + 64 * q < a.npix) wsb[(long)co * a.ws_npix + lane + 64 * q] = stage[(wave * RPW + rr) * BNT + lane + 64 * q];
     }
     return;
   }
 
-  // ---- fused epilogue, 8-channel groups: thread = (pixel `col`, group parity `plane`), groups plane, plane + 2, ... of the tile's 16.
-  // y = act2( act1( (acc + pre) * scale + shift ) + post ); written as fp32 NCHW rows (a.y) and / or as planes chunks (a.ys) ------------
   {
-    const long ybase = ((long)pn * a.out_ctot + a.out_coff) * HWo + phw;
-    const long rbase = (long)pn * a.cout * HWo + phw;
-    const int oc8tot = a.out_ctot >> 3;
-#pragma unroll 1
-    for (int it = 0; it < 8; ++it) {
-      const int g8 = plane + 2 * it;                       // wave-uniform
-      const int co0 = m0 + g8 * 8;
-      if (co0 >= a.cout) break;
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = stage[(g8 * 8 + r) * BN + col];
-      if (!pvalid) continue;
-      float t[8];
-      if (a.pre) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) t[r] = a.pre[rbase + (long)min(co0 + r, a.cout - 1) * HWo];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += t[r];
-      }
-      auto affine_act1 = [&]() {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
 #if !CL4_S_NO_AFFINE_LDS
-          const float sc = affine[g8 * 8 + r], sh = affine[BM + g8 * 8 + r];
+    const float* aff = affine;
 #else
-          const int cc = min(co0 + r, a.cout - 1);
-          const float sc = a.scale ? a.scale[cc] : 1.f;
-          const float sh = a.shift ? a.shift[cc] : 0.f;
+    const float* aff = nullptr;
 #endif
-          const float u = v[r] * sc + sh;
-          v[r] = u > 0.f ? u : u * a.neg1;
-        }
-      };
-      // three separate straight-line variants (residual in planes / fp32 / none): with one merged body hipcc shared registers between
-      // the two residual forms and the fp32 one came out wrong on a few lanes once the scale / shift loads had moved to LDS
-      if (a.post_s) {                                      // residual in planes format: the same channel group of the same pixel
-        const u32x4* ps = reinterpret_cast<const u32x4*>(a.post_s) + (((long)pn * (a.cout >> 3) + (co0 >> 3)) * 2) * HWo + phw;
-        const u32x4 ph = ps[0], pl_ = ps[HWo];
-        affine_act1();
-        float tq[8];
-        join8(ph, pl_, tq);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += tq[r];
-      } else if (a.post) {
-        float tq[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) tq[r] = a.post[rbase + (long)min(co0 + r, a.cout - 1) * HWo];
-        affine_act1();
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += tq[r];
-      } else {
-        affine_act1();
-      }
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.neg2;
-      if (a.y) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-          if (co0 + r < a.cout) a.y[ybase + (long)(co0 + r) * HWo] = v[r];
-      }
-      if (a.ys) {                                          // cout % 8 == 0 whenever ys is requested (checked on the host)
-        u32x4 hi, lo;
-        split8(v, hi, lo);
-        u32x4* ys = reinterpret_cast<u32x4*>(a.ys) + (((long)pn * oc8tot + ((a.out_coff + co0) >> 3)) * 2) * HWo + phw;
-        ys[0] = hi;
-        ys[HWo] = lo;
-      }
+    if (res_kind == 2) {
+      ep2.finish(a, stage, aff, m0, col, plane, 2, pvalid, pn, phw, HWo);
+      if constexpr (WIDE) ex2.finish(a, stage, aff, m0, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+    } else if (res_kind == 1) {
+      ep1.finish(a, stage, aff, m0, col, plane, 2, pvalid, pn, phw, HWo);
+      if constexpr (WIDE) ex1.finish(a, stage, aff, m0, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+    } else {
+      SEpilogue<0, 8, BNT> ep0;
+      ep0.finish(a, stage, aff, m0, col, plane, 2, pvalid, pn, phw, HWo);
+      if constexpr (WIDE) { SEpilogue<0, 1, BNT> ex0; ex0.finish(a, stage, aff, m0, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo); }
     }
   }
   if (tl) {
@@ -477,14 +577,16 @@ extern "C" int cl4_from_planes(const void* xs, float* y, int n, int c, int hw, i
 
 namespace cl4 {
 
-int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st) {
+int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st, int bn) {
   static const int mf = [] { const char* e = getenv("CL4_CONV_S_MFMA"); return e ? atoi(e) : 16; }();   // 16x16x32: 3-6 % faster on the long-K layers (higher sustained clock), equal elsewhere
   const dim3 g(grid), b(256);
   ++g_s_launches;
+  if (bn != 128 && bn != 144) { set_error("conv_s: tile width %d not built", bn); return CL4_EINVAL; }
 #define CL4_S_GO(KS_, SP_)                                                                                   \
   do {                                                                                                       \
-    if (mf == 16) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16>), g, b, 0, st, a);                          \
-    else hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 32>), g, b, 0, st, a);                                   \
+    if (bn == 144) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16, 144>), g, b, 0, st, a);                    \
+    else if (mf == 16) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16, 128>), g, b, 0, st, a);                \
+    else hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 32, 128>), g, b, 0, st, a);                              \
   } while (0)
   if (ks == 1) { if (split) CL4_S_GO(1, true); else CL4_S_GO(1, false); }
   else if (ks == 3) { if (split) CL4_S_GO(3, true); else CL4_S_GO(3, false); }

@@ -131,6 +131,8 @@ class _Scratch:
     * a key seen for the first time (the capture stream of torch.cuda.graph is one) starts at the largest size any stream of the
       device has needed so far, so a capture that follows an eager warm-up step never grows a buffer inside the capture."""
 
+    keep_retired = True         # tests only: False restores the r02 behaviour (the replaced buffer is dropped) to show they have teeth
+
     def __init__(self, min_bytes):
         self.min_bytes = min_bytes
         self.cur = {}
@@ -147,7 +149,8 @@ class _Scratch:
         if ws is None or ws.numel() < nbytes:
             size = max(peak, self.min_bytes)
             if ws is not None:
-                self.retired.append(ws)
+                if self.keep_retired:
+                    self.retired.append(ws)
                 size = max(size, ws.numel() + ws.numel() // 2)
             old = ws.data_ptr() if ws is not None else 0
             ws = torch.empty(size, dtype=torch.uint8, device=device)
@@ -250,8 +253,12 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
     _tuned[key] = (best, best_ms)
 
 
+PLANES_TILES = [int(v) for v in os.environ.get("CL4_PLANES_TILES", "128,144").split(",")]   # pixel widths of the planes kernel's tiles the tuner may pick
+
+
 def _autotune_planes(d, args, reps=6):
-    """_autotune_conv for the planes-input entry point (128x128 tiles only: unsplit, K-split, or main + split tail)."""
+    """_autotune_conv for the planes-input entry point: 128 output channels x 128 or 144 pixels per tile (144: the 33 x 33 maps fill
+    one round of resident workgroups, conv_s.hip), each unsplit, K-split, or main + split tail."""
     dev = torch.cuda.current_device()
     key = (d.n, d.cin, d.hin, d.win, d.cout, d.kh, d.stride, d.pad, d.dil, d.precision, dev)
     if key in _tuned:
@@ -260,29 +267,32 @@ def _autotune_planes(d, args, reps=6):
     K = d.cin * d.kh * d.kw
     best, best_ms = None, float("inf")
     seen = set()
-    for impl, tile, splits in _CANDIDATES:
-        if impl != 2 or tile != 128 or splits == -1 or abs(splits) > max(1, K // 64):
-            continue
-        if splits > 1 and _fills_the_chip(d):
-            continue
-        call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, tile, splits)
-        need = lib.cl4_conv2d_fwd_workspace_bytes(C.byref(d))
-        sig = (need, splits < 0)
-        if sig in seen or need > (1 << 30):
-            continue
-        seen.add(sig)
-        ws = _conv_workspace(torch.device("cuda", dev), need) if need else None
-        run = lambda: call("cl4_conv2d_fwd_planes", C.byref(d), *args, ptr(ws), need, stream())
-        run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+    npix = d.n * d.hout * d.wout
+    for tile in PLANES_TILES:
+        tiles = -(-d.cout // 128) * -(-npix // tile)
+        for splits in _SPLITS:
+            if splits == -1 or abs(splits) > max(1, K // 64):
+                continue
+            if splits > 1 and tiles >= 256 and d.n < _FULL_SPLITS_MIN_N:      # whole-launch splits only where a launch cannot fill the chip (_fills_the_chip)
+                continue
+            call("cl4_conv2d_fwd_set_plan", C.byref(d), 2, tile, splits)
+            need = lib.cl4_conv2d_fwd_workspace_bytes(C.byref(d))
+            sig = (tile, need, splits < 0)
+            if sig in seen or need > (1 << 30):
+                continue
+            seen.add(sig)
+            ws = _conv_workspace(torch.device("cuda", dev), need) if need else None
+            run = lambda: call("cl4_conv2d_fwd_planes", C.byref(d), *args, ptr(ws), need, stream())
             run()
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        if ms < best_ms:
-            best, best_ms = (impl, tile, splits), ms
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            if ms < best_ms:
+                best, best_ms = (2, tile, splits), ms
     call("cl4_conv2d_fwd_set_plan", C.byref(d), *best)
     _tuned[key] = (best, best_ms)
 
@@ -482,6 +492,31 @@ def maxpool3x3s2(x):
     y = torch.empty((n, c, ho, wo), dtype=torch.float32, device=x.device)
     call("cl4_maxpool3x3s2", ptr(x), ptr(y), n * c, h, w, ho, wo, stream())
     return y
+
+
+def pack_stem_weight(w):
+    """[64, 3, 7, 7] -> the MFMA fragment image cl4_stem_fused reads (48 KB)."""
+    _f32(w, "pack_stem_weight")
+    if tuple(w.shape) != (64, 3, 7, 7):
+        raise RuntimeError(f"pack_stem_weight: a [64, 3, 7, 7] weight expected, got {tuple(w.shape)}")
+    wq = torch.empty(_hip.load().cl4_stem_weight_bytes(), dtype=torch.uint8, device=w.device)
+    call("cl4_pack_stem_weight", ptr(w.contiguous()), ptr(wq), stream())
+    return wq
+
+
+def stem_fused(x, wq, scale, shift, slope=0.01, want_fp32=True, want_planes=True):
+    """conv 7x7/2 (3 -> 64) + folded eval ABN + leaky-ReLU + max-pool 3x3/2 in one kernel (csrc/stem.hip). Returns (fp32 output or
+    None, planes output or None)."""
+    _f32(x, "stem_fused.x")
+    n, c, h, w = x.shape
+    if c != 3 or not x.is_contiguous():
+        raise RuntimeError("stem_fused: contiguous [n, 3, h, w] input expected")
+    hp, wp = conv_out_size(conv_out_size(h, 7, 2, 3, 1), 3, 2, 1, 1), conv_out_size(conv_out_size(w, 7, 2, 3, 1), 3, 2, 1, 1)
+    y = torch.empty((n, 64, hp, wp), dtype=torch.float32, device=x.device) if want_fp32 else None
+    ys = Planes(n, 64, hp, wp, x.device) if want_planes else None
+    call("cl4_stem_fused", ptr(x), ptr(wq), ptr(scale), ptr(shift), C.c_float(slope), ptr(y), ptr(ys.data) if ys is not None else None,
+         n, h, w, stream())
+    return y, ys
 
 
 def avgpool_s1(x, kh, kw):

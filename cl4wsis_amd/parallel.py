@@ -41,6 +41,81 @@ def rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
+def agree_on_direct_comm(make_lib, dev, world, rank_, group=None):
+    """Set up the library's own RCCL communicator on every rank, or on none. `make_lib()` returns an object with world(), destroy(),
+    unique_id() -> 128 bytes, init(rank, world, id) and probe() (a collective on the new communicator); any of them may raise on
+    any rank. The decision is COLLECTIVE: every rank takes part in every torch.distributed call below whatever happened to it
+    locally (rank 0 broadcasts a zeroed id plus a failure flag when it could not make one), the ranks enter the collective init /
+    probe only when all of them can, and they agree on the verdict with an all-reduce(MIN) of their success flags — either every
+    rank returns True, or every rank destroys what it created and returns False (torch.distributed's all_reduce then carries the
+    gradients). A partial fallback would pair cl4_allreduce_bucket on some ranks with dist.all_reduce on the others and deadlock
+    the first training step."""
+    import warnings
+
+    def all_agree(flag, op=dist.ReduceOp.MIN):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=op, group=group)
+        return bool(int(t.item()))
+
+    ok, why, lib = True, "", None
+    try:
+        lib = make_lib()
+    except Exception as e:      # noqa: BLE001 - any failure must degrade to the torch.distributed collectives, on every rank
+        ok, why = False, str(e)
+    have_world = -1
+    if ok:
+        try:
+            have_world = lib.world()
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, str(e)
+    # (1) does any rank need a new communicator? then every rank makes a new one
+    if all_agree((not ok) or have_world != world, dist.ReduceOp.MAX):
+        if ok and have_world not in (0, -1):
+            try:
+                lib.destroy()
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, str(e)
+        raw, flag = bytes(128), 1
+        if rank_ == 0:
+            try:
+                if not ok:
+                    raise RuntimeError(why)
+                raw = lib.unique_id()
+            except Exception as e:  # noqa: BLE001
+                ok, why, flag, raw = False, str(e), 0, bytes(128)
+        t = torch.frombuffer(bytearray(raw[:128]) + bytearray([flag]), dtype=torch.uint8).to(dev)
+        dist.broadcast(t, src=0, group=group)                         # always executed, on every rank
+        got = bytes(t.cpu().numpy().tobytes())
+        if got[128] == 0 and ok:
+            ok, why = False, "rank 0 could not create an RCCL id"
+        # (2) ncclCommInitRank is itself a collective: enter it together or not at all
+        if all_agree(ok):
+            try:
+                lib.init(rank_, world, got[:128])
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, str(e)
+        elif ok:
+            ok, why = False, "a peer rank could not initialise"
+    # (3) the probe is a collective on the new communicator: only if every rank holds one
+    if all_agree(ok):
+        try:
+            lib.probe()
+        except Exception as e:  # noqa: BLE001
+            ok, why = False, str(e)
+    elif ok:
+        ok, why = False, "a peer rank holds no communicator"
+    # (4) the verdict, agreed
+    if all_agree(ok):
+        return True
+    try:
+        if lib is not None and lib.world() != 0:
+            lib.destroy()
+    except Exception:           # noqa: BLE001
+        pass
+    warnings.warn(f"cl4wsis_amd: direct RCCL communicator not used ({why or 'a peer rank failed'}); every rank uses torch.distributed all_reduce")
+    return False
+
+
 class FlatBuffer:
     """Parameters (and gradients) of a list of tensors packed into one contiguous fp32 buffer, in the given order.
 
@@ -97,35 +172,40 @@ class GradBuckets:
         self.reset()
 
     def _init_direct(self):
-        """One RCCL communicator per process, created from an id that rank 0 makes and torch.distributed broadcasts; checked
-        with a sum of ones before it is trusted. Any failure leaves the torch.distributed path in charge."""
+        """One RCCL communicator per process (cl4_comm_*, include/cl4wsis.h), agreed on by every rank: see `agree_on_direct_comm`."""
         import ctypes as C
         from . import _hip
-        try:
-            lib = _hip.load()
-            dev = self.fb.flat.device
-            if lib.cl4_comm_world() != self.world:
-                if lib.cl4_comm_world() != 0:
-                    _hip.call("cl4_comm_destroy")
+        dev = self.fb.flat.device
+        world = self.world
+
+        class _Lib:
+            def __init__(self):
+                self.lib = _hip.load()
+
+            def world(self):
+                return self.lib.cl4_comm_world()
+
+            def destroy(self):
+                _hip.call("cl4_comm_destroy")
+
+            def unique_id(self):
                 buf = (C.c_char * 128)()
-                if rank() == 0:
-                    _hip.call("cl4_comm_unique_id", buf)
-                t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(dev)
-                dist.broadcast(t, src=0)
-                raw = bytes(t.cpu().numpy().tobytes())
+                _hip.call("cl4_comm_unique_id", buf)
+                return bytes(buf.raw)
+
+            def init(self, r, w, raw):
                 with torch.cuda.device(dev):
-                    _hip.call("cl4_comm_init", rank(), self.world, C.c_char_p(raw))
-            probe = torch.ones(8, dtype=torch.float32, device=dev)
-            s = torch.cuda.current_stream(dev)
-            _hip.call("cl4_allreduce_bucket", C.c_void_p(probe.data_ptr()), 8, 0, C.c_void_p(s.cuda_stream))
-            s.synchronize()
-            if not bool((probe == float(self.world)).all()):
-                raise RuntimeError(f"probe all-reduce returned {probe.tolist()} for world size {self.world}")
-            return True
-        except Exception as e:      # noqa: BLE001 - any failure here must degrade to the torch.distributed collectives
-            import warnings
-            warnings.warn(f"cl4wsis_amd: direct RCCL communicator unavailable ({e}); using torch.distributed all_reduce")
-            return False
+                    _hip.call("cl4_comm_init", r, w, C.c_char_p(raw))
+
+            def probe(self):
+                probe = torch.ones(8, dtype=torch.float32, device=dev)
+                s = torch.cuda.current_stream(dev)
+                _hip.call("cl4_allreduce_bucket", C.c_void_p(probe.data_ptr()), 8, 0, C.c_void_p(s.cuda_stream))
+                s.synchronize()
+                if not bool((probe == float(world)).all()):
+                    raise RuntimeError(f"probe all-reduce returned {probe.tolist()} for world size {world}")
+
+        return agree_on_direct_comm(_Lib, dev, world, rank())
 
     def reset(self):
         self.pending = [hi - lo for lo, hi in self.bounds]

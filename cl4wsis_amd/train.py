@@ -106,7 +106,9 @@ class Trainer:
         self._pipe_fork = os.environ.get("CL4_PIPE_FORK", "body")
         self._label_override = None
         self._label_acc = torch.zeros(5, dtype=torch.int32, device=self.device)   # sticky label-stage counters, see check_label_overflow
-        self._seed_dev = torch.tensor([opts.random_seed * 1000003 + 7919 * (dist.get_rank() if dist.is_initialized() else 0)],
+        # the launch advances the seed by 1 per step: the rank lives in bits 40+ so that no rank ever replays another rank's stream
+        # of masks (with "+ 7919 * rank", rank r at step t drew rank 0's mask of step t + 7919 r: ADVICE r02)
+        self._seed_dev = torch.tensor([(opts.random_seed * 1000003) % (1 << 40) + ((dist.get_rank() if dist.is_initialized() else 0) << 40)],
                                       dtype=torch.int64, device=self.device)
 
     # ------------------------------------------------------------------------------------------ optimizer

@@ -123,6 +123,15 @@ int cl4_bn_fold(const float* gamma, const float* beta, const float* mean, const 
 /* ------------------------------------------------------------------------
  * Spatial / streaming kernels (HBM-bound). "planes" = n*c of an NCHW tensor.
  * ------------------------------------------------------------------------ */
+/* The ResNet stem in eval mode, ONE kernel: conv 7x7 / stride 2 / pad 3 (3 -> 64, no bias) -> InPlaceABN with running statistics
+ * folded to scale / shift + leaky-ReLU(slope) -> max-pool 3x3 / stride 2 / pad 1 — models/resnet.py:59-63 (mod1.conv1, mod1.bn1,
+ * pool1) as the frozen networks of phase 2 run it. bf16x3 arithmetic like cl4_conv2d_fwd precision 1. `wq`: the weight
+ * [64][3][7][7] packed by cl4_pack_stem_weight (cl4_stem_weight_bytes() bytes). Outputs: `y` fp32 [n][64][hp][wp] and / or `ys` the
+ * same tensor as planes (either may be NULL), hp = ((h - 1) / 2) / 2 + 1 for odd h (129 for 513). */
+size_t cl4_stem_weight_bytes(void);
+int cl4_pack_stem_weight(const float* w, void* wq, void* stream);
+int cl4_stem_fused(const float* x, const void* wq, const float* scale, const float* shift, float slope, float* y, void* ys,
+                   int n, int h, int w, void* stream);
 /* nn.MaxPool2d(3, stride=2, padding=1) — models/resnet.py:63. */
 int cl4_maxpool3x3s2(const float* x, float* y, long planes, int hin, int win, int hout, int wout, void* stream);
 /* F.avg_pool2d(x, (kh,kw), stride=1) -> [planes, h-kh+1, w-kw+1] — modules/deeplab.py:87. */

@@ -99,30 +99,37 @@ SHAPES = [
     (1, 128, 9, 7, 144, 3, 1, 1, 1),        # 63 pixels
     (5, 64, 65, 67, 256, 3, 1, 1, 1),       # more tiles than resident workgroups
     (1, 64, 12, 12, 64, 3, 1, 0, 1),        # no padding ("valid"), cout = 64 on a 128-row tile
+    (20, 64, 33, 33, 1024, 1, 1, 0, 1),     # 1368 tiles = 2.7 rounds of resident workgroups
 ]
 
 
+TILES = [128, 144]      # pixels per tile (144: r03, one round of the 33 x 33 maps; two column parts of 80 + 64 pixels per wave pair)
+
+
+@pytest.mark.parametrize("tile", TILES)
 @pytest.mark.parametrize("shape", SHAPES)
-def test_conv_planes_plain(gpu, shape):
-    _run(gpu, *shape, plan=(2, 128, 1), seed=sum(shape))
+def test_conv_planes_plain(gpu, shape, tile):
+    _run(gpu, *shape, plan=(2, tile, 1), seed=sum(shape))
 
 
+@pytest.mark.parametrize("tile", TILES)
 @pytest.mark.parametrize("planes_post", [False, True])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_conv_planes_fused_epilogue(gpu, shape, planes_post):
-    _run(gpu, *shape, plan=(2, 128, 1), seed=1 + sum(shape), epilogue=True, planes_post=planes_post)
+def test_conv_planes_fused_epilogue(gpu, shape, planes_post, tile):
+    _run(gpu, *shape, plan=(2, tile, 1), seed=1 + sum(shape), epilogue=True, planes_post=planes_post)
 
 
-@pytest.mark.parametrize("plan", [(2, 128, 2), (2, 128, 5), (2, 128, -8)])
+@pytest.mark.parametrize("plan", [(2, 128, 2), (2, 128, 5), (2, 128, -8), (2, 144, 2), (2, 144, 3), (2, 144, -8)])
 @pytest.mark.parametrize("shape", [(5, 64, 65, 67, 256, 3, 1, 1, 1), (2, 160, 21, 19, 192, 3, 1, 2, 2), (4, 256, 33, 33, 256, 1, 1, 0, 1)])
 def test_conv_planes_split_plans(gpu, shape, plan):
     _run(gpu, *shape, plan=plan, seed=2 + sum(shape), epilogue=True, planes_post=True)
 
 
-def test_conv_planes_channel_slices(gpu):
-    _run(gpu, 2, 64, 15, 15, 128, 3, 1, 2, 2, plan=(2, 128, 1), seed=5, in_ctot=104, in_coff=24, out_ctot=200, out_coff=24)
-    _run(gpu, 2, 32, 15, 15, 160, 1, 1, 0, 1, plan=(2, 128, 1), seed=6, in_ctot=40, in_coff=8, out_ctot=176, out_coff=8, epilogue=True)
-    _run(gpu, 2, 32, 15, 15, 132, 1, 1, 0, 1, plan=(2, 128, 1), seed=7, out_ctot=133, out_coff=1)      # fp32 output only (cout % 8 != 0)
+@pytest.mark.parametrize("tile", TILES)
+def test_conv_planes_channel_slices(gpu, tile):
+    _run(gpu, 2, 64, 15, 15, 128, 3, 1, 2, 2, plan=(2, tile, 1), seed=5, in_ctot=104, in_coff=24, out_ctot=200, out_coff=24)
+    _run(gpu, 2, 32, 15, 15, 160, 1, 1, 0, 1, plan=(2, tile, 1), seed=6, in_ctot=40, in_coff=8, out_ctot=176, out_coff=8, epilogue=True)
+    _run(gpu, 2, 32, 15, 15, 132, 1, 1, 0, 1, plan=(2, tile, 1), seed=7, out_ctot=133, out_coff=1)      # fp32 output only (cout % 8 != 0)
 
 
 def test_conv_planes_both_mfma_shapes_agree_with_the_fp32_input_kernel(gpu):

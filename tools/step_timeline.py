@@ -7,7 +7,7 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 f = glob.glob(d + '/*/*_kernel_trace.csv')[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-adam = [i for i, r in enumerate(rows) if 'adam' in r['Kernel_Name']]
+adam = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]][1::2]      # two Adam launches per step: the second closes it
 sel = rows[adam[first - 1] + 1:adam[first - 1 + nsteps] + 1]
 short = lambda r: re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name']).split('(')[0][:70]
 t0 = int(sel[0]['Start_Timestamp'])
