@@ -347,6 +347,14 @@ def worker(a):
             traffic_note = ("bytes per launch, average over the %d bf16x3 forward launches of one step; rocprofv3 --pmc "
                             "FETCH_SIZE + WRITE_SIZE in separate passes, corrected as calibrated in %s"
                             % (t["launches_per_step"], os.path.relpath(pmcs[-1], ROOT)))
+        # matrix-pipe busy share of the same kernel family, from the committed counter pass of the same command (tools/prof_pmc.sh third
+        # pass + tools/pmc_kernels.py: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)); null when absent
+        mfma_busy, hbm_gbs = None, None
+        pk = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_kernels.json")))
+        if pk and b == GLOBAL_BATCH:
+            with open(pk[-1]) as f:
+                fam = json.load(f)["bf16x3_forward_family"]
+            mfma_busy, hbm_gbs = fam["mfma_busy"], fam["hbm_gbs"]
         # algorithmic operand bytes of the same launches: input + output activations (fp32) + split weights (4 B / weight);
         # epilogue operands (residual, scale / shift) not counted
         alg_bytes, alg_n = 0.0, 0
@@ -368,14 +376,15 @@ def worker(a):
                        "arithmetic": "fp32 tensors; convolutions as split-bf16 MFMA products with fp32 accumulation (bf16x3 frozen networks, "
                                      "bf16x6 = fp32-level for the differentiated convs, bf16x3 weight gradients)"},
             "label_counters": counters_random,
-            "roofline": {"bound": "mfma", "kernel": "bf16x3 forward convolution (cl4_conv2d_fwd precision 1 + cl4_conv2d_fwd_planes: kernels "
-                                                    "conv_igemm_bf16x3 / conv_u_bf16x3 / conv_s_bf16x3): all its launches of 2 "
+            "roofline": {"bound": "mfma", "kernel": "bf16x3 forward convolution (cl4_conv2d_fwd precision 1 + cl4_conv2d_fwd_planes + cl4_stem_fused: kernels "
+                                                    "conv_igemm_bf16x3 / conv_u_bf16x3 / conv_s_bf16x3 / stem_fused): all its launches of 2 "
                                                     "eager steps run right after the timed region (graph replay and two-stream "
                                                     "overlap off), HIP events on the launch stream around every launch",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes / max(alg_n, 1),
                          "peak_note": "2500 TFLOP/s dense bf16 MFMA / 3 MFMA products per fp32-equivalent MAC",
+                         "mfma_busy": mfma_busy, "hbm_gbs": hbm_gbs,
                          "mfma_issued_tflops": 3 * ach, "launches_per_step": n / 2,
                          "algorithmic_gflop_per_step": fl / 2 / 1e9, "avg_launch_ms": ms / n,
                          "kernel_ms_per_step": ms / 2},

@@ -216,10 +216,46 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   const unsigned by_ = tile_ / (unsigned)a.gx, bx_ = tile_ - by_ * (unsigned)a.gx;
   const int m0 = bx_ * BM, n0 = by_ * BNT;
   const int HWo = a.hout * a.wout, HWi = a.hin * a.win;
-  const int kbeg = SPLIT ? bz * a.kchunk : 0;
-  const int kend = SPLIT ? min(a.K, kbeg + a.kchunk) : a.K;
-  const int nk = (kend - kbeg + BKS - 1) / BKS;
-  const int T0 = kbeg >> 5;
+  // ---- K-tiles of this workgroup. A K-tile = one tap x 32 channels. Taps whose input row (column) lies outside the image for EVERY
+  // pixel of the tile are dropped (r03): a dilated 3x3 layer on a 33 x 33 map multiplies zeros for most of its outer taps — dilation
+  // 18: the upper tap row is valid for output rows >= 18 only, so the tiles of rows 0..17 skip a third of their K loop (36 % of the
+  // layer's K-tiles over all tiles, 24 % at dilation 12, 12 % at dilation 6). `vlist` = the surviving taps (4 bits each), nv of them;
+  // the K loop walks the compacted index u = cb * nv + j (cb = block of 32 channels), and a K split divides THAT range.
+  unsigned long long vlist = 0;
+  int nv = 1;
+  if constexpr (KS == 3) {
+    const int pl = min(n0 + BNT, a.npix) - 1;             // last pixel of the tile (n0 < npix by construction of the grid)
+    const int im0 = n0 / HWo, im1 = pl / HWo;
+    int ymin = (n0 - im0 * HWo) / a.wout, ymax = (pl - im1 * HWo) / a.wout;
+    if (im0 != im1) { ymin = 0; ymax = a.hout - 1; }      // the tile crosses an image boundary: every row may occur
+    nv = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int lo = ymin * a.stride - a.pad + ky * a.dil, hi = ymax * a.stride - a.pad + ky * a.dil;   // input rows this tap touches
+      if (hi < 0 || lo >= a.hin) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xlo = -a.pad + kx * a.dil, xhi = (a.wout - 1) * a.stride - a.pad + kx * a.dil;      // a tile holds whole rows: every column occurs
+        if (xhi < 0 || xlo >= a.win) continue;
+        vlist |= (unsigned long long)(ky * 3 + kx) << (4 * nv);
+        ++nv;
+      }
+    }
+    nv = __builtin_amdgcn_readfirstlane(nv);
+    vlist = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(vlist >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)vlist);
+  }
+  const int nkc = (a.cin >> 5) * nv;                       // compacted K-tiles of this tile
+  const int nsplit = SPLIT ? (a.K + a.kchunk - 1) / a.kchunk : 1;
+  const int chunk_c = (nkc + nsplit - 1) / nsplit;
+  const int u0 = SPLIT ? (int)bz * chunk_c : 0;
+  const int nk = max(0, min(nkc - u0, chunk_c));
+  // iterator over (channel block, tap) in load order: every K-tile is requested exactly once, in increasing order
+  int it_cb = nv > 0 ? u0 / nv : 0, it_j = nv > 0 ? u0 - it_cb * nv : 0;
+  auto next_tile = [&](int& cb, int& tap) {
+    cb = it_cb;
+    tap = KS == 3 ? (int)((vlist >> (4 * it_j)) & 15ull) : 0;
+    if (++it_j >= nv) { it_j = 0; ++it_cb; }
+  };
 #if !CL4_S_NO_AFFINE_LDS
   // The epilogue multiplies every output by its channel's folded-ABN scale / shift. Read from global memory inside the epilogue loop
   // they were 16 dependent vector loads per 8-channel group (hipcc cannot use scalar loads: the pointers may alias the output);
@@ -271,19 +307,17 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
     ekeep = (unsigned)(-(int)(ex.valid && tid < 128));
   }
 
-  auto tap_of = [&](int kt, int& cg0, int& dy, int& dx) {  // wave-uniform: first channel group and tap offset of K-tile kt
-    const int T = T0 + kt;
-    if (KS == 1) { cg0 = T * 4; dy = 0; dx = 0; }
+  auto tap_off = [&](int tap, int& dy, int& dx) {          // wave-uniform
+    if (KS == 1) { dy = 0; dx = 0; }
     else {
-      const int cb = T / KHW, tap = T - cb * KHW;
-      cg0 = cb * 4;
       const int ky = tap / KS, kx = tap - ky * KS;
       dy = ky * a.dil; dx = kx * a.dil;
     }
   };
-  auto loadB = [&](u32x4 (&br)[4], int kt) {
-    int cg0, dy, dx;
-    tap_of(kt, cg0, dy, dx);
+  auto loadB = [&](u32x4 (&br)[4], int kt, int cb, int tap) {
+    int dy, dx;
+    tap_off(tap, dy, dx);
+    const int cg0 = cb * 4;                                // first channel group (of 8) of this K-tile
     const int iy = iy0 + dy, ix = ix0 + dx;                // pad == 0 for every 1x1 layer of the networks; general for safety
     const unsigned keep = pkeep & (unsigned)(-(int)(kt < nk)) & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
     const unsigned vo = (cbase + (unsigned)(iy * a.win + ix)) * 16u;
@@ -294,23 +328,30 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
       br[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
     }
   };
-  auto loadX = [&](u32x4& bx, int kt) {                    // wide tiles: this thread's extra pixel chunk (k-group erow >> 1, plane erow & 1)
-    int cg0, dy, dx;
-    tap_of(kt, cg0, dy, dx);
+  auto loadX = [&](u32x4& bx, int kt, int cb, int tap) {   // wide tiles: this thread's extra pixel chunk (k-group erow >> 1, plane erow & 1)
+    int dy, dx;
+    tap_off(tap, dy, dx);
     const int iy = ex.iy0 + dy, ix = ex.ix0 + dx;
     const unsigned keep = ekeep & (unsigned)(-(int)(kt < nk)) & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
-    const unsigned vo = (ebase + (unsigned)(iy * a.win + ix)) * 16u + (unsigned)((cg0 + (erow >> 1)) * 2 * HWi * 16);
+    const unsigned vo = (ebase + (unsigned)(iy * a.win + ix)) * 16u + (unsigned)((cb * 4 + (erow >> 1)) * 2 * HWi * 16);
     bx = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (vo & keep) | (OOB & ~keep), 0, 0);
   };
-  auto loadA = [&](u32x4 (&ar)[4], int kt) {
+  auto loadA = [&](u32x4 (&ar)[4], int kt, int cb, int tap) {
     const unsigned kkeep = (unsigned)(-(int)(kt < nk));
     const unsigned voff = (a_voff & kkeep) | (OOB & ~kkeep);
+    const int T = cb * KHW + tap;                          // K-tile index in the packed weight (tap-major within a block of 32 channels)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int kgg = (kbeg >> 3) + kt * 4 + i;
-      const int soff = __builtin_amdgcn_readfirstlane((kgg * P + plane) * a.cout * 16);
+      const int soff = __builtin_amdgcn_readfirstlane(((T * 4 + i) * P + plane) * a.cout * 16);
       ar[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, soff, 0);
     }
+  };
+  auto load_tile = [&](u32x4 (&ar)[4], u32x4 (&br)[4], u32x4& bxr, int kt) {
+    int cb, tap;
+    next_tile(cb, tap);
+    loadA(ar, kt, cb, tap);
+    loadB(br, kt, cb, tap);
+    if constexpr (WIDE) loadX(bxr, kt, cb, tap);
   };
   auto storeAB = [&](const u32x4 (&ar)[4], const u32x4 (&br)[4], const u32x4& bx, int stage) {
     u32x4* As = lds + stage * STG;
@@ -406,11 +447,11 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   // launches stream their residual and output at the HBM rate either way. profiles/r02d_planes_prefetch.txt)
   u32x4 ar[2][4], br[2][4], bx[2];
   bx[0] = bx[1] = u32x4{0, 0, 0, 0};
-  loadA(ar[0], 0); loadB(br[0], 0); if constexpr (WIDE) loadX(bx[0], 0);
-  loadA(ar[1], 1); loadB(br[1], 1); if constexpr (WIDE) loadX(bx[1], 1);
+  load_tile(ar[0], br[0], bx[0], 0);
+  load_tile(ar[1], br[1], bx[1], 1);
   wait_vmcnt<LPT>();
   storeAB(ar[0], br[0], bx[0], 0);
-  loadA(ar[0], 2); loadB(br[0], 2); if constexpr (WIDE) loadX(bx[0], 2);
+  load_tile(ar[0], br[0], bx[0], 2);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   stamp(1);
@@ -423,9 +464,7 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
     storeAB(a1, b1, x1, stage ^ 1);
 #endif
 #if !(CL4_S_DBG & 1)
-    loadA(a1, t + 3);
-    loadB(b1, t + 3);
-    if constexpr (WIDE) loadX(x1, t + 3);
+    load_tile(a1, b1, x1, t + 3);
 #endif
     mfma_half(stage, 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

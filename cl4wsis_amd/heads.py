@@ -286,8 +286,12 @@ class InstanceBranch:
         aspp = d.aspp
         cout = aspp.convs[0][0].out_channels
         cat = torch.empty((n, 5 * cout, h, w), dtype=torch.float32, device=x.device)
+        xp = planes_of(x)
         for i in range(4):
-            conv_abn(x, aspp.convs[i][0], aspp.convs[i][1], out=cat, out_coff=i * cout)
+            if xp is not None and planes_ok(aspp.convs[i][0]):     # res5 arrives with its planes twin: the branches read that (conv_s.hip)
+                conv_abn_planes(xp, aspp.convs[i][0], aspp.convs[i][1], out=cat, out_coff=i * cout, want_planes=False)
+            else:
+                conv_abn(x, aspp.convs[i][0], aspp.convs[i][1], out=cat, out_coff=i * cout)
         g = ops.global_mean(x)
         pconv = aspp.convs[4].aspp_pooling[1]
         g = ops.conv2d(g, packed_weight(pconv), 1, act1=ops.ACT_RELU)

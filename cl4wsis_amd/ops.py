@@ -376,6 +376,15 @@ class Planes:
         return (self.n, self.c, self.h, self.w)
 
 
+def batch_slice(t, bs):
+    """t[:bs] of an NCHW activation, keeping its planes twin (the first `bs` images of a Planes tensor are contiguous as well)."""
+    v = t[:bs]
+    ps = getattr(t, "_cl4_planes", None)
+    if ps is not None and bs <= ps.n:
+        v._cl4_planes = Planes(bs, ps.c, ps.h, ps.w, ps.data.device, data=ps.data[:bs * ps.c * ps.h * ps.w])
+    return v
+
+
 def to_planes(x, in_coff=0, c=None, out=None):
     _f32(x, "to_planes")
     n, ctot, h, w = x.shape
@@ -514,8 +523,14 @@ def stem_fused(x, wq, scale, shift, slope=0.01, want_fp32=True, want_planes=True
     hp, wp = conv_out_size(conv_out_size(h, 7, 2, 3, 1), 3, 2, 1, 1), conv_out_size(conv_out_size(w, 7, 2, 3, 1), 3, 2, 1, 1)
     y = torch.empty((n, 64, hp, wp), dtype=torch.float32, device=x.device) if want_fp32 else None
     ys = Planes(n, 64, hp, wp, x.device) if want_planes else None
+    if TIMER is not None:     # the convolution's algorithmic FLOPs (147 real taps); the fused ABN / pooling are not counted
+        hc, wc = conv_out_size(h, 7, 2, 3, 1), conv_out_size(w, 7, 2, 3, 1)
+        e0, e1 = TIMER.span("conv_fwd_bf16x3", 2.0 * n * hc * wc * 64 * 147, (n, 3, h, 64, 7, 2, 1))
+        e0.record()
     call("cl4_stem_fused", ptr(x), ptr(wq), ptr(scale), ptr(shift), C.c_float(slope), ptr(y), ptr(ys.data) if ys is not None else None,
          n, h, w, stream())
+    if TIMER is not None:
+        e1.record()
     return y, ys
 
 

@@ -436,7 +436,7 @@ class Trainer:
             outputs, features = self.model.forward_seg(x2, interpolate=False)
             if prefetch_old is not None:
                 fork_old()
-        feats = {k: v[:bs] for k, v in features["features"].items()}   # first half = un-flipped images (contiguous views)
+        feats = {k: ops.batch_slice(v, bs) for k, v in features["features"].items()}   # first half = un-flipped images (contiguous views, planes twins kept)
         # train.py:265-272 — trainable instance decoder + heads on the detached features
         if dropout_keep is None:
             n5, _, h5, w5 = feats["res5"].shape
@@ -448,7 +448,7 @@ class Trainer:
         # train.py:421-436 — CAM of the new classes -> peaks
         self.pseudolabeler.eval()
         self.peakgenerator.eval()
-        int_masks = self.pseudolabeler(features["body"][:bs])
+        int_masks = self.pseudolabeler(ops.batch_slice(features["body"], bs))
         label_new = l1h[:, oc - 1:].contiguous()
         seg2b, lab_center, lab_offset = outputs["seg"], pred["center"], pred["offset"]
         if self._label_override is not None:    # benchmark-only: see set_label_override (every network above still ran)

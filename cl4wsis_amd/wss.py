@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .nn import conv_abn, conv_bias
+from .nn import conv_abn, conv_abn_planes, conv_bias, planes_of, planes_ok
 
 
 class PseudoLabeler(nn.Module):
@@ -34,8 +34,14 @@ class PseudoLabeler(nn.Module):
             if self.training:
                 from . import heads_train
                 return heads_train.pseudolabeler_forward(self, x.contiguous())[0]
-            y = conv_abn(x, self.conv1, self.norm1)
-            y = conv_abn(y, self.conv2, self.norm2)
+            xp = planes_of(x)
+            if xp is not None and planes_ok(self.conv1) and planes_ok(self.conv2):
+                # the body handed its output out pre-split: both 3x3 convolutions run on the planes kernel (csrc/conv_s.hip)
+                yp = conv_abn_planes(xp, self.conv1, self.norm1)[1]
+                y = conv_abn_planes(yp, self.conv2, self.norm2, want_fp32=True, want_planes=False)[0]
+            else:
+                y = conv_abn(x, self.conv1, self.norm1)
+                y = conv_abn(y, self.conv2, self.norm2)
             return conv_bias(y, self.cls)
 
 

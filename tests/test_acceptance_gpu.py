@@ -48,6 +48,31 @@ def _report(tag, errs, cpu):
     return e, c
 
 
+_P2_ORACLE = {}
+
+
+def _p2_case(opts, new, old, pl, pg):
+    """Inputs and the two CPU evaluations (float64, fp32) of the phase-2 case — identical for the three arithmetic settings of the HIP
+    path, so they are computed once per module (the r02 suite evaluated them three times: 864 s of a 900 s limit)."""
+    from oracle import step as ostep
+    if not _P2_ORACLE:
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(4, 3, CROP, CROP, generator=g)
+        l1h = torch.zeros(4, 20)
+        for i, cs in enumerate(((15,), (16, 19), (17,), (18, 15))):
+            l1h[i, list(cs)] = 1
+        keep = torch.rand(4, 256, 13, 13, generator=g) >= 0.5
+        cp = lambda d: {k: v.clone() for k, v in d.items()}
+        r64 = ostep.p2_step(_to64(new), _to64(old), _to64(pl), _to64(pg), x.double(), l1h.double(), 16, pooling=opts.pooling,
+                            dropout_mask=keep.double(), lr=opts.lr * opts.lr_head)
+        r32 = ostep.p2_step(cp(new), cp(old), cp(pl), cp(pg), x, l1h, 16, pooling=opts.pooling, dropout_mask=keep.float(),
+                            lr=opts.lr * opts.lr_head)
+        keys = ("seg_gt", "center_old", "offset_old", "center_new", "offset_new", "pseudo", "refined", "grads")
+        _P2_ORACLE.update(x=x, l1h=l1h, keep=keep, r64={k: r64[k] for k in keys}, r32={"grads": r32["grads"]})
+    c = _P2_ORACLE
+    return c["x"], c["l1h"], c["keep"], c["r64"], c["r32"]
+
+
 @pytest.mark.parametrize("frozen_precision", [0, 2, 1])
 def test_phase2_gradients_well_conditioned(gpu, monkeypatch, frozen_precision):
     """frozen_precision 0: exact fp32 MFMA products everywhere (frozen nets, trainable branch, weight gradients); 2: bf16x6 in
@@ -55,7 +80,6 @@ def test_phase2_gradients_well_conditioned(gpu, monkeypatch, frozen_precision):
     1 = the default bf16x3 frozen networks — the measured price of each choice against the CPU fp32 oracle's own distance."""
     from cl4wsis_amd import heads, ops
     from cl4wsis_amd.train import Trainer
-    from oracle import step as ostep
     monkeypatch.setattr(ops, "CONV_PRECISION", frozen_precision)
     if frozen_precision == 0:
         monkeypatch.setattr(heads, "TRAIN_PRECISION", 0)
@@ -64,18 +88,8 @@ def test_phase2_gradients_well_conditioned(gpu, monkeypatch, frozen_precision):
     opts.max_iters, opts.start_decay = 1000, 1000
     torch.manual_seed(0)
     tr = Trainer(QuietLogger(), gpu, opts)
-    new, old, pl, pg = _fill(tr, 71)
-    g = torch.Generator().manual_seed(7)
-    x = torch.randn(4, 3, CROP, CROP, generator=g)
-    l1h = torch.zeros(4, 20)
-    for i, cs in enumerate(((15,), (16, 19), (17,), (18, 15))):
-        l1h[i, list(cs)] = 1
-    keep = torch.rand(4, 256, 13, 13, generator=g) >= 0.5
-    cp = lambda d: {k: v.clone() for k, v in d.items()}
-    r64 = ostep.p2_step(_to64(new), _to64(old), _to64(pl), _to64(pg), x.double(), l1h.double(), 16, pooling=opts.pooling,
-                        dropout_mask=keep.double(), lr=opts.lr * opts.lr_head)
-    r32 = ostep.p2_step(cp(new), cp(old), cp(pl), cp(pg), x, l1h, 16, pooling=opts.pooling, dropout_mask=keep.float(),
-                        lr=opts.lr * opts.lr_head)
+    new, old, pl, pg = _fill(tr, 71)                       # deterministic in the seed: the same weights for every parameter value
+    x, l1h, keep, r64, r32 = _p2_case(opts, new, old, pl, pg)
     out = tr.step((x, l1h), dropout_keep=keep.to(torch.uint8).to(gpu))
     torch.cuda.synchronize()
     # the three evaluations must have made the same discrete label decisions, or the gradients are not comparable
@@ -91,14 +105,17 @@ def test_phase2_gradients_well_conditioned(gpu, monkeypatch, frozen_precision):
         d = (a.cpu().double() - b.double()).abs()
         print(f"WELLCOND labels {name}: {int((d > 1e-3).sum())} of {d.numel()} elements differ by > 1e-3 (max {float(d.max()):.2e})")
     params = dict(tr.model.named_parameters())
-    errs, cpu = [], []
+    errs, cpu, keys = [], [], []
     for k, g64 in r64["grads"].items():
         if float(g64.norm()) == 0:
             continue
         ours = tr._grad_map[id(params[k])].cpu().double()
         errs.append(((ours - g64).norm() / g64.norm()).item())
         cpu.append(((r32["grads"][k].double() - g64).norm() / g64.norm()).item())
+        keys.append(k)
     e, c = _report(f"phase 2 (frozen nets precision {frozen_precision})", errs, cpu)
+    for i in sorted(range(len(errs)), key=lambda i: -errs[i])[:6]:      # the per-tensor table of the outliers
+        print(f"WELLCOND   worst: {keys[i]:58s} HIP {errs[i]:.2e}  CPU-fp32 {cpu[i]:.2e}  |g64| {float(r64['grads'][keys[i]].norm()):.3e}")
     assert len(errs) >= 55
     if frozen_precision == 0:
         assert e.median() <= 3 * c.median() and e.max() < 0.05, (e.median(), e.max(), c.median(), c.max())
@@ -159,86 +176,133 @@ def _oracle_predict(sd, img, target, opts):
     return lab, msk, sc
 
 
-def test_map_proxy_after_training_both_paths(gpu, tmp_path):
-    """Three trajectories from identical weights, batches and Dropout masks: the HIP path, the CPU oracle (A), and the CPU oracle
-    again with the input images perturbed by 1e-6 relative (B) — what a second run of the reference itself amounts to on a GPU,
-    whose atomics / algorithm choices are not bit-reproducible. Adam turns any gradient difference on weights with near-zero
-    gradients into +-lr steps, so after K iterations even A and B have visibly different weights and, on these untrained
-    networks, different thresholded instance predictions; B calibrates how much. Acceptance: the per-iteration losses of the
-    HIP path follow A as closely as B does (x2), and |mAP(HIP) - mAP(A)| <= max(0.2 points, 1.5 x |mAP(B) - mAP(A)|)."""
+def test_map_after_training_inside_the_reference_arithmetics_own_spread(gpu, tmp_path):
+    """North star: "<= 0.2 mAP delta vs reference after one epoch on fixed seeds". No dataset and no trained checkpoint exist
+    offline, so the statement is tested in the form that CAN be decided here:
+
+    * a common, CONDITIONED start: K0 = 30 phase-2 iterations (HIP path) from the seeded weights — the decoder has left its
+      initialisation, Adam's first sign-like steps are behind it;
+    * from that state K = 8 iterations on identical batches / Dropout masks along SEVEN trajectories: the HIP path, the CPU oracle
+      (A), and five more runs of the CPU oracle whose input images are perturbed by 1e-6 relative (B1..B5) — what five re-runs of
+      the reference itself amount to on a GPU (atomics and algorithm choices are not bit-reproducible). Adam turns any gradient
+      difference on weights with near-zero gradients into +-lr steps, so the B runs do NOT stay within 1e-3 of A; they measure
+      the reference arithmetic's own spread, with five samples instead of the single one of r02;
+    * iteration 1 (identical weights) must meet the 1e-3 bar outright; afterwards the HIP path's loss deviation and weight distance
+      from A must stay inside the envelope of the five B runs;
+    * validation (train.py:588-651) of all seven weight sets against ONE ground truth that favours none of them — the instances the
+      COMMON start state predicts on 12 held-out images, degraded (first instance shifted by 3 px, last one dropped) — through ONE
+      evaluation path (Trainer.validate on the GPU), plus A through the oracle's own evaluation as a check of that path. The HIP
+      path's mAP must lie inside the B runs' range widened by 0.2 points; |mAP(HIP) - mAP(A)| is reported next to the spread."""
     from cl4wsis_amd import metrics as MT
     from cl4wsis_amd.dataset import DeviceLoader, get_dataset
     from cl4wsis_amd.train import Trainer
     from oracle import step as ostep
-    K, crop = 20, 97
-    make_mini_voc(tmp_path, n_train=9, n_val=4)
-    opts = p2_opts(crop, extra=["--data_root", str(tmp_path), "--crop_size_val", "97", "--batch_size", "2"])
-    opts.max_iters, opts.start_decay = 10000, 10000          # constant learning rate over the K iterations
+    K0, K, NB, crop = 30, 6, 5, 65
+    make_mini_voc(tmp_path, n_train=9, n_val=12)
+    opts = p2_opts(crop, extra=["--data_root", str(tmp_path), "--crop_size_val", str(crop), "--batch_size", "2"])
+    opts.max_iters, opts.start_decay = 10000, 10000          # constant learning rate, as in the first 5 epochs of scripts/run.sh
     opts.val_flip = False
-    torch.manual_seed(0)
-    tr = Trainer(QuietLogger(), gpu, opts)
-    sds = _fill(tr, 91)
-    A = [{k: v.clone() for k, v in d.items()} for d in sds]
-    B = [{k: v.clone() for k, v in d.items()} for d in sds]
     random.seed(5)
     train_dst, val_dst, _, _, _ = get_dataset(opts)
     loader = DeviceLoader(train_dst, 2, gpu, shuffle=False, drop_last=True)
-    g = torch.Generator().manual_seed(13)
-    names = ("center_old", "offset_old", "center_new", "offset_new")
-    state_a = state_b = None
-    it, traj = 0, {"hip": [], "a": [], "b": []}
-    while it < K:
-        for batch in loader:
-            if it >= K:
-                break
-            images, l1h = batch[0], batch[-1].float()
-            keep = torch.rand(2, 256, 7, 7, generator=g) >= 0.5
-            noise = 1.0 + 1e-6 * torch.randn(images.shape, generator=g)
-            out = tr.step((images, l1h), dropout_keep=keep.to(torch.uint8).to(gpu))
-            traj["hip"].append(out["losses"].cpu().tolist())
-            kw = dict(pooling=opts.pooling, dropout_mask=keep.float(), lr=opts.lr * opts.lr_head, step=it + 1)
-            ra = ostep.p2_step(*A, images.cpu(), l1h.cpu(), 16, adam_state=state_a, **kw)
-            rb = ostep.p2_step(*B, images.cpu() * noise, l1h.cpu(), 16, adam_state=state_b, **kw)
-            state_a, state_b = ra["adam_state"], rb["adam_state"]
-            traj["a"].append([float(ra[k].detach()) for k in names])
-            traj["b"].append([float(rb[k].detach()) for k in names])
-            it += 1
+
+    def batches(n, seed):
+        g, out = torch.Generator().manual_seed(seed), []
+        while len(out) < n:
+            for batch in loader:
+                if len(out) >= n:
+                    break
+                out.append((batch[0].clone(), batch[-1].float().clone(), torch.rand(2, 256, 5, 5, generator=g) >= 0.5))
+        return out
+
+    # ---- conditioning: K0 iterations on the HIP path; its weights are the common start of every trajectory ---------------------------
+    torch.manual_seed(0)
+    tr0 = Trainer(QuietLogger(), gpu, opts)
+    _fill(tr0, 91)
+    for images, l1h, keep in batches(K0, 11):
+        tr0.step((images, l1h), dropout_keep=keep.to(torch.uint8).to(gpu))
     torch.cuda.synchronize()
-    th, ta, tb = (torch.tensor(traj[k], dtype=torch.float64) for k in ("hip", "a", "b"))
-    tot = lambda t: t.sum(1)
-    dev_h = ((tot(th) - tot(ta)).abs() / tot(ta)).tolist()
-    dev_b = ((tot(tb) - tot(ta)).abs() / tot(ta)).tolist()
-    print("MAPPROXY total loss per iteration, oracle A:", [round(v, 3) for v in tot(ta).tolist()])
-    print("MAPPROXY relative loss deviation from A — HIP:", ["%.1e" % v for v in dev_h])
-    print("MAPPROXY relative loss deviation from A — B  :", ["%.1e" % v for v in dev_b])
+    start = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+             for m in (tr0.model, tr0.model_old, tr0.pseudolabeler, tr0.peakgenerator)]
+    del tr0
+    torch.manual_seed(0)
+    tr = Trainer(QuietLogger(), gpu, opts)                   # fresh optimiser state, like the oracle trajectories
+    for m, sd in zip((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator), start):
+        m.load_state_dict(sd)
+    tr._realias()
+    cp = lambda sds: [{k: v.clone() for k, v in d.items()} for d in sds]
+    A, Bs = cp(start), [cp(start) for _ in range(NB)]
+    names = ("center_old", "offset_old", "center_new", "offset_new")
+    state_a, state_b = None, [None] * NB
+    gn = torch.Generator().manual_seed(13)
+    traj = {"hip": [], "a": [], "b": [[] for _ in range(NB)]}
+    for it, (images, l1h, keep) in enumerate(batches(K, 12)):
+        out = tr.step((images, l1h), dropout_keep=keep.to(torch.uint8).to(gpu))
+        traj["hip"].append(out["losses"].cpu().tolist())
+        kw = dict(pooling=opts.pooling, dropout_mask=keep.float(), lr=opts.lr * opts.lr_head, step=it + 1)
+        ra = ostep.p2_step(*A, images.cpu(), l1h.cpu(), 16, adam_state=state_a, **kw)
+        state_a = ra["adam_state"]
+        traj["a"].append([float(ra[k].detach()) for k in names])
+        for i in range(NB):
+            noise = 1.0 + 1e-6 * torch.randn(images.shape, generator=gn)
+            rb = ostep.p2_step(*Bs[i], images.cpu() * noise, l1h.cpu(), 16, adam_state=state_b[i], **kw)
+            state_b[i] = rb["adam_state"]
+            traj["b"][i].append([float(rb[k].detach()) for k in names])
+    torch.cuda.synchronize()
+    tot = lambda t: torch.tensor(t, dtype=torch.float64).sum(1)
+    ta = tot(traj["a"])
+    dev_h = ((tot(traj["hip"]) - ta).abs() / ta).tolist()
+    dev_b = [((tot(t) - ta).abs() / ta).tolist() for t in traj["b"]]
+    env = [max(d[it] for d in dev_b) for it in range(K)]
+    print("MAPPROXY total loss per iteration, oracle A:", [round(v, 3) for v in ta.tolist()])
+    print("MAPPROXY relative loss deviation from A — HIP          :", ["%.1e" % v for v in dev_h])
+    print("MAPPROXY relative loss deviation from A — max of B1..B5:", ["%.1e" % v for v in env])
     params = dict(tr.model.named_parameters())
     tn = ostep.trainable_names(A[0])
-    den = sum(float(A[0][k].double().pow(2).sum()) for k in tn) ** 0.5
+    den = sum(float((A[0][k] - start[0][k]).double().pow(2).sum()) for k in tn) ** 0.5      # how far A itself moved
     dist_h = sum(float((params[k].detach().cpu() - A[0][k]).double().pow(2).sum()) for k in tn) ** 0.5 / den
-    dist_b = sum(float((B[0][k] - A[0][k]).double().pow(2).sum()) for k in tn) ** 0.5 / den
-    print(f"MAPPROXY relative weight distance to A after {K} iterations: HIP {dist_h:.3e}, B {dist_b:.3e}")
-    assert dev_h[0] < 1e-3                                        # first iteration: identical weights, 1e-3 bar
-    assert max(dev_h) <= 2 * max(dev_b) + 2e-3, (max(dev_h), max(dev_b))
-    assert dist_h <= 2 * dist_b + 1e-3, (dist_h, dist_b)
-    # Validation against one ground truth for all three weight sets. Networks that saw 20 iterations from synthetic weights score
-    # 0 AP against the photos' real annotations on every path (measured), which would make the comparison vacuous; the ground
-    # truth is therefore built from oracle A's own predictions, degraded (first instance shifted by 3 px, last one dropped).
+    dist_b = [sum(float((B[0][k] - A[0][k]).double().pow(2).sum()) for k in tn) ** 0.5 / den for B in Bs]
+    print(f"MAPPROXY distance to A after {K} iterations, relative to the distance A moved: HIP {dist_h:.3e}, B1..B5 {['%.3e' % v for v in dist_b]}")
+    assert dev_h[0] < 1e-3                                        # first iteration: identical weights, the 1e-3 bar itself
+    assert max(dev_h) <= 1.5 * max(env) + 2e-3, (dev_h, env)
+    assert dist_h <= 1.5 * max(dist_b) + 1e-3, (dist_h, dist_b)
+
+    # ---- validation: one ground truth (from the common start state), one evaluation path, seven weight sets --------------------------
     val_loader = DeviceLoader(val_dst, 1, gpu)
-    thr = np.arange(0.5, 0.95, 0.05).tolist()
     images = [img.cpu() for img, seg, mask, mask_label, fname in val_loader]
-    gts, n_pred = [], 0
+    ev = Trainer(QuietLogger(), gpu, opts)
+
+    def load(sds):
+        for m, sd in zip((ev.model, ev.model_old, ev.pseudolabeler, ev.peakgenerator), sds):
+            m.load_state_dict(sd)
+        ev._realias()
+
+    load(start)
+    ev.model.eval()                                          # predict_instances outside validate(): eval-mode networks, like validate()
+    gts, n_inst = [], 0
     for img in images:
-        lab, msk, sc = _oracle_predict(A[0], img, tuple(img.shape[-2:]), opts)
+        with torch.no_grad():
+            lab, msk, sc = ev.predict_instances(img, tuple(img.shape[-2:]), opts)
         keep = sc > 0
         lab, msk = lab[keep], msk[keep]
-        n_pred += len(lab)
         gm, gl = msk.copy(), lab.copy()
         if len(gl) > 1:
             gm[0] = np.roll(gm[0], 3, axis=1)
             gm, gl = gm[:-1], gl[:-1]
+        n_inst += len(gl)
         gts.append((gm, gl))
 
+    class _Val:                       # the validation loader contract: (img, seg, masks [1,R,H,W], labels+1 [1,R], name)
+        def __iter__(self):
+            for img, (gm, gl) in zip(images, gts):
+                yield img, torch.zeros(1, *img.shape[-2:]), torch.from_numpy(gm)[None], torch.from_numpy(gl + 1)[None], "x"
+
+    def hip_map(sds):
+        load(sds)
+        return 100.0 * float(ev.validate(_Val(), opts)["map"])
+
     def oracle_map(sd):
+        thr = np.arange(0.5, 0.95, 0.05).tolist()
         acc = [MT.DetectionAccumulator() for _ in thr]
         for img, (gm, gl) in zip(images, gts):
             lab, msk, sc = _oracle_predict(sd, img, tuple(img.shape[-2:]), opts)
@@ -251,16 +315,18 @@ def test_map_proxy_after_training_both_paths(gpu, tmp_path):
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)
-            return float(np.nanmean(np.nanmean(ap, axis=0)))
+            return 100.0 * float(np.nanmean(np.nanmean(ap, axis=0)))
 
-    class _Val:                       # the validation loader contract: (img, seg, masks [1,R,H,W], labels+1 [1,R], name)
-        def __iter__(self):
-            for img, (gm, gl) in zip(images, gts):
-                yield img, torch.zeros(1, *img.shape[-2:]), torch.from_numpy(gm)[None], torch.from_numpy(gl + 1)[None], "x"
-
-    map_h = float(tr.validate(_Val(), opts)["map"])
-    map_a, map_b = oracle_map(A[0]), oracle_map(B[0])
-    print(f"MAPPROXY mAP vs A-derived ground truth: HIP {map_h:.4f}, oracle A {map_a:.4f}, oracle B (inputs * (1 + 1e-6 noise)) {map_b:.4f}; "
-          f"{n_pred} instances")
-    assert n_pred > 4 and 0.0 < map_a < 1.0
-    assert 100 * abs(map_h - map_a) <= max(0.2, 1.5 * 100 * abs(map_b - map_a)), (map_h, map_a, map_b)
+    trained_h = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+                 for m in (tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)]
+    map_start = hip_map(start)
+    map_h, map_a = hip_map(trained_h), hip_map(A)
+    map_b = [hip_map(B) for B in Bs]
+    map_a_oracle = oracle_map(A[0])
+    lo, hi = min(map_b + [map_a]), max(map_b + [map_a])
+    print(f"MAPPROXY mAP (points) against the start state's degraded predictions, {n_inst} instances on {len(images)} images: "
+          f"start {map_start:.2f}; after {K} iterations HIP {map_h:.2f}, oracle A {map_a:.2f} (A through the oracle's own evaluation: "
+          f"{map_a_oracle:.2f}), B1..B5 {['%.2f' % v for v in map_b]}; |HIP - A| = {abs(map_h - map_a):.2f}, reference spread {hi - lo:.2f}")
+    assert n_inst >= 40 and 20.0 < map_start < 100.0      # non-vacuous: the start state scores high but not 100 against its own degraded predictions
+    assert abs(map_a - map_a_oracle) <= 1.0, (map_a, map_a_oracle)          # the evaluation path itself
+    assert lo - 0.2 <= map_h <= hi + 0.2, (map_h, map_a, map_b)

@@ -120,7 +120,9 @@ def test_conv_planes_fused_epilogue(gpu, shape, planes_post, tile):
 
 
 @pytest.mark.parametrize("plan", [(2, 128, 2), (2, 128, 5), (2, 128, -8), (2, 144, 2), (2, 144, 3), (2, 144, -8)])
-@pytest.mark.parametrize("shape", [(5, 64, 65, 67, 256, 3, 1, 1, 1), (2, 160, 21, 19, 192, 3, 1, 2, 2), (4, 256, 33, 33, 256, 1, 1, 0, 1)])
+@pytest.mark.parametrize("shape", [(5, 64, 65, 67, 256, 3, 1, 1, 1), (2, 160, 21, 19, 192, 3, 1, 2, 2), (4, 256, 33, 33, 256, 1, 1, 0, 1),
+                                   (3, 96, 33, 33, 136, 3, 1, 18, 18),      # taps dropped per tile (rows outside the image): K splits divide the surviving K-tiles
+                                   (2, 64, 33, 33, 128, 3, 1, 40, 40)])     # dilation > map: only the centre tap survives
 def test_conv_planes_split_plans(gpu, shape, plan):
     _run(gpu, *shape, plan=plan, seed=2 + sum(shape), epilogue=True, planes_post=True)
 

@@ -19,7 +19,7 @@ def rows(d, counter):
 
 
 def is_x3(name):
-    if "conv_u_bf16x3" in name or "conv_s_bf16x3" in name:
+    if "conv_u_bf16x3" in name or "conv_s_bf16x3" in name or "stem_fused" in name:
         return True
     m = re.search(r"conv_igemm_bf16x3<([^>]*)>", name)
     return bool(m) and m.group(1).split(",")[5].strip() == "2"

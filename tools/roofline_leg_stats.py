@@ -20,7 +20,7 @@ import sys
 def is_x3(name):
     """The bf16x3 forward kernels behind cl4_conv2d_fwd (precision 1) / cl4_conv2d_fwd_planes: the role-split kernel's two-plane
     instantiations, the unified-wave kernel and the planes-input kernel."""
-    if "conv_u_bf16x3" in name or "conv_s_bf16x3" in name:
+    if "conv_u_bf16x3" in name or "conv_s_bf16x3" in name or "stem_fused" in name:
         return True
     m = re.search(r"conv_igemm_bf16x3<([^>]*)>", name)
     return bool(m) and m.group(1).split(",")[5].strip() == "2"
