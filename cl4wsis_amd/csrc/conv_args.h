@@ -50,4 +50,9 @@ int launch_conv_u(const ConvArgs& a, int ks, bool split, unsigned grid, hipStrea
 // bn = pixels per tile: 128, or 144 (one round of the 33 x 33 maps, see conv_s.hip).
 int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st, int bn = 128);
 
+// conv_p.hip: the persistent, software-pipelined planes kernel for short-K 1x1 layers with planes output (and planes residual): one
+// 512-thread workgroup per CU walks the 128 x 128 tiles and overlaps tile t's register-direct epilogue with tile t+1's K loop.
+bool conv_p_eligible(const ConvArgs& a, int ks);
+int launch_conv_p(const ConvArgs& a, unsigned ntile, hipStream_t st);
+
 }  // namespace cl4

@@ -1312,6 +1312,10 @@ std::mutex& plan_mutex() { static std::mutex m; return m; }
 
 FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision = 0) {
   FwdPlan p{1, 128, 1, 0, 0};
+  if (impl == 3 && precision == 3) {                                         // persistent pipelined planes kernel (conv_p.hip): unsplit 128 x 128 tiles
+    p.impl = 3; p.tile = 128; p.splits = 1; p.kchunk = cl4::cdiv(K, BK2) * BK2;
+    return p;
+  }
   if (impl != 2 || cout % 4 != 0 || cout < 64) return p;
   p.impl = 2;
   p.tile = ((tile == 128 && cout >= 128) || precision == 3) ? 128 : 64;      // planes-input kernel (precision code 3): 128 output channels per tile
@@ -1466,7 +1470,16 @@ int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace
     return CL4_EINVAL;
   } else {
     const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 4 + 3});
-    if (pl.impl != 2 || pl.tile != 128) { cl4::set_error("conv2d_fwd_planes: no 128x128 plan for this shape"); return CL4_EINVAL; }
+    if ((pl.impl != 2 && pl.impl != 3) || pl.tile != 128) { cl4::set_error("conv2d_fwd_planes: no 128x128 plan for this shape"); return CL4_EINVAL; }
+    if (pl.impl == 3) {
+      if (cl4::conv_p_eligible(a, KS)) {
+        a.gx = cl4::cdiv(a.cout, 128);
+        a.ntile_l = a.gx * cl4::cdiv(a.npix, 128);
+        a.tile_base = 0; a.ws = nullptr; a.ws_p0 = 0; a.ws_npix = a.npix; a.kchunk = pl.kchunk;
+        return cl4::launch_conv_p(a, (unsigned)a.ntile_l, st);
+      }
+      // a plan pinned for this shape by a call with other operands (fp32 output, fp32 residual, ...): the plain kernel, unsplit
+    }
     const TailGeom tg = tail_geometry(pl, a.cout, a.npix, 3);
     const bool hybrid = tg.main > 0 && pl.tail > 1;
     const int nsplit = hybrid ? pl.tail : pl.splits;
@@ -2111,7 +2124,7 @@ extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
   va.pad = d->pad; va.in_ctot = d->in_ctot; va.dil = d->dil;
   if (pl.impl == 2 && (vec_gather_plan(va, d->kh, d->precision, pl.tile) || u_plan(va, d->kh, d->precision, pl.tile)))
     npix = d->n * ((d->hout * d->wout + 3) & ~3);
-  if (d->precision == 3 && (pl.impl != 2 || pl.tile != 128)) return 0;
+  if (d->precision == 3 && (pl.impl != 2 || pl.tile != 128)) return 0;      // also impl 3 (persistent kernel): no slabs
   if (d->precision != 0 && pl.impl == 2 && pl.tail > 0) {
     const TailGeom tg = tail_geometry(pl, d->cout, npix, d->precision);
     return (tg.main > 0 && pl.tail > 1) ? (size_t)pl.tail * d->cout * (npix - tg.p0) * sizeof(float) : 0;   // small-tile tail / degenerate: no slabs
@@ -2128,7 +2141,7 @@ extern "C" int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int til
   const PlanKey key{d->cout, d->n * d->hout * d->wout, K, d->kh, d->stride, d->dil, d->hin * 4 + d->precision};
   std::lock_guard<std::mutex> g(plan_mutex());
   if (impl == 0) { plan_table().erase(key); return CL4_OK; }
-  CL4_REQUIRE(impl == 1 || impl == 2, "set_plan: impl must be 0, 1 or 2");
+  CL4_REQUIRE(impl == 1 || impl == 2 || (impl == 3 && d->precision == 3), "set_plan: impl must be 0, 1 or 2 (3: planes-input launches only)");
   CL4_REQUIRE(tile == 64 || tile == 128 || (tile == 144 && d->precision == 3), "set_plan: tile must be 64 or 128 (144: planes-input launches only)");
   plan_table()[key] = make_plan(impl, tile, splits, d->cout, K, d->precision);
   return CL4_OK;

@@ -253,6 +253,7 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
     _tuned[key] = (best, best_ms)
 
 
+CONV_P = os.environ.get("CL4_CONV_P", "1") != "0"      # 0: never pick the persistent pipelined planes kernel (A/B measurements)
 PLANES_TILES = [int(v) for v in os.environ.get("CL4_PLANES_TILES", "128,144").split(",")]   # pixel widths of the planes kernel's tiles the tuner may pick
 
 
@@ -268,16 +269,22 @@ def _autotune_planes(d, args, reps=6):
     best, best_ms = None, float("inf")
     seen = set()
     npix = d.n * d.hout * d.wout
-    for tile in PLANES_TILES:
+    cands = [(2, tile, splits) for tile in PLANES_TILES for splits in _SPLITS]
+    # the persistent pipelined kernel (csrc/conv_p.hip): short-K 1x1 layers that write planes only (and read a planes residual)
+    pre, post_f, out_f32, out_pl = args[4], args[5], args[7], args[8]
+    if (CONV_P and d.kh == 1 and d.stride == 1 and d.pad == 0 and d.cout % 128 == 0 and K >= 128 and pre is None and post_f is None
+            and out_f32 is None and out_pl is not None and -(-d.cout // 128) * -(-npix // 128) >= 512):
+        cands.append((3, 128, 1))
+    for impl, tile, splits in cands:
         tiles = -(-d.cout // 128) * -(-npix // tile)
-        for splits in _SPLITS:
+        if True:
             if splits == -1 or abs(splits) > max(1, K // 64):
                 continue
             if splits > 1 and tiles >= 256 and d.n < _FULL_SPLITS_MIN_N:      # whole-launch splits only where a launch cannot fill the chip (_fills_the_chip)
                 continue
-            call("cl4_conv2d_fwd_set_plan", C.byref(d), 2, tile, splits)
+            call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, tile, splits)
             need = lib.cl4_conv2d_fwd_workspace_bytes(C.byref(d))
-            sig = (tile, need, splits < 0)
+            sig = (impl, tile, need, splits < 0)
             if sig in seen or need > (1 << 30):
                 continue
             seen.add(sig)
@@ -292,7 +299,7 @@ def _autotune_planes(d, args, reps=6):
             e1.synchronize()
             ms = e0.elapsed_time(e1) / reps
             if ms < best_ms:
-                best, best_ms = (2, tile, splits), ms
+                best, best_ms = (impl, tile, splits), ms
     call("cl4_conv2d_fwd_set_plan", C.byref(d), *best)
     _tuned[key] = (best, best_ms)
 
@@ -442,7 +449,11 @@ def conv2d_planes(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre
     args = (ptr(xs.data), ptr(wp.data), ptr(scale), ptr(shift), ptr(pre), ptr(post_f), ptr(post_s.data) if post_s is not None else None,
             ptr(out), ptr(out_planes.data) if out_planes is not None else None)
     if AUTOTUNE:
-        _autotune_planes(d, args)
+        targs = args
+        if post_s is not None and out_planes is not None and out_planes.data.data_ptr() == post_s.data.data_ptr():
+            # in-place residual (the output overwrites the residual operand): the tuner's repeated launches must not touch it
+            targs = args[:8] + (ptr(Planes(out_planes.n, out_planes.c, out_planes.h, out_planes.w, dev).data),)
+        _autotune_planes(d, targs)
     need = _hip.load().cl4_conv2d_fwd_workspace_bytes(C.byref(d))
     ws = _conv_workspace(dev, need) if need else None
     call("cl4_conv2d_fwd_planes", C.byref(d), *args, ptr(ws), need, stream())

@@ -146,3 +146,86 @@ def test_conv_planes_both_mfma_shapes_agree_with_the_fp32_input_kernel(gpu):
     y1, _ = ops.conv2d_planes(ops.to_planes(x), wp, 3, pad=1)
     torch.cuda.synchronize()
     assert _rel_err(y1.cpu(), y0.cpu()) < 2e-6
+
+
+# (n, cin, h, w, cout): 1x1 layers on the persistent pipelined kernel (csrc/conv_p.hip, plan impl 3): planes in, planes out
+P_SHAPES = [
+    (9, 256, 33, 33, 1024),      # res4 conv3: 8 K-tiles; 77 pixel tiles x 8 = 616 tiles = 2.4 per workgroup, ragged last pixel tile
+    (3, 128, 33, 31, 512),       # 4 K-tiles (the minimum): the four epilogue chunks fill the whole next K loop
+    (2, 160, 17, 19, 256),       # 5 K-tiles, fewer tiles than CUs: most workgroups own one tile (drain path only)
+    (5, 512, 20, 20, 128),       # 16 K-tiles, one channel tile
+    (4, 192, 33, 33, 384),       # 6 K-tiles
+    (4, 224, 33, 33, 384),       # 7 K-tiles (odd count after the peeled steps)
+]
+
+
+@pytest.mark.parametrize("residual", [False, True])
+@pytest.mark.parametrize("shape", P_SHAPES)
+def test_conv_persistent_pipelined_planes_kernel(gpu, shape, residual):
+    """Same results as the plain planes kernel, bit for bit on the planes output: both form the same products in the same K order
+    (one K-tile after the other, two row-block halves per tile) and apply the same epilogue arithmetic."""
+    from cl4wsis_amd import _hip, ops
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    post = torch.randn(n, cout, h, w, generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double()) * scale[None, :, None, None] + shift[None, :, None, None], 0.01)
+    if residual:
+        ref = F.leaky_relu(ref + post.double(), 0.01)
+    xs, wp = ops.to_planes(x.to(gpu)), ops.pack_conv_weight(wt.to(gpu), 1)
+    kw = dict(scale=scale.to(gpu), shift=shift.to(gpu), act1=ops.ACT_LEAKY, slope1=0.01, want_fp32=False, want_planes=True)
+    if residual:
+        kw.update(post=ops.to_planes(post.to(gpu)), act2=ops.ACT_LEAKY, slope2=0.01)
+    d = ops.ConvDescFor(n, cin, h, w, cin, 0, cout, 1, 1, 0, 1, cout, 0, 0, 0.0, 0, 0.0, 3)
+    outs = {}
+    for impl in (2, 3):
+        _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, 128, 1)
+        try:
+            outs[impl] = ops.conv2d_planes(xs, wp, 1, **kw)[1]
+            torch.cuda.synchronize()
+        finally:
+            _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 0, 64, 1)
+    y = ops.from_planes(outs[3]).cpu()
+    assert _rel_err(y, ref.float()) < TOL, _rel_err(y, ref.float())
+    assert torch.equal(outs[3].data, outs[2].data)
+
+
+def test_conv_persistent_kernel_in_place_and_channel_slice(gpu):
+    """The two ways the networks call it: output written in place over the residual (identity blocks of a frozen stage), and output
+    into a channel slice of a wider planes tensor."""
+    from cl4wsis_amd import _hip, ops
+    g = torch.Generator().manual_seed(5)
+    n, cin, h, cout = 6, 128, 33, 256
+    x, post = torch.randn(n, cin, h, h, generator=g), torch.randn(n, cout, h, h, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    xs, wp = ops.to_planes(x.to(gpu)), ops.pack_conv_weight(wt.to(gpu), 1)
+    d = ops.ConvDescFor(n, cin, h, h, cin, 0, cout, 1, 1, 0, 1, cout, 0, 0, 0.0, 0, 0.0, 3)
+    res = {}
+    for impl in (2, 3):
+        _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, 128, 1)
+        try:
+            ps = ops.to_planes(post.to(gpu))
+            out = ops.conv2d_planes(xs, wp, 1, post=ps, act2=ops.ACT_RELU, want_fp32=False, out_planes=ps)[1]
+            torch.cuda.synchronize()
+            res[impl] = out.data.clone()
+        finally:
+            _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 0, 64, 1)
+    assert torch.equal(res[2], res[3])
+    ref = F.relu(F.conv2d(x.double(), wt.double()) + post.double()).float()
+    assert _rel_err(ops.from_planes(ops.Planes(n, cout, h, h, gpu, data=res[3])).cpu(), ref) < TOL
+    # channel slice: 256 channels into [64, 320) of a 384-channel planes tensor
+    d2 = ops.ConvDescFor(n, cin, h, h, cin, 0, cout, 1, 1, 0, 1, 384, 64, 0, 0.0, 0, 0.0, 3)
+    wide = {}
+    for impl in (2, 3):
+        _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d2), impl, 128, 1)
+        try:
+            big = ops.Planes(n, 384, h, h, gpu)
+            big.data.fill_(0)
+            ops.conv2d_planes(xs, wp, 1, want_fp32=False, out_planes=big, out_coff=64)
+            torch.cuda.synchronize()
+            wide[impl] = big.data.clone()
+        finally:
+            _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d2), 0, 64, 1)
+    assert torch.equal(wide[2], wide[3])

@@ -59,3 +59,35 @@ def test_resnet_body_uses_the_fused_stem(gpu, monkeypatch):
     for u, v in zip(a, b):
         assert tuple(u.shape) == tuple(v.shape)
         assert ((u - v).abs().max() / v.abs().max()).item() < 5e-5
+
+
+def test_inplace_trunk_gives_identical_stage_outputs(gpu, monkeypatch):
+    """Identity bottleneck blocks overwrite their residual operand (backbone.INPLACE_TRUNK): same kernels, same operands, so the five
+    stage outputs must be bit-identical to the out-of-place run — also in iteration 0, when the launch-plan tuner re-runs every
+    convolution (it must not touch the residual it would then read again)."""
+    from cl4wsis_amd import backbone, ops
+    torch.manual_seed(4)
+    body = backbone.net_resnet50(keep_outputs=True).to(gpu).eval()
+    for m in body.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_(0, 0.1)
+    x = torch.randn(3, 3, 129, 129, device=gpu)
+    with torch.no_grad():
+        monkeypatch.setattr(backbone, "INPLACE_TRUNK", False)
+        ref = [t.clone() for t in body(x)]
+        monkeypatch.setattr(backbone, "INPLACE_TRUNK", True)
+        monkeypatch.setattr(ops, "AUTOTUNE", True)
+        tuned = body(x)                                 # tuner active: plans may change, the operands must not
+        monkeypatch.setattr(ops, "AUTOTUNE", False)
+        again = body(x)
+    for r, t, a in zip(ref, tuned, again):
+        assert ((r - t).abs().max() / r.abs().max()).item() < 1e-4      # another launch plan sums in another order (50 layers deep)
+        assert torch.equal(t, a)
+        assert planes_equal(t, a)
+
+
+def planes_equal(t, a):
+    from cl4wsis_amd.nn import planes_of
+    pt, pa = planes_of(t), planes_of(a)
+    return (pt is None and pa is None) or torch.equal(pt.data, pa.data)
