@@ -170,17 +170,27 @@ def cpu_baseline(opts, iters):
                       f"{iters} timed iterations after a batch-2 warm-up, torch threads = {cores}"}
 
 
-def stock_rocm(opts, device, iters=2):
+def stock_rocm(opts, device, iters=2, rank=0, world=1):
     """BASELINE.md §4 second comparator: the same restatement with stock PyTorch-ROCm ops (MIOpen convolutions, ATen
     elementwise kernels) on this GPU, batch 16 — like the reference on a GPU it keeps the label stage on the host
-    (OpenCV/numpy loops behind .cpu() copies, modules/utils.py:179-385) — under the reference's own autocast (train.py:252)."""
+    (OpenCV/numpy loops behind .cpu() copies, modules/utils.py:179-385) — under the reference's own autocast (train.py:252).
+    At N > 1 it is the stock DATA-PARALLEL comparator: every rank runs the step on its 16 / N images and the gradients are averaged
+    with torch.distributed all-reduces between backward and Adam (what the DDP wrappers of train.py:187-196 do); the value is the
+    global batch over the slowest rank's iteration time. A collective leg: every rank must call it."""
     import torch
+    import torch.distributed as dist
     from cl4wsis_amd.synthetic import synthetic_batch
     from oracle import step as ostep
-    torch.set_num_threads(_host_cores())
-    b = GLOBAL_BATCH
-    images, l1h = synthetic_batch(b, 42, device, CROP)
-    res = {"unit": "images/s", "batch": b, "iterations": iters}
+    torch.set_num_threads(max(1, _host_cores() // max(1, world)))
+    b = GLOBAL_BATCH // world
+    images, l1h = synthetic_batch(b, 42 + rank, device, CROP)
+    sync = None
+    if world > 1:
+        def sync(grads):
+            for t in grads.values():
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                t.div_(world)
+    res = {"unit": "images/s", "batch": GLOBAL_BATCH, "per_gpu_batch": b, "iterations": iters}
     modes = (("fp32", False), ("autocast_fp16", True)) if os.environ.get("CL4_BENCH_STOCK_FP32") == "1" else (("autocast_fp16", True),)
     for name, amp in modes:
         new, old, pl, pg = _oracle_state(opts, device)
@@ -189,15 +199,23 @@ def stock_rocm(opts, device, iters=2):
             torch.cuda.synchronize()
             t0 = time.time()
             out = ostep.p2_step(new, old, pl, pg, images, l1h, 16, pooling=opts.pooling, lr=opts.lr * opts.lr_head,
-                                adam_state=state, step=i + 1, autocast=amp)
+                                adam_state=state, step=i + 1, autocast=amp, grad_sync=sync)
             state = out["adam_state"]
             torch.cuda.synchronize()
-            _progress(f"stock_rocm[{name}]: iteration {i} {time.time() - t0:.2f} s")
+            dt = time.time() - t0
+            if world > 1:                                       # the step ends when the slowest rank has finished
+                tt = torch.tensor([dt], device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            if rank == 0:
+                _progress(f"stock_rocm[{name}]: iteration {i} {dt:.2f} s")
             if i:
-                times.append(time.time() - t0)
+                times.append(dt)
         del out, state
         torch.cuda.empty_cache()
-        res[name] = {"value": b / min(times), "ms_per_step": 1e3 * min(times), "seconds_per_iteration": [round(t, 2) for t in times]}
+        res[name] = {"value": GLOBAL_BATCH / min(times), "ms_per_step": 1e3 * min(times), "seconds_per_iteration": [round(t, 2) for t in times]}
+    if world > 1:
+        res["parallelism"] = f"dp{world}: per-rank step + torch.distributed all-reduce (SUM / N) of the 61 trainable gradient tensors before Adam"
     res["note"] = ("oracle p2_step on cuda: stock torch ops (MIOpen convolutions), the label stage as the reference runs it on a GPU "
                    "(per-contour torch ops on the device, masks / centroids via .cpu(), modules/utils.py:257-385), under the reference's "
                    f"own amp.autocast(float16) (train.py:252); 1 warm-up + {iters} timed iterations, best of them (MIOpen's kernel search "
@@ -404,14 +422,21 @@ def worker(a):
                 res[kind] = {"achieved": kf / (kms * 1e-3) / 1e12, "peak": pk, "unit": "TFLOP/s",
                              "frac": kf / (kms * 1e-3) / 1e12 / pk, "ms_per_step": kms / 2,
                              "launches_per_step": kn / 2}
-        if world == 1 and not a.no_cpu_baseline:
-            del trainer, out
-            torch.cuda.empty_cache()
+    # Comparator legs, outside the timed region. stock_rocm is a COLLECTIVE leg at N > 1 (every rank takes part: stock PyTorch-ROCm
+    # ops + gradient all-reduce = the DDP comparator BASELINE.md section 4 names); cpu_baseline runs on rank 0 at N = 1 only.
+    stock = None
+    if not a.no_cpu_baseline:
+        del trainer, out
+        torch.cuda.empty_cache()
+        stock = stock_rocm(opts, device, rank=rank, world=world)
+    if rank == 0:
+        if stock is not None:
             # BASELINE.md publishes no number for this metric; its §4 names stock PyTorch-ROCm as the comparator to beat (>= 4x),
-            # measured here on the same GPU, same batch, same synthetic inputs.
-            res["stock_rocm"] = stock_rocm(opts, device)
-            res["vs_baseline"] = res["value"] / res["stock_rocm"]["value"]
+            # measured here on the same GPUs, same global batch, same synthetic inputs.
+            res["stock_rocm"] = stock
+            res["vs_baseline"] = res["value"] / stock["value"]
             res["vs_baseline_note"] = "value / stock_rocm.value (no published number exists, BASELINE.md §1)"
+        if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(opts, a.cpu_baseline_iters)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -4,9 +4,11 @@ environment, seeding, loaders, `Trainer`, epoch loop, checkpoints.
     python -m torch.distributed.run --nproc-per-node 8 -m cl4wsis_amd.run --dataset voc --task 15-5 --step 1 \\
         --weakly --phase 2 --optim adam --lr 5e-5 --weight_decay 0 --lr_policy warmup --batch_size 16 ...
 
-The reference's data pipeline (`dataset/`) is outside the hot-path scope: when a module named
-`dataset` with the reference's `get_dataset(opts)` is importable it is used unchanged, otherwise `--data_root synthetic`
-drives the step with VOC-shaped synthetic batches (the same generator bench.py uses).
+Data: when `<data_root>/voc/pascal_sbd_train.json` (or the COCO tree of the coco-voc task) exists, the loaders come from
+`cl4wsis_amd.dataset` — the mirror of the reference's `dataset/` package (`get_dataset`, the VOC / COCO classes, the incremental
+wrapper) whose pixel work (crop, Pillow-exact resampling, normalisation, label_generation) runs on the device behind
+`DeviceLoader`; without such a tree (`--data_root synthetic`, the default of the tests and of bench.py) the step is driven
+by VOC-shaped synthetic batches from `cl4wsis_amd.synthetic`.
 """
 import os
 import random

@@ -70,9 +70,10 @@ def trainable_names(sd):
 
 
 def p2_step(sd_new, sd_old, sd_pl, sd_pg, images, l1h, old_classes, pooling=32, dropout_mask=None, lr=5e-4,
-            adam_state=None, step=1, betas=(0.9, 0.999), eps=1e-8, autocast=False, **label_kw):
+            adam_state=None, step=1, betas=(0.9, 0.999), eps=1e-8, autocast=False, grad_sync=None, **label_kw):
     """One phase-2 iteration on the CPU (train.py:241-541): returns losses, intermediates, gradients and applies Adam
-    to `sd_new` in place (torch.optim.Adam arithmetic). `autocast` (timing legs only): run the networks under
+    to `sd_new` in place (torch.optim.Adam arithmetic). `grad_sync(grads)` (optional) is called between backward and Adam.
+    `autocast` (timing legs only): run the networks under
     torch.autocast(float16) like the reference's amp.autocast block (train.py:252); outputs are widened to fp32 before the
     label stage."""
     bs = images.shape[0]
@@ -99,6 +100,8 @@ def p2_step(sd_new, sd_old, sd_pl, sd_pg, images, l1h, old_classes, pooling=32, 
                          sd_pg, size, old_classes, **label_kw)
     out["loss"].backward()
     grads = {k: sd_new[k].grad.clone() for k in names}
+    if grad_sync is not None:       # data-parallel legs (bench.py stock_rocm at N > 1): what DDP's bucketed all-reduce does between
+        grad_sync(grads)            # backward and optimizer.step() — averages the gradients across ranks, in place
     if adam_state is None:
         adam_state = {k: (torch.zeros_like(sd_new[k]), torch.zeros_like(sd_new[k])) for k in names}
     b1, b2 = betas

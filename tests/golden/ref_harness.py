@@ -4,6 +4,12 @@ installed here and exposes the reference modules.
 
 This file contains no reference source: it only arranges sys.modules so that the reference's own
 files can be imported unmodified from /root/reference.
+
+The stand-ins are NOT neutral plumbing in one place: the `inplace_abn` stub (absent PyPI package, version unpinned by the
+reference) encodes this repository's BELIEF about that package's arithmetic — InPlaceABN / InPlaceABNSync normalise with
+`|weight| + eps` and back-propagate `sign(weight)` into the weight, plain ABN uses the signed weight (DESIGN.md section 2,
+"Unpinned third-party arithmetic"). Every fixture generated through this harness inherits that assumption; so do the OpenCV
+connected-components stand-in (the oracle's own `connected_components`) and the chainercv / pycocotools restatements.
 """
 import importlib
 import importlib.util

@@ -11,11 +11,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(args, tmp, monkeypatch):
+def _run(args, tmp, monkeypatch, autotune="1"):
     from cl4wsis_amd import argparser, run
     monkeypatch.chdir(tmp)
     monkeypatch.setenv("CL4_SYNTH_LEN", "4")
-    monkeypatch.setenv("CL4_AUTOTUNE", "1")               # the CLI flow runs with the warm-up autotuner, like production
+    monkeypatch.setenv("CL4_AUTOTUNE", autotune)          # the CLI flow runs with the warm-up autotuner, like production
     opts = argparser.modify_command_options(argparser.get_argparser().parse_args(args))
     run.main(opts)
 
@@ -59,13 +59,16 @@ def test_cli_trains_from_a_voc_tree_through_the_device_loader(gpu, tmp_path, mon
     supervised phase-2 epoch on the tiny VOC-shaped tree, with worker processes."""
     from util import make_mini_voc
     make_mini_voc(tmp_path / "data", n_train=8, n_val=2)
-    common = ["--dataset", "voc", "--task", "15-5", "--crop_size", "65", "--batch_size", "2", "--epochs", "1", "--num_workers", "2",
+    # worker processes (each one pages the whole torch image in: ~10 s per loader on a fresh box) and the warm-up autotuner only in the
+    # phase-2 run, where the device loader's weakly-supervised path is the point; the step-0 run decodes in the main process
+    common = ["--dataset", "voc", "--task", "15-5", "--crop_size", "65", "--batch_size", "2", "--epochs", "1",
               "--no_pretrained", "--name", "D", "--print_interval", "1", "--data_root", str(tmp_path / "data")]
-    _run(common + ["--step", "0", "--bce", "--lr", "5e-5", "--optim", "adam", "--weight_decay", "0"], tmp_path, monkeypatch)
+    _run(common + ["--num_workers", "0", "--step", "0", "--bce", "--lr", "5e-5", "--optim", "adam", "--weight_decay", "0"], tmp_path, monkeypatch,
+         autotune="0")
     ck0 = tmp_path / "checkpoints/step/voc-15-5/D_0.pth"
     c0 = torch.load(ck0, map_location="cpu")
     assert all(torch.isfinite(v).all() for v in c0["model_state"].values() if v.is_floating_point())
-    _run(common + ["--step", "1", "--weakly", "--alpha", "0.5", "--loss_de", "1", "--lr_policy", "warmup", "--affinity", "--phase", "2",
+    _run(common + ["--num_workers", "1", "--step", "1", "--weakly", "--alpha", "0.5", "--loss_de", "1", "--lr_policy", "warmup", "--affinity", "--phase", "2",
                    "--optim", "adam", "--lr", "5e-5", "--weight_decay", "0", "--step_ckpt", str(ck0)], tmp_path, monkeypatch)
     c1 = torch.load(tmp_path / "checkpoints/step/voc-15-5/D_1.pth", map_location="cpu")
     ki = "module.decoder.instance_decoder.aspp.convs.0.0.weight"

@@ -174,57 +174,4 @@ def test_eval_after_graph_training_sees_current_weights(gpu):
     assert torch.allclose(c2, ref, rtol=1e-5, atol=1e-6), (c2 - ref).abs().max()
 
 
-@pytest.mark.parametrize("lookahead", [False, True])
-def test_graph_steps_unchanged_by_an_eval_pass_in_between(gpu, lookahead):
-    """The captured step reads the frozen networks' packed weights / folded BN at fixed addresses. An eval pass between two training
-    steps clears the derived-tensor cache and rebuilds those tensors eagerly; the graph must keep reading valid operands (the trainer
-    pins what its graphs captured). Twin trainers, same batches; one of them validates (and churns the allocator) after step 3 —
-    the losses of the following steps must agree. lookahead=True drives the pipelined two-graph path."""
-    from cl4wsis_amd.train import Trainer
-    from cl4wsis_amd.nn import CACHE
-    from oracle import weights
-    crop = 97
-    opts = p2_opts(crop)
-    opts.val_flip = False
-    opts.max_iters, opts.start_decay = 1000, 1000
-    g = torch.Generator().manual_seed(9)
-    batches = [(torch.randn(4, 3, crop, crop, generator=g), torch.eye(20)[[16 + i % 4, 15, 17, 18]].clone()) for i in range(7)]
-    x_eval = torch.randn(1, 3, crop, crop, generator=g)
-
-    def run(with_eval):
-        torch.manual_seed(0)
-        tr = Trainer(_Log(), gpu, opts)
-        for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
-            m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=31 + i))
-        tr._realias()
-        losses = []
-        for i, b in enumerate(batches):
-            nb = batches[i + 1] if lookahead and i + 1 < len(batches) else None
-            out = tr.step(b, next_batch=nb)
-            losses.append(out["losses"].clone())
-            if with_eval and i == 3:
-                tr.model.eval()
-                tr.predict_instances(x_eval, (crop, crop), opts)
-                tr.model.train()
-                CACHE.clear()
-                with torch.no_grad():
-                    tr.model_old(x_eval.to(gpu), interpolate=False)      # rebuilds the old model's derived tensors eagerly
-                junk = [torch.full((n,), 7.0, device=gpu) for n in (1 << 12, 1 << 16, 1 << 20, 1 << 22) for _ in range(8)]
-                del junk
-        torch.cuda.synchronize()
-        assert (tr._pipe is not None) if lookahead else (tr._graph is not None)
-        return torch.stack(losses).cpu()
-
-    import os
-    if os.environ.get("CL4_TEST_NO_PIN"):                 # one-off check that this test has teeth: drop the pin, expect a failure
-        Trainer._derived_snapshot = lambda self: []
-    a, a2, b = run(False), run(False), run(True)
-    assert torch.isfinite(a).all()
-    # not bit-equal run to run: the weight gradients accumulate with fp32 atomics and the label stage is discrete, so the bar is
-    # what two UNPERTURBED runs differ by (a corrupted operand shows as a gross change of the losses, not as a drift)
-    noise = ((a - a2).abs() / a.abs().clamp_min(1e-6)).max().item()
-    dev = ((a - b).abs() / a.abs().clamp_min(1e-6)).max().item()
-    torch.set_printoptions(profile="full")
-    print("run-to-run noise %.3e, deviation with the eval pass %.3e" % (noise, dev))
-    assert torch.equal(a[:4], b[:4]) or torch.allclose(a[:4], b[:4], rtol=max(2e-3, 3 * noise)), (a, b)     # before the eval pass
-    assert dev <= max(2e-3, 3 * noise), (noise, dev, a, a2, b)
+# (the eval-pass-between-replays check lives in tests/test_graph_safety_gpu.py::test_graph_steps_survive_regrow_short_batch_and_eval_pass)
