@@ -48,7 +48,8 @@ int launch_conv_u(const ConvArgs& a, int ks, bool split, unsigned grid, hipStrea
 // conv_s.hip: the planes-input bf16x3 kernel (activations arrive pre-split: no conversion in the K loop). Any stride / pad / dilation,
 // ks = 1 | 3, cin % 32 == 0. Same launch conventions as launch_conv_u.
 // bn = pixels per tile: 128, or 144 (one round of the 33 x 33 maps, see conv_s.hip).
-int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st, int bn = 128);
+// planes = bf16 planes per operand: 2 (bf16x3) or 3 (bf16x6; 144-pixel tiles only).
+int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st, int bn = 128, int planes = 2);
 
 // conv_p.hip: the persistent, software-pipelined planes kernel for short-K 1x1 layers with planes output (and planes residual): one
 // 512-thread workgroup per CU walks the 128 x 128 tiles and overlaps tile t's register-direct epilogue with tile t+1's K loop.

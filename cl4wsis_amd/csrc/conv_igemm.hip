@@ -1310,6 +1310,9 @@ struct PlanKey {
 std::map<PlanKey, FwdPlan>& plan_table() { static std::map<PlanKey, FwdPlan> t; return t; }
 std::mutex& plan_mutex() { static std::mutex m; return m; }
 
+// precision codes of the planes-input launches: 3 = two planes (bf16x3), 4 = three planes (bf16x6, 144-pixel tiles only)
+static inline bool planes_code(int precision) { return precision == 3 || precision == 4; }
+
 FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision = 0) {
   FwdPlan p{1, 128, 1, 0, 0};
   if (impl == 3 && precision == 3) {                                         // persistent pipelined planes kernel (conv_p.hip): unsplit 128 x 128 tiles
@@ -1318,15 +1321,15 @@ FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision
   }
   if (impl != 2 || cout % 4 != 0 || cout < 64) return p;
   p.impl = 2;
-  p.tile = ((tile == 128 && cout >= 128) || precision == 3) ? 128 : 64;      // planes-input kernel (precision code 3): 128 output channels per tile
-  if (precision == 3 && tile == 144) p.bn = 144;                             // ... x 128 or 144 pixels
+  p.tile = ((tile == 128 && cout >= 128) || planes_code(precision)) ? 128 : 64;      // planes-input kernel: 128 output channels per tile
+  if ((precision == 3 && tile == 144) || precision == 4) p.bn = 144;                   // ... x 128 or 144 pixels (three planes: 144 only)
   const int ktiles = cl4::cdiv(K, BK2);
   int s = splits < 0 ? -splits : (splits < 1 ? 1 : splits);
   if (s > ktiles) s = ktiles;
   const int per = cl4::cdiv(ktiles, s);
   p.kchunk = per * BK2;
   const int actual = cl4::cdiv(K, p.kchunk);
-  if (splits == -1 && precision != 0 && precision != 3 && p.tile == 128) { p.tail = 1; p.splits = 1; }     // main + SMALL-TILE tail (64x64, unsplit)
+  if (splits == -1 && precision != 0 && !planes_code(precision) && p.tile == 128) { p.tail = 1; p.splits = 1; }     // main + SMALL-TILE tail (64x64, unsplit)
   else if (splits < 0 && precision != 0 && actual > 1) { p.tail = actual; p.splits = 1; }
   else p.splits = actual;
   return p;
@@ -1344,15 +1347,15 @@ FwdPlan plan_fwd(const PlanKey& key) {
     auto it = plan_table().find(key);
     if (it != plan_table().end()) return it->second;
   }
-  const int cout = key.cout, npix = key.npix, K = key.K, precision = key.hin % 4;
+  const int cout = key.cout, npix = key.npix, K = key.K, precision = key.hin % 8;
   if (impl != 2 || cout % 4 != 0 || cout < 64) return FwdPlan{1, 128, 1, 0, 0};
   if (force_tile || force_split) return make_plan(2, force_tile ? force_tile : 128, force_split ? force_split : 1, cout, K, precision);
   const int ktiles = cl4::cdiv(K, BK2);
   double best = 1e30;
   FwdPlan bestp = make_plan(2, 64, 1, cout, K, precision);
   for (int tile = 64; tile <= 128; tile += 64) {
-    if (precision == 3 && tile != 128) continue;
-    if (tile == 128 && precision != 3 && (cout < 128 || (precision == 2 && ktiles < 64))) continue;   // bf16x6 at 128x128: 96 KB LDS, one WG per CU — long K only
+    if (planes_code(precision) && tile != 128) continue;
+    if (tile == 128 && !planes_code(precision) && (cout < 128 || (precision == 2 && ktiles < 64))) continue;   // bf16x6 at 128x128: 96 KB LDS, one WG per CU — long K only
     const long wgs = (long)cl4::cdiv(cout, tile) * cl4::cdiv(npix, tile);
     const double t_tile = tile == 128 ? 2.4 : 0.65;   // us per K-tile of one workgroup at ~70 % MFMA issue
     const double t_fixed = tile == 128 ? 5.0 : 2.5;   // prologue + epilogue
@@ -1379,7 +1382,7 @@ TailGeom tail_geometry(const FwdPlan& pl, int cout, int npix, int precision) {
   g.main = 0;
   g.p0 = 0;
   if (pl.tail > 0) {
-    int slots = (precision == 2 && pl.tile == 128) ? 256 : 512;     // resident workgroups: one / two per CU
+    int slots = ((precision == 2 && pl.tile == 128) || precision == 4) ? 256 : 512;     // resident workgroups: one / two per CU
     if (g.ntiles < slots + slots / 16) slots = 256;
     int m = (g.ntiles / slots) * slots;
     m -= m % g.gx;
@@ -1464,15 +1467,15 @@ __global__ void conv_splitk_epilogue_s(ConvArgs a, int splits) {
 // Planes-input launch (precision code 3, conv_s.hip): same plan machinery as the bf16 launches — unsplit, K-split, or whole rounds
 // unsplit + split tail — on 128x128 tiles only.
 template <int KS>
-int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes) {
+int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes, int pcode) {
   if constexpr (KS == 7) {
     cl4::set_error("conv2d_fwd_planes: 7x7 kernels are not built for planes input");
     return CL4_EINVAL;
   } else {
-    const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 4 + 3});
+    const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 8 + pcode});
     if ((pl.impl != 2 && pl.impl != 3) || pl.tile != 128) { cl4::set_error("conv2d_fwd_planes: no 128x128 plan for this shape"); return CL4_EINVAL; }
     if (pl.impl == 3) {
-      if (cl4::conv_p_eligible(a, KS)) {
+      if (pcode == 3 && cl4::conv_p_eligible(a, KS)) {
         a.gx = cl4::cdiv(a.cout, 128);
         a.ntile_l = a.gx * cl4::cdiv(a.npix, 128);
         a.tile_base = 0; a.ws = nullptr; a.ws_p0 = 0; a.ws_npix = a.npix; a.kchunk = pl.kchunk;
@@ -1480,7 +1483,7 @@ int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace
       }
       // a plan pinned for this shape by a call with other operands (fp32 output, fp32 residual, ...): the plain kernel, unsplit
     }
-    const TailGeom tg = tail_geometry(pl, a.cout, a.npix, 3);
+    const TailGeom tg = tail_geometry(pl, a.cout, a.npix, pcode);
     const bool hybrid = tg.main > 0 && pl.tail > 1;
     const int nsplit = hybrid ? pl.tail : pl.splits;
     a.gx = tg.gx;
@@ -1496,7 +1499,7 @@ int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace
     auto go = [&](int base, int ntile, int sp) {
       a.tile_base = base;
       a.ntile_l = ntile;
-      return cl4::launch_conv_s(a, KS, sp > 1, (unsigned)ntile * (unsigned)(sp > 1 ? sp : 1), st, pl.pix());
+      return cl4::launch_conv_s(a, KS, sp > 1, (unsigned)ntile * (unsigned)(sp > 1 ? sp : 1), st, pl.pix(), pcode == 4 ? 3 : 2);
     };
     int rc;
     if (hybrid) {
@@ -1519,8 +1522,8 @@ bool u_plan(const ConvArgs& a, int ks, int precision, int tile) {
 
 template <int KS>
 int launch_fwd(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace_bytes, int precision) {
-  if (precision == 3) return launch_planes<KS>(a, st, workspace, workspace_bytes);
-  const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 4 + precision});
+  if (planes_code(precision)) return launch_planes<KS>(a, st, workspace, workspace_bytes, precision);
+  const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 8 + precision});
   if (precision == 1 || precision == 2) {
     static float* zp3 = nullptr;
     if (!zp3 && hipGetSymbolAddress((void**)&zp3, HIP_SYMBOL(g_zero_page)) != hipSuccess) return (int)hipGetLastError();
@@ -2118,13 +2121,13 @@ extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
   if (!d || d->cout <= 0 || d->n <= 0) return 0;
   const int K = d->cin * d->kh * d->kw;
   int npix = d->n * d->hout * d->wout;
-  const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin * 4 + d->precision});
+  const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin * 8 + d->precision});
   ConvArgs va;      // the fields vec_gather_plan looks at
   va.n = d->n; va.cin = d->cin; va.hin = d->hin; va.win = d->win; va.hout = d->hout; va.wout = d->wout; va.stride = d->stride;
   va.pad = d->pad; va.in_ctot = d->in_ctot; va.dil = d->dil;
   if (pl.impl == 2 && (vec_gather_plan(va, d->kh, d->precision, pl.tile) || u_plan(va, d->kh, d->precision, pl.tile)))
     npix = d->n * ((d->hout * d->wout + 3) & ~3);
-  if (d->precision == 3 && (pl.impl != 2 || pl.tile != 128)) return 0;      // also impl 3 (persistent kernel): no slabs
+  if (planes_code(d->precision) && (pl.impl != 2 || pl.tile != 128)) return 0;      // also impl 3 (persistent kernel): no slabs
   if (d->precision != 0 && pl.impl == 2 && pl.tail > 0) {
     const TailGeom tg = tail_geometry(pl, d->cout, npix, d->precision);
     return (tg.main > 0 && pl.tail > 1) ? (size_t)pl.tail * d->cout * (npix - tg.p0) * sizeof(float) : 0;   // small-tile tail / degenerate: no slabs
@@ -2138,11 +2141,11 @@ extern "C" int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int til
   int rc = check_desc(d);
   if (rc) return rc;
   const int K = d->cin * d->kh * d->kw;
-  const PlanKey key{d->cout, d->n * d->hout * d->wout, K, d->kh, d->stride, d->dil, d->hin * 4 + d->precision};
+  const PlanKey key{d->cout, d->n * d->hout * d->wout, K, d->kh, d->stride, d->dil, d->hin * 8 + d->precision};
   std::lock_guard<std::mutex> g(plan_mutex());
   if (impl == 0) { plan_table().erase(key); return CL4_OK; }
   CL4_REQUIRE(impl == 1 || impl == 2 || (impl == 3 && d->precision == 3), "set_plan: impl must be 0, 1 or 2 (3: planes-input launches only)");
-  CL4_REQUIRE(tile == 64 || tile == 128 || (tile == 144 && d->precision == 3), "set_plan: tile must be 64 or 128 (144: planes-input launches only)");
+  CL4_REQUIRE(tile == 64 || tile == 128 || (tile == 144 && planes_code(d->precision)), "set_plan: tile must be 64 or 128 (144: planes-input launches only)");
   plan_table()[key] = make_plan(impl, tile, splits, d->cout, K, d->precision);
   return CL4_OK;
 }
@@ -2198,14 +2201,15 @@ extern "C" int cl4_conv2d_fwd_planes(const cl4_conv_desc* d, const void* xs, con
   int rc = check_desc(d);
   if (rc) return rc;
   CL4_REQUIRE(xs && wp && (y || ys), "conv2d_fwd_planes: null tensor");
-  CL4_REQUIRE(d->precision == 3, "conv2d_fwd_planes: the descriptor's precision must be 3 (bf16x3 on a planes input)");
+  CL4_REQUIRE(d->precision == 3 || d->precision == 4, "conv2d_fwd_planes: the descriptor's precision must be 3 (bf16x3 on a two-plane input) or 4 (bf16x6 on a three-plane input)");
+  CL4_REQUIRE(d->precision == 3 || (!ys && !post_s), "conv2d_fwd_planes: a three-plane (bf16x6) launch writes fp32 only and takes no planes residual");
   CL4_REQUIRE(d->kh == 1 || d->kh == 3, "conv2d_fwd_planes: 1x1 and 3x3 kernels only");
   CL4_REQUIRE(d->cin % 32 == 0 && d->in_ctot % 8 == 0 && d->in_coff % 8 == 0, "conv2d_fwd_planes: cin %% 32 == 0 and 8-aligned input channel slices");
   CL4_REQUIRE(d->cout % 4 == 0 && d->cout >= 64, "conv2d_fwd_planes: cout %% 4 == 0 and cout >= 64");
   CL4_REQUIRE(!ys || (d->cout % 8 == 0 && d->out_ctot % 8 == 0 && d->out_coff % 8 == 0), "conv2d_fwd_planes: a planes output needs 8-aligned output channels");
   CL4_REQUIRE(!post_s || d->cout % 8 == 0, "conv2d_fwd_planes: a planes residual needs cout %% 8 == 0");
   CL4_REQUIRE(!(post && post_s), "conv2d_fwd_planes: one residual operand (post or post_s)");
-  CL4_REQUIRE((long)d->n * d->in_ctot * d->hin * d->win * 4 < 0x7FFFFFFFL, "conv2d_fwd_planes: input >= 2 GiB is not addressable by the 32-bit buffer offsets");
+  CL4_REQUIRE((long)d->n * d->in_ctot * d->hin * d->win * (d->precision == 4 ? 6 : 4) < 0x7FFFFFFFL, "conv2d_fwd_planes: input >= 2 GiB is not addressable by the 32-bit buffer offsets");
   return conv2d_fwd_common(d, nullptr, xs, wp, scale, shift, pre, post, post_s, y, ys, workspace, workspace_bytes, stream);
 }
 

@@ -37,8 +37,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define CL4_S_DBG 0   // experiments only: 1 = no loads in the loop, 2 = no LDS stores, 4 = no MFMA
 #endif
 
-constexpr int BM = 128, BKS = 32, P = 2, KG = 4;
-constexpr int A_CHUNKS = KG * P * BM;
+constexpr int BM = 128, BKS = 32, KG = 4;
 constexpr unsigned OOB = 0x80000000u;
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {   // {bf16(lo), bf16(hi)} in one dword (round to nearest even)
@@ -170,10 +169,18 @@ struct SEpilogue {
 // round (or a second workgroup on 18 of the 256 CUs) for 7 % of the work. With 144 pixels there are 242 and 121 pixel tiles: one round
 // at two workgroups per CU (n = 32), or one workgroup per CU / a whole-launch K split that fills both slots (n = 16).
 // Wave layout for 144: two row halves x two column parts of 80 and 64 pixels (5 and 4 blocks of 16).
-template <int KS, bool SPLIT, int MF, int BNT>
-__global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
+// PL = bf16 planes per operand: 2 = bf16x3 (hi, lo; three products), 3 = bf16x6 (hi, mid, lo; six products — the arithmetic of the
+// differentiated convolutions, r03: the trainable ASPP of phase 2 reads a three-plane copy of the frozen res5 features). PL = 3 is built
+// for 144-pixel tiles and the 16x16x32 MFMA only: 102 KB of LDS (two stages of 1536 + 1728 chunks), one workgroup per CU, 13 loads per
+// thread and K-tile, 120 MFMAs per wave and K-tile.
+template <int KS, bool SPLIT, int MF, int BNT, int PL>
+__global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a) {
   static_assert(MF == 32 || MF == 16, "MFMA shape");
   static_assert(BNT == 128 || (BNT == 144 && MF == 16), "tile width");
+  static_assert(PL == 2 || (PL == 3 && MF == 16 && BNT == 144), "planes");
+  constexpr int P = PL;
+  constexpr int A_CHUNKS = KG * P * BM;
+  constexpr int NCH = KG * P / 2;                          // chunk rows (k-group, plane) per staging thread and operand
   constexpr bool WIDE = BNT == 144;
   constexpr int WTM = 64;
   constexpr int KHW = KS * KS;
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   constexpr int BCH = KG * P * BNT;                        // B chunks per stage
   constexpr int STG = A_CHUNKS + BCH;                      // chunks per stage
   constexpr int LDSC = (2 * STG * 16 > BM * BNT * 4) ? 2 * STG : BM * BNT / 4;
-  constexpr int LPT = WIDE ? 9 : 8;                        // vector-memory loads per thread and K-tile
+  constexpr int LPT = 2 * NCH + (WIDE ? 1 : 0);            // vector-memory loads per thread and K-tile
   __shared__ u32x4 lds[LDSC];                              // two K-tile stages; reused as the parked [128][BNT] fp32 tile (64 / 72 KB)
 #if !CL4_S_NO_AFFINE_LDS
   __shared__ float affine[2 * BM];                         // scale / shift of the tile's 128 output channels, fetched once at the start
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   // plane for its weight row AND for its pixel: 8 x 16 bytes in, 8 x ds_write_b128 out. A wide tile has 16 more pixel columns = 128 more
   // chunks per K-tile: threads 0..127 move one each (column 128 + (tid & 15), chunk row tid >> 4 = 2 * k-group + plane); the other
   // half issues the same load out of range, so that every wave counts 9 loads per K-tile ------------------------------------------------
-  const int col = tid & 127, plane = wave >> 1;            // plane is wave-uniform
+  const int col = tid & 127, half = wave >> 1;             // this thread moves the chunk rows r = half * NCH + i (r = k-group * P + plane); wave-uniform
   const int c8tot = a.in_ctot >> 3;
   struct Pix { bool valid; int pn, phw, iy0, ix0; };
   auto decode = [&](int pcol) {
@@ -289,8 +296,8 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   const bool pvalid = px.valid;
   const int pn = px.pn, phw = px.phw, iy0 = px.iy0, ix0 = px.ix0;
   // chunk index of (image, first channel group of the slice, plane, pixel 0) — the tap's pixel and the K-tile's channel groups are added per tile
-  const unsigned cbase = (unsigned)((((long)pn * c8tot + (a.in_coff >> 3)) * 2 + plane) * HWi);
-  const unsigned x_bytes = (unsigned)((long)a.n * a.in_ctot * HWi * 4);       // planes: 4 bytes per element too; < 2^31 checked on the host
+  const unsigned cbase = (unsigned)(((long)pn * c8tot + (a.in_coff >> 3)) * P * HWi);    // plane and k-group are added per chunk row
+  const unsigned x_bytes = (unsigned)((long)a.n * a.in_ctot * HWi * 2 * P);   // planes: 2 bytes per element and plane; < 2^31 checked on the host
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, x_bytes, 0x00020000);
   const int KGtot = a.K / 8;
   const unsigned w_bytes = (unsigned)((long)KGtot * P * a.cout * 16);
@@ -298,13 +305,13 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   const unsigned a_voff = (m0 + col) < a.cout ? (unsigned)(m0 + col) * 16u : OOB;
   const unsigned pkeep = (unsigned)(-(int)pvalid);
   // the 16 extra columns of a wide tile (also this thread's extra epilogue item: column ecol, 8-channel group tid >> 4)
-  const int ecol = 128 + (tid & 15), erow = tid >> 4;      // erow: chunk row 2 * k-group + plane (staging, tid < 128) / channel group (epilogue)
+  const int ecol = 128 + (tid & 15), erow = tid >> 4;      // erow: chunk row k-group * P + plane (staging, tid < 64 * P) / channel group (epilogue)
   Pix ex = px;
   unsigned ebase = 0, ekeep = 0;
   if constexpr (WIDE) {
     ex = decode(ecol);
-    ebase = (unsigned)((((long)ex.pn * c8tot + (a.in_coff >> 3)) * 2 + (erow & 1)) * HWi);
-    ekeep = (unsigned)(-(int)(ex.valid && tid < 128));
+    ebase = (unsigned)((((long)ex.pn * c8tot + (a.in_coff >> 3)) * P + (erow % P)) * HWi);
+    ekeep = (unsigned)(-(int)(ex.valid && tid < 64 * P));
   }
 
   auto tap_off = [&](int tap, int& dy, int& dx) {          // wave-uniform
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
       dy = ky * a.dil; dx = kx * a.dil;
     }
   };
-  auto loadB = [&](u32x4 (&br)[4], int kt, int cb, int tap) {
+  auto loadB = [&](u32x4 (&br)[NCH], int kt, int cb, int tap) {
     int dy, dx;
     tap_off(tap, dy, dx);
     const int cg0 = cb * 4;                                // first channel group (of 8) of this K-tile
@@ -322,8 +329,9 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
     const unsigned keep = pkeep & (unsigned)(-(int)(kt < nk)) & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
     const unsigned vo = (cbase + (unsigned)(iy * a.win + ix)) * 16u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned co = (unsigned)__builtin_amdgcn_readfirstlane((cg0 + i) * 2 * HWi * 16);
+    for (int i = 0; i < NCH; ++i) {
+      const int r = half * NCH + i;                        // chunk row: k-group r / P, plane r % P
+      const unsigned co = (unsigned)__builtin_amdgcn_readfirstlane(((cg0 + r / P) * P + r % P) * HWi * 16);
       const unsigned voff = ((vo + co) & keep) | (OOB & ~keep);   // whole address in the bounds-checked offset
       br[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
     }
@@ -333,35 +341,36 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
     tap_off(tap, dy, dx);
     const int iy = ex.iy0 + dy, ix = ex.ix0 + dx;
     const unsigned keep = ekeep & (unsigned)(-(int)(kt < nk)) & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
-    const unsigned vo = (ebase + (unsigned)(iy * a.win + ix)) * 16u + (unsigned)((cb * 4 + (erow >> 1)) * 2 * HWi * 16);
+    const unsigned vo = (ebase + (unsigned)(iy * a.win + ix)) * 16u + (unsigned)((cb * 4 + erow / P) * P * HWi * 16);
     bx = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (vo & keep) | (OOB & ~keep), 0, 0);
   };
-  auto loadA = [&](u32x4 (&ar)[4], int kt, int cb, int tap) {
+  auto loadA = [&](u32x4 (&ar)[NCH], int kt, int cb, int tap) {
     const unsigned kkeep = (unsigned)(-(int)(kt < nk));
     const unsigned voff = (a_voff & kkeep) | (OOB & ~kkeep);
     const int T = cb * KHW + tap;                          // K-tile index in the packed weight (tap-major within a block of 32 channels)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int soff = __builtin_amdgcn_readfirstlane(((T * 4 + i) * P + plane) * a.cout * 16);
+    for (int i = 0; i < NCH; ++i) {
+      const int r = half * NCH + i;
+      const int soff = __builtin_amdgcn_readfirstlane(((T * 4 + r / P) * P + r % P) * a.cout * 16);
       ar[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, soff, 0);
     }
   };
-  auto load_tile = [&](u32x4 (&ar)[4], u32x4 (&br)[4], u32x4& bxr, int kt) {
+  auto load_tile = [&](u32x4 (&ar)[NCH], u32x4 (&br)[NCH], u32x4& bxr, int kt) {
     int cb, tap;
     next_tile(cb, tap);
     loadA(ar, kt, cb, tap);
     loadB(br, kt, cb, tap);
     if constexpr (WIDE) loadX(bxr, kt, cb, tap);
   };
-  auto storeAB = [&](const u32x4 (&ar)[4], const u32x4 (&br)[4], const u32x4& bx, int stage) {
+  auto storeAB = [&](const u32x4 (&ar)[NCH], const u32x4 (&br)[NCH], const u32x4& bx, int stage) {
     u32x4* As = lds + stage * STG;
     u32x4* Bs = As + A_CHUNKS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) As[(2 * i + plane) * BM + col] = ar[i];
+    for (int i = 0; i < NCH; ++i) As[(half * NCH + i) * BM + col] = ar[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Bs[(2 * i + plane) * BNT + col] = br[i];
+    for (int i = 0; i < NCH; ++i) Bs[(half * NCH + i) * BNT + col] = br[i];
     if constexpr (WIDE)
-      if (wave < 2) Bs[erow * BNT + ecol] = bx;
+      if (tid < 64 * P) Bs[erow * BNT + ecol] = bx;        // wave-uniform: waves 0, 1 (and 2 for three planes)
   };
 
   typedef float accv_t __attribute__((ext_vector_type(ACCV)));
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < ACCV; ++r) acc[i][j][r] = 0.f;
 
-  bf16x8 bh16[NBJ], bl16[NBJ];                             // MF = 16: the B fragments of the current K-tile (read by half 0, reused by half 1)
+  bf16x8 bfr[P][NBJ];                                      // MF = 16: the B fragments of the current K-tile (read by half 0, reused by half 1)
   // one half of a K-tile's MFMAs (MF = 32: 16 of the 32 k; MF = 16: two of the four row blocks)
   auto mfma_half = [&](int stage, int s2) {
     if constexpr (MF == 32) {
@@ -408,22 +417,22 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
       // 16x16x32: lane l holds row / column l & 15 and k-group l >> 4 — one fragment spans the whole 32-deep K-tile. Half s2 = the row
       // blocks 2*s2, 2*s2+1 against all column blocks of the wave; the B fragments are read by half 0 and stay in registers for half 1
       // (16 fragment reads per K-tile, like the 32x32x16 path; 18 / 16 for the two column parts of a wide tile).
+      // Products, smallest first: two planes lo*hi, hi*lo, hi*hi; three planes (hi = 0, mid = 1, lo = 2) lo*hi, hi*lo, mid*mid,
+      // mid*hi, hi*mid, hi*hi (the dropped terms are <= 2^-26 relative).
       const int l15 = lane & 15, kg = lane >> 4;
       const u32x4* As = lds + stage * STG + wm * WTM + l15;
       const u32x4* Bs = lds + stage * STG + A_CHUNKS + cb0 + l15;
-      bf16x8 ah[2], al[2];
+      bf16x8 afr[P][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 0) * BM + (2 * s2 + i) * 16]);
-        al[i] = __builtin_bit_cast(bf16x8, As[(kg * P + 1) * BM + (2 * s2 + i) * 16]);
-      }
+      for (int pl = 0; pl < P; ++pl)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) afr[pl][i] = __builtin_bit_cast(bf16x8, As[(kg * P + pl) * BM + (2 * s2 + i) * 16]);
       if (s2 == 0) {
 #pragma unroll
-        for (int j = 0; j < NBJ; ++j)
-          if (j < nbj) {
-            bh16[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 0) * BNT + j * 16]);
-            bl16[j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + 1) * BNT + j * 16]);
-          }
+        for (int pl = 0; pl < P; ++pl)
+#pragma unroll
+          for (int j = 0; j < NBJ; ++j)
+            if (j < nbj) bfr[pl][j] = __builtin_bit_cast(bf16x8, Bs[(kg * P + pl) * BNT + j * 16]);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -432,11 +441,20 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
           if (j < nbj) {
             accv_t& c = acc[2 * s2 + i][j];
 #if CL4_S_DBG & 4
-            c[0] += (float)al[i][0] * (float)bh16[j][0] + (float)ah[i][1] * (float)bl16[j][1];
+            c[0] += (float)afr[P - 1][i][0] * (float)bfr[0][j][0] + (float)afr[0][i][1] * (float)bfr[P - 1][j][1];
 #else
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh16[j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl16[j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh16[j], c, 0, 0, 0);
+            if constexpr (P == 2) {
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][i], bfr[0][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0][i], bfr[1][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0][i], bfr[0][j], c, 0, 0, 0);
+            } else {
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[2][i], bfr[0][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0][i], bfr[2][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][i], bfr[1][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][i], bfr[0][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0][i], bfr[1][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0][i], bfr[0][j], c, 0, 0, 0);
+            }
 #endif
           }
     }
@@ -445,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   // (Measured and dropped: touching the residual tile's lines at the start of the K loop, as conv_igemm_bf16x3 does. On the short-K
   // residual layers — 256 -> 1024 at 33x33 — it moved 6,000 cycles from the epilogue into the prologue and nothing else: those
   // launches stream their residual and output at the HBM rate either way. profiles/r02d_planes_prefetch.txt)
-  u32x4 ar[2][4], br[2][4], bx[2];
+  u32x4 ar[2][NCH], br[2][NCH], bx[2];
   bx[0] = bx[1] = u32x4{0, 0, 0, 0};
   load_tile(ar[0], br[0], bx[0], 0);
   load_tile(ar[1], br[1], bx[1], 1);
@@ -457,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   stamp(1);
 
   // one K-tile: multiply tile t out of `stage` while tile t+1 (register set a1 / b1) goes into the other stage and tile t+3 is requested
-  auto step = [&](u32x4 (&a1)[4], u32x4 (&b1)[4], u32x4& x1, int t, int stage) {
+  auto step = [&](u32x4 (&a1)[NCH], u32x4 (&b1)[NCH], u32x4& x1, int t, int stage) {
     wait_vmcnt<LPT>();                                     // tile t+1 has landed (requested a whole K-tile ago); tile t+2's loads stay in flight
     mfma_half(stage, 0);
 #if !(CL4_S_DBG & 2)
@@ -484,10 +502,10 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
   SEpilogue<1, 1, BNT> ex1;
   const int res_kind = SPLIT ? 0 : (a.post_s ? 2 : (a.post ? 1 : 0));     // wave-uniform (kernel argument)
   if (res_kind == 2) {
-    ep2.issue(a, m0, plane, 2, pvalid, pn, phw, HWo);
+    ep2.issue(a, m0, half, 2, pvalid, pn, phw, HWo);
     if constexpr (WIDE) ex2.issue(a, m0, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
   } else if (res_kind == 1) {
-    ep1.issue(a, m0, plane, 2, pvalid, pn, phw, HWo);
+    ep1.issue(a, m0, half, 2, pvalid, pn, phw, HWo);
     if constexpr (WIDE) ex1.issue(a, m0, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
   }
   float* stage = reinterpret_cast<float*>(&lds[0]);
@@ -537,14 +555,14 @@ __global__ __launch_bounds__(256, 2) void conv_s_bf16x3(ConvArgs a) {
     const float* aff = nullptr;
 #endif
     if (res_kind == 2) {
-      ep2.finish(a, stage, aff, m0, col, plane, 2, pvalid, pn, phw, HWo);
+      ep2.finish(a, stage, aff, m0, col, half, 2, pvalid, pn, phw, HWo);
       if constexpr (WIDE) ex2.finish(a, stage, aff, m0, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
     } else if (res_kind == 1) {
-      ep1.finish(a, stage, aff, m0, col, plane, 2, pvalid, pn, phw, HWo);
+      ep1.finish(a, stage, aff, m0, col, half, 2, pvalid, pn, phw, HWo);
       if constexpr (WIDE) ex1.finish(a, stage, aff, m0, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
     } else {
       SEpilogue<0, 8, BNT> ep0;
-      ep0.finish(a, stage, aff, m0, col, plane, 2, pvalid, pn, phw, HWo);
+      ep0.finish(a, stage, aff, m0, col, half, 2, pvalid, pn, phw, HWo);
       if constexpr (WIDE) { SEpilogue<0, 1, BNT> ex0; ex0.finish(a, stage, aff, m0, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo); }
     }
   }
@@ -593,6 +611,35 @@ __global__ void from_planes_kernel(const u32x4* __restrict__ xs, float* __restri
   }
 }
 
+// fp32 NCHW (channel slice) -> THREE planes [n][c/8][hi, mid, lo][hw][8 x bf16]: x = hi + mid + lo to 24 significant bits — the operand
+// format of the bf16x6 launches (PL = 3).
+__global__ void to_planes3_kernel(const float* __restrict__ x, u32x4* __restrict__ xs, int n, int ctot, int coff, int c, int hw) {
+  const int c8 = c >> 3;
+  const long total = (long)n * c8 * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % hw);
+    const long r = i / hw;
+    const int g = (int)(r % c8), im = (int)(r / c8);
+    const float* src = x + ((long)im * ctot + coff + g * 8) * hw + px;
+    float v[8], rest[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(long)j * hw];
+    u32x4 hi, mid, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      hi[q] = pack_bf16(v[2 * q], v[2 * q + 1]);
+      rest[2 * q] = sub_f32(v[2 * q], __builtin_bit_cast(float, hi[q] << 16));
+      rest[2 * q + 1] = sub_f32(v[2 * q + 1], __builtin_bit_cast(float, hi[q] & 0xFFFF0000u));
+      mid[q] = pack_bf16(rest[2 * q], rest[2 * q + 1]);
+      lo[q] = pack_bf16(sub_f32(rest[2 * q], __builtin_bit_cast(float, mid[q] << 16)), sub_f32(rest[2 * q + 1], __builtin_bit_cast(float, mid[q] & 0xFFFF0000u)));
+    }
+    u32x4* dst = xs + (((long)im * c8 + g) * 3) * hw + px;
+    dst[0] = hi;
+    dst[hw] = mid;
+    dst[2 * (long)hw] = lo;
+  }
+}
+
 }  // namespace
 
 static long g_s_launches = 0;
@@ -606,6 +653,14 @@ extern "C" int cl4_to_planes(const float* x, void* xs, int n, int ctot, int coff
   return cl4::launch_status();
 }
 
+extern "C" int cl4_to_planes3(const float* x, void* xs, int n, int ctot, int coff, int c, int hw, void* stream) {
+  CL4_REQUIRE(x && xs, "to_planes3: null tensor");
+  CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0 && coff >= 0 && coff + c <= ctot, "to_planes3: bad channel slice (c %% 8 == 0 required)");
+  const long total = (long)n * (c >> 3) * hw;
+  hipLaunchKernelGGL(to_planes3_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, (u32x4*)xs, n, ctot, coff, c, hw);
+  return cl4::launch_status();
+}
+
 extern "C" int cl4_from_planes(const void* xs, float* y, int n, int c, int hw, int out_ctot, int out_coff, void* stream) {
   CL4_REQUIRE(xs && y, "from_planes: null tensor");
   CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0 && out_coff >= 0 && out_coff + c <= out_ctot, "from_planes: bad channel slice");
@@ -616,16 +671,18 @@ extern "C" int cl4_from_planes(const void* xs, float* y, int n, int c, int hw, i
 
 namespace cl4 {
 
-int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st, int bn) {
+int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStream_t st, int bn, int planes) {
   static const int mf = [] { const char* e = getenv("CL4_CONV_S_MFMA"); return e ? atoi(e) : 16; }();   // 16x16x32: 3-6 % faster on the long-K layers (higher sustained clock), equal elsewhere
   const dim3 g(grid), b(256);
   ++g_s_launches;
   if (bn != 128 && bn != 144) { set_error("conv_s: tile width %d not built", bn); return CL4_EINVAL; }
+  if (planes != 2 && !(planes == 3 && bn == 144)) { set_error("conv_s: %d planes at tile width %d not built", planes, bn); return CL4_EINVAL; }
 #define CL4_S_GO(KS_, SP_)                                                                                   \
   do {                                                                                                       \
-    if (bn == 144) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16, 144>), g, b, 0, st, a);                    \
-    else if (mf == 16) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16, 128>), g, b, 0, st, a);                \
-    else hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 32, 128>), g, b, 0, st, a);                              \
+    if (planes == 3) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16, 144, 3>), g, b, 0, st, a);               \
+    else if (bn == 144) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16, 144, 2>), g, b, 0, st, a);            \
+    else if (mf == 16) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16, 128, 2>), g, b, 0, st, a);             \
+    else hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 32, 128, 2>), g, b, 0, st, a);                           \
   } while (0)
   if (ks == 1) { if (split) CL4_S_GO(1, true); else CL4_S_GO(1, false); }
   else if (ks == 3) { if (split) CL4_S_GO(3, true); else CL4_S_GO(3, false); }

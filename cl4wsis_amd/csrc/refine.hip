@@ -233,8 +233,8 @@ __global__ __launch_bounds__(256) void nms_center_kernel(IO io, WS ws) {
   const long HW = (long)io.H * io.W;
   if (threadIdx.x == 0) any_cand = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < TS * TS; i += blockDim.x) {
-    int ty = i / TS, tx = i - ty * TS;
+  // value / component root of one pixel of the (tile + halo) window
+  auto fetch = [&](int ty, int tx, bool interior) {
     int Y = ty0 - R + ty, X = tx0 - R + tx;
     float v = -1.f;
     int r = -1;
@@ -245,14 +245,23 @@ __global__ __launch_bounds__(256) void nms_center_kernel(IO io, WS ws) {
         r = rr;
         float cv = center_up(io, b, (int)io.seg_gt[p] - io.old_classes, Y, X);
         v = cv > io.refine_thresh ? cv : -1.f;  // F.threshold(x, thr, -1)
-        if (v > 0.f && ty >= R && ty < R + NT && tx >= R && tx < R + NT) any_cand = 1;
+        if (interior && v > 0.f) any_cand = 1;
       }
     }
     val[ty * NTS + tx] = v;
     root[ty * NTS + tx] = r;
-  }
+  };
+  // the 32 x 32 interior first: a tile without a candidate (most tiles: the maps hold a few dozen centres) never reads its halo,
+  // which is 4 of the 5 bilinear samples of the window at R = 20 (r03: 0.50 -> 0.12 ms per step)
+  for (int i = threadIdx.x; i < NT * NT; i += blockDim.x) fetch(R + i / NT, R + i % NT, true);
   __syncthreads();
   if (!any_cand) return;
+  for (int i = threadIdx.x; i < TS * TS; i += blockDim.x) {
+    int ty = i / TS, tx = i - ty * TS;
+    if (ty >= R && ty < R + NT && tx >= R && tx < R + NT) continue;
+    fetch(ty, tx, false);
+  }
+  __syncthreads();
   for (int i = threadIdx.x; i < NT * NT; i += blockDim.x) {
     int y = i / NT, x = i - y * NT;
     int Y = ty0 + y, X = tx0 + x;

@@ -28,6 +28,7 @@ EPS = 1e-5
 # (about twice the speed of the fp32 MFMA kernels). 0 = exact fp32 MFMA, 1 = bf16x3 (fastest, ~4e-6 per layer). The frozen,
 # no-grad networks (old model, flip-TTA semantic forward, PseudoLabeler) run at ops.CONV_PRECISION (bf16x3 by default).
 TRAIN_PRECISION = int(__import__("os").environ.get("CL4_TRAIN_PRECISION", "2"))
+X6_PLANES = __import__("os").environ.get("CL4_X6_PLANES", "0") == "1"
 
 
 def _dx_1x1(dz, conv):
@@ -353,12 +354,23 @@ class InstanceBranch:
         cout = aspp.convs[0][0].out_channels
         cat5 = torch.empty((n, 5 * cout, h, w), dtype=torch.float32, device=x.device)
         recs = []
+        # bf16x6 on the planes kernel (r03): the four ASPP branches read ONE three-plane copy of the (frozen, detached) res5 features —
+        # 144-pixel tiles, no conversion in the K loop — instead of re-splitting the fp32 map per tile and tap in the r01 role-split kernel
+        x3 = None
+        if (X6_PLANES and TRAIN_PRECISION == 2 and x.is_contiguous() and x.shape[1] % 32 == 0
+                and all(ops.bf16x3_ok(aspp.convs[i][0].out_channels) for i in range(4))):
+            x3 = ops.to_planes(x, planes=3)
         for i in range(4):
             conv, bn = aspp.convs[i][0], aspp.convs[i][1]
-            z = ops.conv2d(x, packed_weight(conv, TRAIN_PRECISION), conv.kernel_size[0], pad=conv.padding[0],
-                           dil=conv.dilation[0])
+            if x3 is not None:
+                z = ops.conv2d_planes(x3, packed_weight(conv, 2), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0],
+                                      want_fp32=True)[0]
+            else:
+                z = ops.conv2d(x, packed_weight(conv, TRAIN_PRECISION), conv.kernel_size[0], pad=conv.padding[0],
+                               dil=conv.dilation[0])
             _, m, v = _bn_train(z, bn, out=cat5, out_coff=i * cout)
             recs.append((z, m, v))
+        del x3
         g = ops.global_mean(x)
         pconv = aspp.convs[4].aspp_pooling[1]
         gp = ops.conv2d(g, packed_weight(pconv, TRAIN_PRECISION), 1, act1=ops.ACT_RELU)

@@ -269,10 +269,10 @@ def _autotune_planes(d, args, reps=6):
     best, best_ms = None, float("inf")
     seen = set()
     npix = d.n * d.hout * d.wout
-    cands = [(2, tile, splits) for tile in PLANES_TILES for splits in _SPLITS]
+    cands = [(2, tile, splits) for tile in ((144,) if d.precision == 4 else PLANES_TILES) for splits in _SPLITS]
     # the persistent pipelined kernel (csrc/conv_p.hip): short-K 1x1 layers that write planes only (and read a planes residual)
     pre, post_f, out_f32, out_pl = args[4], args[5], args[7], args[8]
-    if (CONV_P and d.kh == 1 and d.stride == 1 and d.pad == 0 and d.cout % 128 == 0 and K >= 128 and pre is None and post_f is None
+    if (CONV_P and d.precision == 3 and d.kh == 1 and d.stride == 1 and d.pad == 0 and d.cout % 128 == 0 and K >= 128 and pre is None and post_f is None
             and out_f32 is None and out_pl is not None and -(-d.cout // 128) * -(-npix // 128) >= 512):
         cands.append((3, 128, 1))
     for impl, tile, splits in cands:
@@ -369,14 +369,15 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
 
 class Planes:
     """An activation tensor [n, c, h, w] kept as pre-split bf16 planes — [n][c/8][hi, lo][h*w][8 x bf16], 4 bytes per element
-    (include/cl4wsis.h, "Planes" activations): what conv2d_planes reads and can write."""
-    __slots__ = ("data", "n", "c", "h", "w")
+    (include/cl4wsis.h, "Planes" activations): what conv2d_planes reads and can write. `planes` = 3: [hi, mid, lo], 6 bytes per
+    element — the operand of the bf16x6 launches (read only)."""
+    __slots__ = ("data", "n", "c", "h", "w", "planes")
 
-    def __init__(self, n, c, h, w, device, data=None):
+    def __init__(self, n, c, h, w, device, data=None, planes=2):
         if c % 8:
             raise RuntimeError(f"Planes: channel count {c} is not a multiple of 8")
-        self.n, self.c, self.h, self.w = n, c, h, w
-        self.data = torch.empty(n * c * h * w, dtype=torch.int32, device=device) if data is None else data
+        self.n, self.c, self.h, self.w, self.planes = n, c, h, w, planes
+        self.data = torch.empty(n * c * h * w * planes // 2, dtype=torch.int32, device=device) if data is None else data
 
     @property
     def shape(self):
@@ -388,20 +389,23 @@ def batch_slice(t, bs):
     v = t[:bs]
     ps = getattr(t, "_cl4_planes", None)
     if ps is not None and bs <= ps.n:
-        v._cl4_planes = Planes(bs, ps.c, ps.h, ps.w, ps.data.device, data=ps.data[:bs * ps.c * ps.h * ps.w])
+        v._cl4_planes = Planes(bs, ps.c, ps.h, ps.w, ps.data.device, data=ps.data[:bs * ps.c * ps.h * ps.w * ps.planes // 2], planes=ps.planes)
     return v
 
 
-def to_planes(x, in_coff=0, c=None, out=None):
+def to_planes(x, in_coff=0, c=None, out=None, planes=2):
+    """fp32 NCHW (channel slice) -> Planes; planes = 3: the three-plane operand of the bf16x6 launches (cl4_to_planes3)."""
     _f32(x, "to_planes")
     n, ctot, h, w = x.shape
     c = ctot - in_coff if c is None else c
-    ps = Planes(n, c, h, w, x.device) if out is None else out
-    call("cl4_to_planes", ptr(x), ptr(ps.data), n, ctot, in_coff, c, h * w, stream())
+    ps = Planes(n, c, h, w, x.device, planes=planes) if out is None else out
+    call("cl4_to_planes3" if ps.planes == 3 else "cl4_to_planes", ptr(x), ptr(ps.data), n, ctot, in_coff, c, h * w, stream())
     return ps
 
 
 def from_planes(ps, out=None, out_coff=0):
+    if ps.planes != 2:
+        raise RuntimeError("from_planes: two-plane tensors only")
     if out is None:
         out = torch.empty(ps.shape, dtype=torch.float32, device=ps.data.device)
         out_coff = 0
@@ -420,8 +424,12 @@ def conv2d_planes(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre
     n, in_ctot, hin, win = xs.shape
     if cin is None:
         cin = in_ctot - in_coff
-    if not isinstance(wp, PackedWeight) or wp.precision != 1:
-        raise RuntimeError("conv2d_planes: bf16x3 packed weights (pack_conv_weight(w, 1)) expected")
+    x6 = xs.planes == 3
+    if not isinstance(wp, PackedWeight) or wp.precision != (2 if x6 else 1):
+        raise RuntimeError("conv2d_planes: bf16x3 packed weights (pack_conv_weight(w, 1)) expected for a two-plane input, bf16x6 "
+                           "(pack_conv_weight(w, 2)) for a three-plane one")
+    if x6 and (isinstance(post, Planes) or out_planes is not None or want_planes):
+        raise RuntimeError("conv2d_planes: a three-plane (bf16x6) launch writes fp32 only and takes no planes residual")
     K, cout = wp.K, wp.cout
     if K != cin * k * k:
         raise RuntimeError(f"conv2d_planes: packed weight K={K} does not match cin*k*k={cin * k * k}")
@@ -442,9 +450,9 @@ def conv2d_planes(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre
     for t, nm in ((pre, "pre"), (post, "post")):
         if t is not None and tuple(t.shape) != (n, cout, hout, wout):
             raise RuntimeError(f"conv2d_planes: {nm} shape {tuple(t.shape)} != {(n, cout, hout, wout)}")
-    d = ConvDescFor(n, cin, hin, win, in_ctot, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, act1, slope1, act2, slope2, 3)
+    d = ConvDescFor(n, cin, hin, win, in_ctot, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, act1, slope1, act2, slope2, 4 if x6 else 3)
     if TIMER is not None:
-        e0, e1 = TIMER.span("conv_fwd_bf16x3", 2.0 * n * hout * wout * cout * K, (n, cin, hin, cout, k, stride, dil))
+        e0, e1 = TIMER.span("conv_fwd_bf16x6" if x6 else "conv_fwd_bf16x3", 2.0 * n * hout * wout * cout * K, (n, cin, hin, cout, k, stride, dil))
         e0.record()
     args = (ptr(xs.data), ptr(wp.data), ptr(scale), ptr(shift), ptr(pre), ptr(post_f), ptr(post_s.data) if post_s is not None else None,
             ptr(out), ptr(out_planes.data) if out_planes is not None else None)

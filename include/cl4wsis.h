@@ -497,8 +497,15 @@ long cl4_conv_debug_s_launches(void);
  * cl4_conv2d_fwd_planes = cl4_conv2d_fwd for a planes INPUT `xs` (descriptor precision 3; 1x1 / 3x3, any stride / pad / dilation,
  * cin % 32 == 0, 8-aligned channel slices, cout % 4 == 0 and >= 64; the packed weights are cl4_pack_conv_weight_bf16x3's). Outputs:
  * `y` (fp32 NCHW, channel slice out_coff of out_ctot) and / or `ys` (planes, the same slice; needs cout % 8 == 0) — at least one.
- * The residual operand is `post` (fp32, [n][cout][hout][wout]) or `post_s` (planes, same shape), not both. */
+ * The residual operand is `post` (fp32, [n][cout][hout][wout]) or `post_s` (planes, same shape), not both.
+ * Tile widths of 128 or 144 pixels and the persistent pipelined variant (csrc/conv_p.hip) are launch plans (cl4_conv2d_fwd_set_plan:
+ * tile 144, impl 3).
+ * THREE planes (r03): cl4_to_planes3 writes [n][c/8][hi, mid, lo][h*w][8 x bf16] (x to 24 significant bits, 6 bytes per element);
+ * cl4_conv2d_fwd_planes with descriptor precision 4 multiplies such an input with cl4_pack_conv_weight_bf16x6 weights as six bf16 MFMA
+ * products = the bf16x6 arithmetic of the differentiated convolutions (train.py:265-272: the trainable ASPP of the instance decoder
+ * reads the frozen res5 features). fp32 output only, no planes residual. */
 int cl4_to_planes(const float* x, void* xs, int n, int ctot, int coff, int c, int hw, void* stream);
+int cl4_to_planes3(const float* x, void* xs, int n, int ctot, int coff, int c, int hw, void* stream);
 int cl4_from_planes(const void* xs, float* y, int n, int c, int hw, int out_ctot, int out_coff, void* stream);
 int cl4_conv2d_fwd_planes(const cl4_conv_desc* d, const void* xs, const float* wp, const float* scale, const float* shift,
                           const float* pre, const float* post, const void* post_s, float* y, void* ys, void* workspace,

@@ -183,10 +183,14 @@ def test_map_after_training_inside_the_reference_arithmetics_own_spread(gpu, tmp
     * a common, CONDITIONED start: K0 = 30 phase-2 iterations (HIP path) from the seeded weights — the decoder has left its
       initialisation, Adam's first sign-like steps are behind it;
     * from that state K = 5 iterations on identical batches / Dropout masks along SEVEN trajectories: the HIP path, the CPU oracle
-      (A), and five more runs of the CPU oracle whose input images are perturbed by 1e-6 relative (B1..B5) — what five re-runs of
-      the reference itself amount to on a GPU (atomics and algorithm choices are not bit-reproducible). Adam turns any gradient
+      (A), and five more runs of the CPU oracle whose input images are perturbed by 3e-5 relative (B1..B5). The size is chosen to
+      make the B runs START where the HIP path starts: its frozen networks (bf16x3 products) agree with the fp32 oracle to ~1e-4 in
+      their outputs (bar: 1e-3), which moves the first iteration's loss by a few 1e-6 — what a 3e-5 input perturbation does to the
+      oracle (a 1e-6 perturbation, r03's first version, starts 15x closer and sometimes has not left the linear regime after five
+      iterations, so that it calibrated nothing: measured 6e-4 vs 1e-2 envelope maxima on two boxes). It is still 30x inside the
+      1e-3 bar and far inside the fp16 autocast the reference itself trains under (train.py:252). Adam turns any gradient
       difference on weights with near-zero gradients into +-lr steps, so the B runs do NOT stay within 1e-3 of A; they measure
-      the reference arithmetic's own spread, with five samples instead of the single one of r02;
+      the reference arithmetic's own spread under admissible perturbations, with five samples instead of the single one of r02;
     * iteration 1 (identical weights) must meet the 1e-3 bar outright; afterwards the HIP path's loss deviation and weight distance
       from A must stay inside the envelope of the five B runs;
     * validation (train.py:588-651) of all seven weight sets against ONE ground truth that favours none of them — the instances the
@@ -198,6 +202,7 @@ def test_map_after_training_inside_the_reference_arithmetics_own_spread(gpu, tmp
     from cl4wsis_amd.train import Trainer
     from oracle import step as ostep
     K0, K, NB, crop = 30, 5, 5, 65
+    NOISE = 3e-5      # relative input perturbation of the B runs, see the docstring
     make_mini_voc(tmp_path, n_train=9, n_val=12)
     opts = p2_opts(crop, extra=["--data_root", str(tmp_path), "--crop_size_val", str(crop), "--batch_size", "2"])
     opts.max_iters, opts.start_decay = 10000, 10000          # constant learning rate, as in the first 5 epochs of scripts/run.sh
@@ -244,7 +249,7 @@ def test_map_after_training_inside_the_reference_arithmetics_own_spread(gpu, tmp
         state_a = ra["adam_state"]
         traj["a"].append([float(ra[k].detach()) for k in names])
         for i in range(NB):
-            noise = 1.0 + 1e-6 * torch.randn(images.shape, generator=gn)
+            noise = 1.0 + NOISE * torch.randn(images.shape, generator=gn)
             rb = ostep.p2_step(*Bs[i], images.cpu() * noise, l1h.cpu(), 16, adam_state=state_b[i], **kw)
             state_b[i] = rb["adam_state"]
             traj["b"][i].append([float(rb[k].detach()) for k in names])

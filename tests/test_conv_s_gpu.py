@@ -229,3 +229,61 @@ def test_conv_persistent_kernel_in_place_and_channel_slice(gpu):
         finally:
             _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d2), 0, 64, 1)
     assert torch.equal(wide[2], wide[3])
+
+
+# (n, cin, h, w, cout, k, pad, dil)
+X6_SHAPES = [
+    (2, 64, 33, 33, 128, 3, 6, 6),
+    (3, 96, 33, 31, 256, 3, 18, 18),      # most taps outside the image; ragged last pixel tile
+    (2, 128, 17, 19, 192, 1, 0, 1),       # 1x1, cout not a multiple of 128
+    (5, 32, 20, 20, 64, 3, 1, 1),         # one K-tile per tap, 64 output channels on a 128-row tile
+]
+
+
+@pytest.mark.parametrize("plan", [(2, 144, 1), (2, 144, 2), (2, 144, -4)])
+@pytest.mark.parametrize("shape", X6_SHAPES)
+def test_conv_planes_three_plane_bf16x6(gpu, shape, plan):
+    """The bf16x6 variant of the planes kernel (three planes per operand, six MFMA products; descriptor precision 4): fp32-level
+    agreement with a float64 convolution (the same bar as the bf16x6 instantiation of cl4_conv2d_fwd), output into a channel slice."""
+    from cl4wsis_amd import _hip, ops
+    n, cin, h, w, cout, k, pad, dil = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w, generator=g) * torch.logspace(-2, 2, cin)[None, :, None, None]
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    ref = F.conv2d(x.double(), wt.double(), padding=pad, dilation=dil)
+    x3 = ops.to_planes(x.to(gpu), planes=3)
+    assert x3.planes == 3 and x3.data.numel() * 4 == n * cin * h * w * 6
+    wp = ops.pack_conv_weight(wt.to(gpu), 2)
+    out = torch.full((n, cout + 16, h, w), 7.0, device=gpu)
+    d = ops.ConvDescFor(n, cin, h, w, cin, 0, cout, k, 1, pad, dil, cout + 16, 8, 0, 0.0, 0, 0.0, 4)
+    _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), *plan)
+    before = _hip.load().cl4_conv_debug_s_launches()
+    try:
+        ops.conv2d_planes(x3, wp, k, pad=pad, dil=dil, out=out, out_coff=8)
+        torch.cuda.synchronize()
+    finally:
+        _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 0, 64, 1)
+    assert _hip.load().cl4_conv_debug_s_launches() > before
+    y = out[:, 8:8 + cout].cpu().double()
+    err = ((y - ref).norm() / ref.norm()).item()
+    y6 = ops.conv2d(x.to(gpu), wp, k, pad=pad, dil=dil).cpu().double()       # the role-split bf16x6 kernel on the fp32 input
+    err6 = ((y6 - ref).norm() / ref.norm()).item()
+    assert err < 5e-7 and err <= 3 * err6 + 1e-8, (err, err6)
+    assert (out[:, :8] == 7).all() and (out[:, 8 + cout:] == 7).all()
+
+
+def test_three_plane_split_is_exact_to_24_bits(gpu):
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 16, 5, 7, generator=g) * torch.logspace(-5, 5, 16)[None, :, None, None]
+    ps = ops.to_planes(x.to(gpu), planes=3)
+    raw = ps.data.cpu().view(torch.int16).view(2, 2, 3, 35, 8)            # [n][c/8][plane][hw][8]
+    parts = [raw[:, :, p].contiguous().view(torch.bfloat16).float() for p in range(3)]
+    back = (parts[0] + parts[1] + parts[2]).permute(0, 1, 3, 2).reshape(2, 16, 5, 7)
+    assert ((back - x).abs() <= x.abs() * 2.0 ** -23).all()
+    hi = x.to(torch.bfloat16).float()
+    mid = (x - hi).to(torch.bfloat16).float()
+    lo = (x - hi - mid).to(torch.bfloat16).float()
+    want = [t.view(2, 2, 8, 35).permute(0, 1, 3, 2) for t in (hi, mid, lo)]
+    for p in range(3):
+        assert torch.equal(parts[p], want[p].contiguous())
