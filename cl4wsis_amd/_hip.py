@@ -208,7 +208,7 @@ def load():
                    ("cl4_input_workspace_bytes", [C.c_int] * 5), ("cl4_target_generation_workspace_bytes", [C.c_int])):
         getattr(lib, nm).restype = C.c_size_t
         getattr(lib, nm).argtypes = at
-    for nm in ("cl4_conv_debug_u_launches", "cl4_conv_debug_s_launches"):
+    for nm in ("cl4_conv_debug_u_launches", "cl4_conv_debug_s_launches", "cl4_conv_debug_b_launches"):
         getattr(lib, nm).restype = C.c_long
         getattr(lib, nm).argtypes = []
     lib.cl4_stem_weight_bytes.restype = C.c_size_t

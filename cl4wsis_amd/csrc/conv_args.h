@@ -56,4 +56,10 @@ int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStrea
 bool conv_p_eligible(const ConvArgs& a, int ks);
 int launch_conv_p(const ConvArgs& a, unsigned ntile, hipStream_t st);
 
+
+// conv_b.hip: the big-tile planes kernel (256 output channels x 144 pixels per 512-thread workgroup, operands by LDS-DMA, three LDS
+// stages; one workgroup per CU) for launches whose K loop dominates. Unsplit; `grid` = cdiv(cout, 256) * cdiv(npix, 144) with a.gx = cdiv(cout, 256).
+bool conv_b_eligible(const ConvArgs& a, int ks);
+int launch_conv_b(const ConvArgs& a, int ks, unsigned grid, hipStream_t st);
+
 }  // namespace cl4

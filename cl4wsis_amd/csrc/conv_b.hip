@@ -1,0 +1,335 @@
+// Big-tile planes-input bf16x3 forward convolution ("B" kernel, r03): 256 output channels x 144 pixels per workgroup, operands brought
+// into LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`), one 512-thread workgroup per CU.
+//
+// Why (profiles/r03_conv_s_attribution.txt): on the long-K layers conv_s's K loop with its operand traffic REMOVED runs at 610-620 TFLOP/s
+// (the MFMA pipe is ~100 % busy at the clock the chip holds), and with the MFMAs removed the operand traffic alone takes ~the same time —
+// 68 KB per K-tile for the two resident 128 x 144 workgroups of a CU, through 72 `buffer_load_dwordx4` into registers and 72
+// `ds_write_b128` (13 cycles each on the register -> LDS path) — and the two only half overlap (sum 1.95, measured 1.39 us per K-tile
+// pair). This kernel moves fewer bytes per MFMA and moves them without the register round trip:
+//   * 256 x 144 tile: 50 KB of operands per K-tile for the same 120 MFMAs per SIMD (0.74 x), 8 waves = 4 row blocks of 64 channels x 2
+//     column parts (64 + 16 and 64 pixels: 5 and 4 MFMA column blocks), the wave-level code of conv_s (16x16x32, lo*hi + hi*lo + hi*hi);
+//   * LDS-DMA: a wave-instruction copies 64 x 16 bytes from per-lane source addresses (a weight row / a pixel's tap — out-of-range lanes
+//     write zeros: padding and tile overhang need no masking) to 1 KB of consecutive LDS; the LDS image of conv_s ([k-group, plane][row])
+//     is exactly that. 50 pieces per K-tile: 4 weight + 2 pixel pieces per wave, and one piece each for waves 0 / 1 (the 16 extra pixel
+//     columns, kept in their own [8][16] block). No staging registers, no ds_write;
+//   * three LDS stages (3 x 50 KB) and a barrier in the MIDDLE of each K-tile's MFMAs: iteration t multiplies row blocks 0, 1 of tile t
+//     (fragments read during the previous iteration), reads the fragments of row blocks 2, 3, waits for tile t+1 (tile t+2 stays in
+//     flight), barrier, requests tile t+3 into the stage tile t just left, multiplies row blocks 2, 3 while reading tile t+1's first
+//     fragments — the MFMA pipe has queued work on both sides of the barrier, and every tile is requested two K-tiles ahead;
+//   * the epilogue is conv_s's (planes_epilogue.h), run by the two 256-thread halves of the workgroup on the two 128-row halves of the
+//     parked 256 x 144 fp32 tile (147 KB, over the three stages).
+// One workgroup per CU means prologue and epilogue are not hidden by a neighbour: the kernel is for launches whose K loop dominates
+// (the tuner decides per shape; plan impl 4). Unsplit launches only. Results are bit-identical to conv_s (same products in the same order).
+#include "planes_epilogue.h"
+
+namespace {
+
+constexpr int BMB = 256, BNB = 144, PB = 2;
+constexpr int A_CH = KG * PB * BMB;        // 2048 chunks: [k-group * 2 + plane][256 rows]
+constexpr int B_CH = KG * PB * 128;        // 1024 chunks: [k-group * 2 + plane][128 pixel columns]
+constexpr int E_CH = KG * PB * 16;         // 128 chunks:  [k-group * 2 + plane][16 extra pixel columns]
+constexpr int STGB = A_CH + B_CH + E_CH;   // 3200 chunks = 50 KB per stage
+constexpr int NSTG = 3;
+
+// one LDS-DMA piece: 64 lanes x 16 bytes -> LDS bytes [lds_addr, lds_addr + 1024); source = descriptor base + voff (per lane,
+// bounds-checked: out of range writes zeros) + soff (wave-uniform). hipcc does not count it: waits are written by hand below.
+__device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+template <int KS>
+__global__ __launch_bounds__(512, 2) void conv_b_bf16x3(ConvArgs a) {
+  constexpr int KHW = KS * KS;
+  __shared__ u32x4 lds[NSTG * STGB];                       // 150 KB: three K-tile stages; reused as the parked [256][144] fp32 tile (144 KB)
+  __shared__ float affine[2][2 * BM];                      // scale / shift of the tile's two 128-channel halves
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;                 // 64-row block, column part
+  const int nbj = wn == 0 ? 5 : 4;                         // wave-uniform
+
+  const unsigned total = gridDim.x, id = blockIdx.x;
+  const unsigned q8 = total >> 3, r8 = total & 7, xcd = id & 7;
+  const unsigned lid = a.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3) : id;
+  const unsigned tile_ = (unsigned)a.tile_base + lid;
+  const unsigned by_ = tile_ / (unsigned)a.gx, bx_ = tile_ - by_ * (unsigned)a.gx;
+  const int m0 = bx_ * BMB, n0 = by_ * BNB;
+  const int HWo = a.hout * a.wout, HWi = a.hin * a.win;
+
+  // ---- surviving taps of this tile (as conv_s.hip: taps that read padding for every pixel of the tile are dropped) ----
+  unsigned long long vlist = 0;
+  int nv = 1;
+  if constexpr (KS == 3) {
+    const int pl = min(n0 + BNB, a.npix) - 1;
+    const int im0 = n0 / HWo, im1 = pl / HWo;
+    int ymin = (n0 - im0 * HWo) / a.wout, ymax = (pl - im1 * HWo) / a.wout;
+    if (im0 != im1) { ymin = 0; ymax = a.hout - 1; }
+    nv = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int lo = ymin * a.stride - a.pad + ky * a.dil, hi = ymax * a.stride - a.pad + ky * a.dil;
+      if (hi < 0 || lo >= a.hin) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xlo = -a.pad + kx * a.dil, xhi = (a.wout - 1) * a.stride - a.pad + kx * a.dil;
+        if (xhi < 0 || xlo >= a.win) continue;
+        vlist |= (unsigned long long)(ky * 3 + kx) << (4 * nv);
+        ++nv;
+      }
+    }
+    nv = __builtin_amdgcn_readfirstlane(nv);
+    vlist = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(vlist >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)vlist);
+  }
+  const int nk = (a.cin >> 5) * nv;
+  int it_cb = 0, it_j = 0;                                 // the next K-tile to request: (block of 32 channels, index into vlist)
+
+  // folded-ABN scale / shift of the tile's 256 channels -> LDS, before any LDS-DMA is in flight (hipcc counts ITS loads only)
+  {
+    const int h = tid >> 8, t = tid & 255;
+    const int ch = min(m0 + h * BM + (t & 127), a.cout - 1);
+    const float* src = t < 128 ? a.scale : a.shift;
+    affine[h][t] = src ? src[ch] : (t < 128 ? 1.f : 0.f);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- this lane's pixel (column tid & 127 of the tile: the column it requests AND the column it finishes in the epilogue) ----
+  struct Pix { bool valid; int pn, phw, iy0, ix0; };
+  auto decode = [&](int pcol) {
+    Pix q;
+    const int p = n0 + pcol;
+    q.valid = p < a.npix;
+    q.pn = q.valid ? p / HWo : 0;
+    q.phw = q.valid ? p - q.pn * HWo : 0;
+    const int oy = q.phw / a.wout, ox = q.phw - oy * a.wout;
+    q.iy0 = oy * a.stride - a.pad;
+    q.ix0 = ox * a.stride - a.pad;
+    return q;
+  };
+  const int col = tid & 127;
+  const Pix px = decode(col);
+  const int ecol = 128 + (tid & 15);
+  const Pix ex = decode(ecol);
+  const int c8tot = a.in_ctot >> 3;
+  const unsigned cbase = (unsigned)(((long)px.pn * c8tot + (a.in_coff >> 3)) * PB * HWi);     // chunk index of (image, slice's first group, plane 0, pixel 0)
+  const unsigned ebase = (unsigned)(((long)ex.pn * c8tot + (a.in_coff >> 3)) * PB * HWi);
+  const unsigned x_bytes = (unsigned)((long)a.n * a.in_ctot * HWi * 2 * PB);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, x_bytes, 0x00020000);
+  const unsigned w_bytes = (unsigned)((long)(a.K / 8) * PB * a.cout * 16);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, w_bytes, 0x00020000);
+
+  // ---- LDS-DMA roles (wave-uniform): weight pieces = rows (wave & 3) * 64 + lane, chunk rows (wave >> 2) * 4 + i;
+  //      pixel pieces = column (wave & 1) * 64 + lane, k-group wave >> 1, planes 0 / 1; extra piece (waves 0, 1) = chunk row wave * 4 + (lane >> 4),
+  //      column 128 + (lane & 15) ----
+  const unsigned lds0 = (unsigned)(size_t)(&lds[0]);
+  const int arow = m0 + (wave & 3) * 64 + lane;
+  const unsigned a_voff = arow < a.cout ? (unsigned)arow * 16u : OOB;
+  const unsigned a_lds = (unsigned)(((wave >> 2) * 4 * BMB + (wave & 3) * 64) * 16);
+  const unsigned b_lds = (unsigned)((A_CH + (wave >> 1) * 2 * 128 + (wave & 1) * 64) * 16);
+  const unsigned e_lds = (unsigned)((A_CH + B_CH + wave * 64) * 16);
+  const int erow_dma = wave * 4 + (lane >> 4);             // waves 0, 1 only
+  const unsigned pkeep = (unsigned)(-(int)px.valid), ekeep = (unsigned)(-(int)ex.valid);
+
+  // A request = 6 (7) pieces. `prepare` forms the addresses of K-tile kt (kt >= nk: every lane out of range -> zeros); `piece<k>` issues
+  // one piece, so that the K loop can spread them between its MFMA groups.
+  struct Req { unsigned avo, T8, voff0, voff1, evoff, stage_bytes; } rq;
+  auto prepare = [&](int kt, unsigned stage_bytes) {
+    const int cb = it_cb;
+    const int tap = KS == 3 ? (int)((vlist >> (4 * it_j)) & 15ull) : 0;
+    if (++it_j >= nv) { it_j = 0; ++it_cb; }
+    const unsigned live = (unsigned)(-(int)(kt < nk));
+    int dy = 0, dx = 0;
+    if (KS == 3) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      dy = ky * a.dil; dx = kx * a.dil;
+    }
+    rq.stage_bytes = stage_bytes;
+    // weights: packed [K-tile T = cb * KHW + tap][k-group][plane][cout] chunks
+    rq.avo = (a_voff & live) | (OOB & ~live);
+    rq.T8 = (unsigned)((cb * KHW + tap) * 8 + (wave >> 2) * 4);
+    {   // pixels: this lane's tap of its pixel, k-group wave >> 1 of the block, planes 0 and 1 (whole address in the bounds-checked offset)
+      const int iy = px.iy0 + dy, ix = px.ix0 + dx;
+      const unsigned keep = pkeep & live & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
+      const unsigned vo = (cbase + (unsigned)(iy * a.win + ix)) * 16u + (unsigned)((cb * 4 + (wave >> 1)) * PB) * (unsigned)HWi * 16u;
+      rq.voff0 = (vo & keep) | (OOB & ~keep);
+      rq.voff1 = ((vo + (unsigned)HWi * 16u) & keep) | (OOB & ~keep);
+    }
+    {   // the extra piece of waves 0, 1
+      const int iy = ex.iy0 + dy, ix = ex.ix0 + dx;
+      const unsigned keep = ekeep & live & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
+      const unsigned vo = (ebase + (unsigned)(iy * a.win + ix)) * 16u + (unsigned)(((cb * 4 + (erow_dma >> 1)) * PB + (erow_dma & 1)) * HWi) * 16u;
+      rq.evoff = (vo & keep) | (OOB & ~keep);
+    }
+  };
+  auto piece_a = [&](int i) { dma16(lds0 + rq.stage_bytes + a_lds + (unsigned)(i * BMB * 16), rq.avo, wrsrc, (rq.T8 + (unsigned)i) * (unsigned)a.cout * 16u); };
+  auto piece_b = [&](int pl) { dma16(lds0 + rq.stage_bytes + b_lds + (unsigned)(pl * 128 * 16), pl ? rq.voff1 : rq.voff0, xrsrc, 0); };
+  auto piece_e = [&]() { if (wave < 2) dma16(lds0 + rq.stage_bytes + e_lds, rq.evoff, xrsrc, 0); };
+  auto request = [&](int kt, unsigned stage_bytes) {
+    prepare(kt, stage_bytes);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece_a(i);
+    piece_b(0);
+    piece_b(1);
+    piece_e();
+  };
+  // all but one K-tile's pieces of this wave have landed (6 pieces per K-tile, 7 for waves 0 and 1)
+  auto wait_all_but_one_tile = [&]() {
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  };
+
+  typedef float accv_t __attribute__((ext_vector_type(4)));
+  accv_t acc[4][5];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = accv_t{0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, kg = lane >> 4;
+  // fragment addresses inside a stage (chunks): A row block i of this wave, plane pl: (kg * 2 + pl) * 256 + wm * 64 + i * 16 + l15
+  const int a_frag = kg * 2 * BMB + wm * 64 + l15;
+  const int b_frag = A_CH + kg * 2 * 128 + wn * 64 + l15;  // column block j < 4: + j * 16; plane: + 128
+  const int e_frag = A_CH + B_CH + kg * 2 * 16 + l15;      // column block 4 (wave part 0): plane: + 16
+  auto read_a = [&](bf16x8 (&af)[2][2], const u32x4* st, int i0) {
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, st[a_frag + pl * BMB + (i0 + i) * 16]);
+  };
+  auto read_b = [&](bf16x8 (&bf)[2], const u32x4* st, int j) {
+    if (j < 4) {
+      bf[0] = __builtin_bit_cast(bf16x8, st[b_frag + j * 16]);
+      bf[1] = __builtin_bit_cast(bf16x8, st[b_frag + 128 + j * 16]);
+    } else {
+      bf[0] = __builtin_bit_cast(bf16x8, st[e_frag]);
+      bf[1] = __builtin_bit_cast(bf16x8, st[e_frag + 16]);
+    }
+  };
+  auto mma = [&](accv_t& c, const bf16x8 (&af)[2][2], int i, const bf16x8 (&bf)[2]) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0], c, 0, 0, 0);
+  };
+
+  // ---- prologue: tiles 0, 1, 2 requested; tile 0 awaited; its first fragments read ----
+  request(0, 0);
+  request(1, STGB * 16);
+  request(2, 2 * STGB * 16);
+  if (wave < 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 a01[2][2], a23[2][2], bfr[5][2];
+  read_a(a01, lds, 0);
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+    if (j < nbj) read_b(bfr[j], lds, j);
+
+  unsigned s_cur = 0, s_nxt = STGB, s_old = 2 * STGB;      // stage (chunks) of tile t, t+1, t+2
+  for (int t = 0; t < nk; ++t) {
+    const u32x4* cur = lds + s_cur;
+    const u32x4* nxt = lds + s_nxt;
+    // first half: row blocks 0, 1 of tile t (fragments already in registers) while the fragments of row blocks 2, 3 are read
+    read_a(a23, cur, 2);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (j < nbj) {
+        mma(acc[0][j], a01, 0, bfr[j]);
+        mma(acc[1][j], a01, 1, bfr[j]);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave no longer reads stage `cur`
+    wait_all_but_one_tile();                               // tile t+1 has landed (tile t+2 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    prepare(t + 3, s_cur * 16);                            // tile t+3 goes into the stage every wave has just left
+    // second half: row blocks 2, 3, column block by column block; block j's B registers are refilled from tile t+1 as soon as they are
+    // free, and the pieces of the request are spread between the blocks (an LDS-DMA issue costs 60+ cycles of this wave's stream)
+    read_a(a01, nxt, 0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j < nbj) {
+        mma(acc[2][j], a23, 0, bfr[j]);
+        mma(acc[3][j], a23, 1, bfr[j]);
+        read_b(bfr[j], nxt, j);
+      }
+      if (j == 0) { piece_a(0); piece_a(1); }
+      else if (j == 1) { piece_a(2); piece_a(3); }
+      else if (j == 2) piece_b(0);
+      else if (j == 3) piece_b(1);
+      else piece_e();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned s = s_cur; s_cur = s_nxt; s_nxt = s_old; s_old = s;
+  }
+
+  // ---- epilogue: the two 256-thread halves of the workgroup finish the two 128-row halves of the tile ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero-filled requests past the last K-tile have landed too
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int hsel = tid >> 8, t2 = tid & 255;
+  const int half = t2 >> 7;
+  const int erow = t2 >> 4;
+  const int m0h = m0 + hsel * BM;
+  SEpilogue<2, 8, BNB> ep2;
+  SEpilogue<1, 8, BNB> ep1;
+  SEpilogue<2, 1, BNB> ex2;
+  SEpilogue<1, 1, BNB> ex1;
+  const int res_kind = a.post_s ? 2 : (a.post ? 1 : 0);
+  if (res_kind == 2) {
+    ep2.issue(a, m0h, half, 2, px.valid, px.pn, px.phw, HWo);
+    ex2.issue(a, m0h, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+  } else if (res_kind == 1) {
+    ep1.issue(a, m0h, half, 2, px.valid, px.pn, px.phw, HWo);
+    ex1.issue(a, m0h, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+  }
+  float* park = reinterpret_cast<float*>(&lds[0]);
+  {
+    const int l4 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        if (j < nbj) {
+          const int cbase_ = j < 4 ? wn * 64 + j * 16 : 128;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) park[(wm * 64 + i * 16 + l4 * 4 + r) * BNB + cbase_ + l15] = acc[i][j][r];
+        }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const float* stage = park + hsel * BM * BNB;
+  const float* aff = affine[hsel];
+  if (res_kind == 2) {
+    ep2.finish(a, stage, aff, m0h, col, half, 2, px.valid, px.pn, px.phw, HWo);
+    ex2.finish(a, stage, aff, m0h, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+  } else if (res_kind == 1) {
+    ep1.finish(a, stage, aff, m0h, col, half, 2, px.valid, px.pn, px.phw, HWo);
+    ex1.finish(a, stage, aff, m0h, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+  } else {
+    SEpilogue<0, 8, BNB> ep0;
+    SEpilogue<0, 1, BNB> ex0;
+    ep0.finish(a, stage, aff, m0h, col, half, 2, px.valid, px.pn, px.phw, HWo);
+    ex0.finish(a, stage, aff, m0h, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+  }
+}
+
+}  // namespace
+
+static long g_b_launches = 0;
+extern "C" long cl4_conv_debug_b_launches(void) { return g_b_launches; }
+
+namespace cl4 {
+
+// conv_b takes what conv_s takes (planes input, two planes, 1x1 / 3x3, cin % 32 == 0), unsplit, with at least one full 256-row tile
+bool conv_b_eligible(const ConvArgs& a, int ks) {
+  return (ks == 1 || ks == 3) && a.cin % 32 == 0 && a.cout >= 256 && a.cout % 8 == 0 && a.xs != nullptr;
+}
+
+int launch_conv_b(const ConvArgs& a, int ks, unsigned grid, hipStream_t st) {
+  const dim3 g(grid), b(512);
+  ++g_b_launches;
+  if (ks == 1) hipLaunchKernelGGL((conv_b_bf16x3<1>), g, b, 0, st, a);
+  else if (ks == 3) hipLaunchKernelGGL((conv_b_bf16x3<3>), g, b, 0, st, a);
+  else { set_error("conv_b: kernel size %d not built", ks); return CL4_EINVAL; }
+  return launch_status();
+}
+
+}  // namespace cl4

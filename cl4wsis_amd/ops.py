@@ -254,6 +254,7 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
 
 
 CONV_P = os.environ.get("CL4_CONV_P", "1") != "0"      # 0: never pick the persistent pipelined planes kernel (A/B measurements)
+CONV_B = os.environ.get("CL4_CONV_B", "1") != "0"      # r03: the tuner may pick the big-tile LDS-DMA planes kernel (plan impl 4)
 PLANES_TILES = [int(v) for v in os.environ.get("CL4_PLANES_TILES", "128,144").split(",")]   # pixel widths of the planes kernel's tiles the tuner may pick
 
 
@@ -275,6 +276,9 @@ def _autotune_planes(d, args, reps=6):
     if (CONV_P and d.precision == 3 and d.kh == 1 and d.stride == 1 and d.pad == 0 and d.cout % 128 == 0 and K >= 128 and pre is None and post_f is None
             and out_f32 is None and out_pl is not None and -(-d.cout // 128) * -(-npix // 128) >= 512):
         cands.append((3, 128, 1))
+    # the big-tile LDS-DMA kernel (csrc/conv_b.hip): 256 x 144 tiles, one workgroup per CU — long-K layers with >= 256 output channels
+    if CONV_B and d.precision == 3 and d.cout >= 256 and d.cout % 8 == 0 and K >= 256:
+        cands.append((4, 144, 1))
     for impl, tile, splits in cands:
         tiles = -(-d.cout // 128) * -(-npix // tile)
         if True:

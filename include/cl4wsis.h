@@ -486,6 +486,7 @@ int cl4_conv_debug_timeline(void* buf);
  * the planes-input kernel (csrc/conv_s.hip). */
 long cl4_conv_debug_u_launches(void);
 long cl4_conv_debug_s_launches(void);
+long cl4_conv_debug_b_launches(void);   /* launches of the big-tile LDS-DMA planes kernel (conv_b.hip, plan impl 4) */
 
 /* "Planes" activations (csrc/conv_s.hip). The dense convolutions of the frozen networks (modules/residual.py:84-97,
  * modules/deeplab.py:54-70, every nn.Conv2d + InPlaceABN + residual add of the eval-mode forward passes at train.py:253-263) multiply

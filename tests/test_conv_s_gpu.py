@@ -43,7 +43,7 @@ def test_planes_round_trip_is_the_bf16_split(gpu):
 
 
 def _run(gpu, n, cin, h, w, cout, k, stride, pad, dil, plan, seed, epilogue=False, planes_post=False, in_ctot=None, in_coff=0,
-         out_ctot=None, out_coff=0):
+         out_ctot=None, out_coff=0, counter="cl4_conv_debug_s_launches", keep=None):
     from cl4wsis_amd import _hip, ops
     g = torch.Generator().manual_seed(seed)
     in_ctot = in_ctot or cin
@@ -67,15 +67,17 @@ def _run(gpu, n, cin, h, w, cout, k, stride, pad, dil, plan, seed, epilogue=Fals
         outp.data.fill_(0)
     d = ops.ConvDescFor(n, cin, h, w, in_ctot, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, 0, 0.0, 0, 0.0, 3)
     _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), *plan)
-    before = _hip.load().cl4_conv_debug_s_launches()
+    before = getattr(_hip.load(), counter)()
     try:
         ops.conv2d_planes(xs, wp, k, stride=stride, pad=pad, dil=dil, in_coff=in_coff, cin=cin, out=out, out_coff=out_coff,
                           out_planes=outp, **kw)
         torch.cuda.synchronize()
     finally:
         _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 0, 64, 1)
-    assert _hip.load().cl4_conv_debug_s_launches() > before
+    assert getattr(_hip.load(), counter)() > before
     y = out[:, out_coff:out_coff + cout].cpu()
+    if keep is not None:
+        keep.append(out.cpu())
     assert _rel_err(y, ref) < TOL, (_rel_err(y, ref), (n, cin, h, w, cout, k, stride, pad, dil, plan))
     if out_ctot != cout:
         assert (out[:, :out_coff] == 7).all() and (out[:, out_coff + cout:] == 7).all()
@@ -146,6 +148,44 @@ def test_conv_planes_both_mfma_shapes_agree_with_the_fp32_input_kernel(gpu):
     y1, _ = ops.conv2d_planes(ops.to_planes(x), wp, 3, pad=1)
     torch.cuda.synchronize()
     assert _rel_err(y1.cpu(), y0.cpu()) < 2e-6
+
+
+# The big-tile LDS-DMA kernel (csrc/conv_b.hip, plan impl 4): 256 x 144 tiles, operands straight into LDS, three stages.
+# (n, cin, h, w, cout, k, stride, pad, dil)
+B_SHAPES = [
+    (2, 64, 17, 17, 256, 1, 1, 0, 1),       # two K-tiles (fewer than the three stages)
+    (3, 32, 10, 10, 256, 1, 1, 0, 1),       # one K-tile
+    (1, 96, 33, 33, 264, 3, 1, 6, 6),       # ragged cout (a second row tile with 8 live rows), 27 K-tiles, dilation 6
+    (2, 64, 33, 33, 256, 3, 1, 18, 18),     # most taps outside the image: tiles with different K-tile counts
+    (2, 160, 21, 19, 320, 3, 1, 2, 2),
+    (2, 128, 33, 33, 256, 3, 2, 1, 1),      # strided 3x3
+    (2, 256, 33, 31, 512, 1, 2, 0, 1),      # strided 1x1
+    (1, 128, 9, 7, 256, 3, 1, 1, 1),        # 63 pixels: half a tile
+    (3, 64, 65, 67, 256, 3, 1, 1, 1),       # 91 tiles
+    (9, 64, 33, 33, 1024, 1, 1, 0, 1),      # 272 tiles: more than one per CU
+    (2, 512, 33, 33, 512, 3, 1, 2, 2),      # res5 conv2: 144 K-tiles
+]
+
+
+@pytest.mark.parametrize("shape", B_SHAPES)
+def test_conv_big_tile_lds_dma_kernel_plain(gpu, shape):
+    _run(gpu, *shape, plan=(4, 144, 1), seed=sum(shape), counter="cl4_conv_debug_b_launches")
+
+
+@pytest.mark.parametrize("planes_post", [False, True])
+@pytest.mark.parametrize("shape", B_SHAPES)
+def test_conv_big_tile_lds_dma_kernel_fused_epilogue(gpu, shape, planes_post):
+    a, b = [], []
+    _run(gpu, *shape, plan=(4, 144, 1), seed=1 + sum(shape), epilogue=True, planes_post=planes_post, counter="cl4_conv_debug_b_launches", keep=a)
+    _run(gpu, *shape, plan=(2, 144, 1), seed=1 + sum(shape), epilogue=True, planes_post=planes_post, keep=b)
+    assert torch.equal(a[0], b[0])          # the same products in the same order as conv_s: bit-identical
+
+
+def test_conv_big_tile_kernel_channel_slices(gpu):
+    _run(gpu, 2, 64, 15, 15, 256, 3, 1, 2, 2, plan=(4, 144, 1), seed=5, in_ctot=104, in_coff=24, out_ctot=328, out_coff=24, counter="cl4_conv_debug_b_launches")
+    _run(gpu, 2, 32, 15, 15, 288, 1, 1, 0, 1, plan=(4, 144, 1), seed=6, in_ctot=40, in_coff=8, out_ctot=304, out_coff=8, epilogue=True,
+         counter="cl4_conv_debug_b_launches")
+    _run(gpu, 2, 32, 15, 15, 128, 1, 1, 0, 1, plan=(4, 144, 1), seed=7)      # cout < 256: the plan falls back to conv_s (144-pixel tiles)
 
 
 # (n, cin, h, w, cout): 1x1 layers on the persistent pipelined kernel (csrc/conv_p.hip, plan impl 3): planes in, planes out
