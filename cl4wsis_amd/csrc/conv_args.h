@@ -57,9 +57,10 @@ bool conv_p_eligible(const ConvArgs& a, int ks);
 int launch_conv_p(const ConvArgs& a, unsigned ntile, hipStream_t st);
 
 
-// conv_b.hip: the big-tile planes kernel (256 output channels x 144 pixels per 512-thread workgroup, operands by LDS-DMA, three LDS
-// stages; one workgroup per CU) for launches whose K loop dominates. Unsplit; `grid` = cdiv(cout, 256) * cdiv(npix, 144) with a.gx = cdiv(cout, 256).
-bool conv_b_eligible(const ConvArgs& a, int ks);
-int launch_conv_b(const ConvArgs& a, int ks, unsigned grid, hipStream_t st);
+// conv_b.hip: the LDS-DMA planes kernel (operands straight into LDS, three LDS stages, one workgroup per CU) for launches whose K loop
+// dominates. rows = output channels per tile: 256 (512 threads) or 128 (256 threads: launches with too few 256-row tiles to fill the
+// chip); 144 pixels per tile. Unsplit; `grid` = cdiv(cout, rows) * cdiv(npix, 144) with a.gx = cdiv(cout, rows).
+bool conv_b_eligible(const ConvArgs& a, int ks, int rows);
+int launch_conv_b(const ConvArgs& a, int ks, int rows, unsigned grid, hipStream_t st);
 
 }  // namespace cl4

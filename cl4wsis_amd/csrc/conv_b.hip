@@ -24,11 +24,16 @@
 
 namespace {
 
-constexpr int BMB = 256, BNB = 144, PB = 2;
-constexpr int A_CH = KG * PB * BMB;        // 2048 chunks: [k-group * 2 + plane][256 rows]
+#ifndef CL4_B_SPREAD
+#define CL4_B_SPREAD 1   // 1: the pixel part of a K-tile's request is issued in the first half of the previous iteration, the weight part in the second half two iterations ahead
+#endif
+#ifndef CL4_B_DBG
+#define CL4_B_DBG 0   // experiments only: 1 = no LDS-DMA in the K loop, 4 = no MFMA
+#endif
+
+constexpr int BNB = 144, PB = 2;
 constexpr int B_CH = KG * PB * 128;        // 1024 chunks: [k-group * 2 + plane][128 pixel columns]
 constexpr int E_CH = KG * PB * 16;         // 128 chunks:  [k-group * 2 + plane][16 extra pixel columns]
-constexpr int STGB = A_CH + B_CH + E_CH;   // 3200 chunks = 50 KB per stage
 constexpr int NSTG = 3;
 
 // one LDS-DMA piece: 64 lanes x 16 bytes -> LDS bytes [lds_addr, lds_addr + 1024); source = descriptor base + voff (per lane,
@@ -37,11 +42,19 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, __amdgpu
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
-template <int KS>
-__global__ __launch_bounds__(512, 2) void conv_b_bf16x3(ConvArgs a) {
+// WM = 64-row blocks per tile: 4 = 256 output channels (8 waves, 50 KB per stage), 2 = 128 output channels (4 waves, 34 KB per stage:
+// the launches with fewer than 256 tiles of 256 rows — 16 images of a 33 x 33 map at 256 output channels — where conv_s has one
+// workgroup per CU and nothing to hide its operand traffic behind).
+template <int KS, int WM>
+__global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvArgs a) {
   constexpr int KHW = KS * KS;
-  __shared__ u32x4 lds[NSTG * STGB];                       // 150 KB: three K-tile stages; reused as the parked [256][144] fp32 tile (144 KB)
-  __shared__ float affine[2][2 * BM];                      // scale / shift of the tile's two 128-channel halves
+  constexpr int BMB = 64 * WM;
+  constexpr int A_CH = KG * PB * BMB;                      // [k-group * 2 + plane][BMB rows]
+  constexpr int STGB = A_CH + B_CH + E_CH;                 // 3200 chunks = 50 KB (WM = 4), 2176 chunks = 34 KB (WM = 2)
+  constexpr int NBP = 8 / WM;                              // pixel pieces per wave and K-tile (16 over 2 * WM waves)
+  constexpr int NPW = 4 + NBP;                             // pieces per wave and K-tile (one more for waves 0 and 1)
+  __shared__ u32x4 lds[NSTG * STGB];                       // three K-tile stages; reused as the parked [BMB][144] fp32 tile
+  __shared__ float affine[WM / 2][2 * BM];                 // scale / shift of the tile's 128-channel halves
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -82,7 +95,6 @@ __global__ __launch_bounds__(512, 2) void conv_b_bf16x3(ConvArgs a) {
     vlist = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(vlist >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)vlist);
   }
   const int nk = (a.cin >> 5) * nv;
-  int it_cb = 0, it_j = 0;                                 // the next K-tile to request: (block of 32 channels, index into vlist)
 
   // folded-ABN scale / shift of the tile's 256 channels -> LDS, before any LDS-DMA is in flight (hipcc counts ITS loads only)
   {
@@ -118,41 +130,55 @@ __global__ __launch_bounds__(512, 2) void conv_b_bf16x3(ConvArgs a) {
   const unsigned w_bytes = (unsigned)((long)(a.K / 8) * PB * a.cout * 16);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, w_bytes, 0x00020000);
 
-  // ---- LDS-DMA roles (wave-uniform): weight pieces = rows (wave & 3) * 64 + lane, chunk rows (wave >> 2) * 4 + i;
-  //      pixel pieces = column (wave & 1) * 64 + lane, k-group wave >> 1, planes 0 / 1; extra piece (waves 0, 1) = chunk row wave * 4 + (lane >> 4),
-  //      column 128 + (lane & 15) ----
+  // ---- LDS-DMA roles (wave-uniform): weight pieces = rows (wave % WM) * 64 + lane, chunk rows (wave / WM) * 4 + i, i < 4;
+  //      pixel pieces = column (wave & 1) * 64 + lane, chunk rows (wave >> 1) * NBP + q, q < NBP; extra piece (waves 0, 1) = chunk row
+  //      wave * 4 + (lane >> 4), column 128 + (lane & 15) ----
   const unsigned lds0 = (unsigned)(size_t)(&lds[0]);
-  const int arow = m0 + (wave & 3) * 64 + lane;
+  const int arow = m0 + (wave % WM) * 64 + lane;
   const unsigned a_voff = arow < a.cout ? (unsigned)arow * 16u : OOB;
-  const unsigned a_lds = (unsigned)(((wave >> 2) * 4 * BMB + (wave & 3) * 64) * 16);
-  const unsigned b_lds = (unsigned)((A_CH + (wave >> 1) * 2 * 128 + (wave & 1) * 64) * 16);
+  const unsigned a_lds = (unsigned)(((wave / WM) * 4 * BMB + (wave % WM) * 64) * 16);
+  const unsigned b_lds = (unsigned)((A_CH + (wave >> 1) * NBP * 128 + (wave & 1) * 64) * 16);
   const unsigned e_lds = (unsigned)((A_CH + B_CH + wave * 64) * 16);
   const int erow_dma = wave * 4 + (lane >> 4);             // waves 0, 1 only
   const unsigned pkeep = (unsigned)(-(int)px.valid), ekeep = (unsigned)(-(int)ex.valid);
 
-  // A request = 6 (7) pieces. `prepare` forms the addresses of K-tile kt (kt >= nk: every lane out of range -> zeros); `piece<k>` issues
-  // one piece, so that the K loop can spread them between its MFMA groups.
-  struct Req { unsigned avo, T8, voff0, voff1, evoff, stage_bytes; } rq;
-  auto prepare = [&](int kt, unsigned stage_bytes) {
-    const int cb = it_cb;
-    const int tap = KS == 3 ? (int)((vlist >> (4 * it_j)) & 15ull) : 0;
-    if (++it_j >= nv) { it_j = 0; ++it_cb; }
+  // A request = the weight part (4 pieces) and the pixel part (NBP pieces, and the extra piece of waves 0 / 1) of one K-tile, each with
+  // its own cursor over the K-tiles: the K loop issues the two parts in different halves of an iteration (CL4_B_SPREAD), so that the
+  // chip's vector-memory path sees an even stream instead of 50 pieces in one burst per K-tile. `prep_*` forms the addresses (K-tile
+  // >= nk: every lane out of range -> zeros); `piece_*` issues one piece, between MFMA groups.
+  struct Cursor { int cb, j; };
+  Cursor ca{0, 0}, cbt{0, 0};
+  auto advance = [&](Cursor& c, int& cb, int& tap) {
+    cb = c.cb;
+    tap = KS == 3 ? (int)((vlist >> (4 * c.j)) & 15ull) : 0;
+    if (++c.j >= nv) { c.j = 0; ++c.cb; }
+  };
+  struct Req { unsigned avo, T8, a_stage, bvo, bso, evoff, b_stage; } rq;
+  auto prep_a = [&](int kt, unsigned stage_bytes) {      // weights: packed [K-tile T = cb * KHW + tap][k-group][plane][cout] chunks
+    int cb, tap;
+    advance(ca, cb, tap);
+    const unsigned live = (unsigned)(-(int)(kt < nk));
+    rq.a_stage = stage_bytes;
+    rq.avo = (a_voff & live) | (OOB & ~live);
+    rq.T8 = (unsigned)((cb * KHW + tap) * 8 + (wave / WM) * 4);
+  };
+  auto prep_b = [&](int kt, unsigned stage_bytes) {
+    int cb, tap;
+    advance(cbt, cb, tap);
     const unsigned live = (unsigned)(-(int)(kt < nk));
     int dy = 0, dx = 0;
     if (KS == 3) {
       const int ky = tap / 3, kx = tap - ky * 3;
       dy = ky * a.dil; dx = kx * a.dil;
     }
-    rq.stage_bytes = stage_bytes;
-    // weights: packed [K-tile T = cb * KHW + tap][k-group][plane][cout] chunks
-    rq.avo = (a_voff & live) | (OOB & ~live);
-    rq.T8 = (unsigned)((cb * KHW + tap) * 8 + (wave >> 2) * 4);
-    {   // pixels: this lane's tap of its pixel, k-group wave >> 1 of the block, planes 0 and 1 (whole address in the bounds-checked offset)
+    rq.b_stage = stage_bytes;
+    {   // pixels: this lane's tap of its pixel in plane 0 of the block's first k-group (bounds-checked per-lane offset); the piece's
+        // chunk row is a wave-uniform offset on top
       const int iy = px.iy0 + dy, ix = px.ix0 + dx;
       const unsigned keep = pkeep & live & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
-      const unsigned vo = (cbase + (unsigned)(iy * a.win + ix)) * 16u + (unsigned)((cb * 4 + (wave >> 1)) * PB) * (unsigned)HWi * 16u;
-      rq.voff0 = (vo & keep) | (OOB & ~keep);
-      rq.voff1 = ((vo + (unsigned)HWi * 16u) & keep) | (OOB & ~keep);
+      const unsigned vo = (cbase + (unsigned)(iy * a.win + ix)) * 16u;
+      rq.bvo = (vo & keep) | (OOB & ~keep);
+      rq.bso = (unsigned)(cb * 4 * PB + (wave >> 1) * NBP) * (unsigned)HWi * 16u;
     }
     {   // the extra piece of waves 0, 1
       const int iy = ex.iy0 + dy, ix = ex.ix0 + dx;
@@ -161,21 +187,24 @@ __global__ __launch_bounds__(512, 2) void conv_b_bf16x3(ConvArgs a) {
       rq.evoff = (vo & keep) | (OOB & ~keep);
     }
   };
-  auto piece_a = [&](int i) { dma16(lds0 + rq.stage_bytes + a_lds + (unsigned)(i * BMB * 16), rq.avo, wrsrc, (rq.T8 + (unsigned)i) * (unsigned)a.cout * 16u); };
-  auto piece_b = [&](int pl) { dma16(lds0 + rq.stage_bytes + b_lds + (unsigned)(pl * 128 * 16), pl ? rq.voff1 : rq.voff0, xrsrc, 0); };
-  auto piece_e = [&]() { if (wave < 2) dma16(lds0 + rq.stage_bytes + e_lds, rq.evoff, xrsrc, 0); };
-  auto request = [&](int kt, unsigned stage_bytes) {
-    prepare(kt, stage_bytes);
+  auto piece_a = [&](int i) { dma16(lds0 + rq.a_stage + a_lds + (unsigned)(i * BMB * 16), rq.avo, wrsrc, (rq.T8 + (unsigned)i) * (unsigned)a.cout * 16u); };
+  auto piece_b = [&](int q) { dma16(lds0 + rq.b_stage + b_lds + (unsigned)(q * 128 * 16), rq.bvo, xrsrc, rq.bso + (unsigned)(q * HWi) * 16u); };
+  auto piece_e = [&]() { if (wave < 2) dma16(lds0 + rq.b_stage + e_lds, rq.evoff, xrsrc, 0); };
+  auto request_a = [&](int kt, unsigned stage_bytes) {
+    prep_a(kt, stage_bytes);
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_a(i);
-    piece_b(0);
-    piece_b(1);
+  };
+  auto request_b = [&](int kt, unsigned stage_bytes) {
+    prep_b(kt, stage_bytes);
+#pragma unroll
+    for (int q = 0; q < NBP; ++q) piece_b(q);
     piece_e();
   };
-  // all but one K-tile's pieces of this wave have landed (6 pieces per K-tile, 7 for waves 0 and 1)
+  // all but one K-tile's pieces of this wave have landed (NPW pieces per K-tile, one more for waves 0 and 1)
   auto wait_all_but_one_tile = [&]() {
-    if (wave < 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (wave < 2) wait_vmcnt<NPW + 1>();
+    else wait_vmcnt<NPW>();
   };
 
   typedef float accv_t __attribute__((ext_vector_type(4)));
@@ -206,17 +235,30 @@ __global__ __launch_bounds__(512, 2) void conv_b_bf16x3(ConvArgs a) {
     }
   };
   auto mma = [&](accv_t& c, const bf16x8 (&af)[2][2], int i, const bf16x8 (&bf)[2]) {
+#if CL4_B_DBG & 4
+    c[0] += (float)af[1][i][0] * (float)bf[0][0] + (float)af[0][i][1] * (float)bf[1][1];
+#else
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[0], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[1], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0], c, 0, 0, 0);
+#endif
   };
 
-  // ---- prologue: tiles 0, 1, 2 requested; tile 0 awaited; its first fragments read ----
-  request(0, 0);
-  request(1, STGB * 16);
-  request(2, 2 * STGB * 16);
-  if (wave < 2) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  // ---- prologue: tiles 0, 1 and the weight part of tile 2 requested (CL4_B_SPREAD = 0: all of tile 2); tile 0 awaited; its first
+  //      fragments read ----
+  request_a(0, 0);
+  request_b(0, 0);
+  request_a(1, STGB * 16);
+  request_b(1, STGB * 16);
+  request_a(2, 2 * STGB * 16);
+#if CL4_B_SPREAD
+  if (wave < 2) wait_vmcnt<NPW + 1 + 4>();
+  else wait_vmcnt<NPW + 4>();
+#else
+  request_b(2, 2 * STGB * 16);
+  if (wave < 2) wait_vmcnt<2 * NPW + 2>();
+  else wait_vmcnt<2 * NPW>();
+#endif
   __builtin_amdgcn_s_barrier();
   bf16x8 a01[2][2], a23[2][2], bfr[5][2];
   read_a(a01, lds, 0);
@@ -228,18 +270,38 @@ __global__ __launch_bounds__(512, 2) void conv_b_bf16x3(ConvArgs a) {
   for (int t = 0; t < nk; ++t) {
     const u32x4* cur = lds + s_cur;
     const u32x4* nxt = lds + s_nxt;
-    // first half: row blocks 0, 1 of tile t (fragments already in registers) while the fragments of row blocks 2, 3 are read
+    // first half: row blocks 0, 1 of tile t (fragments already in registers) while the fragments of row blocks 2, 3 are read and the
+    // pixel part of tile t+2 is requested (its stage was left by every wave before the previous barrier; its weight part is on its way)
     read_a(a23, cur, 2);
+#if CL4_B_SPREAD && !(CL4_B_DBG & 1)
+    prep_b(t + 2, s_old * 16);
+#endif
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < 5; ++j) {
       if (j < nbj) {
         mma(acc[0][j], a01, 0, bfr[j]);
         mma(acc[1][j], a01, 1, bfr[j]);
       }
+#if CL4_B_SPREAD && !(CL4_B_DBG & 1)
+      if (j == 0) {
+#pragma unroll
+        for (int q = 0; q < NBP / 2; ++q) piece_b(q);
+      } else if (j == 1) {
+#pragma unroll
+        for (int q = NBP / 2; q < NBP; ++q) piece_b(q);
+      } else if (j == 2) piece_e();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave no longer reads stage `cur`
     wait_all_but_one_tile();                               // tile t+1 has landed (tile t+2 may be in flight)
     __builtin_amdgcn_s_barrier();
-    prepare(t + 3, s_cur * 16);                            // tile t+3 goes into the stage every wave has just left
+#if !(CL4_B_DBG & 1)
+    prep_a(t + 3, s_cur * 16);                             // tile t+3 goes into the stage every wave has just left
+#if !CL4_B_SPREAD
+    prep_b(t + 3, s_cur * 16);
+#endif
+#endif
     // second half: row blocks 2, 3, column block by column block; block j's B registers are refilled from tile t+1 as soon as they are
     // free, and the pieces of the request are spread between the blocks (an LDS-DMA issue costs 60+ cycles of this wave's stream)
     read_a(a01, nxt, 0);
@@ -250,11 +312,21 @@ __global__ __launch_bounds__(512, 2) void conv_b_bf16x3(ConvArgs a) {
         mma(acc[3][j], a23, 1, bfr[j]);
         read_b(bfr[j], nxt, j);
       }
+#if !(CL4_B_DBG & 1)
+#if CL4_B_SPREAD
+      if (j < 4) piece_a(j);
+#else
       if (j == 0) { piece_a(0); piece_a(1); }
       else if (j == 1) { piece_a(2); piece_a(3); }
-      else if (j == 2) piece_b(0);
-      else if (j == 3) piece_b(1);
-      else piece_e();
+      else if (j == 2) {
+#pragma unroll
+        for (int q = 0; q < NBP / 2; ++q) piece_b(q);
+      } else if (j == 3) {
+#pragma unroll
+        for (int q = NBP / 2; q < NBP; ++q) piece_b(q);
+      } else piece_e();
+#endif
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     const unsigned s = s_cur; s_cur = s_nxt; s_nxt = s_old; s_old = s;
@@ -319,16 +391,18 @@ extern "C" long cl4_conv_debug_b_launches(void) { return g_b_launches; }
 namespace cl4 {
 
 // conv_b takes what conv_s takes (planes input, two planes, 1x1 / 3x3, cin % 32 == 0), unsplit, with at least one full 256-row tile
-bool conv_b_eligible(const ConvArgs& a, int ks) {
-  return (ks == 1 || ks == 3) && a.cin % 32 == 0 && a.cout >= 256 && a.cout % 8 == 0 && a.xs != nullptr;
+bool conv_b_eligible(const ConvArgs& a, int ks, int rows) {
+  return (ks == 1 || ks == 3) && (rows == 128 || rows == 256) && a.cin % 32 == 0 && a.cout >= rows && a.cout % 8 == 0 && a.xs != nullptr;
 }
 
-int launch_conv_b(const ConvArgs& a, int ks, unsigned grid, hipStream_t st) {
-  const dim3 g(grid), b(512);
+int launch_conv_b(const ConvArgs& a, int ks, int rows, unsigned grid, hipStream_t st) {
+  const dim3 g(grid), b(2 * rows);
   ++g_b_launches;
-  if (ks == 1) hipLaunchKernelGGL((conv_b_bf16x3<1>), g, b, 0, st, a);
-  else if (ks == 3) hipLaunchKernelGGL((conv_b_bf16x3<3>), g, b, 0, st, a);
-  else { set_error("conv_b: kernel size %d not built", ks); return CL4_EINVAL; }
+  if (ks == 1 && rows == 256) hipLaunchKernelGGL((conv_b_bf16x3<1, 4>), g, b, 0, st, a);
+  else if (ks == 3 && rows == 256) hipLaunchKernelGGL((conv_b_bf16x3<3, 4>), g, b, 0, st, a);
+  else if (ks == 1 && rows == 128) hipLaunchKernelGGL((conv_b_bf16x3<1, 2>), g, b, 0, st, a);
+  else if (ks == 3 && rows == 128) hipLaunchKernelGGL((conv_b_bf16x3<3, 2>), g, b, 0, st, a);
+  else { set_error("conv_b: kernel size %d / %d rows not built", ks, rows); return CL4_EINVAL; }
   return launch_status();
 }
 
