@@ -1327,6 +1327,7 @@ FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision
   p.impl = 2;
   p.tile = ((tile == 128 && cout >= 128) || planes_code(precision)) ? 128 : 64;      // planes-input kernel: 128 output channels per tile
   if ((precision == 3 && tile == 144) || precision == 4) p.bn = 144;                   // ... x 128 or 144 pixels (three planes: 144 only)
+  else if (precision == 3 && tile == 64) p.bn = 64;                                    // ... or 64 pixels (three workgroups per CU: short-K, HBM-bound layers)
   const int ktiles = cl4::cdiv(K, BK2);
   int s = splits < 0 ? -splits : (splits < 1 ? 1 : splits);
   if (s > ktiles) s = ktiles;
@@ -1386,7 +1387,7 @@ TailGeom tail_geometry(const FwdPlan& pl, int cout, int npix, int precision) {
   g.main = 0;
   g.p0 = 0;
   if (pl.tail > 0) {
-    int slots = ((precision == 2 && pl.tile == 128) || precision == 4) ? 256 : 512;     // resident workgroups: one / two per CU
+    int slots = ((precision == 2 && pl.tile == 128) || precision == 4) ? 256 : (pl.bn == 64 ? 768 : 512);     // resident workgroups: one / two / three per CU
     if (g.ntiles < slots + slots / 16) slots = 256;
     int m = (g.ntiles / slots) * slots;
     m -= m % g.gx;

@@ -33,23 +33,29 @@ namespace {
 // for 144-pixel tiles and the 16x16x32 MFMA only: 102 KB of LDS (two stages of 1536 + 1728 chunks), one workgroup per CU, 13 loads per
 // thread and K-tile, 120 MFMAs per wave and K-tile.
 template <int KS, bool SPLIT, int MF, int BNT, int PL>
-__global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a) {
+__global__ __launch_bounds__(256, PL == 3 ? 1 : (BNT == 64 ? 3 : 2)) void conv_s_bf16x3(ConvArgs a) {
   static_assert(MF == 32 || MF == 16, "MFMA shape");
-  static_assert(BNT == 128 || (BNT == 144 && MF == 16), "tile width");
+  static_assert(BNT == 128 || ((BNT == 144 || BNT == 64) && MF == 16), "tile width");
   static_assert(PL == 2 || (PL == 3 && MF == 16 && BNT == 144), "planes");
   constexpr int P = PL;
   constexpr int A_CHUNKS = KG * P * BM;
-  constexpr int NCH = KG * P / 2;                          // chunk rows (k-group, plane) per staging thread and operand
+  constexpr int NCH = KG * P / 2;                          // chunk rows (k-group, plane) per staging thread of the weight tile
   constexpr bool WIDE = BNT == 144;
+  // 64-pixel tiles (r03): 48 KB of LDS and ~150 registers, three workgroups per CU — for the short-K layers whose time is their
+  // epilogue's HBM stream (256 -> 1024 + residual: 8 K-tiles, then 64 KB in and 64 KB out per 128-pixel tile): a third resident
+  // workgroup in another phase keeps the memory pipe busy while the other two multiply. Pixel staging: thread = (column tid & 63,
+  // quarter tid >> 6) moves 2 chunk rows; epilogue: 4 channel groups per thread.
+  constexpr bool NARROW = BNT == 64;
+  constexpr int NCHB = NARROW ? KG * P / 4 : NCH;          // chunk rows per staging thread of the pixel tile
   constexpr int WTM = 64;
   constexpr int KHW = KS * KS;
   constexpr int NB = MF == 32 ? 2 : 4;                     // MFMA row blocks per wave
-  constexpr int NBJ = MF == 32 ? 2 : (WIDE ? 5 : 4);       // MFMA column blocks per wave (the second column part of a wide tile has 4)
+  constexpr int NBJ = MF == 32 ? 2 : (WIDE ? 5 : (NARROW ? 2 : 4));   // MFMA column blocks per wave (the second column part of a wide tile has 4)
   constexpr int ACCV = MF == 32 ? 16 : 4;                  // accumulator registers per block
   constexpr int BCH = KG * P * BNT;                        // B chunks per stage
   constexpr int STG = A_CHUNKS + BCH;                      // chunks per stage
   constexpr int LDSC = (2 * STG * 16 > BM * BNT * 4) ? 2 * STG : BM * BNT / 4;
-  constexpr int LPT = 2 * NCH + (WIDE ? 1 : 0);            // vector-memory loads per thread and K-tile
+  constexpr int LPT = NCH + NCHB + (WIDE ? 1 : 0);         // vector-memory loads per thread and K-tile
   __shared__ u32x4 lds[LDSC];                              // two K-tile stages; reused as the parked [128][BNT] fp32 tile (64 / 72 KB)
 #if !CL4_S_NO_AFFINE_LDS
   __shared__ float affine[2 * BM];                         // scale / shift of the tile's 128 output channels, fetched once at the start
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int cb0 = WIDE ? wn * 80 : wn * 64;                // first pixel column of this wave's part
+  const int cb0 = WIDE ? wn * 80 : (NARROW ? wn * 32 : wn * 64);   // first pixel column of this wave's part
   const int nbj = (WIDE && wn == 1) ? 4 : NBJ;             // wave-uniform
 
   const unsigned total = gridDim.x, id = blockIdx.x;
@@ -137,7 +143,9 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a
   // plane for its weight row AND for its pixel: 8 x 16 bytes in, 8 x ds_write_b128 out. A wide tile has 16 more pixel columns = 128 more
   // chunks per K-tile: threads 0..127 move one each (column 128 + (tid & 15), chunk row tid >> 4 = 2 * k-group + plane); the other
   // half issues the same load out of range, so that every wave counts 9 loads per K-tile ------------------------------------------------
-  const int col = tid & 127, half = wave >> 1;             // this thread moves the chunk rows r = half * NCH + i (r = k-group * P + plane); wave-uniform
+  const int col = tid & 127, half = wave >> 1;             // this thread moves the chunk rows r = half * NCH + i (r = k-group * P + plane) of weight row `col`; wave-uniform
+  const int colB = NARROW ? (tid & 63) : col;              // ... and the chunk rows qB * NCHB + i of pixel column colB (also its epilogue column)
+  const int qB = NARROW ? wave : half;
   const int c8tot = a.in_ctot >> 3;
   struct Pix { bool valid; int pn, phw, iy0, ix0; };
   auto decode = [&](int pcol) {
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a
     q.ix0 = ox * a.stride - a.pad;
     return q;
   };
-  const Pix px = decode(col);
+  const Pix px = decode(colB);
   const bool pvalid = px.valid;
   const int pn = px.pn, phw = px.phw, iy0 = px.iy0, ix0 = px.ix0;
   // chunk index of (image, first channel group of the slice, plane, pixel 0) — the tap's pixel and the K-tile's channel groups are added per tile
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a
       dy = ky * a.dil; dx = kx * a.dil;
     }
   };
-  auto loadB = [&](u32x4 (&br)[NCH], int kt, int cb, int tap) {
+  auto loadB = [&](u32x4 (&br)[NCHB], int kt, int cb, int tap) {
     int dy, dx;
     tap_off(tap, dy, dx);
     const int cg0 = cb * 4;                                // first channel group (of 8) of this K-tile
@@ -188,8 +196,8 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a
     const unsigned keep = pkeep & (unsigned)(-(int)(kt < nk)) & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
     const unsigned vo = (cbase + (unsigned)(iy * a.win + ix)) * 16u;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int r = half * NCH + i;                        // chunk row: k-group r / P, plane r % P
+    for (int i = 0; i < NCHB; ++i) {
+      const int r = qB * NCHB + i;                         // chunk row: k-group r / P, plane r % P
       const unsigned co = (unsigned)__builtin_amdgcn_readfirstlane(((cg0 + r / P) * P + r % P) * HWi * 16);
       const unsigned voff = ((vo + co) & keep) | (OOB & ~keep);   // whole address in the bounds-checked offset
       br[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, 0, 0);
@@ -214,20 +222,20 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a
       ar[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, soff, 0);
     }
   };
-  auto load_tile = [&](u32x4 (&ar)[NCH], u32x4 (&br)[NCH], u32x4& bxr, int kt) {
+  auto load_tile = [&](u32x4 (&ar)[NCH], u32x4 (&br)[NCHB], u32x4& bxr, int kt) {
     int cb, tap;
     next_tile(cb, tap);
     loadA(ar, kt, cb, tap);
     loadB(br, kt, cb, tap);
     if constexpr (WIDE) loadX(bxr, kt, cb, tap);
   };
-  auto storeAB = [&](const u32x4 (&ar)[NCH], const u32x4 (&br)[NCH], const u32x4& bx, int stage) {
+  auto storeAB = [&](const u32x4 (&ar)[NCH], const u32x4 (&br)[NCHB], const u32x4& bx, int stage) {
     u32x4* As = lds + stage * STG;
     u32x4* Bs = As + A_CHUNKS;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) As[(half * NCH + i) * BM + col] = ar[i];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) Bs[(half * NCH + i) * BNT + col] = br[i];
+    for (int i = 0; i < NCHB; ++i) Bs[(qB * NCHB + i) * BNT + colB] = br[i];
     if constexpr (WIDE)
       if (tid < 64 * P) Bs[erow * BNT + ecol] = bx;        // wave-uniform: waves 0, 1 (and 2 for three planes)
   };
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a
   // (Measured and dropped: touching the residual tile's lines at the start of the K loop, as conv_igemm_bf16x3 does. On the short-K
   // residual layers — 256 -> 1024 at 33x33 — it moved 6,000 cycles from the epilogue into the prologue and nothing else: those
   // launches stream their residual and output at the HBM rate either way. profiles/r02d_planes_prefetch.txt)
-  u32x4 ar[2][NCH], br[2][NCH], bx[2];
+  u32x4 ar[2][NCH], br[2][NCHB], bx[2];
   bx[0] = bx[1] = u32x4{0, 0, 0, 0};
   load_tile(ar[0], br[0], bx[0], 0);
   load_tile(ar[1], br[1], bx[1], 1);
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a
   stamp(1);
 
   // one K-tile: multiply tile t out of `stage` while tile t+1 (register set a1 / b1) goes into the other stage and tile t+3 is requested
-  auto step = [&](u32x4 (&a1)[NCH], u32x4 (&b1)[NCH], u32x4& x1, int t, int stage) {
+  auto step = [&](u32x4 (&a1)[NCH], u32x4 (&b1)[NCHB], u32x4& x1, int t, int stage) {
     wait_vmcnt<LPT>();                                     // tile t+1 has landed (requested a whole K-tile ago); tile t+2's loads stay in flight
     mfma_half(stage, 0);
 #if !(CL4_S_DBG & 2)
@@ -355,16 +363,18 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a
 
   // ---- residual operands requested (everything this thread will add, one burst), then the accumulators are parked: stage[row][col] fp32 ----
   wait_vmcnt<0>();
-  SEpilogue<2, 8, BNT> ep2;
-  SEpilogue<1, 8, BNT> ep1;
+  constexpr int NGE = NARROW ? 4 : 8;                      // channel groups per thread: g0, g0 + gstep, ...
+  const int g0 = NARROW ? wave : half, gstep = NARROW ? 4 : 2;
+  SEpilogue<2, NGE, BNT> ep2;
+  SEpilogue<1, NGE, BNT> ep1;
   SEpilogue<2, 1, BNT> ex2;                                // the extra (column, group) item of a wide tile
   SEpilogue<1, 1, BNT> ex1;
   const int res_kind = SPLIT ? 0 : (a.post_s ? 2 : (a.post ? 1 : 0));     // wave-uniform (kernel argument)
   if (res_kind == 2) {
-    ep2.issue(a, m0, half, 2, pvalid, pn, phw, HWo);
+    ep2.issue(a, m0, g0, gstep, pvalid, pn, phw, HWo);
     if constexpr (WIDE) ex2.issue(a, m0, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
   } else if (res_kind == 1) {
-    ep1.issue(a, m0, half, 2, pvalid, pn, phw, HWo);
+    ep1.issue(a, m0, g0, gstep, pvalid, pn, phw, HWo);
     if constexpr (WIDE) ex1.issue(a, m0, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
   }
   float* stage = reinterpret_cast<float*>(&lds[0]);
@@ -414,14 +424,14 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : 2) void conv_s_bf16x3(ConvArgs a
     const float* aff = nullptr;
 #endif
     if (res_kind == 2) {
-      ep2.finish(a, stage, aff, m0, col, half, 2, pvalid, pn, phw, HWo);
+      ep2.finish(a, stage, aff, m0, colB, g0, gstep, pvalid, pn, phw, HWo);
       if constexpr (WIDE) ex2.finish(a, stage, aff, m0, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
     } else if (res_kind == 1) {
-      ep1.finish(a, stage, aff, m0, col, half, 2, pvalid, pn, phw, HWo);
+      ep1.finish(a, stage, aff, m0, colB, g0, gstep, pvalid, pn, phw, HWo);
       if constexpr (WIDE) ex1.finish(a, stage, aff, m0, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
     } else {
-      SEpilogue<0, 8, BNT> ep0;
-      ep0.finish(a, stage, aff, m0, col, half, 2, pvalid, pn, phw, HWo);
+      SEpilogue<0, NGE, BNT> ep0;
+      ep0.finish(a, stage, aff, m0, colB, g0, gstep, pvalid, pn, phw, HWo);
       if constexpr (WIDE) { SEpilogue<0, 1, BNT> ex0; ex0.finish(a, stage, aff, m0, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo); }
     }
   }
@@ -534,12 +544,13 @@ int launch_conv_s(const ConvArgs& a, int ks, bool split, unsigned grid, hipStrea
   static const int mf = [] { const char* e = getenv("CL4_CONV_S_MFMA"); return e ? atoi(e) : 16; }();   // 16x16x32: 3-6 % faster on the long-K layers (higher sustained clock), equal elsewhere
   const dim3 g(grid), b(256);
   ++g_s_launches;
-  if (bn != 128 && bn != 144) { set_error("conv_s: tile width %d not built", bn); return CL4_EINVAL; }
+  if (bn != 128 && bn != 144 && bn != 64) { set_error("conv_s: tile width %d not built", bn); return CL4_EINVAL; }
   if (planes != 2 && !(planes == 3 && bn == 144)) { set_error("conv_s: %d planes at tile width %d not built", planes, bn); return CL4_EINVAL; }
 #define CL4_S_GO(KS_, SP_)                                                                                   \
   do {                                                                                                       \
     if (planes == 3) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16, 144, 3>), g, b, 0, st, a);               \
     else if (bn == 144) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16, 144, 2>), g, b, 0, st, a);            \
+    else if (bn == 64) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16, 64, 2>), g, b, 0, st, a);              \
     else if (mf == 16) hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 16, 128, 2>), g, b, 0, st, a);             \
     else hipLaunchKernelGGL((conv_s_bf16x3<KS_, SP_, 32, 128, 2>), g, b, 0, st, a);                           \
   } while (0)

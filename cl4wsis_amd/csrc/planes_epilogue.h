@@ -17,6 +17,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #ifndef CL4_S_NO_AFFINE_LDS
 #define CL4_S_NO_AFFINE_LDS 0   // experiments only: 1 = read scale / shift from global memory inside the epilogue loop (the r02e kernel)
 #endif
+#ifndef CL4_EPI_NT
+#define CL4_EPI_NT 0  // experiments only: 1 = non-temporal loads of a planes residual, 2 = non-temporal stores of the planes output
+#endif
 #ifndef CL4_S_DBG
 #define CL4_S_DBG 0   // experiments only: 1 = no loads in the loop, 2 = no LDS stores, 4 = no MFMA
 #endif
@@ -72,8 +75,13 @@ struct SEpilogue {
         const int co0 = m0 + (g0 + gstep * it) * 8;
         if (pvalid && co0 < a.cout) {
           const u32x4* ps = reinterpret_cast<const u32x4*>(a.post_s) + (((long)pn * (a.cout >> 3) + (co0 >> 3)) * 2) * HWo + phw;
+#if CL4_EPI_NT & 1
+          rh[it] = __builtin_nontemporal_load(ps);
+          rl[it] = __builtin_nontemporal_load(ps + HWo);
+#else
           rh[it] = ps[0];
           rl[it] = ps[HWo];
+#endif
         }
       }
     } else if constexpr (RES == 1) {
@@ -140,8 +148,13 @@ struct SEpilogue {
           u32x4 hi, lo;
           split8(v, hi, lo);
           u32x4* ys = reinterpret_cast<u32x4*>(a.ys) + (((long)pn * oc8tot + ((a.out_coff + co0) >> 3)) * 2) * HWo + phw;
+#if CL4_EPI_NT & 2
+          __builtin_nontemporal_store(hi, ys);
+          __builtin_nontemporal_store(lo, ys + HWo);
+#else
           ys[0] = hi;
           ys[HWo] = lo;
+#endif
         }
       }
     }

@@ -255,7 +255,7 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
 
 CONV_P = os.environ.get("CL4_CONV_P", "1") != "0"      # 0: never pick the persistent pipelined planes kernel (A/B measurements)
 CONV_B = os.environ.get("CL4_CONV_B", "1") != "0"      # r03: the tuner may pick the big-tile LDS-DMA planes kernel (plan impl 4)
-PLANES_TILES = [int(v) for v in os.environ.get("CL4_PLANES_TILES", "128,144").split(",")]   # pixel widths of the planes kernel's tiles the tuner may pick
+PLANES_TILES = [int(v) for v in os.environ.get("CL4_PLANES_TILES", "128,144").split(",")]   # pixel widths of the planes kernel's tiles the tuner may pick (64 is built too: three workgroups per CU, measured no faster — profiles/r03_conv_s_tile64.txt)
 
 
 def _autotune_planes(d, args, reps=6):

@@ -105,7 +105,7 @@ SHAPES = [
 ]
 
 
-TILES = [128, 144]      # pixels per tile (144: r03, one round of the 33 x 33 maps; two column parts of 80 + 64 pixels per wave pair)
+TILES = [64, 128, 144]  # pixels per tile (144: r03, one round of the 33 x 33 maps; two column parts of 80 + 64 pixels per wave pair. 64: r03, three workgroups per CU)
 
 
 @pytest.mark.parametrize("tile", TILES)
@@ -121,7 +121,7 @@ def test_conv_planes_fused_epilogue(gpu, shape, planes_post, tile):
     _run(gpu, *shape, plan=(2, tile, 1), seed=1 + sum(shape), epilogue=True, planes_post=planes_post)
 
 
-@pytest.mark.parametrize("plan", [(2, 128, 2), (2, 128, 5), (2, 128, -8), (2, 144, 2), (2, 144, 3), (2, 144, -8)])
+@pytest.mark.parametrize("plan", [(2, 128, 2), (2, 128, 5), (2, 128, -8), (2, 144, 2), (2, 144, 3), (2, 144, -8), (2, 64, 2), (2, 64, -8)])
 @pytest.mark.parametrize("shape", [(5, 64, 65, 67, 256, 3, 1, 1, 1), (2, 160, 21, 19, 192, 3, 1, 2, 2), (4, 256, 33, 33, 256, 1, 1, 0, 1),
                                    (3, 96, 33, 33, 136, 3, 1, 18, 18),      # taps dropped per tile (rows outside the image): K splits divide the surviving K-tiles
                                    (2, 64, 33, 33, 128, 3, 1, 40, 40)])     # dilation > map: only the centre tap survives
