@@ -342,10 +342,23 @@ def worker(a):
         # per-shape table of the conv launches (experiments / profiles): ms per step, TFLOP/s, share of conv time
         rows = sorted(timer_excl.by_shape().items(), key=lambda kv: -kv[1][2])
         tot = sum(v[2] for _, v in rows)
+        # the launch plan the tuner pinned for the shape: impl (1 register-staged / role-split, 2 conv_u or conv_s, 3 conv_p, 4 / 5 conv_b
+        # with 256 / 128 rows), pixel tile, K splits, @ precision code (1 bf16x3 fp32 input, 2 bf16x6, 3 planes input, 4 three planes)
+        from cl4wsis_amd import ops as _ops
+        plans = {}
+        for (n_, cin_, hin_, _win, cout_, k_, st_, _pad, dil_, prec_, _dev), (best, _ms) in _ops._tuned.items():
+            plans.setdefault((n_, cin_, hin_, cout_, k_, st_, dil_), []).append("%d/%d/%d@%d" % (best + (prec_,)))
+        variants = {}
         with open(os.environ["CL4_BENCH_LAYER_TABLE"], "w") as f:
-            f.write("kind (n,cin,hin,cout,k,stride,dil) launches/step ms/step TFLOP/s share\n")
+            f.write("kind (n,cin,hin,cout,k,stride,dil) launches/step ms/step TFLOP/s share plan(impl/tile/splits@precision)\n")
             for (kind, shp), (n_, fl_, ms_) in rows:
-                f.write(f"{kind:16s} {str(shp):34s} {n_ / 2:6.1f} {ms_ / 2:8.3f} {fl_ / ms_ / 1e9:8.1f} {100 * ms_ / tot:5.1f}%\n")
+                pl = "|".join(sorted(plans.get(shp, []))) or "-"
+                f.write(f"{kind:16s} {str(shp):34s} {n_ / 2:6.1f} {ms_ / 2:8.3f} {fl_ / ms_ / 1e9:8.1f} {100 * ms_ / tot:5.1f}%  {pl}\n")
+                v = variants.setdefault((kind, pl.split("/")[0] + "/" + pl.split("/")[1] if "/" in pl and "|" not in pl else pl), [0.0, 0.0, 0.0])
+                v[0] += n_ / 2; v[1] += fl_ / 2; v[2] += ms_ / 2
+            f.write("\n# per kernel variant (kind, impl/tile): launches/step GFLOP/step ms/step TFLOP/s\n")
+            for (kind, var), (n_, fl_, ms_) in sorted(variants.items(), key=lambda kv: -kv[1][2]):
+                f.write(f"{kind:16s} {var:22s} {n_:7.1f} {fl_ / 1e9:10.1f} {ms_:8.3f} {fl_ / ms_ / 1e9:8.1f}\n")
     if rank == 0:
         summ = timer_excl.summary()
         n, fl, ms = summ["conv_fwd_bf16x3"]

@@ -254,6 +254,7 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
 
 
 CONV_P = os.environ.get("CL4_CONV_P", "1") != "0"      # 0: never pick the persistent pipelined planes kernel (A/B measurements)
+SMALL_TILE_BELOW = int(os.environ.get("CL4_SMALL_TILE_BELOW", "384"))    # planes launches with fewer 128 x 128 tiles than this also try 64-pixel tiles (0: never)
 CONV_B = os.environ.get("CL4_CONV_B", "1") != "0"      # r03: the tuner may pick the big-tile LDS-DMA planes kernel (plan impl 4)
 PLANES_TILES = [int(v) for v in os.environ.get("CL4_PLANES_TILES", "128,144").split(",")]   # pixel widths of the planes kernel's tiles the tuner may pick (64 is built too: three workgroups per CU, measured no faster — profiles/r03_conv_s_tile64.txt)
 
@@ -270,7 +271,10 @@ def _autotune_planes(d, args, reps=6):
     best, best_ms = None, float("inf")
     seen = set()
     npix = d.n * d.hout * d.wout
-    cands = [(2, tile, splits) for tile in ((144,) if d.precision == 4 else PLANES_TILES) for splits in _SPLITS]
+    tiles_ = list(PLANES_TILES)
+    if SMALL_TILE_BELOW and 64 not in tiles_ and -(-d.cout // 128) * -(-npix // 128) < SMALL_TILE_BELOW:
+        tiles_.append(64)       # launches that cannot fill the chip with 128-pixel tiles (small per-GPU batches): twice the workgroups, three per CU
+    cands = [(2, tile, splits) for tile in ((144,) if d.precision == 4 else tiles_) for splits in _SPLITS]
     # the persistent pipelined kernel (csrc/conv_p.hip): short-K 1x1 layers that write planes only (and read a planes residual)
     pre, post_f, out_f32, out_pl = args[4], args[5], args[7], args[8]
     if (CONV_P and d.precision == 3 and d.kh == 1 and d.stride == 1 and d.pad == 0 and d.cout % 128 == 0 and K >= 128 and pre is None and post_f is None

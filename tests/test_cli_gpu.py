@@ -16,6 +16,8 @@ def _run(args, tmp, monkeypatch, autotune="1"):
     monkeypatch.chdir(tmp)
     monkeypatch.setenv("CL4_SYNTH_LEN", "4")
     monkeypatch.setenv("CL4_AUTOTUNE", autotune)          # the CLI flow runs with the warm-up autotuner, like production
+    from cl4wsis_amd import ops
+    monkeypatch.setattr(ops, "_SPLITS", [1, 2, -4])       # ... over a short list of K splits (13 by default): the tuner's time is not the point here
     opts = argparser.modify_command_options(argparser.get_argparser().parse_args(args))
     run.main(opts)
 
