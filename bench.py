@@ -352,7 +352,8 @@ def worker(a):
         with open(os.environ["CL4_BENCH_LAYER_TABLE"], "w") as f:
             f.write("kind (n,cin,hin,cout,k,stride,dil) launches/step ms/step TFLOP/s share plan(impl/tile/splits@precision)\n")
             for (kind, shp), (n_, fl_, ms_) in rows:
-                pl = "|".join(sorted(plans.get(shp, []))) or "-"
+                codes = {"conv_fwd_bf16x3": ("@1", "@3"), "conv_fwd_bf16x6": ("@2", "@4"), "conv_fwd_f32": ("@0",)}.get(kind, ())
+                pl = "|".join(sorted(q for q in plans.get(shp, []) if q.endswith(codes))) or "-"
                 f.write(f"{kind:16s} {str(shp):34s} {n_ / 2:6.1f} {ms_ / 2:8.3f} {fl_ / ms_ / 1e9:8.1f} {100 * ms_ / tot:5.1f}%  {pl}\n")
                 v = variants.setdefault((kind, pl.split("/")[0] + "/" + pl.split("/")[1] if "/" in pl and "|" not in pl else pl), [0.0, 0.0, 0.0])
                 v[0] += n_ / 2; v[1] += fl_ / 2; v[2] += ms_ / 2
