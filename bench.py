@@ -409,12 +409,18 @@ def worker(a):
                                      "bf16x6 = fp32-level for the differentiated convs, bf16x3 weight gradients)"},
             "label_counters": counters_random,
             "roofline": {"bound": "mfma", "kernel": "bf16x3 forward convolution (cl4_conv2d_fwd precision 1 + cl4_conv2d_fwd_planes + cl4_stem_fused: kernels "
-                                                    "conv_igemm_bf16x3 / conv_u_bf16x3 / conv_s_bf16x3 / stem_fused): all its launches of 2 "
+                                                    "conv_igemm_bf16x3 / conv_u_bf16x3 / conv_s_bf16x3 / conv_b_bf16x3 / stem_fused): all its launches of 2 "
                                                     "eager steps run right after the timed region (graph replay and two-stream "
                                                     "overlap off), HIP events on the launch stream around every launch",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes / max(alg_n, 1),
+                         # ... and with the operands the fused epilogues add (residual of every bottleneck's last conv: as large as its
+                         # output) — the bytes a launch cannot avoid moving; traffic / this = re-read factor
+                         "algorithmic_bytes_per_launch_incl_epilogue_operands":
+                             (alg_bytes + timer_excl.epilogue_bytes.get("conv_fwd_bf16x3", 0)) / max(alg_n, 1),
+                         "traffic_over_algorithmic": (traffic / ((alg_bytes + timer_excl.epilogue_bytes.get("conv_fwd_bf16x3", 0)) / max(alg_n, 1))
+                                                      if traffic else None),
                          "peak_note": "2500 TFLOP/s dense bf16 MFMA / 3 MFMA products per fp32-equivalent MAC",
                          "mfma_busy": mfma_busy, "hbm_gbs": hbm_gbs,
                          "mfma_issued_tflops": 3 * ach, "launches_per_step": n / 2,

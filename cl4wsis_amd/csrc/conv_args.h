@@ -58,9 +58,9 @@ int launch_conv_p(const ConvArgs& a, unsigned ntile, hipStream_t st);
 
 
 // conv_b.hip: the LDS-DMA planes kernel (operands straight into LDS, three LDS stages, one workgroup per CU) for launches whose K loop
-// dominates. rows = output channels per tile: 256 (512 threads) or 128 (256 threads: launches with too few 256-row tiles to fill the
-// chip); 144 pixels per tile. Unsplit; `grid` = cdiv(cout, rows) * cdiv(npix, 144) with a.gx = cdiv(cout, rows).
+// dominates. rows = output channels per tile: 256 (8 waves) or 128 (4 waves, or 8 waves of 32 rows each: launches with too few 256-row
+// tiles to fill the chip); 144 pixels per tile. Unsplit; `grid` = cdiv(cout, rows) * cdiv(npix, 144) with a.gx = cdiv(cout, rows).
 bool conv_b_eligible(const ConvArgs& a, int ks, int rows);
-int launch_conv_b(const ConvArgs& a, int ks, int rows, unsigned grid, hipStream_t st);
+int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, unsigned grid, hipStream_t st);
 
 }  // namespace cl4

@@ -42,24 +42,31 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, __amdgpu
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 
-// WM = 64-row blocks per tile: 4 = 256 output channels (8 waves, 50 KB per stage), 2 = 128 output channels (4 waves, 34 KB per stage:
-// the launches with fewer than 256 tiles of 256 rows — 16 images of a 33 x 33 map at 256 output channels — where conv_s has one
-// workgroup per CU and nothing to hide its operand traffic behind).
-template <int KS, int WM>
-__global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvArgs a) {
+// BMB = output channels per tile, NW = waves: <256, 8> = 256 channels, 64 rows per wave, 50 KB per stage; <128, 4> = 128 channels,
+// 64 rows per wave, 34 KB per stage; <128, 8> = 128 channels, 32 rows per wave (two waves per SIMD again: one wave's LDS-DMA issue and
+// fragment reads run under the other's MFMAs) — the launches with fewer than 256 tiles of 256 rows (16 images of a 33 x 33 map at 256
+// output channels), where conv_s has one workgroup per CU and nothing to hide its operand traffic behind.
+template <int KS, int BMB, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvArgs a) {
   constexpr int KHW = KS * KS;
-  constexpr int BMB = 64 * WM;
+  constexpr int WR = 2 * BMB / NW;                         // rows per wave: 64 or 32
+  constexpr int NRB = WR / 32;                             // MFMA row blocks per half of a K-tile's work: 2 or 1
+  constexpr int RB64 = BMB / 64;                           // 64-row groups of the tile (= weight pieces per chunk row)
   constexpr int A_CH = KG * PB * BMB;                      // [k-group * 2 + plane][BMB rows]
-  constexpr int STGB = A_CH + B_CH + E_CH;                 // 3200 chunks = 50 KB (WM = 4), 2176 chunks = 34 KB (WM = 2)
-  constexpr int NBP = 8 / WM;                              // pixel pieces per wave and K-tile (16 over 2 * WM waves)
-  constexpr int NPW = 4 + NBP;                             // pieces per wave and K-tile (one more for waves 0 and 1)
+  constexpr int STGB = A_CH + B_CH + E_CH;                 // 3200 chunks = 50 KB (256 rows), 2176 chunks = 34 KB (128 rows)
+  constexpr int NAP = 8 * RB64 / NW;                       // weight pieces per wave and K-tile: 4, or 2 (<128, 8>)
+  constexpr int NBP = 16 / NW;                             // pixel pieces per wave and K-tile
+  constexpr int NPW = NAP + NBP;                           // pieces per wave and K-tile (one more for waves 0 and 1)
+  constexpr int NHALF = BMB / 128;                         // 128-row halves of the tile, each finished by TH threads
+  constexpr int TH = 64 * NW / NHALF;                      // 256, or 512 (<128, 8>)
+  static_assert((BMB == 256 && NW == 8) || (BMB == 128 && (NW == 4 || NW == 8)), "tile");
   __shared__ u32x4 lds[NSTG * STGB];                       // three K-tile stages; reused as the parked [BMB][144] fp32 tile
-  __shared__ float affine[WM / 2][2 * BM];                 // scale / shift of the tile's 128-channel halves
+  __shared__ float affine[NHALF][2 * BM];                  // scale / shift of the tile's 128-channel halves
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;                 // 64-row block, column part
+  const int wm = wave >> 1, wn = wave & 1;                 // WR-row block, column part
   const int nbj = wn == 0 ? 5 : 4;                         // wave-uniform
 
   const unsigned total = gridDim.x, id = blockIdx.x;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvA
   const int nk = (a.cin >> 5) * nv;
 
   // folded-ABN scale / shift of the tile's 256 channels -> LDS, before any LDS-DMA is in flight (hipcc counts ITS loads only)
-  {
+  if (tid < 256 * NHALF) {
     const int h = tid >> 8, t = tid & 255;
     const int ch = min(m0 + h * BM + (t & 127), a.cout - 1);
     const float* src = t < 128 ? a.scale : a.shift;
@@ -130,13 +137,13 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvA
   const unsigned w_bytes = (unsigned)((long)(a.K / 8) * PB * a.cout * 16);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, w_bytes, 0x00020000);
 
-  // ---- LDS-DMA roles (wave-uniform): weight pieces = rows (wave % WM) * 64 + lane, chunk rows (wave / WM) * 4 + i, i < 4;
+  // ---- LDS-DMA roles (wave-uniform): weight pieces = rows (wave % RB64) * 64 + lane, chunk rows (wave / RB64) * NAP + i, i < NAP;
   //      pixel pieces = column (wave & 1) * 64 + lane, chunk rows (wave >> 1) * NBP + q, q < NBP; extra piece (waves 0, 1) = chunk row
   //      wave * 4 + (lane >> 4), column 128 + (lane & 15) ----
   const unsigned lds0 = (unsigned)(size_t)(&lds[0]);
-  const int arow = m0 + (wave % WM) * 64 + lane;
+  const int arow = m0 + (wave % RB64) * 64 + lane;
   const unsigned a_voff = arow < a.cout ? (unsigned)arow * 16u : OOB;
-  const unsigned a_lds = (unsigned)(((wave / WM) * 4 * BMB + (wave % WM) * 64) * 16);
+  const unsigned a_lds = (unsigned)(((wave / RB64) * NAP * BMB + (wave % RB64) * 64) * 16);
   const unsigned b_lds = (unsigned)((A_CH + (wave >> 1) * NBP * 128 + (wave & 1) * 64) * 16);
   const unsigned e_lds = (unsigned)((A_CH + B_CH + wave * 64) * 16);
   const int erow_dma = wave * 4 + (lane >> 4);             // waves 0, 1 only
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvA
     const unsigned live = (unsigned)(-(int)(kt < nk));
     rq.a_stage = stage_bytes;
     rq.avo = (a_voff & live) | (OOB & ~live);
-    rq.T8 = (unsigned)((cb * KHW + tap) * 8 + (wave / WM) * 4);
+    rq.T8 = (unsigned)((cb * KHW + tap) * 8 + (wave / RB64) * NAP);
   };
   auto prep_b = [&](int kt, unsigned stage_bytes) {
     int cb, tap;
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvA
   auto request_a = [&](int kt, unsigned stage_bytes) {
     prep_a(kt, stage_bytes);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) piece_a(i);
+    for (int i = 0; i < NAP; ++i) piece_a(i);
   };
   auto request_b = [&](int kt, unsigned stage_bytes) {
     prep_b(kt, stage_bytes);
@@ -208,22 +215,22 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvA
   };
 
   typedef float accv_t __attribute__((ext_vector_type(4)));
-  accv_t acc[4][5];
+  accv_t acc[2 * NRB][5];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2 * NRB; ++i)
 #pragma unroll
     for (int j = 0; j < 5; ++j) acc[i][j] = accv_t{0.f, 0.f, 0.f, 0.f};
 
   const int l15 = lane & 15, kg = lane >> 4;
-  // fragment addresses inside a stage (chunks): A row block i of this wave, plane pl: (kg * 2 + pl) * 256 + wm * 64 + i * 16 + l15
-  const int a_frag = kg * 2 * BMB + wm * 64 + l15;
+  // fragment addresses inside a stage (chunks): A row block i of this wave, plane pl: (kg * 2 + pl) * BMB + wm * WR + i * 16 + l15
+  const int a_frag = kg * 2 * BMB + wm * WR + l15;
   const int b_frag = A_CH + kg * 2 * 128 + wn * 64 + l15;  // column block j < 4: + j * 16; plane: + 128
   const int e_frag = A_CH + B_CH + kg * 2 * 16 + l15;      // column block 4 (wave part 0): plane: + 16
-  auto read_a = [&](bf16x8 (&af)[2][2], const u32x4* st, int i0) {
+  auto read_a = [&](bf16x8 (&af)[2][NRB], const u32x4* st, int i0) {
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, st[a_frag + pl * BMB + (i0 + i) * 16]);
+      for (int i = 0; i < NRB; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, st[a_frag + pl * BMB + (i0 + i) * 16]);
   };
   auto read_b = [&](bf16x8 (&bf)[2], const u32x4* st, int j) {
     if (j < 4) {
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvA
       bf[1] = __builtin_bit_cast(bf16x8, st[e_frag + 16]);
     }
   };
-  auto mma = [&](accv_t& c, const bf16x8 (&af)[2][2], int i, const bf16x8 (&bf)[2]) {
+  auto mma = [&](accv_t& c, const bf16x8 (&af)[2][NRB], int i, const bf16x8 (&bf)[2]) {
 #if CL4_B_DBG & 4
     c[0] += (float)af[1][i][0] * (float)bf[0][0] + (float)af[0][i][1] * (float)bf[1][1];
 #else
@@ -252,15 +259,15 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvA
   request_b(1, STGB * 16);
   request_a(2, 2 * STGB * 16);
 #if CL4_B_SPREAD
-  if (wave < 2) wait_vmcnt<NPW + 1 + 4>();
-  else wait_vmcnt<NPW + 4>();
+  if (wave < 2) wait_vmcnt<NPW + 1 + NAP>();
+  else wait_vmcnt<NPW + NAP>();
 #else
   request_b(2, 2 * STGB * 16);
   if (wave < 2) wait_vmcnt<2 * NPW + 2>();
   else wait_vmcnt<2 * NPW>();
 #endif
   __builtin_amdgcn_s_barrier();
-  bf16x8 a01[2][2], a23[2][2], bfr[5][2];
+  bf16x8 a01[2][NRB], a23[2][NRB], bfr[5][2];      // fragments of the first / second half of the wave's row blocks
   read_a(a01, lds, 0);
 #pragma unroll
   for (int j = 0; j < 5; ++j)
@@ -272,15 +279,15 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvA
     const u32x4* nxt = lds + s_nxt;
     // first half: row blocks 0, 1 of tile t (fragments already in registers) while the fragments of row blocks 2, 3 are read and the
     // pixel part of tile t+2 is requested (its stage was left by every wave before the previous barrier; its weight part is on its way)
-    read_a(a23, cur, 2);
+    read_a(a23, cur, NRB);
 #if CL4_B_SPREAD && !(CL4_B_DBG & 1)
     prep_b(t + 2, s_old * 16);
 #endif
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       if (j < nbj) {
-        mma(acc[0][j], a01, 0, bfr[j]);
-        mma(acc[1][j], a01, 1, bfr[j]);
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) mma(acc[i][j], a01, i, bfr[j]);
       }
 #if CL4_B_SPREAD && !(CL4_B_DBG & 1)
       if (j == 0) {
@@ -308,14 +315,15 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvA
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       if (j < nbj) {
-        mma(acc[2][j], a23, 0, bfr[j]);
-        mma(acc[3][j], a23, 1, bfr[j]);
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) mma(acc[NRB + i][j], a23, i, bfr[j]);
         read_b(bfr[j], nxt, j);
       }
 #if !(CL4_B_DBG & 1)
 #if CL4_B_SPREAD
-      if (j < 4) piece_a(j);
+      if (j < NAP) piece_a(j);
 #else
+      static_assert(NAP == 4, "CL4_B_SPREAD = 0 is kept for the 64-row-per-wave tiles only");
       if (j == 0) { piece_a(0); piece_a(1); }
       else if (j == 1) { piece_a(2); piece_a(3); }
       else if (j == 2) {
@@ -336,33 +344,36 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero-filled requests past the last K-tile have landed too
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  const int hsel = tid >> 8, t2 = tid & 255;
-  const int half = t2 >> 7;
-  const int erow = t2 >> 4;
+  const int hsel = tid / TH, t2 = tid % TH;                 // 128-row half, thread within it
+  constexpr int GST = TH / 128;                            // channel groups: g0, g0 + GST, ... (16 per half)
+  constexpr int NGE = 16 / GST;
+  const int g0 = t2 >> 7;
+  const int erow = (t2 >> 4) & 15;
+  const bool xvalid = ex.valid && t2 < 256;                // the 16 x 16 (column, group) extra items of a half: its first 256 threads
   const int m0h = m0 + hsel * BM;
-  SEpilogue<2, 8, BNB> ep2;
-  SEpilogue<1, 8, BNB> ep1;
+  SEpilogue<2, NGE, BNB> ep2;
+  SEpilogue<1, NGE, BNB> ep1;
   SEpilogue<2, 1, BNB> ex2;
   SEpilogue<1, 1, BNB> ex1;
   const int res_kind = a.post_s ? 2 : (a.post ? 1 : 0);
   if (res_kind == 2) {
-    ep2.issue(a, m0h, half, 2, px.valid, px.pn, px.phw, HWo);
-    ex2.issue(a, m0h, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+    ep2.issue(a, m0h, g0, GST, px.valid, px.pn, px.phw, HWo);
+    ex2.issue(a, m0h, erow, 0, xvalid, ex.pn, ex.phw, HWo);
   } else if (res_kind == 1) {
-    ep1.issue(a, m0h, half, 2, px.valid, px.pn, px.phw, HWo);
-    ex1.issue(a, m0h, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+    ep1.issue(a, m0h, g0, GST, px.valid, px.pn, px.phw, HWo);
+    ex1.issue(a, m0h, erow, 0, xvalid, ex.pn, ex.phw, HWo);
   }
   float* park = reinterpret_cast<float*>(&lds[0]);
   {
     const int l4 = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2 * NRB; ++i)
 #pragma unroll
       for (int j = 0; j < 5; ++j)
         if (j < nbj) {
           const int cbase_ = j < 4 ? wn * 64 + j * 16 : 128;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) park[(wm * 64 + i * 16 + l4 * 4 + r) * BNB + cbase_ + l15] = acc[i][j][r];
+          for (int r = 0; r < 4; ++r) park[(wm * WR + i * 16 + l4 * 4 + r) * BNB + cbase_ + l15] = acc[i][j][r];
         }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -370,16 +381,16 @@ __global__ __launch_bounds__(128 * WM, WM == 4 ? 2 : 1) void conv_b_bf16x3(ConvA
   const float* stage = park + hsel * BM * BNB;
   const float* aff = affine[hsel];
   if (res_kind == 2) {
-    ep2.finish(a, stage, aff, m0h, col, half, 2, px.valid, px.pn, px.phw, HWo);
-    ex2.finish(a, stage, aff, m0h, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+    ep2.finish(a, stage, aff, m0h, col, g0, GST, px.valid, px.pn, px.phw, HWo);
+    ex2.finish(a, stage, aff, m0h, ecol, erow, 0, xvalid, ex.pn, ex.phw, HWo);
   } else if (res_kind == 1) {
-    ep1.finish(a, stage, aff, m0h, col, half, 2, px.valid, px.pn, px.phw, HWo);
-    ex1.finish(a, stage, aff, m0h, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+    ep1.finish(a, stage, aff, m0h, col, g0, GST, px.valid, px.pn, px.phw, HWo);
+    ex1.finish(a, stage, aff, m0h, ecol, erow, 0, xvalid, ex.pn, ex.phw, HWo);
   } else {
-    SEpilogue<0, 8, BNB> ep0;
+    SEpilogue<0, NGE, BNB> ep0;
     SEpilogue<0, 1, BNB> ex0;
-    ep0.finish(a, stage, aff, m0h, col, half, 2, px.valid, px.pn, px.phw, HWo);
-    ex0.finish(a, stage, aff, m0h, ecol, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
+    ep0.finish(a, stage, aff, m0h, col, g0, GST, px.valid, px.pn, px.phw, HWo);
+    ex0.finish(a, stage, aff, m0h, ecol, erow, 0, xvalid, ex.pn, ex.phw, HWo);
   }
 }
 
@@ -395,14 +406,17 @@ bool conv_b_eligible(const ConvArgs& a, int ks, int rows) {
   return (ks == 1 || ks == 3) && (rows == 128 || rows == 256) && a.cin % 32 == 0 && a.cout >= rows && a.cout % 8 == 0 && a.xs != nullptr;
 }
 
-int launch_conv_b(const ConvArgs& a, int ks, int rows, unsigned grid, hipStream_t st) {
-  const dim3 g(grid), b(2 * rows);
+// waves: 8 (rows 256 or 128) or 4 (rows 128)
+int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, unsigned grid, hipStream_t st) {
+  const dim3 g(grid), b(64 * waves);
   ++g_b_launches;
-  if (ks == 1 && rows == 256) hipLaunchKernelGGL((conv_b_bf16x3<1, 4>), g, b, 0, st, a);
-  else if (ks == 3 && rows == 256) hipLaunchKernelGGL((conv_b_bf16x3<3, 4>), g, b, 0, st, a);
-  else if (ks == 1 && rows == 128) hipLaunchKernelGGL((conv_b_bf16x3<1, 2>), g, b, 0, st, a);
-  else if (ks == 3 && rows == 128) hipLaunchKernelGGL((conv_b_bf16x3<3, 2>), g, b, 0, st, a);
-  else { set_error("conv_b: kernel size %d / %d rows not built", ks, rows); return CL4_EINVAL; }
+  if (ks == 1 && rows == 256 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<1, 256, 8>), g, b, 0, st, a);
+  else if (ks == 3 && rows == 256 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<3, 256, 8>), g, b, 0, st, a);
+  else if (ks == 1 && rows == 128 && waves == 4) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 4>), g, b, 0, st, a);
+  else if (ks == 3 && rows == 128 && waves == 4) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 4>), g, b, 0, st, a);
+  else if (ks == 1 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8>), g, b, 0, st, a);
+  else if (ks == 3 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 8>), g, b, 0, st, a);
+  else { set_error("conv_b: kernel size %d / %d rows / %d waves not built", ks, rows, waves); return CL4_EINVAL; }
   return launch_status();
 }
 

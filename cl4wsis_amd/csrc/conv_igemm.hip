@@ -1319,7 +1319,7 @@ FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision
     p.impl = 3; p.tile = 128; p.splits = 1; p.kchunk = cl4::cdiv(K, BK2) * BK2;
     return p;
   }
-  if ((impl == 4 || impl == 5) && precision == 3) {                          // LDS-DMA planes kernel (conv_b.hip): unsplit 256 x 144 (4) or 128 x 144 (5) tiles
+  if (impl >= 4 && impl <= 6 && precision == 3) {                            // LDS-DMA planes kernel (conv_b.hip): unsplit 256 x 144 (4) or 128 x 144 tiles (5: four waves, 6: eight)
     p.impl = impl; p.tile = 128; p.bn = 144; p.splits = 1; p.kchunk = cl4::cdiv(K, BK2) * BK2;
     return p;
   }
@@ -1478,7 +1478,7 @@ int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace
     return CL4_EINVAL;
   } else {
     const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 8 + pcode});
-    if (pl.impl < 2 || pl.impl > 5 || pl.tile != 128) { cl4::set_error("conv2d_fwd_planes: no 128x128 plan for this shape"); return CL4_EINVAL; }
+    if (pl.impl < 2 || pl.impl > 6 || pl.tile != 128) { cl4::set_error("conv2d_fwd_planes: no 128x128 plan for this shape"); return CL4_EINVAL; }
     if (pl.impl == 3) {
       if (pcode == 3 && cl4::conv_p_eligible(a, KS)) {
         a.gx = cl4::cdiv(a.cout, 128);
@@ -1488,12 +1488,12 @@ int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace
       }
       // a plan pinned for this shape by a call with other operands (fp32 output, fp32 residual, ...): the plain kernel, unsplit
     }
-    if ((pl.impl == 4 || pl.impl == 5) && pcode == 3 && cl4::conv_b_eligible(a, KS, pl.impl == 4 ? 256 : 128)) {
+    if (pl.impl >= 4 && pl.impl <= 6 && pcode == 3 && cl4::conv_b_eligible(a, KS, pl.impl == 4 ? 256 : 128)) {
       const int rows = pl.impl == 4 ? 256 : 128;
       a.gx = cl4::cdiv(a.cout, rows);
       a.ntile_l = a.gx * cl4::cdiv(a.npix, 144);
       a.tile_base = 0; a.ws = nullptr; a.ws_p0 = 0; a.ws_npix = a.npix; a.kchunk = pl.kchunk;
-      return cl4::launch_conv_b(a, KS, rows, (unsigned)a.ntile_l, st);
+      return cl4::launch_conv_b(a, KS, rows, pl.impl == 5 ? 4 : 8, (unsigned)a.ntile_l, st);
     }
     const TailGeom tg = tail_geometry(pl, a.cout, a.npix, pcode);
     const bool hybrid = tg.main > 0 && pl.tail > 1;
@@ -2139,7 +2139,7 @@ extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
   va.pad = d->pad; va.in_ctot = d->in_ctot; va.dil = d->dil;
   if (pl.impl == 2 && (vec_gather_plan(va, d->kh, d->precision, pl.tile) || u_plan(va, d->kh, d->precision, pl.tile)))
     npix = d->n * ((d->hout * d->wout + 3) & ~3);
-  if (planes_code(d->precision) && (pl.impl != 2 || pl.tile != 128)) return 0;      // also impl 3 / 4 / 5 (persistent / LDS-DMA kernels): no slabs
+  if (planes_code(d->precision) && (pl.impl != 2 || pl.tile != 128)) return 0;      // also impl 3 ... 6 (persistent / LDS-DMA kernels): no slabs
   if (d->precision != 0 && pl.impl == 2 && pl.tail > 0) {
     const TailGeom tg = tail_geometry(pl, d->cout, npix, d->precision);
     return (tg.main > 0 && pl.tail > 1) ? (size_t)pl.tail * d->cout * (npix - tg.p0) * sizeof(float) : 0;   // small-tile tail / degenerate: no slabs
@@ -2156,7 +2156,7 @@ extern "C" int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int til
   const PlanKey key{d->cout, d->n * d->hout * d->wout, K, d->kh, d->stride, d->dil, d->hin * 8 + d->precision};
   std::lock_guard<std::mutex> g(plan_mutex());
   if (impl == 0) { plan_table().erase(key); return CL4_OK; }
-  CL4_REQUIRE(impl == 1 || impl == 2 || (impl >= 3 && impl <= 5 && d->precision == 3), "set_plan: impl must be 0, 1 or 2 (3, 4, 5: planes-input launches only)");
+  CL4_REQUIRE(impl == 1 || impl == 2 || (impl >= 3 && impl <= 6 && d->precision == 3), "set_plan: impl must be 0, 1 or 2 (3 ... 6: planes-input launches only)");
   CL4_REQUIRE(tile == 64 || tile == 128 || (tile == 144 && planes_code(d->precision)), "set_plan: tile must be 64 or 128 (144: planes-input launches only)");
   plan_table()[key] = make_plan(impl, tile, splits, d->cout, K, d->precision);
   return CL4_OK;

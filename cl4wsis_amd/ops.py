@@ -22,12 +22,14 @@ class KernelTimer:
     def __init__(self):
         self.records = []   # (kind, flops, start_event, end_event)
         self.shapes = []    # per record: (n, cin, hin, cout, k, stride, dil) of the launch
+        self.epilogue_bytes = {}   # kind -> bytes of the epilogue operands (residual / pre-activation addend) the launches read
 
-    def span(self, kind, flops, shape=None):
+    def span(self, kind, flops, shape=None, epilogue_bytes=0):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         self.records.append((kind, flops, e0, e1))
         self.shapes.append(shape)
+        self.epilogue_bytes[kind] = self.epilogue_bytes.get(kind, 0) + epilogue_bytes
         return e0, e1
 
     def by_shape(self):
@@ -286,6 +288,7 @@ def _autotune_planes(d, args, reps=6):
             cands.append((4, 144, 1))
         if d.cout >= 128:
             cands.append((5, 144, 1))       # 128-row tiles of the same kernel: launches with too few 256-row tiles to fill the chip
+            cands.append((6, 144, 1))       # ... as eight waves of 32 rows (two waves per SIMD)
     for impl, tile, splits in cands:
         tiles = -(-d.cout // 128) * -(-npix // tile)
         if True:
@@ -365,7 +368,7 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     wp = wp.data
     if TIMER is not None:
         e0, e1 = TIMER.span(("conv_fwd_f32", "conv_fwd_bf16x3", "conv_fwd_bf16x6")[d.precision], 2.0 * n * hout * wout * cout * K,
-                            (n, cin, hin, cout, k, stride, dil))
+                            (n, cin, hin, cout, k, stride, dil), 4 * n * cout * hout * wout * ((pre is not None) + (post is not None)))
         e0.record()
     if AUTOTUNE:
         _autotune_conv(d, x, wp, scale, shift, pre, post, out)
@@ -463,7 +466,8 @@ def conv2d_planes(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre
             raise RuntimeError(f"conv2d_planes: {nm} shape {tuple(t.shape)} != {(n, cout, hout, wout)}")
     d = ConvDescFor(n, cin, hin, win, in_ctot, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, act1, slope1, act2, slope2, 4 if x6 else 3)
     if TIMER is not None:
-        e0, e1 = TIMER.span("conv_fwd_bf16x6" if x6 else "conv_fwd_bf16x3", 2.0 * n * hout * wout * cout * K, (n, cin, hin, cout, k, stride, dil))
+        e0, e1 = TIMER.span("conv_fwd_bf16x6" if x6 else "conv_fwd_bf16x3", 2.0 * n * hout * wout * cout * K, (n, cin, hin, cout, k, stride, dil),
+                            4 * n * cout * hout * wout * ((pre is not None) + (post is not None)))
         e0.record()
     args = (ptr(xs.data), ptr(wp.data), ptr(scale), ptr(shift), ptr(pre), ptr(post_f), ptr(post_s.data) if post_s is not None else None,
             ptr(out), ptr(out_planes.data) if out_planes is not None else None)

@@ -167,13 +167,13 @@ B_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("impl", [4, 5])     # 256- and 128-row tiles
+@pytest.mark.parametrize("impl", [4, 5, 6])  # 256-row tiles; 128-row tiles with four / eight waves
 @pytest.mark.parametrize("shape", B_SHAPES)
 def test_conv_big_tile_lds_dma_kernel_plain(gpu, shape, impl):
     _run(gpu, *shape, plan=(impl, 144, 1), seed=sum(shape), counter="cl4_conv_debug_b_launches")
 
 
-@pytest.mark.parametrize("impl", [4, 5])
+@pytest.mark.parametrize("impl", [4, 5, 6])
 @pytest.mark.parametrize("planes_post", [False, True])
 @pytest.mark.parametrize("shape", B_SHAPES)
 def test_conv_big_tile_lds_dma_kernel_fused_epilogue(gpu, shape, planes_post, impl):
@@ -188,6 +188,8 @@ def test_conv_big_tile_kernel_channel_slices(gpu):
     _run(gpu, 2, 32, 15, 15, 288, 1, 1, 0, 1, plan=(4, 144, 1), seed=6, in_ctot=40, in_coff=8, out_ctot=304, out_coff=8, epilogue=True,
          counter="cl4_conv_debug_b_launches")
     _run(gpu, 2, 32, 15, 15, 128, 1, 1, 0, 1, plan=(4, 144, 1), seed=7)      # cout < 256: the plan falls back to conv_s (144-pixel tiles)
+    _run(gpu, 2, 64, 15, 15, 136, 3, 1, 2, 2, plan=(6, 144, 1), seed=9, in_ctot=104, in_coff=24, out_ctot=208, out_coff=24, epilogue=True, planes_post=True,
+         counter="cl4_conv_debug_b_launches")
     _run(gpu, 2, 64, 15, 15, 136, 3, 1, 2, 2, plan=(5, 144, 1), seed=8, in_ctot=104, in_coff=24, out_ctot=208, out_coff=24, epilogue=True, planes_post=True,
          counter="cl4_conv_debug_b_launches")
 

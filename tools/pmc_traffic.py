@@ -19,7 +19,9 @@ def rows(d, counter):
 
 
 def is_x3(name):
-    if "conv_u_bf16x3" in name or "conv_s_bf16x3" in name or "stem_fused" in name:
+    if "conv_s_bf16x3" in name:                          # conv_s<KS, SPLIT, MF, BNT, PL>: PL = 3 is a bf16x6 launch
+        return re.search(r"conv_s_bf16x3<([^>]*)>", name).group(1).split(",")[4].strip() == "2"
+    if "conv_u_bf16x3" in name or "conv_b_bf16x3" in name or "conv_p_bf16x3" in name or "stem_fused" in name:
         return True
     m = re.search(r"conv_igemm_bf16x3<([^>]*)>", name)
     return bool(m) and m.group(1).split(",")[5].strip() == "2"
@@ -62,8 +64,9 @@ for k in sorted(fetch, key=lambda k: -fetch[k][1]):
     w = write.get(k, [0, 0.0])[1]
     out["kernels"][k] = {"launches": l, "fetch_counter_bytes": f, "write_counter_bytes": w}
     if is_x3(k):
-        args = re.search(r"<([^>]*)>", k).group(1).split(",")
-        vec = "conv_u_bf16x3" in k or "conv_s_bf16x3" in k or (len(args) > 9 and args[9].strip() == "true")   # 16-byte-per-lane activation loads
+        m = re.search(r"<([^>]*)>", k)
+        args = m.group(1).split(",") if m else []
+        vec = "conv_u_bf16x3" in k or "conv_s_bf16x3" in k or "conv_b_bf16x3" in k or "conv_p_bf16x3" in k or "stem_fused" in k or (len(args) > 9 and args[9].strip() == "true")   # 16-byte-per-lane activation loads
         fac = f_fac if vec else f_fac0
         out["kernels"][k]["fetch_factor_used"] = fac
         tot_l += l

@@ -20,7 +20,9 @@ import sys
 def is_x3(name):
     """The bf16x3 forward kernels behind cl4_conv2d_fwd (precision 1) / cl4_conv2d_fwd_planes: the role-split kernel's two-plane
     instantiations, the unified-wave kernel and the planes-input kernel."""
-    if "conv_u_bf16x3" in name or "conv_s_bf16x3" in name or "stem_fused" in name:
+    if "conv_s_bf16x3" in name:                          # conv_s<KS, SPLIT, MF, BNT, PL>: PL = 3 is a bf16x6 launch
+        return re.search(r"conv_s_bf16x3<([^>]*)>", name).group(1).split(",")[4].strip() == "2"
+    if "conv_u_bf16x3" in name or "conv_b_bf16x3" in name or "conv_p_bf16x3" in name or "stem_fused" in name:
         return True
     m = re.search(r"conv_igemm_bf16x3<([^>]*)>", name)
     return bool(m) and m.group(1).split(",")[5].strip() == "2"
@@ -51,7 +53,7 @@ def main():
         if is_x3(k):
             x3_n += c
             x3_ms += t
-    print(f"bf16x3 forward family (conv_igemm_bf16x3 P=2, conv_u_bf16x3, conv_s_bf16x3): {x3_n / n:.1f} launches/step, {x3_ms / n:.3f} ms/step, "
+    print(f"bf16x3 forward family (conv_igemm_bf16x3 P=2, conv_u / conv_s / conv_b / conv_p _bf16x3, stem_fused): {x3_n / n:.1f} launches/step, {x3_ms / n:.3f} ms/step, "
           f"avg launch {x3_ms / max(x3_n, 1):.5f} ms")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"{k[:80]:80s} calls/step {c / n:7.1f}  ms/step {t / n:8.3f}  {100 * t / tot:5.1f}%")
