@@ -61,6 +61,7 @@ int launch_conv_p(const ConvArgs& a, unsigned ntile, hipStream_t st);
 // dominates. rows = output channels per tile: 256 (8 waves) or 128 (4 waves, or 8 waves of 32 rows each: launches with too few 256-row
 // tiles to fill the chip); 144 pixels per tile. Unsplit; `grid` = cdiv(cout, rows) * cdiv(npix, 144) with a.gx = cdiv(cout, rows).
 bool conv_b_eligible(const ConvArgs& a, int ks, int rows);
-int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, unsigned grid, hipStream_t st);
+// planes = 2, or 3 (bf16x6 operands; rows 128 / 8 waves only).
+int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, int planes, unsigned grid, hipStream_t st);
 
 }  // namespace cl4

@@ -31,9 +31,7 @@ namespace {
 #define CL4_B_DBG 0   // experiments only: 1 = no LDS-DMA in the K loop, 4 = no MFMA
 #endif
 
-constexpr int BNB = 144, PB = 2;
-constexpr int B_CH = KG * PB * 128;        // 1024 chunks: [k-group * 2 + plane][128 pixel columns]
-constexpr int E_CH = KG * PB * 16;         // 128 chunks:  [k-group * 2 + plane][16 extra pixel columns]
+constexpr int BNB = 144;
 constexpr int NSTG = 3;
 
 // one LDS-DMA piece: 64 lanes x 16 bytes -> LDS bytes [lds_addr, lds_addr + 1024); source = descriptor base + voff (per lane,
@@ -46,16 +44,23 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, __amdgpu
 // 64 rows per wave, 34 KB per stage; <128, 8> = 128 channels, 32 rows per wave (two waves per SIMD again: one wave's LDS-DMA issue and
 // fragment reads run under the other's MFMAs) — the launches with fewer than 256 tiles of 256 rows (16 images of a 33 x 33 map at 256
 // output channels), where conv_s has one workgroup per CU and nothing to hide its operand traffic behind.
-template <int KS, int BMB, int NW>
+// PB = bf16 planes per operand: 2 (bf16x3: three products) or 3 (bf16x6: hi, mid, lo planes and six products — the arithmetic of the
+// differentiated convolutions; <128, 8> only: 51 KB per stage, 120 MFMAs per SIMD and K-tile).
+template <int KS, int BMB, int NW, int PB>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvArgs a) {
   constexpr int KHW = KS * KS;
+  constexpr int R = KG * PB;                               // chunk rows (k-group, plane) of an operand tile: 8 or 12
+  constexpr int B_CH = R * 128;                            // [k-group * PB + plane][128 pixel columns]
+  constexpr int E_CH = R * 16;                             // [k-group * PB + plane][16 extra pixel columns]
+  constexpr int NE = R / 4;                                // extra pieces per K-tile (4 chunk rows x 16 columns each): waves 0 .. NE-1
+  static_assert(PB == 2 || (PB == 3 && BMB == 128 && NW == 8), "planes");
   constexpr int WR = 2 * BMB / NW;                         // rows per wave: 64 or 32
   constexpr int NRB = WR / 32;                             // MFMA row blocks per half of a K-tile's work: 2 or 1
   constexpr int RB64 = BMB / 64;                           // 64-row groups of the tile (= weight pieces per chunk row)
-  constexpr int A_CH = KG * PB * BMB;                      // [k-group * 2 + plane][BMB rows]
+  constexpr int A_CH = R * BMB;                            // [k-group * PB + plane][BMB rows]
   constexpr int STGB = A_CH + B_CH + E_CH;                 // 3200 chunks = 50 KB (256 rows), 2176 chunks = 34 KB (128 rows)
-  constexpr int NAP = 8 * RB64 / NW;                       // weight pieces per wave and K-tile: 4, or 2 (<128, 8>)
-  constexpr int NBP = 16 / NW;                             // pixel pieces per wave and K-tile
+  constexpr int NAP = R * RB64 / NW;                       // weight pieces per wave and K-tile: 4, or 2 / 3 (<128, 8>)
+  constexpr int NBP = 2 * R / NW;                          // pixel pieces per wave and K-tile
   constexpr int NPW = NAP + NBP;                           // pieces per wave and K-tile (one more for waves 0 and 1)
   constexpr int NHALF = BMB / 128;                         // 128-row halves of the tile, each finished by TH threads
   constexpr int TH = 64 * NW / NHALF;                      // 256, or 512 (<128, 8>)
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
   const unsigned a_lds = (unsigned)(((wave / RB64) * NAP * BMB + (wave % RB64) * 64) * 16);
   const unsigned b_lds = (unsigned)((A_CH + (wave >> 1) * NBP * 128 + (wave & 1) * 64) * 16);
   const unsigned e_lds = (unsigned)((A_CH + B_CH + wave * 64) * 16);
-  const int erow_dma = wave * 4 + (lane >> 4);             // waves 0, 1 only
+  const int erow_dma = wave * 4 + (lane >> 4);             // waves 0 .. NE-1 only
   const unsigned pkeep = (unsigned)(-(int)px.valid), ekeep = (unsigned)(-(int)ex.valid);
 
   // A request = the weight part (4 pieces) and the pixel part (NBP pieces, and the extra piece of waves 0 / 1) of one K-tile, each with
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
     const unsigned live = (unsigned)(-(int)(kt < nk));
     rq.a_stage = stage_bytes;
     rq.avo = (a_voff & live) | (OOB & ~live);
-    rq.T8 = (unsigned)((cb * KHW + tap) * 8 + (wave / RB64) * NAP);
+    rq.T8 = (unsigned)((cb * KHW + tap) * R + (wave / RB64) * NAP);
   };
   auto prep_b = [&](int kt, unsigned stage_bytes) {
     int cb, tap;
@@ -185,18 +190,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
       const unsigned keep = pkeep & live & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
       const unsigned vo = (cbase + (unsigned)(iy * a.win + ix)) * 16u;
       rq.bvo = (vo & keep) | (OOB & ~keep);
-      rq.bso = (unsigned)(cb * 4 * PB + (wave >> 1) * NBP) * (unsigned)HWi * 16u;
+      rq.bso = (unsigned)(cb * R + (wave >> 1) * NBP) * (unsigned)HWi * 16u;
     }
     {   // the extra piece of waves 0, 1
       const int iy = ex.iy0 + dy, ix = ex.ix0 + dx;
       const unsigned keep = ekeep & live & (unsigned)(-(int)((unsigned)iy < (unsigned)a.hin && (unsigned)ix < (unsigned)a.win));
-      const unsigned vo = (ebase + (unsigned)(iy * a.win + ix)) * 16u + (unsigned)(((cb * 4 + (erow_dma >> 1)) * PB + (erow_dma & 1)) * HWi) * 16u;
+      const unsigned vo = (ebase + (unsigned)(iy * a.win + ix)) * 16u + (unsigned)((cb * R + erow_dma) * HWi) * 16u;
       rq.evoff = (vo & keep) | (OOB & ~keep);
     }
   };
   auto piece_a = [&](int i) { dma16(lds0 + rq.a_stage + a_lds + (unsigned)(i * BMB * 16), rq.avo, wrsrc, (rq.T8 + (unsigned)i) * (unsigned)a.cout * 16u); };
   auto piece_b = [&](int q) { dma16(lds0 + rq.b_stage + b_lds + (unsigned)(q * 128 * 16), rq.bvo, xrsrc, rq.bso + (unsigned)(q * HWi) * 16u); };
-  auto piece_e = [&]() { if (wave < 2) dma16(lds0 + rq.b_stage + e_lds, rq.evoff, xrsrc, 0); };
+  auto piece_e = [&]() { if (wave < NE) dma16(lds0 + rq.b_stage + e_lds, rq.evoff, xrsrc, 0); };
   auto request_a = [&](int kt, unsigned stage_bytes) {
     prep_a(kt, stage_bytes);
 #pragma unroll
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
   };
   // all but one K-tile's pieces of this wave have landed (NPW pieces per K-tile, one more for waves 0 and 1)
   auto wait_all_but_one_tile = [&]() {
-    if (wave < 2) wait_vmcnt<NPW + 1>();
+    if (wave < NE) wait_vmcnt<NPW + 1>();
     else wait_vmcnt<NPW>();
   };
 
@@ -223,31 +228,38 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
 
   const int l15 = lane & 15, kg = lane >> 4;
   // fragment addresses inside a stage (chunks): A row block i of this wave, plane pl: (kg * 2 + pl) * BMB + wm * WR + i * 16 + l15
-  const int a_frag = kg * 2 * BMB + wm * WR + l15;
-  const int b_frag = A_CH + kg * 2 * 128 + wn * 64 + l15;  // column block j < 4: + j * 16; plane: + 128
-  const int e_frag = A_CH + B_CH + kg * 2 * 16 + l15;      // column block 4 (wave part 0): plane: + 16
-  auto read_a = [&](bf16x8 (&af)[2][NRB], const u32x4* st, int i0) {
+  const int a_frag = kg * PB * BMB + wm * WR + l15;
+  const int b_frag = A_CH + kg * PB * 128 + wn * 64 + l15; // column block j < 4: + j * 16; plane: + 128
+  const int e_frag = A_CH + B_CH + kg * PB * 16 + l15;     // column block 4 (wave part 0): plane: + 16
+  auto read_a = [&](bf16x8 (&af)[PB][NRB], const u32x4* st, int i0) {
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int pl = 0; pl < PB; ++pl)
 #pragma unroll
       for (int i = 0; i < NRB; ++i) af[pl][i] = __builtin_bit_cast(bf16x8, st[a_frag + pl * BMB + (i0 + i) * 16]);
   };
-  auto read_b = [&](bf16x8 (&bf)[2], const u32x4* st, int j) {
-    if (j < 4) {
-      bf[0] = __builtin_bit_cast(bf16x8, st[b_frag + j * 16]);
-      bf[1] = __builtin_bit_cast(bf16x8, st[b_frag + 128 + j * 16]);
-    } else {
-      bf[0] = __builtin_bit_cast(bf16x8, st[e_frag]);
-      bf[1] = __builtin_bit_cast(bf16x8, st[e_frag + 16]);
-    }
+  auto read_b = [&](bf16x8 (&bf)[PB], const u32x4* st, int j) {
+#pragma unroll
+    for (int pl = 0; pl < PB; ++pl)
+      bf[pl] = __builtin_bit_cast(bf16x8, j < 4 ? st[b_frag + pl * 128 + j * 16] : st[e_frag + pl * 16]);
   };
-  auto mma = [&](accv_t& c, const bf16x8 (&af)[2][NRB], int i, const bf16x8 (&bf)[2]) {
+  // products, smallest first (as conv_s.hip): two planes lo*hi, hi*lo, hi*hi; three planes (hi = 0, mid = 1, lo = 2) lo*hi, hi*lo,
+  // mid*mid, mid*hi, hi*mid, hi*hi
+  auto mma = [&](accv_t& c, const bf16x8 (&af)[PB][NRB], int i, const bf16x8 (&bf)[PB]) {
 #if CL4_B_DBG & 4
-    c[0] += (float)af[1][i][0] * (float)bf[0][0] + (float)af[0][i][1] * (float)bf[1][1];
+    c[0] += (float)af[PB - 1][i][0] * (float)bf[0][0] + (float)af[0][i][1] * (float)bf[PB - 1][1];
 #else
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0], c, 0, 0, 0);
+    if constexpr (PB == 2) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0], c, 0, 0, 0);
+    } else {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][i], bf[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0], c, 0, 0, 0);
+    }
 #endif
   };
 
@@ -259,15 +271,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
   request_b(1, STGB * 16);
   request_a(2, 2 * STGB * 16);
 #if CL4_B_SPREAD
-  if (wave < 2) wait_vmcnt<NPW + 1 + NAP>();
+  if (wave < NE) wait_vmcnt<NPW + 1 + NAP>();
   else wait_vmcnt<NPW + NAP>();
 #else
   request_b(2, 2 * STGB * 16);
-  if (wave < 2) wait_vmcnt<2 * NPW + 2>();
+  if (wave < NE) wait_vmcnt<2 * NPW + 2>();
   else wait_vmcnt<2 * NPW>();
 #endif
   __builtin_amdgcn_s_barrier();
-  bf16x8 a01[2][NRB], a23[2][NRB], bfr[5][2];      // fragments of the first / second half of the wave's row blocks
+  bf16x8 a01[PB][NRB], a23[PB][NRB], bfr[5][PB];      // fragments of the first / second half of the wave's row blocks
   read_a(a01, lds, 0);
 #pragma unroll
   for (int j = 0; j < 5; ++j)
@@ -406,16 +418,22 @@ bool conv_b_eligible(const ConvArgs& a, int ks, int rows) {
   return (ks == 1 || ks == 3) && (rows == 128 || rows == 256) && a.cin % 32 == 0 && a.cout >= rows && a.cout % 8 == 0 && a.xs != nullptr;
 }
 
-// waves: 8 (rows 256 or 128) or 4 (rows 128)
-int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, unsigned grid, hipStream_t st) {
+// waves: 8 (rows 256 or 128) or 4 (rows 128); planes: 2, or 3 (bf16x6; rows 128 / 8 waves only)
+int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, int planes, unsigned grid, hipStream_t st) {
   const dim3 g(grid), b(64 * waves);
   ++g_b_launches;
-  if (ks == 1 && rows == 256 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<1, 256, 8>), g, b, 0, st, a);
-  else if (ks == 3 && rows == 256 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<3, 256, 8>), g, b, 0, st, a);
-  else if (ks == 1 && rows == 128 && waves == 4) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 4>), g, b, 0, st, a);
-  else if (ks == 3 && rows == 128 && waves == 4) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 4>), g, b, 0, st, a);
-  else if (ks == 1 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8>), g, b, 0, st, a);
-  else if (ks == 3 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 8>), g, b, 0, st, a);
+  if (planes == 3) {
+    if (ks == 1 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 3>), g, b, 0, st, a);
+    else if (ks == 3 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 8, 3>), g, b, 0, st, a);
+    else { set_error("conv_b: three planes are built for 128 rows / 8 waves only"); return CL4_EINVAL; }
+    return launch_status();
+  }
+  if (ks == 1 && rows == 256 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<1, 256, 8, 2>), g, b, 0, st, a);
+  else if (ks == 3 && rows == 256 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<3, 256, 8, 2>), g, b, 0, st, a);
+  else if (ks == 1 && rows == 128 && waves == 4) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 4, 2>), g, b, 0, st, a);
+  else if (ks == 3 && rows == 128 && waves == 4) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 4, 2>), g, b, 0, st, a);
+  else if (ks == 1 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 2>), g, b, 0, st, a);
+  else if (ks == 3 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 8, 2>), g, b, 0, st, a);
   else { set_error("conv_b: kernel size %d / %d rows / %d waves not built", ks, rows, waves); return CL4_EINVAL; }
   return launch_status();
 }

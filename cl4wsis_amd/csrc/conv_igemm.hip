@@ -1319,7 +1319,7 @@ FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision
     p.impl = 3; p.tile = 128; p.splits = 1; p.kchunk = cl4::cdiv(K, BK2) * BK2;
     return p;
   }
-  if (impl >= 4 && impl <= 6 && precision == 3) {                            // LDS-DMA planes kernel (conv_b.hip): unsplit 256 x 144 (4) or 128 x 144 tiles (5: four waves, 6: eight)
+  if ((impl >= 4 && impl <= 6 && precision == 3) || (impl == 6 && precision == 4)) {                            // LDS-DMA planes kernel (conv_b.hip): unsplit 256 x 144 (4) or 128 x 144 tiles (5: four waves, 6: eight)
     p.impl = impl; p.tile = 128; p.bn = 144; p.splits = 1; p.kchunk = cl4::cdiv(K, BK2) * BK2;
     return p;
   }
@@ -1488,12 +1488,12 @@ int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace
       }
       // a plan pinned for this shape by a call with other operands (fp32 output, fp32 residual, ...): the plain kernel, unsplit
     }
-    if (pl.impl >= 4 && pl.impl <= 6 && pcode == 3 && cl4::conv_b_eligible(a, KS, pl.impl == 4 ? 256 : 128)) {
+    if (pl.impl >= 4 && pl.impl <= 6 && (pcode == 3 || pl.impl == 6) && cl4::conv_b_eligible(a, KS, pl.impl == 4 ? 256 : 128)) {
       const int rows = pl.impl == 4 ? 256 : 128;
       a.gx = cl4::cdiv(a.cout, rows);
       a.ntile_l = a.gx * cl4::cdiv(a.npix, 144);
       a.tile_base = 0; a.ws = nullptr; a.ws_p0 = 0; a.ws_npix = a.npix; a.kchunk = pl.kchunk;
-      return cl4::launch_conv_b(a, KS, rows, pl.impl == 5 ? 4 : 8, (unsigned)a.ntile_l, st);
+      return cl4::launch_conv_b(a, KS, rows, pl.impl == 5 ? 4 : 8, pcode == 4 ? 3 : 2, (unsigned)a.ntile_l, st);
     }
     const TailGeom tg = tail_geometry(pl, a.cout, a.npix, pcode);
     const bool hybrid = tg.main > 0 && pl.tail > 1;
@@ -2156,7 +2156,8 @@ extern "C" int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int til
   const PlanKey key{d->cout, d->n * d->hout * d->wout, K, d->kh, d->stride, d->dil, d->hin * 8 + d->precision};
   std::lock_guard<std::mutex> g(plan_mutex());
   if (impl == 0) { plan_table().erase(key); return CL4_OK; }
-  CL4_REQUIRE(impl == 1 || impl == 2 || (impl >= 3 && impl <= 6 && d->precision == 3), "set_plan: impl must be 0, 1 or 2 (3 ... 6: planes-input launches only)");
+  CL4_REQUIRE(impl == 1 || impl == 2 || (impl >= 3 && impl <= 6 && d->precision == 3) || (impl == 6 && d->precision == 4),
+              "set_plan: impl must be 0, 1 or 2 (3 ... 6: planes-input launches only; three planes: 6 only)");
   CL4_REQUIRE(tile == 64 || tile == 128 || (tile == 144 && planes_code(d->precision)), "set_plan: tile must be 64 or 128 (144: planes-input launches only)");
   plan_table()[key] = make_plan(impl, tile, splits, d->cout, K, d->precision);
   return CL4_OK;

@@ -28,7 +28,9 @@ EPS = 1e-5
 # (about twice the speed of the fp32 MFMA kernels). 0 = exact fp32 MFMA, 1 = bf16x3 (fastest, ~4e-6 per layer). The frozen,
 # no-grad networks (old model, flip-TTA semantic forward, PseudoLabeler) run at ops.CONV_PRECISION (bf16x3 by default).
 TRAIN_PRECISION = int(__import__("os").environ.get("CL4_TRAIN_PRECISION", "2"))
-X6_PLANES = __import__("os").environ.get("CL4_X6_PLANES", "0") == "1"
+# The trainable ASPP reads a three-plane (hi, mid, lo) copy of the frozen res5 features through the LDS-DMA planes kernel (conv_b.hip,
+# plan impl 6): 0.82 -> 0.61 ms per dilated branch (r03); 0 = the role-split bf16x6 kernel on the fp32 features.
+X6_PLANES = __import__("os").environ.get("CL4_X6_PLANES", "1") == "1"
 
 
 def _dx_1x1(dz, conv):

@@ -283,12 +283,14 @@ def _autotune_planes(d, args, reps=6):
             and out_f32 is None and out_pl is not None and -(-d.cout // 128) * -(-npix // 128) >= 512):
         cands.append((3, 128, 1))
     # the big-tile LDS-DMA kernel (csrc/conv_b.hip): 256 x 144 tiles, one workgroup per CU — long-K layers with >= 256 output channels
+    if CONV_B and d.precision == 4 and d.cout % 8 == 0 and d.cout >= 128 and K >= 256:
+        cands.append((6, 144, 1))           # three planes: the 128-row / eight-wave tile only
     if CONV_B and d.precision == 3 and d.cout % 8 == 0 and K >= 256:
         if d.cout >= 256:
             cands.append((4, 144, 1))
         if d.cout >= 128:
-            cands.append((5, 144, 1))       # 128-row tiles of the same kernel: launches with too few 256-row tiles to fill the chip
-            cands.append((6, 144, 1))       # ... as eight waves of 32 rows (two waves per SIMD)
+            cands.append((6, 144, 1))       # 128-row tiles of the same kernel, eight waves of 32 rows: launches with too few 256-row tiles to fill
+                                            # the chip (impl 5 = the same tile as four waves of 64 rows is built and tested, but never faster)
     for impl, tile, splits in cands:
         tiles = -(-d.cout // 128) * -(-npix // tile)
         if True:

@@ -173,7 +173,7 @@ def test_conv_big_tile_lds_dma_kernel_plain(gpu, shape, impl):
     _run(gpu, *shape, plan=(impl, 144, 1), seed=sum(shape), counter="cl4_conv_debug_b_launches")
 
 
-@pytest.mark.parametrize("impl", [4, 5, 6])
+@pytest.mark.parametrize("impl", [4, 6])
 @pytest.mark.parametrize("planes_post", [False, True])
 @pytest.mark.parametrize("shape", B_SHAPES)
 def test_conv_big_tile_lds_dma_kernel_fused_epilogue(gpu, shape, planes_post, impl):
@@ -286,7 +286,7 @@ X6_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("plan", [(2, 144, 1), (2, 144, 2), (2, 144, -4)])
+@pytest.mark.parametrize("plan", [(2, 144, 1), (2, 144, 2), (2, 144, -4), (6, 144, 1)])      # 6 = the LDS-DMA kernel (conv_b.hip), 128 rows x 8 waves
 @pytest.mark.parametrize("shape", X6_SHAPES)
 def test_conv_planes_three_plane_bf16x6(gpu, shape, plan):
     """The bf16x6 variant of the planes kernel (three planes per operand, six MFMA products; descriptor precision 4): fp32-level
@@ -303,14 +303,24 @@ def test_conv_planes_three_plane_bf16x6(gpu, shape, plan):
     out = torch.full((n, cout + 16, h, w), 7.0, device=gpu)
     d = ops.ConvDescFor(n, cin, h, w, cin, 0, cout, k, 1, pad, dil, cout + 16, 8, 0, 0.0, 0, 0.0, 4)
     _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), *plan)
-    before = _hip.load().cl4_conv_debug_s_launches()
+    counter = "cl4_conv_debug_b_launches" if plan[0] == 6 and cout >= 128 else "cl4_conv_debug_s_launches"     # cout < 128: conv_b falls back to conv_s
+    before = getattr(_hip.load(), counter)()
     try:
         ops.conv2d_planes(x3, wp, k, pad=pad, dil=dil, out=out, out_coff=8)
         torch.cuda.synchronize()
     finally:
         _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 0, 64, 1)
-    assert _hip.load().cl4_conv_debug_s_launches() > before
+    assert getattr(_hip.load(), counter)() > before
     y = out[:, 8:8 + cout].cpu().double()
+    if plan[0] == 6:        # the same six products in the same order as the planes kernel: bit-identical
+        out2 = torch.full_like(out, 7.0)
+        _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 2, 144, 1)
+        try:
+            ops.conv2d_planes(x3, wp, k, pad=pad, dil=dil, out=out2, out_coff=8)
+            torch.cuda.synchronize()
+        finally:
+            _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 0, 64, 1)
+        assert torch.equal(out, out2)
     err = ((y - ref).norm() / ref.norm()).item()
     y6 = ops.conv2d(x.to(gpu), wp, k, pad=pad, dil=dil).cpu().double()       # the role-split bf16x6 kernel on the fp32 input
     err6 = ((y6 - ref).norm() / ref.norm()).item()
