@@ -500,8 +500,8 @@ long cl4_conv_debug_b_launches(void);   /* launches of the big-tile LDS-DMA plan
  * `y` (fp32 NCHW, channel slice out_coff of out_ctot) and / or `ys` (planes, the same slice; needs cout % 8 == 0) — at least one.
  * The residual operand is `post` (fp32, [n][cout][hout][wout]) or `post_s` (planes, same shape), not both.
  * Tile widths of 64, 128 or 144 pixels, the persistent pipelined variant (csrc/conv_p.hip) and the LDS-DMA big-tile kernel
- * (csrc/conv_b.hip: 256 or 128 output channels x 144 pixels per workgroup, operands straight into LDS) are launch plans
- * (cl4_conv2d_fwd_set_plan: tile 64 / 144, impl 3, impl 4 / 5); every plan computes the same products in the same order.
+ * (csrc/conv_b.hip: 256 or 128 output channels x 144 pixels per workgroup, operands straight into LDS; two or three planes) are
+ * launch plans (cl4_conv2d_fwd_set_plan: tile 64 / 144, impl 3, impl 4 / 5 / 6); every plan computes the same products in the same order.
  * THREE planes (r03): cl4_to_planes3 writes [n][c/8][hi, mid, lo][h*w][8 x bf16] (x to 24 significant bits, 6 bytes per element);
  * cl4_conv2d_fwd_planes with descriptor precision 4 multiplies such an input with cl4_pack_conv_weight_bf16x6 weights as six bf16 MFMA
  * products = the bf16x6 arithmetic of the differentiated convolutions (train.py:265-272: the trainable ASPP of the instance decoder
