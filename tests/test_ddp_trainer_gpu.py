@@ -78,6 +78,10 @@ def _rank(rank, world, port, ret):
 
 def test_two_rank_phase2_step_matches_sharded_single_process_emulation(gpu, monkeypatch):
     monkeypatch.setenv("CL4_AUTOTUNE", "0")
+    # the two ranks start first: their start-up (interpreter, torch, HIP context, rendezvous: most of this test's time) runs beside the emulation
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ranks = mp.spawn(_rank, args=(2, _free_port(), ret), nprocs=2, join=False)
     # ---- the emulation: one trainer, two shards per iteration, averaged gradients, one Adam step -------------------------------------
     tr = _make_trainer(gpu)
     assert not tr.buckets.distributed
@@ -102,9 +106,8 @@ def test_two_rank_phase2_step_matches_sharded_single_process_emulation(gpu, monk
     w_emu = _weights(tr)
     assert not torch.equal(w_emu, w0)
     # ---- two ranks on this GPU over gloo ---------------------------------------------------------------------------------------------
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_rank, args=(2, _free_port(), ret), nprocs=2, join=True)
+    while not ranks.join():
+        pass
     (l0, w_r0), (l1, w_r1) = ret[0], ret[1]
     assert torch.equal(w_r0, w_r1), "the two ranks diverged"
     for it in range(STEPS):
