@@ -182,8 +182,13 @@ class Trainer:
             raise NotImplementedError("Trainer.step: built for step 0 (supervised, --bce) and for the weakly-supervised phase-1 / "
                                       "phase-2 steps (BASELINE configs 1-3); other option combinations are not on the CL4WSIS path")
         images, l1h = (batch[0], batch[-1])
-        images = images.to(self.device, dtype=torch.float32).contiguous()
-        l1h = l1h.to(self.device, dtype=torch.float32).contiguous()
+        P = self._pipe
+        if P is not None and P["have_old"][P["cur"]] and P.get("announced") is batch:
+            # the batch the previous call announced: it went up then, into this parity's static inputs (no second upload)
+            images, l1h = P["x"][P["cur"]], P["l"][P["cur"]]
+        else:
+            images = images.to(self.device, dtype=torch.float32).contiguous()
+            l1h = l1h.to(self.device, dtype=torch.float32).contiguous()
         self._set_phase2_modes()
         use_graph = (self._use_graph and dropout_keep is None and self._iter >= 1 and ops.TIMER is None
                      and (self._static is None or tuple(images.shape) == tuple(self._static["images"].shape))
@@ -361,8 +366,9 @@ class Trainer:
         p = P["cur"]
         if P["have_old"][p] and P.get("announced") is not batch:
             P["have_old"][p] = False                     # the caller came with another batch object than it announced: prefetch void
-        P["x"][p].copy_(images)
-        P["l"][p].copy_(l1h)
+        if images is not P["x"][p]:                      # (the announced batch is already there: step() handed the static tensors back)
+            P["x"][p].copy_(images)
+            P["l"][p].copy_(l1h)
         if not P["have_old"][p]:                         # not announced by the previous call: the old model runs now, up front
             with torch.no_grad():
                 o, _ = self.model_old(P["x"][p], interpolate=False)

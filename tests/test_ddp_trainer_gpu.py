@@ -59,19 +59,26 @@ def _weights(tr):
 def _rank(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       CL4_DIST_BACKEND="gloo", CL4_AUTOTUNE="0")
+    import time
+    t0 = time.time()
+    stamp = (lambda what: print(f"[rank {rank}] {what}: {time.time() - t0:.1f} s", flush=True)) if os.environ.get("CL4_TEST_TIMING") else (lambda what: None)
     import torch.distributed as dist
     from cl4wsis_amd.parallel import init_distributed
     init_distributed()
+    stamp("rendezvous")
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     tr = _make_trainer(dev)
+    stamp("trainer built")
     assert tr.buckets.distributed and tr.buckets.world == world and not tr.buckets.direct
     losses = []
     for x, l1h, keep in _inputs():
         out = tr.step((x[rank:rank + 1], l1h[rank:rank + 1]), dropout_keep=keep[rank:rank + 1].to(dev))
         losses.append(out["losses"].cpu())
+        stamp("step")
     torch.cuda.synchronize()
     ret[rank] = (torch.stack(losses), _weights(tr))
+    stamp("results handed over")
     dist.barrier()
     dist.destroy_process_group()
 
