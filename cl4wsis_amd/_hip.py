@@ -93,6 +93,9 @@ _decl("cl4_conv2d_fwd", C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, C.c
 _decl("cl4_conv2d_fwd_set_plan", C.POINTER(ConvDesc), _I, _I, _I)
 _decl("cl4_conv2d_fwd_clear_plans")
 _decl("cl4_conv2d_wgrad", C.POINTER(ConvDesc), _P, _P, _P, _P)
+_decl("cl4_kpack", _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P)
+_decl("cl4_gemm_kplanes", _P, _P, _P, _I, _I, _I, _P)
+_decl("cl4_wgrad_scatter", _P, _P, _I, _I, _I, _P)
 _decl("cl4_bn_fold", _P, _P, _P, _P, _F, _P, _P, _I, _P)
 
 _decl("cl4_maxpool3x3s2", _P, _P, _L, _I, _I, _I, _I, _P)
@@ -213,6 +216,8 @@ def load():
         getattr(lib, nm).argtypes = []
     lib.cl4_stem_weight_bytes.restype = C.c_size_t
     lib.cl4_stem_weight_bytes.argtypes = []
+    lib.cl4_kpack_bytes.restype = C.c_size_t
+    lib.cl4_kpack_bytes.argtypes = [C.c_int, C.c_int]
     lib.cl4_input_ksize.restype = C.c_int
     lib.cl4_input_ksize.argtypes = [C.c_int, C.c_int]
     for name, args in PROTOTYPES.items():

@@ -24,15 +24,11 @@
 
 namespace {
 
-#ifndef CL4_B_SPREAD
-#define CL4_B_SPREAD 1   // 1: the pixel part of a K-tile's request is issued in the first half of the previous iteration, the weight part in the second half two iterations ahead
-#endif
 #ifndef CL4_B_DBG
 #define CL4_B_DBG 0   // experiments only: 1 = no LDS-DMA in the K loop, 4 = no MFMA
 #endif
 
 constexpr int BNB = 144;
-constexpr int NSTG = 3;
 
 // one LDS-DMA piece: 64 lanes x 16 bytes -> LDS bytes [lds_addr, lds_addr + 1024); source = descriptor base + voff (per lane,
 // bounds-checked: out of range writes zeros) + soff (wave-uniform). hipcc does not count it: waits are written by hand below.
@@ -46,7 +42,11 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, __amdgpu
 // output channels), where conv_s has one workgroup per CU and nothing to hide its operand traffic behind.
 // PB = bf16 planes per operand: 2 (bf16x3: three products) or 3 (bf16x6: hi, mid, lo planes and six products — the arithmetic of the
 // differentiated convolutions; <128, 8> only: 51 KB per stage, 120 MFMAs per SIMD and K-tile).
-template <int KS, int BMB, int NW, int PB>
+// GEMM = true: the same kernel under another name for cl4_gemm_kplanes (wgrad_gemm.hip: the weight gradient as a K-major GEMM), so that
+// kernel traces keep the forward-convolution family and the weight-gradient launches apart.
+// NSTG = LDS stages (K-tiles in flight + 1): 3; 4 where they fit (the 128-row tile with two planes: 136 KB) — a tile is then requested
+// three K-tiles ahead, which is what the K-major GEMM of the weight gradient needs (both its operands miss L2 on every K-tile).
+template <int KS, int BMB, int NW, int PB, bool GEMM = false, int NSTG = 3>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvArgs a) {
   constexpr int KHW = KS * KS;
   constexpr int R = KG * PB;                               // chunk rows (k-group, plane) of an operand tile: 8 or 12
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
   constexpr int NHALF = BMB / 128;                         // 128-row halves of the tile, each finished by TH threads
   constexpr int TH = 64 * NW / NHALF;                      // 256, or 512 (<128, 8>)
   static_assert((BMB == 256 && NW == 8) || (BMB == 128 && (NW == 4 || NW == 8)), "tile");
-  __shared__ u32x4 lds[NSTG * STGB];                       // three K-tile stages; reused as the parked [BMB][144] fp32 tile
+  static_assert(NSTG == 3 || NSTG == 4, "stages");
+  __shared__ u32x4 lds[NSTG * STGB];                       // the K-tile stages; reused as the parked [BMB][144] fp32 tile
   __shared__ float affine[NHALF][2 * BM];                  // scale / shift of the tile's 128-channel halves
 
   const int tid = threadIdx.x;
@@ -78,7 +79,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
   const unsigned q8 = total >> 3, r8 = total & 7, xcd = id & 7;
   const unsigned lid = a.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3) : id;
   const unsigned tile_ = (unsigned)a.tile_base + lid;
-  const unsigned by_ = tile_ / (unsigned)a.gx, bx_ = tile_ - by_ * (unsigned)a.gx;
+  unsigned by_ = tile_ / (unsigned)a.gx, bx_ = tile_ - by_ * (unsigned)a.gx;
+  if constexpr (GEMM) {
+    // xcd_remap == 2 (cl4_gemm_kplanes): both operands are large matrices, so an XCD's workgroups should share rows AND columns:
+    // XCD x takes the row tiles of group x >> 1 (of 4) and the column tiles of group x & 1 (of 2) — for 16 x 16 tiles each L2 streams
+    // 1/4 of A and 1/2 of B instead of all of A and 1/8 of B (0.93 instead of 1.30 GB through the fabric per launch)
+    if (a.xcd_remap == 2) {
+      const unsigned rt = (unsigned)a.gx, pt = total / rt, rg = rt >> 2, pg = pt >> 1;
+      const unsigned w = id >> 3;
+      bx_ = (xcd >> 1) * rg + w % rg;
+      by_ = (xcd & 1) * pg + w / rg;
+    }
+  }
   const int m0 = bx_ * BMB, n0 = by_ * BNB;
   const int HWo = a.hout * a.wout, HWi = a.hin * a.win;
 
@@ -214,9 +226,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
     piece_e();
   };
   // all but one K-tile's pieces of this wave have landed (NPW pieces per K-tile, one more for waves 0 and 1)
-  auto wait_all_but_one_tile = [&]() {
-    if (wave < NE) wait_vmcnt<NPW + 1>();
-    else wait_vmcnt<NPW>();
+  auto wait_all_but_one_tile = [&]() {                    // ... but NSTG - 2 tiles: tile t+1 has landed, tiles t+2 .. t+NSTG-1 may be in flight
+    if (wave < NE) wait_vmcnt<(NSTG - 2) * (NPW + 1)>();
+    else wait_vmcnt<(NSTG - 2) * NPW>();
   };
 
   typedef float accv_t __attribute__((ext_vector_type(4)));
@@ -263,21 +275,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
 #endif
   };
 
-  // ---- prologue: tiles 0, 1 and the weight part of tile 2 requested (CL4_B_SPREAD = 0: all of tile 2); tile 0 awaited; its first
-  //      fragments read ----
-  request_a(0, 0);
-  request_b(0, 0);
-  request_a(1, STGB * 16);
-  request_b(1, STGB * 16);
-  request_a(2, 2 * STGB * 16);
-#if CL4_B_SPREAD
-  if (wave < NE) wait_vmcnt<NPW + 1 + NAP>();
-  else wait_vmcnt<NPW + NAP>();
-#else
-  request_b(2, 2 * STGB * 16);
-  if (wave < NE) wait_vmcnt<2 * NPW + 2>();
-  else wait_vmcnt<2 * NPW>();
-#endif
+  // ---- prologue: tiles 0 .. NSTG-2 and the weight part of tile NSTG-1 requested; tile 0 awaited; its first fragments read ----
+#pragma unroll
+  for (int k = 0; k < NSTG - 1; ++k) {
+    request_a(k, (unsigned)(k * STGB * 16));
+    request_b(k, (unsigned)(k * STGB * 16));
+  }
+  request_a(NSTG - 1, (unsigned)((NSTG - 1) * STGB * 16));
+  if (wave < NE) wait_vmcnt<(NSTG - 2) * (NPW + 1) + NAP>();
+  else wait_vmcnt<(NSTG - 2) * NPW + NAP>();
   __builtin_amdgcn_s_barrier();
   bf16x8 a01[PB][NRB], a23[PB][NRB], bfr[5][PB];      // fragments of the first / second half of the wave's row blocks
   read_a(a01, lds, 0);
@@ -285,15 +291,18 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
   for (int j = 0; j < 5; ++j)
     if (j < nbj) read_b(bfr[j], lds, j);
 
-  unsigned s_cur = 0, s_nxt = STGB, s_old = 2 * STGB;      // stage (chunks) of tile t, t+1, t+2
+  int ring = 0;                                            // stage of tile t (tile k lives in stage k % NSTG)
   for (int t = 0; t < nk; ++t) {
+    const unsigned s_cur = (unsigned)ring * STGB;
+    const unsigned s_nxt = (unsigned)(ring + 1 == NSTG ? 0 : ring + 1) * STGB;
+    const unsigned s_last = (unsigned)(ring == 0 ? NSTG - 1 : ring - 1) * STGB;     // stage of tile t + NSTG - 1 (= of tile t - 1)
     const u32x4* cur = lds + s_cur;
     const u32x4* nxt = lds + s_nxt;
-    // first half: row blocks 0, 1 of tile t (fragments already in registers) while the fragments of row blocks 2, 3 are read and the
-    // pixel part of tile t+2 is requested (its stage was left by every wave before the previous barrier; its weight part is on its way)
+    // first half: the first row blocks of tile t (fragments already in registers) while the fragments of the second half are read and the
+    // pixel part of tile t+NSTG-1 is requested (its stage was left by every wave before the previous barrier; its weight part is on its way)
     read_a(a23, cur, NRB);
-#if CL4_B_SPREAD && !(CL4_B_DBG & 1)
-    prep_b(t + 2, s_old * 16);
+#if !(CL4_B_DBG & 1)
+    prep_b(t + NSTG - 1, s_last * 16);
 #endif
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
 #pragma unroll
         for (int i = 0; i < NRB; ++i) mma(acc[i][j], a01, i, bfr[j]);
       }
-#if CL4_B_SPREAD && !(CL4_B_DBG & 1)
+#if !(CL4_B_DBG & 1)
       if (j == 0) {
 #pragma unroll
         for (int q = 0; q < NBP / 2; ++q) piece_b(q);
@@ -313,16 +322,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
 #endif
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave no longer reads stage `cur`
-    wait_all_but_one_tile();                               // tile t+1 has landed (tile t+2 may be in flight)
+    wait_all_but_one_tile();                               // tile t+1 has landed
     __builtin_amdgcn_s_barrier();
 #if !(CL4_B_DBG & 1)
-    prep_a(t + 3, s_cur * 16);                             // tile t+3 goes into the stage every wave has just left
-#if !CL4_B_SPREAD
-    prep_b(t + 3, s_cur * 16);
+    prep_a(t + NSTG, s_cur * 16);                          // the weight part of tile t+NSTG goes into the stage every wave has just left
 #endif
-#endif
-    // second half: row blocks 2, 3, column block by column block; block j's B registers are refilled from tile t+1 as soon as they are
-    // free, and the pieces of the request are spread between the blocks (an LDS-DMA issue costs 60+ cycles of this wave's stream)
+    // second half: the remaining row blocks, column block by column block; block j's B registers are refilled from tile t+1 as soon as
+    // they are free, and the pieces of the request are spread between the blocks (an LDS-DMA issue costs 60+ cycles of this wave's stream)
     read_a(a01, nxt, 0);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -332,24 +338,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
         read_b(bfr[j], nxt, j);
       }
 #if !(CL4_B_DBG & 1)
-#if CL4_B_SPREAD
       if (j < NAP) piece_a(j);
-#else
-      static_assert(NAP == 4, "CL4_B_SPREAD = 0 is kept for the 64-row-per-wave tiles only");
-      if (j == 0) { piece_a(0); piece_a(1); }
-      else if (j == 1) { piece_a(2); piece_a(3); }
-      else if (j == 2) {
-#pragma unroll
-        for (int q = 0; q < NBP / 2; ++q) piece_b(q);
-      } else if (j == 3) {
-#pragma unroll
-        for (int q = NBP / 2; q < NBP; ++q) piece_b(q);
-      } else piece_e();
-#endif
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
-    const unsigned s = s_cur; s_cur = s_nxt; s_nxt = s_old; s_old = s;
+    ring = ring + 1 == NSTG ? 0 : ring + 1;
   }
 
   // ---- epilogue: the two 256-thread halves of the workgroup finish the two 128-row halves of the tile ----
@@ -439,3 +432,24 @@ int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, int planes, un
 }
 
 }  // namespace cl4
+
+// Y[m][p] = sum_k A[m][k] * B[p][k] (fp32 out [M][N]): A, B in the k-planes format of wgrad_gemm.hip (chunks of 8 consecutive k:
+// ((k / 8) * 2 + plane) * rows + row), kpad % 32 == 0. One 128 x 144 tile per workgroup, eight waves, unsplit.
+extern "C" int cl4_gemm_kplanes(const void* a_kplanes, const void* b_kplanes, float* y, int M, int N, int kpad, void* stream) {
+  CL4_REQUIRE(a_kplanes && b_kplanes && y, "gemm_kplanes: null operand");
+  CL4_REQUIRE(M >= 128 && M % 8 == 0 && N > 0 && kpad > 0 && kpad % 32 == 0, "gemm_kplanes: M >= 128, M %% 8 == 0, kpad %% 32 == 0 expected (M %d, N %d, kpad %d)", M, N, kpad);
+  CL4_REQUIRE((long)kpad * M * 4 < (1L << 31) && (long)kpad * N * 4 < (1L << 31), "gemm_kplanes: operand exceeds the 2 GiB buffer range");
+  cl4::ConvArgs a{};
+  a.xs = b_kplanes; a.wp = (const float*)a_kplanes; a.y = y;
+  a.n = 1; a.cin = kpad; a.hin = 1; a.win = N; a.cout = M; a.stride = 1; a.pad = 0; a.dil = 1; a.hout = 1; a.wout = N;
+  a.in_ctot = kpad; a.in_coff = 0; a.out_ctot = M; a.out_coff = 0;
+  a.K = kpad; a.npix = N; a.hw_pad = N; a.xcd_remap = 1; a.neg1 = 1.f; a.neg2 = 1.f;
+  a.gx = cl4::cdiv(M, 128); a.ntile_l = a.gx * cl4::cdiv(N, 144); a.tile_base = 0; a.ws_npix = N; a.kchunk = kpad;
+  static const int map2d = [] { const char* e = getenv("CL4_GEMM_XCD_2D"); return e ? atoi(e) : 1; }();
+  if (map2d && a.gx % 4 == 0 && cl4::cdiv(N, 144) % 2 == 0) a.xcd_remap = 2;      // (then the tile count is a multiple of 8 as well)
+  static const int stages = [] { const char* e = getenv("CL4_GEMM_STAGES"); return e ? atoi(e) : 4; }();
+  if (stages == 4) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 2, true, 4>), dim3((unsigned)a.ntile_l), dim3(512), 0, cl4::as_stream(stream), a);
+  else hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 2, true, 3>), dim3((unsigned)a.ntile_l), dim3(512), 0, cl4::as_stream(stream), a);
+  return cl4::launch_status();
+}
+

@@ -506,8 +506,42 @@ def ConvDescFor(n, cin, hin, win, in_ctot, in_coff, cout, k, stride, pad, dil, o
 WGRAD_PRECISION = int(os.environ.get("CL4_WGRAD_PRECISION", "1"))
 
 
-def conv2d_wgrad(x, dy, dw, k, stride=1, pad=0, dil=1, in_coff=0, cin=None, dy_coff=0, cout=None, precision=None):
-    """dw[cout,cin,k,k] += conv weight gradient. dw is accumulated into (zero it first)."""
+# The 3x3 weight gradients of wide layers as one K-major GEMM on the LDS-DMA planes kernel (csrc/wgrad_gemm.hip, r03): 0 = always the
+# role-split conv_wgrad kernels.
+WGRAD_GEMM = os.environ.get("CL4_WGRAD_GEMM", "1") != "0"
+
+
+def _wgrad_gemm_ok(n, cin, hin, win, cout, k, stride, precision):
+    kq = n * hin * win
+    kpad = (kq + 31) // 32 * 32
+    return (WGRAD_GEMM and k == 3 and stride == 1 and precision == 1 and cin >= 1024 and cin % 128 == 0 and cout % 16 == 0
+            and 9 * cout >= 1024 and kq >= 4096 and kpad * max(cin, 9 * cout) * 4 < (1 << 31))
+
+
+def _wgrad_gemm(x, dy, dw, n, cin, in_coff, cout, dy_coff, hin, win, hout, wout, pad, dil, kcache):
+    """dw += the 3x3 weight gradient as Y[ci][(tap, co)] = xK . dyK^T (cl4_kpack x 2, cl4_gemm_kplanes, cl4_wgrad_scatter).
+    `kcache`: a dict the caller keeps for as long as x's CONTENTS stay what they are (one backward pass): x's pack is made once."""
+    lib = _hip.load()
+    dev = x.device
+    kq = n * hin * win
+    kpad = (kq + 31) // 32 * 32
+    key = ("xk", x.data_ptr(), tuple(x.shape), in_coff, cin)
+    xk = kcache.get(key) if kcache is not None else None
+    if xk is None:
+        xk = torch.empty(lib.cl4_kpack_bytes(cin, kq) // 4, dtype=torch.int32, device=dev)
+        call("cl4_kpack", ptr(x), ptr(xk), n, x.shape[1], in_coff, cin, hin, win, hin, win, 1, 1, 0, stream())
+        if kcache is not None:
+            kcache[key] = xk
+    dyk = torch.empty(lib.cl4_kpack_bytes(9 * cout, kq) // 4, dtype=torch.int32, device=dev)
+    call("cl4_kpack", ptr(dy), ptr(dyk), n, dy.shape[1], dy_coff, cout, hout, wout, hin, win, 3, dil, pad, stream())
+    y = torch.empty((cin, 9 * cout), dtype=torch.float32, device=dev)
+    call("cl4_gemm_kplanes", ptr(xk), ptr(dyk), ptr(y), cin, 9 * cout, kpad, stream())
+    call("cl4_wgrad_scatter", ptr(y), ptr(dw), cin, cout, 9, stream())
+
+
+def conv2d_wgrad(x, dy, dw, k, stride=1, pad=0, dil=1, in_coff=0, cin=None, dy_coff=0, cout=None, precision=None, kcache=None):
+    """dw[cout,cin,k,k] += conv weight gradient. dw is accumulated into (zero it first). `kcache` (optional dict, valid while x's
+    contents do not change): lets several layers on one input share x's repacked copy on the GEMM path (_wgrad_gemm)."""
     n, in_ctot, hin, win = x.shape
     if cin is None:
         cin = in_ctot - in_coff
@@ -522,7 +556,10 @@ def conv2d_wgrad(x, dy, dw, k, stride=1, pad=0, dil=1, in_coff=0, cin=None, dy_c
     if TIMER is not None:
         e0, e1 = TIMER.span("conv_wgrad", 2.0 * n * d.hout * d.wout * cout * cin * k * k)
         e0.record()
-    call("cl4_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), stream())
+    if _wgrad_gemm_ok(n, cin, hin, win, cout, k, stride, d.precision) and x.is_contiguous() and dy.is_contiguous() and dw.is_contiguous():
+        _wgrad_gemm(x, dy, dw, n, cin, in_coff, cout, dy_coff, hin, win, d.hout, d.wout, pad, dil, kcache)
+    else:
+        call("cl4_conv2d_wgrad", C.byref(d), ptr(x), ptr(dy), ptr(dw), stream())
     if TIMER is not None:
         e1.record()
     return dw

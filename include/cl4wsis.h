@@ -114,6 +114,20 @@ int cl4_conv2d_fwd(const cl4_conv_desc* d, const float* x, const float* wp,
  * fp32 MFMA (step 0 / phase 1: the whole network trains), 1 bf16x3 split products (phase 2's trainable branch). */
 int cl4_conv2d_wgrad(const cl4_conv_desc* d, const float* x, const float* dy, float* dw, void* stream);
 
+/* The same weight gradient (autograd of nn.Conv2d, train.py:537) for 3x3 stride-1 layers as ONE K-major GEMM on the LDS-DMA planes kernel
+ * (csrc/wgrad_gemm.hip, r03): dW[co][ci][tap] = sum_q dy[co][q - s(tap)] * x[ci][q] over the input pixels q. Three calls:
+ *   cl4_kpack           repack x (ks = 1: rows = cin) or dy (ks = 3: rows = 9 * cout, shifted per tap, zero outside dy) into "k-planes":
+ *                       chunks of 8 consecutive pixels, bf16 hi / lo, ((q / 8) * 2 + plane) * rows + row; q runs over n x hq x wq
+ *                       (the INPUT map), padded with zeros to a multiple of 32; cl4_kpack_bytes(rows, n * hq * wq) bytes
+ *   cl4_gemm_kplanes    Y[m][p] = sum_k A[m][k] * B[p][k] (fp32 [M][N]), bf16x3 products (lo*hi + hi*lo + hi*hi), no atomics
+ *   cl4_wgrad_scatter   dw[co][ci][tap] += Y[ci][tap * cout + co]
+ * x's pack depends on x only: a caller with several layers on one input (the ASPP branches) packs it once. */
+size_t cl4_kpack_bytes(int rows, int kq);
+int cl4_kpack(const float* src, void* dst, int n, int ctot, int coff, int c, int hs, int ws, int hq, int wq, int ks, int dil, int pad,
+              void* stream);
+int cl4_gemm_kplanes(const void* a_kplanes, const void* b_kplanes, float* y, int M, int N, int kpad, void* stream);
+int cl4_wgrad_scatter(const float* y, float* dw, int cin, int cout, int taps, void* stream);
+
 /* Fold BN running statistics into scale/shift:
  *   scale = gamma / sqrt(var + eps), shift = beta - mean*scale (+ bias*scale if bias).
  * Replaces the eval branch of InPlaceABN / nn.BatchNorm2d (segmentation_module.py:17-29). */
