@@ -568,13 +568,14 @@ class InstanceBranch:
             # be all-reduced under the remaining weight-gradient kernels. The tensors are independent: same values.
             dgp = ops.relu_bwd(gp, ops.resize_bilinear_bwd(dcat5, (1, 1), True, dy_coff=4 * cout, c=cout))
             ops.conv2d_wgrad(g, dgp, G(pconv.weight), 1)
+        kcache = {}       # the three dilated branches share one pixel-major pack of x on the GEMM path of the weight gradient (ops._wgrad_gemm)
         for j in (range(4) if feature_grads is not None else (3, 2, 1, 0)):
             conv, bn = aspp.convs[j][0], aspp.convs[j][1]
             z, m, v = recs[j]
             dz = ops.bn_train_bwd(z, dcat5, m, v, bn.weight.detach(), bn.bias.detach(), G(bn.weight), G(bn.bias), bn.eps,
                                   dy_coff=j * cout)
             k, pad, dil = conv.kernel_size[0], conv.padding[0], conv.dilation[0]
-            ops.conv2d_wgrad(x, dz, G(conv.weight), k, pad=pad, dil=dil)
+            ops.conv2d_wgrad(x, dz, G(conv.weight), k, pad=pad, dil=dil, kcache=kcache)
             if feature_grads is not None:
                 from .body_train import _dgrad_weight
                 part = ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(x.shape[2:]), k, pad=pad, dil=dil)

@@ -72,9 +72,10 @@ def deeplab_backward(head, tape, dy, grad_of, group=None):
     da = _conv1x1_bwd(a, head.red_conv, dout, grad_of)
     dcat = _abn_bwd(r_map, head.map_bn, da, grad_of, group)
     dx = None
+    kcache = {}           # one pixel-major pack of x for the dilated branches (GEMM path of the weight gradient)
     for i, conv in enumerate(head.map_convs):
         k, p, d = conv.kernel_size[0], conv.padding[0], conv.dilation[0]
-        ops.conv2d_wgrad(x, dcat, grad_of(conv.weight), k, pad=p, dil=d, dy_coff=i * hid, cout=hid, precision=BT.WGRAD_PRECISION)
+        ops.conv2d_wgrad(x, dcat, grad_of(conv.weight), k, pad=p, dil=d, dy_coff=i * hid, cout=hid, precision=BT.WGRAD_PRECISION, kcache=kcache)
         if k == 1:
             part = ops.conv2d(dcat, conv.weight.detach().reshape(hid, cin), 1, in_coff=i * hid, cin=hid)
         else:
