@@ -25,6 +25,13 @@ def gpu():
         pytest.skip("no GPU visible")
     from cl4wsis_amd import _hip
     _hip.load()  # raises loudly when the HIP library is missing
+    # A 1-GPU box is a 16-thread share of a 256-thread host whose affinity mask still lists all 256: left alone, the CPU oracle of the
+    # parity tests runs 256 threads on that share and the kernel throttles it (bench.py::_host_cores; the suite took 840 s that way).
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 16 * max(1, torch.cuda.device_count()))))
     return torch.device("cuda:0")
 
 

@@ -62,6 +62,7 @@ def _rank(rank, world, port, ret):
     import time
     t0 = time.time()
     stamp = (lambda what: print(f"[rank {rank}] {what}: {time.time() - t0:.1f} s", flush=True)) if os.environ.get("CL4_TEST_TIMING") else (lambda what: None)
+    torch.set_num_threads(8)          # two ranks + the parent share the box's 16-thread share (the affinity mask lists the whole host)
     import torch.distributed as dist
     from cl4wsis_amd.parallel import init_distributed
     init_distributed()
