@@ -414,6 +414,7 @@ bool conv_b_eligible(const ConvArgs& a, int ks, int rows) {
 // waves: 8 (rows 256 or 128) or 4 (rows 128); planes: 2, or 3 (bf16x6; rows 128 / 8 waves only)
 int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, int planes, unsigned grid, hipStream_t st) {
   const dim3 g(grid), b(64 * waves);
+  static const bool stages4 = [] { const char* e = getenv("CL4_CONV_B_STAGES"); return e && atoi(e) == 4; }();   // experiments: four LDS stages on the 128-row / 8-wave tile
   ++g_b_launches;
   if (planes == 3) {
     if (ks == 1 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 3>), g, b, 0, st, a);
@@ -425,6 +426,8 @@ int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, int planes, un
   else if (ks == 3 && rows == 256 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<3, 256, 8, 2>), g, b, 0, st, a);
   else if (ks == 1 && rows == 128 && waves == 4) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 4, 2>), g, b, 0, st, a);
   else if (ks == 3 && rows == 128 && waves == 4) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 4, 2>), g, b, 0, st, a);
+  else if (ks == 1 && rows == 128 && waves == 8 && stages4) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 2, false, 4>), g, b, 0, st, a);
+  else if (ks == 3 && rows == 128 && waves == 8 && stages4) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 8, 2, false, 4>), g, b, 0, st, a);
   else if (ks == 1 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 2>), g, b, 0, st, a);
   else if (ks == 3 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 8, 2>), g, b, 0, st, a);
   else { set_error("conv_b: kernel size %d / %d rows / %d waves not built", ks, rows, waves); return CL4_EINVAL; }
