@@ -1,4 +1,4 @@
-# Round-2 measurement pass: (1) the default bench command (all legs) and (2) the same workload under rocprofv3 --kernel-trace
+# Measurement pass of a round: (1) the default bench command (all legs) and (2) the same workload under rocprofv3 --kernel-trace
 # --stats, from which the per-step tables are cut: graph-replayed steps (the timed mode) and the two eager overlap-off steps of
 # the roofline leg (the mode roofline.frac is measured in).
 set -e

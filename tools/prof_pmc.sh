@@ -18,4 +18,4 @@ done
 timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/bench_MFMA -- python3 $R/bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-structured > $O/bench_MFMA.json 2> $O/bench_MFMA.err
 echo "pass bench MFMA done"
 python3 $R/tools/pmc_traffic.py $O $O/traffic.json
-# per-kernel table (needs the kernel trace of tools/prof_r03.sh for the durations): python3 tools/pmc_kernels.py $O <trace dir> 13 <out.json>
+# per-kernel table (needs the kernel trace of tools/prof_bench_trace.sh for the durations): python3 tools/pmc_kernels.py $O <trace dir> 13 <out.json>

@@ -1,7 +1,7 @@
-# Final measurement pass of a round: default bench + rocprof kernel trace (tools/prof_r02.sh), timeline, PMC passes, per-kernel PMC table, soak.
+# Final measurement pass of a round: default bench + rocprof kernel trace (tools/prof_bench_trace.sh), timeline, PMC passes, per-kernel PMC table, soak.
 TAG=${1:-r03y}
 cd $GRAFT_REPO_ROOT
-bash tools/prof_r02.sh $TAG || exit 1
+bash tools/prof_bench_trace.sh $TAG || exit 1
 python tools/step_timeline.py gpurun_out/$TAG/prof 8 4 > gpurun_out/$TAG/timeline.txt 2>&1
 echo "trace done"
 bash tools/prof_pmc.sh $TAG || exit 1
