@@ -111,6 +111,7 @@ _decl("cl4_axpy", _P, _P, _F, _L, _P)
 _decl("cl4_copy_channels", _P, _P, _I, _I, _L, _I, _I, _I, _I, _P)
 _decl("cl4_bn_train_stats", _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, C.c_size_t, _P)
 _decl("cl4_bn_apply", _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _F, _P)
+_decl("cl4_bn_train_fwd", _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _F, _I, _F, _P, _F, _P, C.c_size_t, _P)
 _decl("cl4_bn_train_bwd", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P, _F, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_relu_bwd", _P, _P, _P, _L, _P)
 _decl("cl4_bias_grad", _P, _P, _I, _I, _I, _I, _I, _P)

@@ -48,6 +48,17 @@ __global__ void bn_stats_partial_kernel(const float* __restrict__ x, double* __r
   }
 }
 
+// {sum a, sum b} of channel c over its SPLIT partials, computed by every wave for itself: lanes 0 .. SPLIT-1 load one partial each,
+// a butterfly adds them (r03: the per-channel "final" kernels between the reduction and the elementwise pass are gone — 36 launches
+// of ~6 us per step on the critical path; every workgroup of the elementwise pass redoes this 32-term sum, in one fixed order)
+__device__ __forceinline__ void channel_sums(const double* __restrict__ partial, int c, double& a, double& b) {
+  const int lane = threadIdx.x & 63;
+  a = lane < SPLIT ? partial[((long)c * SPLIT + lane) * 2 + 0] : 0.0;
+  b = lane < SPLIT ? partial[((long)c * SPLIT + lane) * 2 + 1] : 0.0;
+  a = cl4::wave_sum_d(a);
+  b = cl4::wave_sum_d(b);
+}
+
 // mean / biased var; running stats updated with the unbiased variance (PyTorch semantics, momentum m).
 __global__ void bn_stats_final_kernel(const double* __restrict__ partial, float* __restrict__ mean, float* __restrict__ var,
                                       float* running_mean, float* running_var, float momentum, long count, int c) {
@@ -129,6 +140,43 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, float* __restrict__
   }
 }
 
+// bn_apply_kernel with the statistics finalised in place: mean / var of the plane's channel from the partial sums; the first
+// workgroup of image 0 also publishes them (mean, var: the backward pass reads them) and updates the running statistics.
+__global__ void bn_apply_fused_kernel(const float* __restrict__ x, float* __restrict__ y, const double* __restrict__ partial,
+                                      float* __restrict__ mean, float* __restrict__ var, float* running_mean, float* running_var,
+                                      float momentum, long count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      float eps, int act, float slope, BnShape s, int y_ctot, int y_coff,
+                                      const uint8_t* __restrict__ keep, float keep_scale) {
+  const int plane = blockIdx.x;
+  const int n = plane / s.c, c = plane - n * s.c;
+  double a, b;
+  channel_sums(partial, c, a, b);
+  const double md = a / (double)count;
+  double vd = b / (double)count - md * md;
+  if (vd < 0.0) vd = 0.0;
+  const float mu = (float)md, vf = (float)vd;
+  if (n == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    mean[c] = mu;
+    var[c] = vf;
+    if (running_mean) {
+      const double unb = count > 1 ? vd * (double)count / (double)(count - 1) : vd;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+  const float rstd = 1.f / sqrtf(vf + eps);
+  const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+  const float* xp = x + ((long)n * s.ctot + s.coff + c) * s.hw;
+  float* yp = y + ((long)n * y_ctot + y_coff + c) * s.hw;
+  const uint8_t* kp = keep ? keep + (long)plane * s.hw : nullptr;
+  for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < s.hw; p += gridDim.y * blockDim.x) {
+    float v = (xp[p] - mu) * rstd * g + bb;
+    v = cl4::apply_act(v, act, slope);
+    if (kp) v = kp[p] ? v * keep_scale : 0.f;
+    yp[p] = v;
+  }
+}
+
 // Derivative of the fused activation at pre-activation z (ReLU: [z > 0]; leaky: slope where z <= 0).
 __device__ __forceinline__ float act_grad(float d, float z, int act, float slope) {
   if (act == CL4_ACT_RELU) return z > 0.f ? d : 0.f;
@@ -185,6 +233,38 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ partial, float* _
   sum_dz_xh[i] = (float)b;
   if (dgamma) dgamma[i] += (float)b;
   if (dbeta) dbeta[i] += (float)a;
+}
+
+// bn_bwd_apply_kernel with the two channel sums taken from the partials in place; the first workgroup of image 0 adds them into
+// dgamma / dbeta.
+__global__ void bn_bwd_apply_fused_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                          const float* __restrict__ mean, const float* __restrict__ var,
+                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          const double* __restrict__ partial, float* dgamma, float* dbeta, float eps, int act,
+                                          float slope, float invn, BnShape s, int dy_ctot, int dy_coff,
+                                          const uint8_t* __restrict__ keep, float keep_scale) {
+  const int plane = blockIdx.x;
+  const int n = plane / s.c, c = plane - n * s.c;
+  double a, b;
+  channel_sums(partial, c, a, b);
+  if (n == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (dgamma) dgamma[c] += (float)b;
+    if (dbeta) dbeta[c] += (float)a;
+  }
+  const float rstd = 1.f / sqrtf(var[c] + eps);
+  const float mu = mean[c], g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+  const float sa = (float)a * invn, sb = (float)b * invn;
+  const float* xp = x + ((long)n * s.ctot + s.coff + c) * s.hw;
+  float* dxp = dx + ((long)n * s.ctot + s.coff + c) * s.hw;
+  const float* dp = dy + ((long)n * dy_ctot + dy_coff + c) * s.hw;
+  const uint8_t* kp = keep ? keep + (long)plane * s.hw : nullptr;
+  for (int p = blockIdx.y * blockDim.x + threadIdx.x; p < s.hw; p += gridDim.y * blockDim.x) {
+    float xh = (xp[p] - mu) * rstd;
+    float d = dp[p];
+    if (kp) d = kp[p] ? d * keep_scale : 0.f;
+    d = act_grad(d, xh * g + bb, act, slope);
+    dxp[p] = g * rstd * (d - sa - xh * sb);
+  }
 }
 
 // dx = gamma * rstd * (dz - sum_dz/N - xhat * sum_dz_xh/N)
@@ -324,11 +404,37 @@ extern "C" int cl4_bn_train_bwd(const float* x, const float* dy, float* dx, int 
   hipStream_t st = cl4::as_stream(stream);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
                      0.f, s, dy_ctot, dy_coff, keep, keep_scale);
+  static const bool fused = [] { const char* e = getenv("CL4_BN_FUSED_FINAL"); return !e || atoi(e) != 0; }();
+  if (fused) {
+    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, st, x, dy, dx, mean,
+                       var, gamma, beta, (const double*)partial, dgamma, dbeta, eps, act, 0.f, 1.f / (float)((long)n * hw), s, dy_ctot, dy_coff,
+                       keep, keep_scale);
+    return cl4::launch_status();
+  }
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, sums + c,
                      dgamma, dbeta, c);
-  long total = (long)n * c * hw;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, st, x, dy, dx, mean, var, gamma,
                      beta, sums, sums + c, eps, act, 0.f, 1.f / (float)((long)n * hw), s, dy_ctot, dy_coff, keep, keep_scale);
+  return cl4::launch_status();
+}
+
+// Train-mode BatchNorm forward in two launches (r03): partial sums, then normalise + activation with the statistics finalised inside
+// the elementwise pass (cl4_bn_train_stats + cl4_bn_apply are three). mean / var are outputs (the backward pass reads them).
+extern "C" int cl4_bn_train_fwd(const float* x, float* y, int n, int c, int hw, int x_ctot, int x_coff, int y_ctot, int y_coff,
+                                float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                                const float* gamma, const float* beta, float eps, int act, float slope, const uint8_t* keep,
+                                float keep_scale, void* workspace, size_t workspace_bytes, void* stream) {
+  BnShape s{n, c, hw, x_ctot, x_coff};
+  int rc = check_shape(s);
+  if (rc) return rc;
+  CL4_REQUIRE(x && y && mean && var && workspace, "bn_train_fwd: null pointer");
+  CL4_REQUIRE(y_coff >= 0 && y_coff + c <= y_ctot, "bn_train_fwd: output slice out of range");
+  if (workspace_bytes < cl4_bn_workspace_bytes(c)) { cl4::set_error("bn_train_fwd: workspace too small"); return CL4_ENOSPC; }
+  hipStream_t st = cl4::as_stream(stream);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, (double*)workspace, s);
+  hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, st, x, y,
+                     (const double*)workspace, mean, var, running_mean, running_var, momentum, (long)n * hw, gamma, beta, eps, act, slope, s,
+                     y_ctot, y_coff, keep, keep_scale);
   return cl4::launch_status();
 }
 

@@ -248,7 +248,16 @@ class _BnConvRec:
     __slots__ = ("x", "x_coff", "cin", "z", "mean", "var", "keep", "y")
 
 
+BN_FUSED_FINAL = __import__("os").environ.get("CL4_BN_FUSED_FINAL", "1") != "0"   # r03: statistics finalised inside the elementwise pass
+
+
 def _bn_train(z, bn, out=None, out_coff=0, keep=None, keep_scale=1.0):
+    if BN_FUSED_FINAL:
+        y, mean, var = ops.bn_train_fwd(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                        ops.ACT_RELU, keep=keep, keep_scale=keep_scale, out=out, out_coff=out_coff)
+        CACHE.touch(bn.running_mean)
+        CACHE.touch(bn.running_var)
+        return y, mean, var
     mean, var = ops.bn_train_stats(z, running_mean=bn.running_mean, running_var=bn.running_var, momentum=bn.momentum)
     CACHE.touch(bn.running_mean)
     CACHE.touch(bn.running_var)

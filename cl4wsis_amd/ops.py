@@ -708,6 +708,24 @@ def bn_train_stats(x, c=None, coff=0, running_mean=None, running_var=None, momen
     return mean, var
 
 
+def bn_train_fwd(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=ACT_RELU, slope=0.01, keep=None,
+                 keep_scale=1.0, c=None, x_coff=0, out=None, out_coff=0):
+    """bn_train_stats + bn_apply in two launches (cl4_bn_train_fwd): returns (y, mean, var)."""
+    n, x_ctot, h, w = x.shape
+    if c is None:
+        c = x_ctot - x_coff
+    if out is None:
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        out_coff = 0
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    var = torch.empty_like(mean)
+    ws = _workspace(x.device, bn_workspace_bytes(c))
+    call("cl4_bn_train_fwd", ptr(x), ptr(out), n, c, h * w, x_ctot, x_coff, out.shape[1], out_coff, ptr(mean), ptr(var),
+         ptr(running_mean), ptr(running_var), C.c_float(momentum), ptr(gamma), ptr(beta), C.c_float(eps), act, C.c_float(slope),
+         ptr(keep), C.c_float(keep_scale), ptr(ws), ws.numel(), stream())
+    return out, mean, var
+
+
 def bn_apply(x, mean, var, gamma, beta, eps=1e-5, act=ACT_RELU, slope=0.01, keep=None, keep_scale=1.0,
              c=None, x_coff=0, out=None, out_coff=0):
     n, x_ctot, h, w = x.shape

@@ -176,6 +176,13 @@ size_t cl4_bn_workspace_bytes(int c);
 int cl4_bn_train_stats(const float* x, int n, int c, int hw, int ctot, int coff, float* mean, float* var,
                        float* running_mean, float* running_var, float momentum,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* cl4_bn_train_stats + cl4_bn_apply in two launches instead of three (r03): the statistics are finalised inside the elementwise
+ * pass; mean / var are outputs (the backward pass reads them), running stats (may be NULL) are updated in place. Same module:
+ * train-mode nn.BatchNorm2d + ReLU (+ Dropout) of modules/panoptic_deeplab.py:26-28,44-46,74-76. */
+int cl4_bn_train_fwd(const float* x, float* y, int n, int c, int hw, int x_ctot, int x_coff, int y_ctot, int y_coff,
+                     float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                     const float* gamma, const float* beta, float eps, int act, float slope, const uint8_t* keep,
+                     float keep_scale, void* workspace, size_t workspace_bytes, void* stream);
 /* y = dropout(act((x-mean)/sqrt(var+eps)*gamma+beta)); keep: uint8 [n,c,hw] or NULL. */
 int cl4_bn_apply(const float* x, float* y, int n, int c, int hw, int x_ctot, int x_coff, int y_ctot, int y_coff,
                  const float* mean, const float* var, const float* gamma, const float* beta, float eps,
