@@ -97,9 +97,9 @@ class Trainer:
         # its own stream while batch t's step runs (it depends on nothing the optimizer touches). CL4_PIPELINE=0 switches it off.
         self._pipeline = os.environ.get("CL4_PIPELINE", "1") != "0" and self._side_stream is not None   # the fork needs a second stream
         self._pipe = None
-        # per-GPU batches below this stay on the one-graph path: measured +4.8 % at b = 16, +1-2 % at 8 / 4, -1.8 % at 2 (where the chip
-        # is far from full and the old model is better placed beside the new model's forward)
-        self._pipe_min_b = int(os.environ.get("CL4_PIPELINE_MIN_BATCH", "4"))
+        # per-GPU batches below this stay on the one-graph path: measured +4.8 % at b = 16, +1-2 % at 8 / 4; at 2 it was -1.8 % in r02
+        # and is +2.2 % with the r03 kernels (8.50 -> 8.31 ms)
+        self._pipe_min_b = int(os.environ.get("CL4_PIPELINE_MIN_BATCH", "2"))
         # where the next batch's old-model forward forks off: after the new model's body ("body") or head ("seg"). Measured (images/s):
         # body 362-364, head 361-362, after mod4 361-363, after mod3 349 = no pipelining: what pays is the overlap with the trainable
         # branch / backward, not with the new model's own convolutions.

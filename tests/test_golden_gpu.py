@@ -320,7 +320,7 @@ def test_pipelined_replay_matches_plain_graph_replay(gpu, monkeypatch):
     results = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("CL4_PIPELINE", mode)
-        monkeypatch.setenv("CL4_PIPELINE_MIN_BATCH", "1")       # the default keeps batches below 4 per GPU on the one-graph path
+        monkeypatch.setenv("CL4_PIPELINE_MIN_BATCH", "1")       # the default keeps a batch of 1 per GPU on the one-graph path
         torch.manual_seed(0)
         tr = Trainer(_L(), gpu, copy.deepcopy(opts))
         assert tr._pipeline == (mode == "1")
