@@ -112,6 +112,8 @@ _decl("cl4_copy_channels", _P, _P, _I, _I, _L, _I, _I, _I, _I, _P)
 _decl("cl4_bn_train_stats", _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, C.c_size_t, _P)
 _decl("cl4_bn_apply", _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _F, _P)
 _decl("cl4_bn_train_fwd", _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _F, _I, _F, _P, _F, _P, C.c_size_t, _P)
+_decl("cl4_bn_train_fwd_partials", _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _F, _I, _F, _P, _F, _P, _I, _P)
+_decl("cl4_dwconv5_fwd_stats", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P)
 _decl("cl4_bn_train_bwd", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P, _F, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_relu_bwd", _P, _P, _P, _L, _P)
 _decl("cl4_bias_grad", _P, _P, _I, _I, _I, _I, _I, _P)
@@ -219,6 +221,8 @@ def load():
     lib.cl4_stem_weight_bytes.argtypes = []
     lib.cl4_kpack_bytes.restype = C.c_size_t
     lib.cl4_kpack_bytes.argtypes = [C.c_int, C.c_int]
+    lib.cl4_dwconv5_stats_parts.restype = C.c_int
+    lib.cl4_dwconv5_stats_parts.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.cl4_input_ksize.restype = C.c_int
     lib.cl4_input_ksize.argtypes = [C.c_int, C.c_int]
     for name, args in PROTOTYPES.items():

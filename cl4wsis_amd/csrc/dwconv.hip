@@ -63,15 +63,25 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
 constexpr int SW = 60;       // output columns per wave
 constexpr int SROWS = 32;    // output rows per wave (upper bound; the launch uses equal chunks)
 
+// STATS (r03): the wave also sums its outputs and their squares in fp64 and writes the pair to
+// stats[(c * nparts + n * units_pad + unit) * 2 + {0, 1}] (nparts = n_images * units_pad) — the partial sums train-mode BatchNorm needs
+// of this tensor (cl4_bn_train_fwd_partials), so that the statistics pass does not read it back.
+template <bool STATS>
 __global__ __launch_bounds__(256) void dwconv5_strip_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
-                                                            float* __restrict__ y, DwArgs a, int strips_x, int srows) {
+                                                            float* __restrict__ y, DwArgs a, int strips_x, int srows,
+                                                            double* __restrict__ stats) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int plane = blockIdx.x;                // n * c + c
   const int n = plane / a.c, c = plane - n * a.c;
   const int unit = blockIdx.y * 4 + wave;      // (row chunk, strip)
   const int chunk = unit / strips_x, strip = unit - chunk * strips_x;
   const int r0 = chunk * srows;
-  if (r0 >= a.h) return;                       // wave-uniform, no barrier in this kernel
+  double s1 = 0.0, s2 = 0.0;
+  const long spos = STATS ? ((long)c * ((long)a.n * gridDim.y * 4) + (long)n * gridDim.y * 4 + unit) * 2 : 0;
+  if (r0 >= a.h) {                             // wave-uniform, no barrier in this kernel
+    if (STATS && lane == 0) { stats[spos] = 0.0; stats[spos + 1] = 0.0; }
+    return;
+  }
   const int r1 = min(a.h, r0 + srows);
   const int xs = strip * SW - 2 + lane;        // this lane's column
   const bool xin = (unsigned)xs < (unsigned)a.w;
@@ -114,8 +124,14 @@ __global__ __launch_bounds__(256) void dwconv5_strip_kernel(const float* __restr
 #pragma unroll
           for (int kx = 0; kx < 5; ++kx) acc = fmaf(wr[ky * 5 + kx], win[ky][kx], acc);
         if (xout) yp[(long)oy * a.w + xs] = acc;
+        if (STATS && xout) { s1 += (double)acc; s2 += (double)acc * (double)acc; }
       }
     }
+  }
+  if (STATS) {
+    s1 = cl4::wave_sum_d(s1);
+    s2 = cl4::wave_sum_d(s2);
+    if (lane == 0) { stats[spos] = s1; stats[spos + 1] = s2; }
   }
 }
 
@@ -257,8 +273,33 @@ extern "C" int cl4_dwconv5_fwd(const float* x, const float* w, float* y, int n, 
     const int srows = cl4::cdiv(h, cl4::cdiv(h, SROWS));      // equal chunks of <= SROWS rows (129 rows: 5 x 26, not 4 x 32 + 1)
     const int units = strips_x * cl4::cdiv(h, srows);
     dim3 g((unsigned)n * c, cl4::cdiv(units, 4));
-    hipLaunchKernelGGL(dwconv5_strip_kernel, g, dim3(256), 0, cl4::as_stream(stream), x, w, y, a, strips_x, srows);
+    hipLaunchKernelGGL(dwconv5_strip_kernel<false>, g, dim3(256), 0, cl4::as_stream(stream), x, w, y, a, strips_x, srows, (double*)nullptr);
   }
+  return cl4::launch_status();
+}
+
+// Partial sums per channel cl4_dwconv5_fwd_stats writes for an n x (h x w) launch (the `nparts` of cl4_bn_train_fwd_partials).
+extern "C" int cl4_dwconv5_stats_parts(int n, int h, int wd) {
+  const int strips_x = cl4::cdiv(wd, SW);
+  const int srows = cl4::cdiv(h, cl4::cdiv(h, SROWS));
+  const int units = strips_x * cl4::cdiv(h, srows);
+  return n * cl4::cdiv(units, 4) * 4;
+}
+
+// cl4_dwconv5_fwd (flip = 0) that also leaves the per-channel partial sums {sum y, sum y^2} of its output in `stats`
+// (c * cl4_dwconv5_stats_parts(n, h, w) pairs of doubles): the depthwise 5x5 convolutions of the trainable instance decoder / heads are
+// followed by a train-mode BatchNorm (modules/panoptic_deeplab.py:26-28,44-46), whose statistics pass then need not read y again.
+extern "C" int cl4_dwconv5_fwd_stats(const float* x, const float* w, float* y, int n, int c, int h, int wd, int x_ctot, int x_coff,
+                                     int y_ctot, int y_coff, double* stats, void* stream) {
+  DwArgs a{n, c, h, wd, x_ctot, x_coff, y_ctot, y_coff, 0};
+  int rc = check(a);
+  if (rc) return rc;
+  CL4_REQUIRE(x && w && y && stats, "dwconv5_fwd_stats: null pointer");
+  const int strips_x = cl4::cdiv(wd, SW);
+  const int srows = cl4::cdiv(h, cl4::cdiv(h, SROWS));
+  const int units = strips_x * cl4::cdiv(h, srows);
+  dim3 g((unsigned)n * c, cl4::cdiv(units, 4));
+  hipLaunchKernelGGL(dwconv5_strip_kernel<true>, g, dim3(256), 0, cl4::as_stream(stream), x, w, y, a, strips_x, srows, stats);
   return cl4::launch_status();
 }
 

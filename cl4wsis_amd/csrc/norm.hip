@@ -51,10 +51,14 @@ __global__ void bn_stats_partial_kernel(const float* __restrict__ x, double* __r
 // {sum a, sum b} of channel c over its SPLIT partials, computed by every wave for itself: lanes 0 .. SPLIT-1 load one partial each,
 // a butterfly adds them (r03: the per-channel "final" kernels between the reduction and the elementwise pass are gone — 36 launches
 // of ~6 us per step on the critical path; every workgroup of the elementwise pass redoes this 32-term sum, in one fixed order)
-__device__ __forceinline__ void channel_sums(const double* __restrict__ partial, int c, double& a, double& b) {
+__device__ __forceinline__ void channel_sums(const double* __restrict__ partial, int c, double& a, double& b, int nparts = SPLIT) {
   const int lane = threadIdx.x & 63;
-  a = lane < SPLIT ? partial[((long)c * SPLIT + lane) * 2 + 0] : 0.0;
-  b = lane < SPLIT ? partial[((long)c * SPLIT + lane) * 2 + 1] : 0.0;
+  a = 0.0;
+  b = 0.0;
+  for (int i = lane; i < nparts; i += 64) {              // nparts = SPLIT (the reduction kernels of this file), or what a producer wrote
+    a += partial[((long)c * nparts + i) * 2 + 0];
+    b += partial[((long)c * nparts + i) * 2 + 1];
+  }
   a = cl4::wave_sum_d(a);
   b = cl4::wave_sum_d(b);
 }
@@ -146,11 +150,11 @@ __global__ void bn_apply_fused_kernel(const float* __restrict__ x, float* __rest
                                       float* __restrict__ mean, float* __restrict__ var, float* running_mean, float* running_var,
                                       float momentum, long count, const float* __restrict__ gamma, const float* __restrict__ beta,
                                       float eps, int act, float slope, BnShape s, int y_ctot, int y_coff,
-                                      const uint8_t* __restrict__ keep, float keep_scale) {
+                                      const uint8_t* __restrict__ keep, float keep_scale, int nparts) {
   const int plane = blockIdx.x;
   const int n = plane / s.c, c = plane - n * s.c;
   double a, b;
-  channel_sums(partial, c, a, b);
+  channel_sums(partial, c, a, b, nparts);
   const double md = a / (double)count;
   double vd = b / (double)count - md * md;
   if (vd < 0.0) vd = 0.0;
@@ -434,7 +438,24 @@ extern "C" int cl4_bn_train_fwd(const float* x, float* y, int n, int c, int hw, 
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, (double*)workspace, s);
   hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, st, x, y,
                      (const double*)workspace, mean, var, running_mean, running_var, momentum, (long)n * hw, gamma, beta, eps, act, slope, s,
-                     y_ctot, y_coff, keep, keep_scale);
+                     y_ctot, y_coff, keep, keep_scale, SPLIT);
+  return cl4::launch_status();
+}
+
+// The same with the partial sums already made by the kernel that PRODUCED x (cl4_dwconv5_fwd_stats: `nparts` pairs {sum, sum of squares}
+// per channel, partial[(c * nparts + i) * 2 + {0, 1}]): one launch, x is read once instead of twice.
+extern "C" int cl4_bn_train_fwd_partials(const float* x, float* y, int n, int c, int hw, int x_ctot, int x_coff, int y_ctot, int y_coff,
+                                         float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                                         const float* gamma, const float* beta, float eps, int act, float slope, const uint8_t* keep,
+                                         float keep_scale, const double* partial, int nparts, void* stream) {
+  BnShape s{n, c, hw, x_ctot, x_coff};
+  int rc = check_shape(s);
+  if (rc) return rc;
+  CL4_REQUIRE(x && y && mean && var && partial && nparts > 0, "bn_train_fwd_partials: null pointer");
+  CL4_REQUIRE(y_coff >= 0 && y_coff + c <= y_ctot, "bn_train_fwd_partials: output slice out of range");
+  hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, cl4::as_stream(stream),
+                     x, y, partial, mean, var, running_mean, running_var, momentum, (long)n * hw, gamma, beta, eps, act, slope, s, y_ctot, y_coff,
+                     keep, keep_scale, nparts);
   return cl4::launch_status();
 }
 

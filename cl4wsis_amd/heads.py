@@ -251,10 +251,10 @@ class _BnConvRec:
 BN_FUSED_FINAL = __import__("os").environ.get("CL4_BN_FUSED_FINAL", "1") != "0"   # r03: statistics finalised inside the elementwise pass
 
 
-def _bn_train(z, bn, out=None, out_coff=0, keep=None, keep_scale=1.0):
+def _bn_train(z, bn, out=None, out_coff=0, keep=None, keep_scale=1.0, partials=None):
     if BN_FUSED_FINAL:
         y, mean, var = ops.bn_train_fwd(z, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                        ops.ACT_RELU, keep=keep, keep_scale=keep_scale, out=out, out_coff=out_coff)
+                                        ops.ACT_RELU, keep=keep, keep_scale=keep_scale, out=out, out_coff=out_coff, partials=partials)
         CACHE.touch(bn.running_mean)
         CACHE.touch(bn.running_var)
         return y, mean, var
@@ -339,8 +339,12 @@ class InstanceBranch:
     def _dwsep_train(self, x, seq, tape):
         blk = seq[0]
         dw, bn0, pw, bn1 = blk[0][0], blk[0][1], blk[1], blk[2]
-        z0 = ops.dwconv5(x, dw.weight.detach())
-        a, m0, v0 = _bn_train(z0, bn0)
+        if BN_FUSED_FINAL:        # the depthwise kernel leaves the partial sums of its output: BatchNorm reads z0 once
+            z0, part, nparts = ops.dwconv5_stats(x, dw.weight.detach())
+            a, m0, v0 = _bn_train(z0, bn0, partials=(part, nparts))
+        else:
+            z0 = ops.dwconv5(x, dw.weight.detach())
+            a, m0, v0 = _bn_train(z0, bn0)
         z1 = ops.conv2d(a, packed_weight(pw, TRAIN_PRECISION), 1)
         y, m1, v1 = _bn_train(z1, bn1)
         tape.append(("dwsep", blk, x, z0, m0, v0, a, z1, m1, v1))

@@ -709,8 +709,9 @@ def bn_train_stats(x, c=None, coff=0, running_mean=None, running_var=None, momen
 
 
 def bn_train_fwd(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=ACT_RELU, slope=0.01, keep=None,
-                 keep_scale=1.0, c=None, x_coff=0, out=None, out_coff=0):
-    """bn_train_stats + bn_apply in two launches (cl4_bn_train_fwd): returns (y, mean, var)."""
+                 keep_scale=1.0, c=None, x_coff=0, out=None, out_coff=0, partials=None):
+    """bn_train_stats + bn_apply in two launches (cl4_bn_train_fwd): returns (y, mean, var). `partials` = (tensor, nparts) from the
+    kernel that produced x (dwconv5_stats): one launch, x is not read for its statistics."""
     n, x_ctot, h, w = x.shape
     if c is None:
         c = x_ctot - x_coff
@@ -719,6 +720,11 @@ def bn_train_fwd(x, gamma, beta, running_mean=None, running_var=None, momentum=0
         out_coff = 0
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     var = torch.empty_like(mean)
+    if partials is not None:
+        call("cl4_bn_train_fwd_partials", ptr(x), ptr(out), n, c, h * w, x_ctot, x_coff, out.shape[1], out_coff, ptr(mean), ptr(var),
+             ptr(running_mean), ptr(running_var), C.c_float(momentum), ptr(gamma), ptr(beta), C.c_float(eps), act, C.c_float(slope),
+             ptr(keep), C.c_float(keep_scale), ptr(partials[0]), partials[1], stream())
+        return out, mean, var
     ws = _workspace(x.device, bn_workspace_bytes(c))
     call("cl4_bn_train_fwd", ptr(x), ptr(out), n, c, h * w, x_ctot, x_coff, out.shape[1], out_coff, ptr(mean), ptr(var),
          ptr(running_mean), ptr(running_var), C.c_float(momentum), ptr(gamma), ptr(beta), C.c_float(eps), act, C.c_float(slope),
@@ -846,6 +852,19 @@ def dwconv5(x, w, flip=False, c=None, x_coff=0, out=None, out_coff=0):
         out_coff = 0
     call("cl4_dwconv5_fwd", ptr(x), ptr(w), ptr(out), n, c, h, wd, x_ctot, x_coff, out.shape[1], out_coff, int(flip), stream())
     return out
+
+
+def dwconv5_stats(x, w):
+    """dwconv5 (whole tensor) that also returns the per-channel partial sums of its output for the train-mode BatchNorm behind it:
+    (y, partial, nparts) — hand (partial, nparts) to bn_train_fwd(partials=...)."""
+    n, c, h, wd = x.shape
+    if tuple(w.shape) != (c, 1, 5, 5):
+        raise RuntimeError(f"dwconv5_stats: weight shape {tuple(w.shape)} != {(c, 1, 5, 5)}")
+    out = torch.empty((n, c, h, wd), dtype=torch.float32, device=x.device)
+    nparts = _hip.load().cl4_dwconv5_stats_parts(n, h, wd)
+    partial = torch.empty(c * nparts * 2, dtype=torch.float64, device=x.device)
+    call("cl4_dwconv5_fwd_stats", ptr(x), ptr(w), ptr(out), n, c, h, wd, c, 0, c, 0, ptr(partial), stream())
+    return out, partial, nparts
 
 
 def dwconv5_wgrad_(dw, x, dy, c=None, x_coff=0, dy_coff=0):

@@ -230,6 +230,17 @@ int cl4_dropout_mask_dev(uint8_t* keep, long n, uint64_t* seed_dev, uint64_t adv
  * ------------------------------------------------------------------------ */
 int cl4_dwconv5_fwd(const float* x, const float* w, float* y, int n, int c, int h, int wd,
                     int x_ctot, int x_coff, int y_ctot, int y_coff, int flip, void* stream);
+/* The same forward (flip = 0) that also writes the per-channel partial sums {sum y, sum y^2} of its output (fp64 pairs,
+ * stats[(c * nparts + i) * 2 + {0, 1}], nparts = cl4_dwconv5_stats_parts(n, h, w)), and the train-mode BatchNorm forward that starts
+ * from such partials (r03): the BatchNorm behind a depthwise convolution (modules/panoptic_deeplab.py:26-28,44-46) reads the
+ * activation once instead of twice. */
+int cl4_dwconv5_stats_parts(int n, int h, int w);
+int cl4_dwconv5_fwd_stats(const float* x, const float* w, float* y, int n, int c, int h, int wd, int x_ctot, int x_coff,
+                          int y_ctot, int y_coff, double* stats, void* stream);
+int cl4_bn_train_fwd_partials(const float* x, float* y, int n, int c, int hw, int x_ctot, int x_coff, int y_ctot, int y_coff,
+                              float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                              const float* gamma, const float* beta, float eps, int act, float slope, const uint8_t* keep,
+                              float keep_scale, const double* partial, int nparts, void* stream);
 int cl4_dwconv5_wgrad(const float* x, const float* dy, float* dw, int n, int c, int h, int wd,
                       int x_ctot, int x_coff, int dy_ctot, int dy_coff, void* stream);
 

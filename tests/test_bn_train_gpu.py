@@ -56,3 +56,29 @@ def test_bn_train_forward_backward_fused_final(gpu, case):
     assert err < 2e-5, err
     assert ((dg.cpu().double() - 0.25) - gr.grad).abs().max().item() < 2e-4 * max(1.0, gr.grad.abs().max().item())
     assert ((db.cpu().double() + 0.5) - br.grad).abs().max().item() < 2e-4 * max(1.0, br.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 33, 33), (3, 8, 129, 65), (16, 5, 9, 7), (1, 40, 130, 190)])
+def test_dwconv5_leaves_the_partial_sums_batchnorm_needs(gpu, shape):
+    """cl4_dwconv5_fwd_stats + cl4_bn_train_fwd_partials (the depthwise 5x5 -> train-mode BatchNorm -> ReLU pairs of the trainable
+    decoder / heads, modules/panoptic_deeplab.py:26-28,44-46) against the separate kernels: same convolution bit for bit, same statistics."""
+    from cl4wsis_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(n, c, h, w, generator=g) * 1.5 + 0.2).to(gpu)
+    wt = (torch.randn(c, 1, 5, 5, generator=g) * 0.2).to(gpu)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(gpu), (torch.randn(c, generator=g) * 0.1).to(gpu)
+    z_ref = ops.dwconv5(x, wt)
+    z, part, nparts = ops.dwconv5_stats(x, wt)
+    assert torch.equal(z, z_ref)
+    rm, rv = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
+    y, mean, var = ops.bn_train_fwd(z, gamma, beta, rm, rv, 0.1, 1e-5, ops.ACT_RELU, partials=(part, nparts))
+    rm2, rv2 = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
+    y2, mean2, var2 = ops.bn_train_fwd(z_ref, gamma, beta, rm2, rv2, 0.1, 1e-5, ops.ACT_RELU)
+    torch.cuda.synchronize()
+    zd = z_ref.double()
+    assert (mean.double() - zd.mean(dim=(0, 2, 3))).abs().max().item() < 1e-6
+    assert (var.double() - zd.var(dim=(0, 2, 3), unbiased=False)).abs().max().item() < 1e-5 * max(1.0, var.max().item())
+    assert torch.allclose(mean, mean2, rtol=0, atol=1e-7) and torch.allclose(var, var2, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(rm, rm2, rtol=0, atol=1e-7) and torch.allclose(rv, rv2, rtol=1e-6, atol=1e-7)
+    assert (y - y2).abs().max().item() < 1e-5
