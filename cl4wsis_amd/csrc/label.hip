@@ -249,12 +249,44 @@ __global__ __launch_bounds__(256) void peak_nms_kernel(const float* __restrict__
 }
 
 // top-K of the n = tiles*K slots of one (b, c): value descending, ties by ascending flat index.
+// LDSK > 0 (r03): the candidates' keys are loaded into LDS once (LDSK of them at most) and the K selection passes run there — the
+// global-memory form below re-read the list twice per pass from 80 workgroups (b * c), a chain of 50 dependent sweeps: 0.25 ms per step.
+template <int LDSK>
 __global__ __launch_bounds__(256) void peak_topk_kernel(PeakCand* __restrict__ cand, int n, int W,
                                                         int K, float* __restrict__ conf, int* __restrict__ ys,
                                                         int* __restrict__ xs) {
   __shared__ unsigned long long best[4];
   const int bc = blockIdx.x;
   PeakCand* cl = cand + (long)bc * n;
+  if constexpr (LDSK > 0) {
+    __shared__ unsigned long long keys[LDSK];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const float v = cl[i].v;
+      keys[i] = v > 0.f ? peak_key(v, cl[i].idx) : 0ull;
+    }
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+      unsigned long long key = 0ull;
+      for (int i = threadIdx.x; i < n; i += blockDim.x) key = keys[i] > key ? keys[i] : key;
+      key = block_max_key(key, best);
+      float v = 0.f;
+      int idx = 0;
+      if (key != 0ull) {
+        v = __uint_as_float((unsigned)(key >> 32));
+        idx = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu));
+        const unsigned low = (unsigned)(key & 0xFFFFFFFFu);
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+          if (keys[i] != 0ull && (unsigned)(keys[i] & 0xFFFFFFFFu) == low) keys[i] = 0ull;     // remove the winner (every copy of that pixel)
+      }
+      if (threadIdx.x == 0) {
+        conf[(long)bc * K + k] = v;
+        ys[(long)bc * K + k] = idx / W;
+        xs[(long)bc * K + k] = idx % W;
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (int k = 0; k < K; ++k) {
     unsigned long long key = 0ull;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -621,7 +653,8 @@ extern "C" int cl4_peak_extract(const float* cam, const float* label_new, int b,
   const int tiles = cl4::cdiv(H, PT) * cl4::cdiv(W, PT);
   dim3 g(tiles, c, b);
   hipLaunchKernelGGL(peak_nms_kernel, g, dim3(256), lds, st, cam, h, w, H, W, (kernel - 1) / 2, K, label_new, cand);
-  hipLaunchKernelGGL(peak_topk_kernel, dim3(b * c), dim3(256), 0, st, cand, tiles * K, W, K, conf, ys, xs);
+  if (tiles * K <= 7680) hipLaunchKernelGGL(peak_topk_kernel<7680>, dim3(b * c), dim3(256), 0, st, cand, tiles * K, W, K, conf, ys, xs);      // 60 KB of keys (513 x 513, K = 25: 7225)
+  else hipLaunchKernelGGL(peak_topk_kernel<0>, dim3(b * c), dim3(256), 0, st, cand, tiles * K, W, K, conf, ys, xs);
   return cl4::launch_status();
 }
 
