@@ -1788,7 +1788,7 @@ __global__ __launch_bounds__(2 * NTHREADS) void conv_wgrad_bf16(WgradArgs a) {
             *reinterpret_cast<u32x2w*>(base + 2 * rows_total * BKP + idx) = u32x2w{pk2(s0, s1), pk2(s2, s3)};
           }
         };
-        // hipcc narrows some of these b128 loads to their first dword although all four elements are read (DESIGN.md finding 15; here:
+        // hipcc narrows some of these b128 loads to their first dword although all four elements are read (FINDINGS.md finding 15; here:
         // every load of register set 0). An empty asm that "modifies" the whole vector at its point of use keeps all elements demanded
         // without forcing a wait where the load is issued.
 #pragma unroll

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_p_bf16x3(ConvArgs a) {
   pv.m0 = 0; pv.pix[0] = pv.pix[1] = OOB;
   int pv_par = 0;                                          // which half of `affine` belongs to the previous tile
   unsigned long long rres[2][2][2];                        // residual half-chunks: [buffer c & 1][j][plane]. 64-bit scalars, not 2-vectors: element 1 of a
-                                                           // vector made from the b64 load builtin's result reads element 0 with this hipcc (DESIGN finding 15, third form)
+                                                           // vector made from the b64 load builtin's result reads element 0 with this hipcc (FINDINGS.md finding 15, third form)
   auto ctx_of_current = [&]() {
     TileCtx t;
     t.m0 = m0;

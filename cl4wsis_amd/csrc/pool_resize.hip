@@ -33,7 +33,7 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
-// The same pooling with two wave-loads per output row instead of nine (DESIGN.md finding 22: a CU retires one wave-load per ~16 cycles
+// The same pooling with two wave-loads per output row instead of nine (FINDINGS.md finding 22: a CU retires one wave-load per ~16 cycles
 // whatever its width, and thread-per-output issues 9 stride-2 dword loads). Workgroup = (plane, band of MPB output rows), thread =
 // output column: per input row ONE unaligned 16-byte buffer load fetches columns 2ox-1 .. 2ox+2 (neighbouring lanes overlap by half;
 // the lines are in L1), its horizontal max is kept, and the vertical window slides: output row oy = max(rows 2oy-1, 2oy, 2oy+1), the

@@ -261,11 +261,19 @@ CONV_B = os.environ.get("CL4_CONV_B", "1") != "0"      # r03: the tuner may pick
 PLANES_TILES = [int(v) for v in os.environ.get("CL4_PLANES_TILES", "128,144").split(",")]   # pixel widths of the planes kernel's tiles the tuner may pick (64 is built too: three workgroups per CU, measured no faster — profiles/r03_conv_s_tile64.txt)
 
 
+def _planes_key(d):
+    return (d.n, d.cin, d.hin, d.win, d.cout, d.kh, d.stride, d.pad, d.dil, d.precision, torch.cuda.current_device())
+
+
+def _planes_tuned(d):
+    return _planes_key(d) in _tuned
+
+
 def _autotune_planes(d, args, reps=6):
     """_autotune_conv for the planes-input entry point: 128 output channels x 128 or 144 pixels per tile (144: the 33 x 33 maps fill
     one round of resident workgroups, conv_s.hip), each unsplit, K-split, or main + split tail."""
     dev = torch.cuda.current_device()
-    key = (d.n, d.cin, d.hin, d.win, d.cout, d.kh, d.stride, d.pad, d.dil, d.precision, dev)
+    key = _planes_key(d)
     if key in _tuned:
         return
     lib = _hip.load()
@@ -293,29 +301,28 @@ def _autotune_planes(d, args, reps=6):
                                             # the chip (impl 5 = the same tile as four waves of 64 rows is built and tested, but never faster)
     for impl, tile, splits in cands:
         tiles = -(-d.cout // 128) * -(-npix // tile)
-        if True:
-            if splits == -1 or abs(splits) > max(1, K // 64):
-                continue
-            if splits > 1 and tiles >= 256 and d.n < _FULL_SPLITS_MIN_N:      # whole-launch splits only where a launch cannot fill the chip (_fills_the_chip)
-                continue
-            call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, tile, splits)
-            need = lib.cl4_conv2d_fwd_workspace_bytes(C.byref(d))
-            sig = (impl, tile, need, splits < 0)
-            if sig in seen or need > (1 << 30):
-                continue
-            seen.add(sig)
-            ws = _conv_workspace(torch.device("cuda", dev), need) if need else None
-            run = lambda: call("cl4_conv2d_fwd_planes", C.byref(d), *args, ptr(ws), need, stream())
+        if splits == -1 or abs(splits) > max(1, K // 64):
+            continue
+        if splits > 1 and tiles >= 256 and d.n < _FULL_SPLITS_MIN_N:      # whole-launch splits only where a launch cannot fill the chip (_fills_the_chip)
+            continue
+        call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, tile, splits)
+        need = lib.cl4_conv2d_fwd_workspace_bytes(C.byref(d))
+        sig = (impl, tile, need, splits < 0)
+        if sig in seen or need > (1 << 30):
+            continue
+        seen.add(sig)
+        ws = _conv_workspace(torch.device("cuda", dev), need) if need else None
+        run = lambda: call("cl4_conv2d_fwd_planes", C.byref(d), *args, ptr(ws), need, stream())
+        run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
             run()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                run()
-            e1.record()
-            e1.synchronize()
-            ms = e0.elapsed_time(e1) / reps
-            if ms < best_ms:
-                best, best_ms = (impl, tile, splits), ms
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        if ms < best_ms:
+            best, best_ms = (impl, tile, splits), ms
     call("cl4_conv2d_fwd_set_plan", C.byref(d), *best)
     _tuned[key] = (best, best_ms)
 
@@ -473,12 +480,16 @@ def conv2d_planes(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre
         e0.record()
     args = (ptr(xs.data), ptr(wp.data), ptr(scale), ptr(shift), ptr(pre), ptr(post_f), ptr(post_s.data) if post_s is not None else None,
             ptr(out), ptr(out_planes.data) if out_planes is not None else None)
-    if AUTOTUNE:
-        targs = args
+    if AUTOTUNE and not _planes_tuned(d):
+        targs, scratch = args, None
         if post_s is not None and out_planes is not None and out_planes.data.data_ptr() == post_s.data.data_ptr():
-            # in-place residual (the output overwrites the residual operand): the tuner's repeated launches must not touch it
-            targs = args[:8] + (ptr(Planes(out_planes.n, out_planes.c, out_planes.h, out_planes.w, dev).data),)
+            # in-place residual (the output overwrites the residual operand): the tuner's repeated launches must not touch it. The scratch
+            # output is held in a local until the tuner returns (a temporary's block goes back to the caching allocator at once
+            # and `_conv_workspace` inside the tuner could be handed the same memory)
+            scratch = Planes(out_planes.n, out_planes.c, out_planes.h, out_planes.w, dev)
+            targs = args[:8] + (ptr(scratch.data),)
         _autotune_planes(d, targs)
+        del scratch
     need = _hip.load().cl4_conv2d_fwd_workspace_bytes(C.byref(d))
     ws = _conv_workspace(dev, need) if need else None
     call("cl4_conv2d_fwd_planes", C.byref(d), *args, ptr(ws), need, stream())

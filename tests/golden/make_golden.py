@@ -29,6 +29,13 @@ from oracle import synth, weights  # noqa: E402
 
 CROP = 65
 MODEL_SEED = 1
+OUT = None      # `--out DIR` (or a caller's out_dir=) redirects every fixture; read at CALL time, so a regeneration into a scratch
+                # directory cannot touch the committed files
+
+
+def _dir(out_dir=None):
+    return out_dir or OUT or HERE
+
 INSMAP_CASES = [(0, 129, 129, False), (3, 129, 129, True), (6, 161, 145, True)]
 LABEL_CASES = [(0, 2, 129, 129), (3, 3, 129, 129), (5, 2, 97, 145), (6, 2, 193, 193), (7, 2, 513, 513)]
 
@@ -44,23 +51,35 @@ def ref_opts(R, crop):
     return ap.modify_command_options(ap.get_argparser().parse_args(args))
 
 
-def model_fixture(R):
+THREE_HEAD_CASES = {      # fname -> (task, step, classes, model seed, input seed, labelled classes per image (0-based, no background))
+    "model_p2_3h_c65.npz": ("10-5", 2, [11, 5, 5], MODEL_SEED + 30, 35, ((16,), (15, 19))),      # scripts/run_10-5.sh:46-60
+    "model_p2_4h_c65.npz": ("15-1", 3, [16, 1, 1, 1], MODEL_SEED + 40, 45, ((17,), (17,))),      # tasks.py:108-117
+}
+
+
+def model_fixture(R, out_dir=None, fname="model_p2_c65.npz", task="15-5", classes=(16, 5), model_seed=MODEL_SEED, x_seed=5,
+                  labels=((16,), (15, 19)), full=True):
+    """The reference's phase-2 networks for one class layout. `full=False` (the >= 3-head layouts): the large feature maps are left
+    out of the fixture, everything the classifier heads / the instance head's per-step convolutions touch is kept."""
+    out_dir = _dir(out_dir)
+    classes = list(classes)
+    tot = sum(classes)
     opts = ref_opts(R, CROP)
+    opts.task = task
     sm, wm = R["segmentation_module"], R["wss_modules"]
     torch.manual_seed(0)
-    new = sm.make_model(opts, classes=[16, 5])
-    old = sm.make_model(opts, classes=[16])
-    pl = wm.PseudoLabeler(2048, 21, sm.get_norm(opts))
-    pg = wm.PeakGenerator(in_channel=21, num_classes=20, old_classes=15)
-    for m, seed in ((new, MODEL_SEED), (old, MODEL_SEED + 1), (pl, MODEL_SEED + 2), (pg, MODEL_SEED + 3)):
+    new = sm.make_model(opts, classes=classes)
+    old = sm.make_model(opts, classes=classes[:-1])
+    pl = wm.PseudoLabeler(2048, tot, sm.get_norm(opts))
+    pg = wm.PeakGenerator(in_channel=tot, num_classes=tot - 1, old_classes=tot - classes[-1] - 1)
+    for m, seed in ((new, model_seed), (old, model_seed + 1), (pl, model_seed + 2), (pg, model_seed + 3)):
         m.load_state_dict(weights.fill_(m.state_dict(), seed=seed))
-    g = torch.Generator().manual_seed(5)
+    g = torch.Generator().manual_seed(x_seed)
     x = torch.randn(2, 3, CROP, CROP, generator=g)
-    l1h = torch.zeros(2, 20)
-    l1h[0, 16] = 1
-    l1h[1, 15] = 1
-    l1h[1, 19] = 1
-    out = {}
+    l1h = torch.zeros(2, tot - 1)           # LabelSelection keeps the classes seen so far (dataset/dataset.py:269-284)
+    for i, cs in enumerate(labels):
+        l1h[i, list(cs)] = 1
+    out = {} if full else {"classes": np.array(classes)}
     old.eval()
     with torch.no_grad():
         o_old, _ = old(x, interpolate=False)
@@ -71,7 +90,7 @@ def model_fixture(R):
     with torch.no_grad():
         o2, f2 = new.forward_seg(torch.cat([x, x.flip(-1)], 0), interpolate=False)
     out["seg2b"] = o2["seg"].numpy()
-    for k in ("res2", "res5"):
+    for k in (("res2", "res5") if full else ()):
         out[f"feat_{k}"] = f2["features"][k][:2].numpy()
     feats = {k: v[:2].detach().clone() for k, v in f2["features"].items()}
     drop = new.decoder.instance_decoder.aspp.project[3]
@@ -105,8 +124,13 @@ def model_fixture(R):
         cam = R["wss_utils"].smoothing(cam)
     out["cam_lo"] = cam.numpy()
     out["l1h"] = l1h.numpy()
-    np.savez_compressed(os.path.join(HERE, "model_p2_c65.npz"), **out)
-    print("model_p2_c65.npz", {k: getattr(v, "shape", None) for k, v in out.items() if k != "grad_names"})
+    np.savez_compressed(os.path.join(out_dir, fname), **out)
+    print(fname, {k: getattr(v, "shape", None) for k, v in out.items() if k != "grad_names"})
+
+
+def three_head_fixtures(R, out_dir=None):
+    for fname, (task, step, classes, ms, xs, labels) in THREE_HEAD_CASES.items():
+        model_fixture(R, out_dir=out_dir, fname=fname, task=task, classes=classes, model_seed=ms, x_seed=xs, labels=labels, full=False)
 
 
 def model_p1_fixture(R):
@@ -142,7 +166,7 @@ def model_p1_fixture(R):
     out["rm_mod5"] = new.body.mod5.block3.convs.bn3.running_mean.numpy().copy()
     out["rv_head"] = new.head.red_bn.running_var.numpy().copy()
     out["rm_pl"] = pl.norm2.running_mean.numpy().copy()
-    np.savez_compressed(os.path.join(HERE, "model_p1_c65.npz"), **out)
+    np.savez_compressed(os.path.join(_dir(), "model_p1_c65.npz"), **out)
     print("model_p1_c65.npz", {k: getattr(v, "shape", None) for k, v in out.items() if k != "grad_names"})
 
 
@@ -155,7 +179,7 @@ def insmap_fixture(R, seed, H, W, flip):
     out = {"seg": seg.clone(), "center": center.clone(), "offset": offset.clone()}
     seg_map, lab, msk, sc = du.get_ins_map(out, False, (H, W), torch.device("cpu"), args)
     order = np.lexsort((msk.reshape(len(msk), -1).argmax(1), lab))
-    np.savez_compressed(os.path.join(HERE, f"insmap_s{seed:02d}.npz"), case=np.array([seed, H, W, int(flip)]),
+    np.savez_compressed(os.path.join(_dir(), f"insmap_s{seed:02d}.npz"), case=np.array([seed, H, W, int(flip)]),
                         seg_map=seg_map.astype(np.uint8), labels=lab[order],
                         masks=np.packbits(msk[order].astype(np.uint8)), n=len(lab), scores=sc[order])
     print(f"insmap_s{seed:02d}.npz", len(lab), "instances, classes", np.unique(lab))
@@ -185,7 +209,7 @@ def wrn_fixture(R):
         out["feat_" + k + "_shape"] = np.array(v.shape)
         out["feat_" + k + "_slice"] = v[:, ::17, ::3, ::3].numpy().copy()
         out["feat_" + k + "_norm"] = np.array(v.double().norm().item())
-    np.savez_compressed(os.path.join(HERE, "model_wrn38_c65.npz"), **out)
+    np.savez_compressed(os.path.join(_dir(), "model_wrn38_c65.npz"), **out)
     print("model_wrn38_c65.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
@@ -225,7 +249,7 @@ def dataset_fixture(R, seed, H, W, size, step, masking):
         out.update({f"in_img{k}": i, f"in_seg{k}": s, f"in_mask{k}": m, f"in_l1h{k}": l,
                     f"img{k}": img.numpy(), f"seg_map{k}": seg_map.numpy(), f"center{k}": center, f"offset{k}": offset,
                     f"weight{k}": weight, f"l1h{k}": np.asarray(l1h)})
-    path = os.path.join(HERE, f"dataset_s{seed:02d}.npz")
+    path = os.path.join(_dir(), f"dataset_s{seed:02d}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
@@ -233,7 +257,7 @@ def dataset_fixture(R, seed, H, W, size, step, masking):
 LABEL_EDGE_CASES = sorted(synth.EDGE_FIXTURES)      # hand-placed scenes, one per branch the seeded cases never take
 
 
-def label_edge_fixture(R, name, out_dir=HERE):
+def label_edge_fixture(R, name, out_dir=None):
     """label_edge_<name>.npz — the reference label stage on oracle.synth.label_stage_edge_inputs(name); see
     tests/golden/trace_label_coverage.py for the proof that these fixtures execute the remaining statements."""
     inp = synth.label_stage_edge_inputs(name)
@@ -243,7 +267,8 @@ def label_edge_fixture(R, name, out_dir=HERE):
                          top_k=10000 if name == "c" else None, extra={"edge_name": np.array(name)})
 
 
-def label_fixture(R, seed, b, H, W, out_dir=HERE, inp=None, fname=None, top_k=None, extra=None):
+def label_fixture(R, seed, b, H, W, out_dir=None, inp=None, fname=None, top_k=None, extra=None):
+    out_dir = _dir(out_dir)
     if inp is None:
         inp = synth.label_stage_inputs(seed, b=b, H=H, W=W)
     fname = fname or f"label_s{seed:02d}.npz"
@@ -379,7 +404,7 @@ def state_dict_fixture(R):
     pre["classifier.fc.bias"] = [[1000], "float32"]
     out["pretrained_resnet101_iabn_sync"] = {"state_dict": pre}
     import gzip
-    with gzip.open(os.path.join(HERE, "state_dicts.json.gz"), "wt") as f:
+    with gzip.open(os.path.join(_dir(), "state_dicts.json.gz"), "wt") as f:
         json.dump(out, f, sort_keys=True)
     print("state_dicts.json.gz", {k: (len(v.get("model", v)) if isinstance(v, dict) else 0) for k, v in out.items()})
 
@@ -439,24 +464,39 @@ def wss_fixture(R, seed, b, c, h, w):
         out["pg_dx"] = x.grad.numpy().copy()
         out["pg_dw"] = pg.extra_conv4.weight.grad.numpy().copy()
         out["pg_db"] = pg.extra_conv4.bias.grad.numpy().copy()
-    np.savez_compressed(os.path.join(HERE, f"wss_s{seed:02d}.npz"), **out)
+    np.savez_compressed(os.path.join(_dir(), f"wss_s{seed:02d}.npz"), **out)
     print(f"wss_s{seed:02d}.npz", {k: (v.shape if v.ndim else float(v)) for k, v in out.items() if k != "case"})
 
 
 if __name__ == "__main__":
+    import argparse
+    cli = argparse.ArgumentParser()
+    cli.add_argument("--out", default=None, help="write the fixtures here instead of tests/golden/")
+    cli.add_argument("--only", default=None, help="comma-separated subset: state,model,three_head,p1,wrn,insmap,dataset,label,edge,wss")
+    a = cli.parse_args()
+    if a.out:
+        os.makedirs(a.out, exist_ok=True)
+        OUT = a.out
+    want = lambda k: a.only is None or k in a.only.split(",")
     R = ref_harness.load_reference()
     torch.set_num_threads(8)
-    state_dict_fixture(R)
-    model_fixture(R)
-    model_p1_fixture(R)
-    wrn_fixture(R)
-    for case in INSMAP_CASES:
+    if want("state"):
+        state_dict_fixture(R)
+    if want("model"):
+        model_fixture(R)
+    if want("three_head"):
+        three_head_fixtures(R)
+    if want("p1"):
+        model_p1_fixture(R)
+    if want("wrn"):
+        wrn_fixture(R)
+    for case in (INSMAP_CASES if want("insmap") else ()):
         insmap_fixture(R, *case)
-    for case in DATASET_CASES:
+    for case in (DATASET_CASES if want("dataset") else ()):
         dataset_fixture(R, *case)
-    for case in LABEL_CASES:
+    for case in (LABEL_CASES if want("label") else ()):
         label_fixture(R, *case)
-    for name in LABEL_EDGE_CASES:
+    for name in (LABEL_EDGE_CASES if want("edge") else ()):
         label_edge_fixture(R, name)
-    for case in WSS_CASES:
+    for case in (WSS_CASES if want("wss") else ()):
         wss_fixture(R, *case)
