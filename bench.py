@@ -46,9 +46,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-side legs (cpu_baseline, stock_rocm)")
-    ap.add_argument("--cpu-baseline-iters", type=int, default=1,
-                    help="timed CPU iterations at batch 16 after the batch-2 warm-up (default 1 = 16 images, ~80 s: a bounded sample so that the "
-                         "default run finishes in ~2.5 minutes; BASELINE.md §4's protocol is 3: profiles/r03zz_bench_default.json)")
+    ap.add_argument("--cpu-baseline-iters", type=int, default=3,
+                    help="timed CPU iterations at batch 16 after the batch-2 warm-up (default 3 = BASELINE.md §4's protocol, ~80 s each on a "
+                         "16-thread box share; the stock-ops GPU comparator pays for it with ONE timed iteration after its MIOpen warm-up)")
     ap.add_argument("--no-structured", action="store_true", help="skip the structured-labels sub-record")
     ap.add_argument("--rehearse-launcher", action="store_true",
                     help="CPU-only check of the self-launch path: rendezvous over gloo, all-reduce of ones, no GPU work")
@@ -115,6 +115,31 @@ def _progress(msg):
 _T0 = time.time()
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources, in name order: identifies the code a counter profile was taken on. The PMC
+    summaries under profiles/ carry the value they were measured at (tools/pmc_traffic.py, tools/pmc_kernels.py); bench.py reports their
+    figures only when it matches the sources this run was built from (there is no .git on the GPU box to ask)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cl4wsis_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def padded_tap_fraction(hin, k, stride, dil):
+    """Share of a convolution's (tap, output pixel) pairs whose input pixel lies in the zero padding ('same'-style padding dil * (k - 1) / 2,
+    square maps): those products are algorithmic FLOPs of 2 * cout * cin * k^2 * pixels that a kernel need not execute."""
+    if k == 1:
+        return 0.0
+    pad = dil * (k - 1) // 2
+    hout = (hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    valid_1d = sum(1 for o in range(hout) for t in range(k) if 0 <= o * stride - pad + t * dil < hin)
+    return 1.0 - (valid_1d / float(hout * k)) ** 2
+
+
 def _host_cores():
     """Host threads for the CPU legs. A 1-GPU box is a 16-thread share of a 256-thread host whose affinity mask still lists all
     256: oversubscribing them made a batch-2 warm-up take 270 s (r02b). 16 threads per visible GPU, capped by the mask."""
@@ -172,7 +197,7 @@ def cpu_baseline(opts, iters):
                       f"{iters} timed iterations after a batch-2 warm-up, torch threads = {cores}"}
 
 
-def stock_rocm(opts, device, iters=2, rank=0, world=1):
+def stock_rocm(opts, device, iters=1, rank=0, world=1):
     """BASELINE.md §4 second comparator: the same restatement with stock PyTorch-ROCm ops (MIOpen convolutions, ATen
     elementwise kernels) on this GPU, batch 16 — like the reference on a GPU it keeps the label stage on the host
     (OpenCV/numpy loops behind .cpu() copies, modules/utils.py:179-385) — under the reference's own autocast (train.py:252).
@@ -372,32 +397,55 @@ def worker(a):
         # HBM-side bytes per launch of the same kernel: PMC counters cannot be read from inside the process, so this is the
         # committed result of the two separate rocprofv3 --pmc passes over the last eager step of this same command
         # (tools/prof_pmc.sh + tools/pmc_traffic.py; newest profiles/r*_pmc_traffic.json); null when absent.
+        # Counter-derived figures are NOT measured by this run: each comes with its source file and the hash of the kernel sources it was
+        # measured on, and is reported as null (the stale value under `pmc.stale_*`) when that hash is not this build's.
+        sha = csrc_sha16()
+        pmc = {"csrc_sha16_of_this_build": sha}
         traffic, traffic_note = None, "no PMC file"
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
         if pmcs and b == GLOBAL_BATCH:
             with open(pmcs[-1]) as f:
-                t = json.load(f)["conv_igemm_bf16x3"]
-            traffic = t["hbm_bytes_per_launch"]
-            traffic_note = ("bytes per launch, average over the %d bf16x3 forward launches of one step; rocprofv3 --pmc "
-                            "FETCH_SIZE + WRITE_SIZE in separate passes, corrected as calibrated in %s"
-                            % (t["launches_per_step"], os.path.relpath(pmcs[-1], ROOT)))
+                tj = json.load(f)
+            t = tj["conv_igemm_bf16x3"]
+            pmc["traffic_source"] = os.path.relpath(pmcs[-1], ROOT)
+            pmc["traffic_source_csrc_sha16"] = tj.get("csrc_sha16")
+            if tj.get("csrc_sha16") == sha:
+                traffic = t["hbm_bytes_per_launch"]
+                traffic_note = ("bytes per launch, average over the %d bf16x3 forward launches of one step; rocprofv3 --pmc "
+                                "FETCH_SIZE + WRITE_SIZE in separate passes, corrected as calibrated in %s (same kernel sources as this run)"
+                                % (t["launches_per_step"], pmc["traffic_source"]))
+            else:
+                pmc["stale_traffic"] = t["hbm_bytes_per_launch"]
+                traffic_note = ("null: %s was measured on other kernel sources (csrc_sha16 %s, this build %s); its figure is under pmc.stale_traffic"
+                                % (pmc["traffic_source"], tj.get("csrc_sha16"), sha))
+                _progress("WARNING: " + traffic_note)
         # matrix-pipe busy share of the same kernel family, from the committed counter pass of the same command (tools/prof_pmc.sh third
-        # pass + tools/pmc_kernels.py: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)); null when absent
+        # pass + tools/pmc_kernels.py: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)); null when absent or stale
         mfma_busy, hbm_gbs = None, None
         pk = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_kernels.json")))
         if pk and b == GLOBAL_BATCH:
             with open(pk[-1]) as f:
-                fam = json.load(f)["bf16x3_forward_family"]
-            mfma_busy, hbm_gbs = fam["mfma_busy"], fam["hbm_gbs"]
+                kj = json.load(f)
+            fam = kj["bf16x3_forward_family"]
+            pmc["kernels_source"] = os.path.relpath(pk[-1], ROOT)
+            pmc["kernels_source_csrc_sha16"] = kj.get("csrc_sha16")
+            if kj.get("csrc_sha16") == sha:
+                mfma_busy, hbm_gbs = fam["mfma_busy"], fam["hbm_gbs"]
+            else:
+                pmc["stale_mfma_busy"], pmc["stale_hbm_gbs"] = fam["mfma_busy"], fam["hbm_gbs"]
+                _progress("WARNING: %s was measured on other kernel sources; roofline.mfma_busy / hbm_gbs are null" % pmc["kernels_source"])
         # algorithmic operand bytes of the same launches: input + output activations (fp32) + split weights (4 B / weight);
         # epilogue operands (residual, scale / shift) not counted
-        alg_bytes, alg_n = 0.0, 0
-        for (kind, shp), (cnt, _, _) in timer_excl.by_shape().items():
+        alg_bytes, alg_n, exec_fl = 0.0, 0, 0.0
+        for (kind, shp), (cnt, fl_, _) in timer_excl.by_shape().items():
             if kind == "conv_fwd_bf16x3" and shp is not None:
-                n_, cin_, hin_, cout_, k_, st_, _ = shp
+                n_, cin_, hin_, cout_, k_, st_, dil_ = shp
                 ho = -(-hin_ // st_)
                 alg_bytes += cnt * 4.0 * (n_ * cin_ * hin_ * hin_ + n_ * cout_ * ho * ho + cin_ * cout_ * k_ * k_)
                 alg_n += cnt
+                exec_fl += fl_ * (1.0 - padded_tap_fraction(hin_, k_, st_, dil_))
+            elif kind == "conv_fwd_bf16x3":
+                exec_fl += fl_
         res = {
             "metric": METRIC,
             "value": GLOBAL_BATCH * a.steps / elapsed, "unit": "images/s", "n_gpus": world, "n_ranks_seen": int(seen.item()),
@@ -414,7 +462,11 @@ def worker(a):
                                                     "conv_igemm_bf16x3 / conv_u_bf16x3 / conv_s_bf16x3 / conv_b_bf16x3 / stem_fused): all its launches of 2 "
                                                     "eager steps run right after the timed region (graph replay and two-stream "
                                                     "overlap off), HIP events on the launch stream around every launch",
-                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                         # the same with the products of zero-padding taps removed from the numerator (a dilated 3x3 layer on a 33 x 33 map
+                         # multiplies padding for 12-60 % of its tap-pixel pairs; the kernels skip most of them, FINDINGS.md finding 27)
+                         "executed_frac": exec_fl / (ms * 1e-3) / 1e12 / peak,
+                         "traffic": traffic, "pmc": pmc,
                          "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": alg_bytes / max(alg_n, 1),
                          # ... and with the operands the fused epilogues add (residual of every bottleneck's last conv: as large as its
@@ -456,8 +508,9 @@ def worker(a):
             # BASELINE.md publishes no number for this metric; its §4 names stock PyTorch-ROCm as the comparator to beat (>= 4x),
             # measured here on the same GPUs, same global batch, same synthetic inputs.
             res["stock_rocm"] = stock
-            res["vs_baseline"] = res["value"] / stock["value"]
-            res["vs_baseline_note"] = "value / stock_rocm.value (no published number exists, BASELINE.md §1)"
+            res["vs_stock_rocm"] = res["value"] / stock["value"]
+            res["vs_baseline_note"] = ("vs_baseline is null: BASELINE.md holds no published number for this metric (§1); vs_stock_rocm = value / "
+                                       "stock_rocm.value is the comparator its §4 names")
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(opts, a.cpu_baseline_iters)
         print(json.dumps(res), flush=True)

@@ -322,9 +322,10 @@ constexpr int SEG_MAXC = 96;   // 21 on VOC, 81 on coco-voc
 constexpr int SEG_REGC = 24;   // class counts up to this keep the per-pixel logits in registers (VOC); beyond: recomputed per pass
 
 // No per-thread arrays with run-time indices here. The r02 kernel kept `float v[SEG_MAXC], mask[SEG_MAXC]` per thread = 784 bytes of
-// scratch (private segment) per lane, ~410 MB for a full chip of waves: above the runtime's per-dispatch scratch limit, so the
-// memory is mapped for one dispatch and reclaimed after it. A captured single-stream step replays a pre-built dispatch packet and
-// the kernel then wrote its private arrays through a stale mapping ("write access to a read-only page"). REGC > 0:
+// scratch (private segment) per lane, ~410 MB for a full chip of waves. Removing them is a register / scratch optimisation (0.66 -> 0.26 ms,
+// and no kernel of the step path uses private-segment scratch any more: tools/kernel_resources.py). It was NOT the cause of the r02
+// single-stream graph fault — that was the runtime's hipMemsetAsync graph nodes (FINDINGS.md finding 23, cl4::fill_bytes_async): the fault
+// came back with these arrays already gone and disappears with kernel fills alone. REGC > 0:
 // fully unrolled loops over REGC classes with compile-time indices (registers); REGC == 0: the logits are re-sampled from LDS in each
 // of the three passes (max, sum of exponentials, arg-max) — the same expressions in the same order, so the same bits.
 template <int REGC>

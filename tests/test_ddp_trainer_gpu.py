@@ -114,8 +114,15 @@ def test_two_rank_phase2_step_matches_sharded_single_process_emulation(gpu, monk
     w_emu = _weights(tr)
     assert not torch.equal(w_emu, w0)
     # ---- two ranks on this GPU over gloo ---------------------------------------------------------------------------------------------
-    while not ranks.join():
-        pass
+    # a mismatched collective between the two ranks — what this test guards against — must FAIL, not hang the suite
+    import time
+    deadline = time.time() + 300
+    while not ranks.join(timeout=5):
+        if time.time() > deadline:
+            for p in ranks.processes:
+                if p.is_alive():
+                    p.terminate()
+            pytest.fail("the two ranks did not finish within 300 s: a collective of the N > 1 path is unpaired")
     (l0, w_r0), (l1, w_r1) = ret[0], ret[1]
     assert torch.equal(w_r0, w_r1), "the two ranks diverged"
     for it in range(STEPS):

@@ -79,8 +79,7 @@ def test_networks_match_reference_golden(gpu, fixture):
     # One tensor is cancellation-dominated and gets its own bar: the pooling branch's weight gradient is a sum over images of (pixel sum of a
     # gradient that a train-mode BatchNorm has just made zero-mean over the batch) x (globally pooled features that are nearly the same for
     # every image) — FINDINGS.md finding 29: the kernels are exact for their inputs to 3e-6, the 1e-6-level element noise upstream is amplified
-    # by the cancellation (measured here: 7e-2 on the four-head fixture, 8e-3 / 3e-3 on the others; the CPU fp32 oracle itself moves by
-    # percents on this tensor under a 3e-5 input perturbation).
+    # by the cancellation (measured here: 7e-2 on the four-head fixture, 8e-3 / 3e-3 on the others).
     rtol = np.where(np.array([str(n).endswith("aspp_pooling.1.weight") for n in gold["grad_names"]]), 0.15, 2e-2)
     assert (dev <= rtol).all(), [(str(gold["grad_names"][i]), float(dev[i])) for i in np.flatnonzero(dev > rtol)]
     med = float(np.median(np.abs(norms / gold["grad_norms"] - 1)))

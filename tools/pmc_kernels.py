@@ -88,6 +88,10 @@ out = {"note": "eager, overlap-off step of bench.py; durations from the un-instr
                "(1024 SIMDs x GRBM_GUI_ACTIVE / 8)" % (f_fac, w_fac),
        "kernels": {k: row([k]) for k in top},
        "bf16x3_forward_family": row([k for k in dur if is_x3(k)])}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha16      # the kernel sources these counters were measured on: bench.py refuses the figures for any other build
+out["csrc_sha16"] = csrc_sha16()
 json.dump(out, open(out_path, "w"), indent=1)
 print(f"{'kernel':72s} {'ms/step':>8s} {'HBM GB/s':>9s} {'MFMA busy':>9s}")
 for k, v in list(out["kernels"].items()) + [("bf16x3 forward family", out["bf16x3_forward_family"])]:

@@ -75,6 +75,10 @@ for k in sorted(fetch, key=lambda k: -fetch[k][1]):
         tot_l += l
         tot_b += fac * f + cal["vec_gather_16B_per_lane"]["write_factor"] * w
 out["conv_igemm_bf16x3"] = {"launches_per_step": tot_l, "hbm_bytes_per_step": tot_b, "hbm_bytes_per_launch": tot_b / max(tot_l, 1)}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha16      # the kernel sources these counters were measured on: bench.py refuses the figures for any other build
+out["csrc_sha16"] = csrc_sha16()
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps({"calibration": {k: {kk: round(vv, 3) if isinstance(vv, float) and vv < 100 else vv for kk, vv in v.items()} for k, v in cal.items()},
                   "conv_igemm_bf16x3": out["conv_igemm_bf16x3"]}))

@@ -3,7 +3,7 @@
 # the roofline leg (the mode roofline.frac is measured in).
 set -e
 TAG=${1:-r02a}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the root of the repository copy)}
 cd $R
 mkdir -p gpurun_out/$TAG
 timeout -k 10 1000 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err || { tail -5 gpurun_out/$TAG/bench.err; exit 1; }

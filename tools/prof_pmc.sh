@@ -2,7 +2,7 @@
 # bench steps, plus calibration launches of the same kernel with known traffic; no tracing options alongside --pmc.
 set -e
 TAG=${1:-r02}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the root of the repository copy)}
 O=$R/gpurun_out/${TAG}_pmc
 mkdir -p $O
 export TMPDIR=/tmp CL4_GRAPH=0 CL4_OVERLAP=0

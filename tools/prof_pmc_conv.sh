@@ -1,5 +1,5 @@
 set -e
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the root of the repository copy)}
 mkdir -p $R/gpurun_out/pmc_conv
 export TMPDIR=/tmp
 cd /tmp

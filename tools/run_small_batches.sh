@@ -1,6 +1,6 @@
 # Per-GPU batches 8 / 4 / 2 (what each rank of an N = 2 / 4 / 8 run executes) on one GPU: step time of the replayed step.
 set -e
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the root of the repository copy)}
 cd $R
 O=gpurun_out/${1:-r02g}_small
 mkdir -p $O

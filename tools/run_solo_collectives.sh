@@ -1,7 +1,7 @@
 # The N > 1 code path on ONE GPU: a world-size-1 RCCL group with CL4_FORCE_COLLECTIVES=1 (graph up to the ASPP backward, eager ASPP
 # tail with bucketed all-reduces on the communication stream, Adam), at the per-GPU batches an N = 1 / 2 / 4 / 8 run executes.
 set -e
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the root of the repository copy)}
 cd $R
 O=gpurun_out/${1:-r02g}_solo
 mkdir -p $O

@@ -1,5 +1,5 @@
 # One bench run (40 steps) per knob setting; prints ms/step. Usage: sweep_knobs.sh <tag> "ENV1=a ENV2=b" "ENV3=c" ...
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the root of the repository copy)}
 cd $R
 TAG=$1; shift
 O=gpurun_out/${TAG}_sweep
