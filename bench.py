@@ -134,6 +134,8 @@ def padded_tap_fraction(hin, k, stride, dil):
     square maps): those products are algorithmic FLOPs of 2 * cout * cin * k^2 * pixels that a kernel need not execute."""
     if k == 1:
         return 0.0
+    if k == 0:       # a fused bottleneck span (ops.bottleneck_fused): only its 3x3 layer has padding taps, 9 / 17 of the block's FLOPs
+        return padded_tap_fraction(hin, 3, stride, dil) * 9.0 / 17.0
     pad = dil * (k - 1) // 2
     hout = (hin + 2 * pad - dil * (k - 1) - 1) // stride + 1
     valid_1d = sum(1 for o in range(hout) for t in range(k) if 0 <= o * stride - pad + t * dil < hin)

@@ -124,6 +124,8 @@ _decl("cl4_dwconv5_wgrad", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 
 _decl("cl4_cam_smooth", _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P, C.c_size_t, _P)
 _decl("cl4_conv_debug_timeline", _P)
+_decl("cl4_bottleneck_fused", _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P)
+_decl("cl4_bottleneck_fused_tile", _I, _P, _P)
 _decl("cl4_to_planes", _P, _P, _I, _I, _I, _I, _I, _P)
 _decl("cl4_to_planes3", _P, _P, _I, _I, _I, _I, _I, _P)
 _decl("cl4_from_planes", _P, _P, _I, _I, _I, _I, _I, _P)
@@ -214,7 +216,7 @@ def load():
                    ("cl4_input_workspace_bytes", [C.c_int] * 5), ("cl4_target_generation_workspace_bytes", [C.c_int])):
         getattr(lib, nm).restype = C.c_size_t
         getattr(lib, nm).argtypes = at
-    for nm in ("cl4_conv_debug_u_launches", "cl4_conv_debug_s_launches", "cl4_conv_debug_b_launches"):
+    for nm in ("cl4_conv_debug_u_launches", "cl4_conv_debug_s_launches", "cl4_conv_debug_b_launches", "cl4_conv_debug_f_launches"):
         getattr(lib, nm).restype = C.c_long
         getattr(lib, nm).argtypes = []
     lib.cl4_stem_weight_bytes.restype = C.c_size_t

@@ -62,9 +62,33 @@ class ResidualBlock(nn.Module):
         act, slope = c.bn1.act_code()
         return conv_abn(y, c.conv3, c.bn3, post=r, act2=act, slope2=slope)
 
-    def planes_capable(self):
+    def planes_capable(self, min_cout=None):
         c = self.convs
-        return all(planes_ok(m) for m in (c.conv1, c.conv2, c.conv3)) and (not hasattr(self, "proj_conv") or planes_ok(self.proj_conv))
+        return (all(planes_ok(m, min_cout) for m in (c.conv1, c.conv2, c.conv3))
+                and (not hasattr(self, "proj_conv") or planes_ok(self.proj_conv, min_cout)))
+
+    def fusable(self):
+        """Identity block that csrc/conv_f.hip runs as ONE launch (frozen networks, planes trunk): 4 cm -> cm -> cm (3x3, stride 1,
+        dilation 1) -> 4 cm with leaky-ReLU ABNs after conv1 / conv2, an identity-activation ABN after conv3 and leaky-ReLU on the sum."""
+        c = self.convs
+        cm = c.conv1.out_channels
+        return (ops.FUSED_BLOCK and not hasattr(self, "proj_conv") and cm in ops.FUSED_CM and planes_ok(c.conv3)
+                and c.conv1.kernel_size == (1, 1) and c.conv3.kernel_size == (1, 1) and c.conv2.kernel_size == (3, 3)
+                and c.conv2.stride == (1, 1) and c.conv2.dilation == (1, 1) and c.conv2.padding == (1, 1) and c.conv2.in_channels == cm
+                and c.conv2.out_channels == cm and c.conv1.in_channels == 4 * cm and c.conv3.out_channels == 4 * cm
+                and all(isinstance(b, ABN) for b in (c.bn1, c.bn2, c.bn3))
+                and c.bn1.activation == "leaky_relu" and c.bn2.activation == "leaky_relu" and c.bn3.activation == "identity")
+
+    def forward_fused(self, xp, want_fp32, f32_images=None):
+        """Eval forward of a fusable block on a planes trunk: (fp32 output or None, planes output), one launch."""
+        import torch
+        from .nn import CACHE, folded_bn
+        c = self.convs
+        srcs = tuple(t for b in (c.bn1, c.bn2, c.bn3) for t in (b.weight, b.bias, b.running_mean, b.running_var))
+        aff = CACHE.get(self, "faff", srcs, lambda: torch.cat([t for b in (c.bn1, c.bn2, c.bn3) for t in folded_bn(b)]).contiguous())
+        return ops.bottleneck_fused(xp, packed_weight(c.conv1, 1), packed_weight(c.conv2, 1), packed_weight(c.conv3, 1), aff,
+                                    float(c.bn1.activation_param), float(c.bn2.activation_param), float(c.bn1.activation_param),
+                                    want_fp32=want_fp32, f32_images=f32_images)
 
     def forward_planes(self, x, xp, want_fp32, own_input=False):
         """Eval forward with planes activations (frozen networks only). `x`: fp32 input or None, `xp`: its planes twin or None (at
@@ -94,6 +118,11 @@ class ResidualBlock(nn.Module):
 
 
 class ResNet(nn.Module):
+    # Hint of the caller (Trainer, phase 2): only the first `f32_images` images of the batch need the fp32 copies of the low-level stage
+    # outputs res2 / res3 (train.py:265-267 hands the un-flipped half of the flip-TTA batch to the decoder; nothing reads the other
+    # half's low-level features). None: all. Honoured by the fused blocks only; the planes twins always cover every image.
+    f32_images = None
+
     def __init__(self, structure, norm_act=ABN, output_stride=16, keep_outputs=False):
         super().__init__()
         if len(structure) != 4:
@@ -119,6 +148,13 @@ class ResNet(nn.Module):
             channels = tuple(c * 2 for c in channels)
         self.out_channels = in_ch
 
+    @staticmethod
+    def _stage_min_cout(stage):
+        """Thinnest layer kept on the planes path in this stage: the default threshold, lowered to the stage's middle width when its
+        identity blocks run fused (they need a planes trunk, so the stage's first block has to produce one)."""
+        fused = [b.convs.conv1.out_channels for b in stage if b.fusable()]
+        return min(fused) if fused else None
+
     def forward(self, x):
         frozen = not (self.training and any(p.requires_grad for p in self.parameters()))
         yp = None                                              # planes twin of y (nn.CONV_PLANES), carried across blocks and stages
@@ -130,15 +166,18 @@ class ResNet(nn.Module):
             wq = CACHE.get(c1, "stemq", (c1.weight,), lambda: ops.pack_stem_weight(c1.weight.detach()))
             scale, shift = folded_bn(b1)
             y0, yp = ops.stem_fused(x, wq, scale, shift, slope=float(b1.activation_param),
-                                    want_planes=CONV_PLANES and self.mod2[0].planes_capable())
+                                    want_planes=CONV_PLANES and self.mod2[0].planes_capable(self._stage_min_cout(self.mod2)))
             outs = [y0]
         else:
             y = conv_abn(x, c1, b1)
             outs = [ops.maxpool3x3s2(y)]
         for m in (self.mod2, self.mod3, self.mod4, self.mod5):
             y = outs[-1]
+            lim = self._stage_min_cout(m) if frozen else None
             for i, blk in enumerate(m):
-                if frozen and blk.planes_capable():
+                if frozen and yp is not None and blk.fusable():
+                    y, yp = blk.forward_fused(yp, want_fp32=(i == len(m) - 1), f32_images=self.f32_images)                          # conv1 -> conv2 -> conv3 + residual, one launch (csrc/conv_f.hip)
+                elif frozen and blk.planes_capable(lim):
                     y, yp = blk.forward_planes(y, yp, want_fp32=(i == len(m) - 1), own_input=(i > 0))     # fp32 only where a stage output is handed out; from the second block on the input belongs to this loop
                 else:
                     y, yp = blk(y if y is not None else ops.from_planes(yp)), None

@@ -1,0 +1,519 @@
+// Fused identity bottleneck on planes ("F" kernel, r04): conv1 1x1 (C4 -> CM) + ABN + leaky, conv2 3x3 (CM -> CM, stride 1, dilation 1) +
+// ABN + leaky, conv3 1x1 (CM -> C4) + ABN + residual add + leaky of ONE ResidualBlock (modules/residual.py:84-97) in ONE launch. The
+// high-resolution stages of the ResNet (res2: 256 channels at 129 x 129, res3: 512 at 65 x 65) are HBM-bound as three launches: every
+// block reads the trunk twice (conv1, residual), writes it once and moves both CM-channel intermediates through HBM as well — 2.2 GB per
+// res2 block at 32 images for 74 GFLOP (FINDINGS.md findings 4, 20, 25, 31). Here a workgroup owns a TH x TW tile
+// of output pixels of one image:
+//
+//   phase 1  y1[CM][halo]  = leaky(bn1(W1 . x[C4][halo]))      halo = (TH + 2) x (TW + 2) pixels; y1 = 0 outside the image (conv2's zero
+//                                                               padding). The x chunks go global -> registers in MFMA B-fragment layout
+//                                                               (a planes chunk IS a fragment row): no LDS traffic for the big operand.
+//   phase 2  y2[CM][tile]  = leaky(bn2(W2 * y1))                the nine taps are nine LDS offsets into the halo image of y1
+//   phase 3  out[C4][tile] = leaky(bn3(W3 . y2) + x)            32 output channels per step; residual chunks re-read (L2 / Infinity
+//                                                               Cache: this workgroup fetched them a few microseconds ago)
+//
+// so the trunk is read once (+ halo overlap, served by L2) and written once, and y1 / y2 never leave the CU: they live in LDS in the
+// planes format (bf16 hi / lo chunks of 8 channels per pixel), which is exactly what the next phase's MFMA B fragments read.
+// All weights stream through one two-stage LDS ring as a single sequence of (8 * CM)-chunk tiles across the three phases (K-tiles of
+// W1, then of W2 in the packed order (channel block, tap), then 32-row slabs of W3), requested two tiles ahead.
+//
+// No accumulator parking: the rows of every weight tile are permuted on their way into LDS so that MFMA row block b of a 32-channel
+// pair holds channels 8q + 4b + r in row 4q + r; lane (pixel c = lane & 15, q = lane >> 4) then owns channels 8q .. 8q + 7 of pixel c
+// across the two row blocks of the pair = one planes chunk, which it splits and stores itself (to LDS for y1 / y2, to HBM for out).
+//
+// Arithmetic: the products, their order (K-tiles ascending; lo*hi, hi*lo, hi*hi per tile) and the epilogue expressions are those of
+// conv_s_bf16x3, so a fused block returns what the three planes launches return (tests/test_conv_f_gpu.py compares bit for bit).
+#include "conv_args.h"
+
+#include "planes_epilogue.h"
+
+#ifndef CL4_F_DBG
+#define CL4_F_DBG 0   // experiments only (tools/probe_f.py): 1 = no x loads in phase 1, 2 = no residual loads, 4 = no output stores, 8 = no MFMAs,
+                      // 16 = no weight loads
+#endif
+
+namespace cl4 {
+
+struct FusedArgs {
+  const void* xs;      // input planes [n][C4/8][hi, lo][h*w][8 x bf16]
+  void* ys;            // output planes, same shape; must not alias xs (neighbouring tiles read each other's halo)
+  float* y;            // optional fp32 NCHW copy of the output
+  const void* w1;      // packed bf16x3 weights (cl4_pack_conv_weight_bf16x3): [K/8][hi, lo][cout][8]
+  const void* w2;
+  const void* w3;
+  const float* aff;    // [sc1 | sh1 | sc2 | sh2] (CM each), [sc3 | sh3] (C4 each): folded eval-mode ABN
+  float neg1, neg2, neg3, negout;   // branch-free activations act(v) = v > 0 ? v : v * neg of bn1, bn2, bn3 (identity: 1) and of the sum
+  int n, h, w, tiles_x, tiles_y, xcd_remap;
+  int n_f32;           // the fp32 copy is written for images [0, n_f32) only (the others' stores are dropped by the descriptor)
+};
+
+}  // namespace cl4
+
+namespace {
+
+using cl4::FusedArgs;
+
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4a mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x4a c) {
+#if CL4_F_DBG & 8
+  c[0] += (float)al[0] * (float)bh[0] + (float)ah[1] * (float)bl[1];
+  return c;
+#endif
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+  return c;
+}
+
+template <int CM, int NW, int TH, int TW, bool F32OUT>
+__global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs a) {
+  constexpr int NT = NW * 64;
+  constexpr int C4 = 4 * CM;
+  constexpr int HWD = TW + 2;                              // halo width
+  constexpr int HP = (TH + 2) * HWD;                       // halo pixels
+  constexpr int NP = TH * TW;                              // output pixels
+  constexpr int CB1 = (HP + 15) / 16, CB2 = (NP + 15) / 16;   // 16-pixel column blocks of phase 1 / phases 2, 3
+  constexpr int NJ1 = (CB1 + NW - 1) / NW, NJ2 = (CB2 + NW - 1) / NW;   // ... per wave (block index = wave + NW * j)
+  constexpr int HPS = (HP + 7) & ~7;                       // chunk stride of one (channel group, plane) row of y1: a multiple of 8 keeps the
+                                                           // four k-groups of a fragment read 128 B-aligned against each other (LDS banks)
+  constexpr int NPS = CB2 * 16;                            // ... of y2
+  static_assert(NPS <= HPS, "y2 reuses y1's LDS");
+  constexpr int RB = CM / 16, RP = CM / 32;                // MFMA row blocks / 32-channel pairs of conv1, conv2
+  constexpr int KT1 = C4 / 32, KT2 = 9 * CM / 32, KT3 = CM / 32, NM3 = C4 / 32;
+  constexpr int G = KT1 + KT2 + NM3;                       // weight tiles of the whole kernel
+  constexpr int WCH = 8 * CM;                              // chunks per weight tile (32 k x CM rows, or 32 rows x CM k: two planes)
+  constexpr int LW = WCH / NT;                             // weight chunks per thread and tile
+  static_assert(WCH % NT == 0 && LW >= 1, "weight staging");
+  constexpr int LB = NJ1 * 2;                              // x chunks per thread and K-tile of phase 1
+  constexpr int NR = NJ2 * 2;                              // residual chunks per thread and step of phase 3
+  constexpr int NS = NJ2 * (F32OUT ? 10 : 2);              // stores per thread and step of phase 3
+
+  __shared__ u32x4 ybuf[(CM / 8) * 2 * HPS];               // y1, then y2: [channel group][hi, lo][pixel] chunks
+  __shared__ u32x4 wst[2][WCH];                            // weight ring
+  __shared__ float aff[4 * CM + 2 * C4];
+#ifdef CL4_F_PAD
+  __shared__ float lds_pad[CL4_F_PAD];                     // experiments: force one workgroup per CU
+  if (a.n < 0) lds_pad[threadIdx.x] = 1.f;
+#endif
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, q = lane >> 4;
+
+  // ---- which tile ------------------------------------------------------------------------------------------------------------------
+  const unsigned total = gridDim.x, id = blockIdx.x;
+  const unsigned q8 = total >> 3, r8 = total & 7, xcd = id & 7;
+  const unsigned lid = a.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3) : id;
+  const int tpi = a.tiles_x * a.tiles_y;
+  const int img = lid / tpi, tl = lid - img * tpi;
+  const int ty = tl / a.tiles_x, tx = tl - ty * a.tiles_x;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int H = a.h, W = a.w, HW = H * W;
+
+  for (int i = tid; i < 4 * CM + 2 * C4; i += NT) aff[i] = a.aff[i];
+
+  const unsigned act_bytes = (unsigned)((long)a.n * C4 * HW * 4);      // < 2^31: checked on the host
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, act_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.ys, 0, act_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (F32OUT && img < a.n_f32) ? act_bytes : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1, 0, (unsigned)(C4 * CM * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, (unsigned)(9 * CM * CM * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w3rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w3, 0, (unsigned)(CM * C4 * 4), 0x00020000);
+
+  // ---- weight stream: tile g -> registers (set g & 1) -> LDS stage g & 1 -------------------------------------------------------------
+  // K-tiles of W1 / W2 (rows = CM): chunk e = r * CM + s, r = 2 * k-group + plane, LDS slot s holds weight row pair * 32 + q * 8 + b * 4 + i
+  // for s = pair * 32 + b * 16 + q * 4 + i (the row permutation of the header). Slabs of W3 (32 rows x CM k): chunk e = rr * 32 + s,
+  // rr = 8 * K-tile + 2 * k-group + plane, slot s = b * 16 + q * 4 + i holds row q * 8 + b * 4 + i of the slab.
+  auto unperm = [](int s) { return (s & ~31) | (((s >> 2) & 3) << 3) | (((s >> 4) & 1) << 2) | (s & 3); };
+  unsigned w12_off[LW], w3_off[LW];                        // per-thread byte offsets inside a tile of W1 / W2 resp. a slab of W3
+#pragma unroll
+  for (int i = 0; i < LW; ++i) {
+    const int e = tid + NT * i;
+    const int r = e / CM, s = e - r * CM;
+    w12_off[i] = (unsigned)((r * CM + unperm(s)) * 16);
+    const int rr = e >> 5, s3 = e & 31;
+    const int kt = rr >> 3, r3 = rr & 7;
+    w3_off[i] = (unsigned)((((kt * 8 + r3) * C4) + unperm(s3)) * 16);
+  }
+  auto wissue = [&](u32x4 (&wr)[LW], int g) {
+#if CL4_F_DBG & 16
+    g = G;
+#endif
+    // uniform: which weight, which tile
+    if (g < KT1) {
+      const unsigned so = (unsigned)g * (unsigned)(WCH * 16);
+#pragma unroll
+      for (int i = 0; i < LW; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(w1rsrc, w12_off[i], so, 0);
+    } else if (g < KT1 + KT2) {
+      const unsigned so = (unsigned)(g - KT1) * (unsigned)(WCH * 16);
+#pragma unroll
+      for (int i = 0; i < LW; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w12_off[i], so, 0);
+    } else {
+      const unsigned so = g < G ? (unsigned)(g - KT1 - KT2) * 32u * 16u : 0u;
+      const unsigned keep = (unsigned)(-(int)(g < G));
+#pragma unroll
+      for (int i = 0; i < LW; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(w3rsrc, (w3_off[i] & keep) | (OOB & ~keep), so, 0);
+    }
+  };
+  auto wstore = [&](const u32x4 (&wr)[LW], int g) {
+    u32x4* st = wst[g & 1];
+#pragma unroll
+    for (int i = 0; i < LW; ++i) st[tid + NT * i] = wr[i];
+  };
+
+  // ---- phase-1 geometry: this lane's halo pixel in each of the wave's column blocks -------------------------------------------------------
+  unsigned xoff[NJ1];                                      // byte offset of (k-group q, plane 0, pixel) inside an image's 32-channel block, or OOB
+  bool inimg[NJ1];
+  int hp1[NJ1];
+#pragma unroll
+  for (int j = 0; j < NJ1; ++j) {
+    const int hp = (wave + NW * j) * 16 + c16;
+    const int hy = hp / HWD, hx = hp - hy * HWD;
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    hp1[j] = hp;
+    inimg[j] = hp < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    xoff[j] = inimg[j] ? (unsigned)((q * 2 * HW + iy * W + ix) * 16) : OOB;
+  }
+  const unsigned img_base = (unsigned)img * (unsigned)(C4 / 8) * 2u * (unsigned)HW * 16u;     // byte offset of the image in a planes tensor
+  auto bissue = [&](u32x4 (&bq)[NJ1][2], int kt) {
+#if CL4_F_DBG & 1
+    kt = KT1;
+#endif
+    const unsigned keep = (unsigned)(-(int)(kt < KT1));
+    const unsigned so = img_base + (unsigned)(kt < KT1 ? kt : 0) * 8u * (unsigned)HW * 16u;   // 4 channel groups x 2 planes per K-tile
+#pragma unroll
+    for (int j = 0; j < NJ1; ++j)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        bq[j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ((xoff[j] + (unsigned)(p * HW * 16)) & keep) | (OOB & ~keep), so, 0);
+  };
+
+  // ===================================================================================================================================
+  // phase 1: y1 = leaky(bn1(W1 . x)) on the halo
+  // ===================================================================================================================================
+  u32x4 wr[2][LW];
+  u32x4 bq[3][NJ1][2];                                     // x chunks of K-tiles g, g + 1, g + 2 (mod 3)
+  // issue stream of phase 1: W0 B0 | W1 B1 | W2 B2 | then iteration g adds W(g+3) B(g+3)
+  wissue(wr[0], 0);
+  bissue(bq[0], 0);
+  wissue(wr[1], 1);
+  bissue(bq[1], 1);
+  wait_vmcnt<LW + 2 * LB>();                               // W0 has landed (B0, W1, B1 may be in flight)
+  wstore(wr[0], 0);
+  wissue(wr[0], 2);
+  bissue(bq[2], 2);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  f32x4a acc1[RB][NJ1];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ1; ++j) acc1[i][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
+
+  // iteration g of phase 1 (K-tile g of conv1). In flight at its start, oldest first: W(g+1) B(g+1) | W(g+2) B(g+2) behind B(g). It needs W(g)
+  // in LDS (stored by the previous iteration), B(g) in registers and W(g+1) in registers (to store it): everything but the last
+  // LB + LW + LB operations.
+  auto step1 = [&](u32x4 (&w_next)[LW], u32x4 (&b_cur)[NJ1][2], int g) {
+    wait_vmcnt<LW + 2 * LB>();
+    const u32x4* As = wst[g & 1];
+    bf16x8 ah[RB], al[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      ah[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 0) * CM + i * 16 + c16]);
+      al[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 1) * CM + i * 16 + c16]);
+    }
+    wstore(w_next, g + 1);
+    wissue(w_next, g + 3);
+#pragma unroll
+    for (int j = 0; j < NJ1; ++j) {
+      if (wave + NW * j < CB1) {                           // wave-uniform
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, b_cur[j][0]), bl = __builtin_bit_cast(bf16x8, b_cur[j][1]);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) acc1[i][j] = mfma3(ah[i], al[i], bh, bl, acc1[i][j]);
+      }
+    }
+    bissue(b_cur, g + 3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  static_assert(KT1 % 2 == 0, "the weight ring's parity continues into phase 2");
+#pragma unroll
+  for (int g = 0; g < KT1; ++g) step1(wr[(g + 1) & 1], bq[g % 3], g);      // fully unrolled: the register sets are compile-time indices
+  wait_vmcnt<0>();                                         // W(KT1 + 1), W(KT1 + 2) are in registers, the dummy x loads are done
+
+  // epilogue 1: scale / shift / leaky, zero outside the image, split, into LDS
+#pragma unroll
+  for (int pr = 0; pr < RP; ++pr) {
+    const int cg = 4 * pr + q;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { sc[r] = aff[cg * 8 + r]; sh[r] = aff[CM + cg * 8 + r]; }
+#pragma unroll
+    for (int j = 0; j < NJ1; ++j) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc1[2 * pr][j][r]; v[4 + r] = acc1[2 * pr + 1][j][r]; }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float u = v[r] * sc[r] + sh[r];
+        const float t = u > 0.f ? u : u * a.neg1;
+        v[r] = inimg[j] ? t : 0.f;
+      }
+      u32x4 hi, lo;
+      split8(v, hi, lo);
+      if (hp1[j] < HP) {
+        ybuf[(cg * 2 + 0) * HPS + hp1[j]] = hi;
+        ybuf[(cg * 2 + 1) * HPS + hp1[j]] = lo;
+      }
+    }
+  }
+
+  // ---- geometry of phases 2 and 3: this lane's output pixel in each of the wave's column blocks ---------------------------------------
+  int h0[NJ2];                                             // chunk index of the pixel's top-left tap inside a y1 row
+  unsigned ooff[NJ2];                                      // byte offset of (channel group q, plane 0, pixel) inside a 32-channel block, or OOB
+  unsigned foff[NJ2];                                      // ... of (channel 8 q, pixel) in the fp32 tensor
+  int pcol[NJ2];
+#pragma unroll
+  for (int j = 0; j < NJ2; ++j) {
+    const int p = (wave + NW * j) * 16 + c16;
+    const int oy = p / TW, ox = p - oy * TW;
+    const bool valid = (wave + NW * j) < CB2 && p < NP && y0 + oy < H && x0 + ox < W;
+    pcol[j] = (wave + NW * j) < CB2 ? p : 0;
+    h0[j] = p < NP ? oy * HWD + ox : 0;
+    ooff[j] = valid ? (unsigned)((q * 2 * HW + (y0 + oy) * W + x0 + ox) * 16) : OOB;
+    foff[j] = valid ? (unsigned)((q * 8 * HW + (y0 + oy) * W + x0 + ox) * 4) : OOB;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                            // y1 is complete
+
+  // ===================================================================================================================================
+  // phase 2: y2 = leaky(bn2(W2 * y1)); K-tile t2 = (channel block, tap) in the packed order
+  // ===================================================================================================================================
+  f32x4a acc2[RB][NJ2];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) acc2[i][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
+  // iteration g: W(g) in LDS, W(g+1) and W(g+2) requested; in flight at most W(g+2) when W(g+1) is needed
+  auto step2 = [&](u32x4 (&w_next)[LW], int g) {
+    wait_vmcnt<LW>();
+    const int t2 = g - KT1;
+    const int cb = t2 / 9, tap = t2 - cb * 9;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int toff = __builtin_amdgcn_readfirstlane(ky * HWD + kx);
+    const u32x4* As = wst[g & 1];
+    const u32x4* Bs = ybuf + ((cb * 4 + q) * 2) * HPS + toff;
+    bf16x8 ah[RB], al[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      ah[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 0) * CM + i * 16 + c16]);
+      al[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 1) * CM + i * 16 + c16]);
+    }
+    bf16x8 bh[NJ2], bl[NJ2];
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) {
+      bh[j] = __builtin_bit_cast(bf16x8, Bs[h0[j]]);
+      bl[j] = __builtin_bit_cast(bf16x8, Bs[HPS + h0[j]]);
+    }
+    wstore(w_next, g + 1);
+    wissue(w_next, g + 3);
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j)
+      if (wave + NW * j < CB2) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) acc2[i][j] = mfma3(ah[i], al[i], bh[j], bl[j], acc2[i][j]);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  static_assert(KT2 % 2 == 0 && KT1 % 2 == 0, "phase 2 is unrolled by two and starts on an even tile");
+  for (int g = KT1; g < KT1 + KT2; g += 2) {
+    step2(wr[1], g);
+    step2(wr[0], g + 1);
+  }
+  wait_vmcnt<0>();
+  // the residual chunks of the first two steps of phase 3 travel under the epilogue of phase 2 (the geometry is known since phase 1)
+  u32x4 rq[2][NJ2][2];                                     // residual chunks of steps m, m + 1
+  auto rissue = [&](u32x4 (&r)[NJ2][2], int m) {
+#if CL4_F_DBG & 2
+    m = NM3;
+#endif
+    const unsigned keep = (unsigned)(-(int)(m < NM3));
+    const unsigned so = img_base + (unsigned)(m < NM3 ? m : 0) * 8u * (unsigned)HW * 16u;
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        r[j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ((ooff[j] + (unsigned)(p * HW * 16)) & keep) | (OOB & ~keep), so, 0);
+  };
+  rissue(rq[0], 0);
+  rissue(rq[1], 1);
+  // every wave has left the K loop (barrier above): y1 is dead, y2 takes its place
+#pragma unroll
+  for (int pr = 0; pr < RP; ++pr) {
+    const int cg = 4 * pr + q;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { sc[r] = aff[2 * CM + cg * 8 + r]; sh[r] = aff[3 * CM + cg * 8 + r]; }
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc2[2 * pr][j][r]; v[4 + r] = acc2[2 * pr + 1][j][r]; }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float u = v[r] * sc[r] + sh[r];
+        v[r] = u > 0.f ? u : u * a.neg2;
+      }
+      u32x4 hi, lo;
+      split8(v, hi, lo);
+      if (wave + NW * j < CB2) {
+        ybuf[(cg * 2 + 0) * NPS + pcol[j]] = hi;
+        ybuf[(cg * 2 + 1) * NPS + pcol[j]] = lo;
+      }
+    }
+  }
+
+  // ===================================================================================================================================
+  // phase 3: out = leaky(bn3(W3 . y2) + x), 32 output channels (one slab of W3) per step
+  // ===================================================================================================================================
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                            // y2 is complete
+  // step m (weight tile g = KT1 + KT2 + m). Issue order of a step: W(g+3), residual R(m+2), stores S(m) — the loads in FRONT of the stores,
+  // because vmcnt retires in order: a wait for a load also waits for every older store's acknowledgement (measured: with the stores
+  // first the steps stalled on them, 102 of 428 us). At the start of step m >= 2 everything up to R(m) has to be there; S(m-2) and the whole
+  // of step m-1 may be in flight: 2 NS + LW + NR (capped by the 6-bit counter). Step 1 has no S(-1) in front of it, step 0 sees only R(0) R(1).
+  constexpr int WAIT3 = (2 * NS + LW + NR) < 63 ? (2 * NS + LW + NR) : 63;
+  auto step3 = [&](u32x4 (&w_next)[LW], u32x4 (&r_cur)[NJ2][2], int m, int which) {
+    if (which == 0) wait_vmcnt<NR>(); else if (which == 1) wait_vmcnt<LW + NR + NS>(); else wait_vmcnt<WAIT3>();
+    const int g = KT1 + KT2 + m;
+    const u32x4* As = wst[g & 1];
+    f32x4a acc3[2][NJ2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int j = 0; j < NJ2; ++j) acc3[b][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT3; ++kt) {
+      bf16x8 ah[2], al[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        ah[b] = __builtin_bit_cast(bf16x8, As[(kt * 8 + q * 2 + 0) * 32 + b * 16 + c16]);
+        al[b] = __builtin_bit_cast(bf16x8, As[(kt * 8 + q * 2 + 1) * 32 + b * 16 + c16]);
+      }
+      const u32x4* Bs = ybuf + ((kt * 4 + q) * 2) * NPS;
+#pragma unroll
+      for (int j = 0; j < NJ2; ++j)
+        if (wave + NW * j < CB2) {
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, Bs[pcol[j]]), bl = __builtin_bit_cast(bf16x8, Bs[NPS + pcol[j]]);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc3[b][j] = mfma3(ah[b], al[b], bh, bl, acc3[b][j]);
+        }
+    }
+    wstore(w_next, g + 1);
+    wissue(w_next, g + 3);
+    // epilogue of the step: channels 32 m + 8 q .. + 7 of this lane's pixels
+    const int cg = 4 * m + q;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { sc[r] = aff[4 * CM + cg * 8 + r]; sh[r] = aff[4 * CM + C4 + cg * 8 + r]; }
+    const unsigned so = img_base + (unsigned)m * 8u * (unsigned)HW * 16u;
+    const unsigned fso = ((unsigned)img * (unsigned)C4 + 32u * (unsigned)m) * (unsigned)HW * 4u;
+    float v[NJ2][8];
+    u32x4 ohi[NJ2], olo[NJ2];
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) {
+      float res[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[j][r] = acc3[0][j][r]; v[j][4 + r] = acc3[1][j][r]; }
+      join8(r_cur[j][0], r_cur[j][1], res);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float u = v[j][r] * sc[r] + sh[r];
+        float t = u > 0.f ? u : u * a.neg3;
+        t += res[r];
+        v[j][r] = t > 0.f ? t : t * a.negout;
+      }
+      split8(v[j], ohi[j], olo[j]);
+    }
+    // Every chunk of the step is complete BEFORE the first store is issued, and nothing is computed between the stores: a
+    // buffer_store_dwordx4 whose soffset is an SGPR gets no wait state from hipcc (ROCm 7.2) in front of a VALU write of its data
+    // registers — the ISA manual exempts that form — but on gfx950 under load the store then picks the NEW value up (first dword of the chunk =
+    // whatever the next instruction wrote there: FINDINGS.md finding 37; found as 4-pixel groups of wrong channels 8 k, 8 k + 1 in
+    // the workgroups of the second round only). Here the stores also keep their whole offset in the VGPR (soffset 0: the form
+    // the compiler does guard), and the scheduler may not move anything across the fence in front of them.
+    unsigned ahi[NJ2], alo[NJ2], af32[NJ2];               // ... and every store address
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) {
+#if CL4_F_DBG & 4
+      const unsigned skeep = v[j][0] == 123.456f ? ~0u : 0u;     // keeps the arithmetic alive, drops (practically) every store
+#else
+      const unsigned skeep = ~0u;
+#endif
+      const unsigned o0 = (ooff[j] & skeep) | (OOB & ~skeep);
+      ahi[j] = o0 == OOB ? OOB : o0 + so;
+      alo[j] = o0 == OOB ? OOB : o0 + so + (unsigned)(HW * 16);
+      af32[j] = (foff[j] & skeep) | (OOB & ~skeep);
+    }
+    rissue(r_cur, m + 2);                                  // into the registers the sums above have just consumed
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) {
+      if constexpr (F32OUT) {                              // dword stores: no multi-cycle data read, the uniform part may stay in the SGPR offset
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j][r]), frsrc, af32[j], fso + (unsigned)(r * HW * 4), 0);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(ohi[j], yrsrc, ahi[j], 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(olo[j], yrsrc, alo[j], 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  static_assert(NM3 % 2 == 0 && (KT1 + KT2) % 2 == 0, "phase 3 is unrolled by two and starts on an even tile");
+  step3(wr[1], rq[0], 0, 0);
+  step3(wr[0], rq[1], 1, 1);
+  for (int m = 2; m < NM3; m += 2) {
+    step3(wr[1], rq[0], m, 2);
+    step3(wr[0], rq[1], m + 1, 2);
+  }
+}
+
+}  // namespace
+
+static long g_f_launches = 0;
+extern "C" long cl4_conv_debug_f_launches(void) { return g_f_launches; }
+
+extern "C" int cl4_bottleneck_fused_tile(int cm, int* th, int* tw) {
+  if (cm != 64) return CL4_EINVAL;
+  *th = 13;
+  *tw = 13;
+  return CL4_OK;
+}
+
+extern "C" int cl4_bottleneck_fused(const void* xs, void* ys, float* y, int n_f32, const void* w1, const void* w2, const void* w3, const float* aff,
+                                    int n, int cm, int h, int w, float slope1, float slope2, float slope_out, void* stream) {
+  CL4_REQUIRE(xs && ys && w1 && w2 && w3 && aff, "bottleneck_fused: null operand");
+  CL4_REQUIRE(xs != ys, "bottleneck_fused: the output must not alias the input (tiles read their neighbours' halo)");
+  CL4_REQUIRE(cm == 64, "bottleneck_fused: middle width %d not built (64)", cm);
+  CL4_REQUIRE(n > 0 && h > 0 && w > 0, "bottleneck_fused: bad shape");
+  CL4_REQUIRE((long)n * 4 * cm * h * w * 4 < (1l << 31), "bottleneck_fused: tensor of %ld bytes exceeds the 2 GiB buffer-descriptor range",
+              (long)n * 4 * cm * h * w * 4);
+  cl4::FusedArgs a;
+  a.xs = xs; a.ys = ys; a.y = y; a.w1 = w1; a.w2 = w2; a.w3 = w3; a.aff = aff;
+  a.neg1 = slope1; a.neg2 = slope2; a.neg3 = 1.f; a.negout = slope_out;
+  a.n = n; a.h = h; a.w = w;
+  a.n_f32 = y ? (n_f32 < 0 || n_f32 > n ? n : n_f32) : 0;
+  constexpr int TH = 13, TW = 13;
+  a.tiles_x = cl4::cdiv(w, TW);
+  a.tiles_y = cl4::cdiv(h, TH);
+  a.xcd_remap = 1;
+  const dim3 grid((unsigned)(n * a.tiles_x * a.tiles_y)), block(256);
+  ++g_f_launches;
+  if (y) hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, TH, TW, true>), grid, block, 0, cl4::as_stream(stream), a);
+  else hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, TH, TW, false>), grid, block, 0, cl4::as_stream(stream), a);
+  return cl4::launch_status();
+}

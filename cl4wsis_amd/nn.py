@@ -161,11 +161,13 @@ CONV_PLANES = os.environ.get("CL4_CONV_PLANES", "1") != "0"
 PLANES_MIN_COUT = int(os.environ.get("CL4_PLANES_MIN_COUT", "128"))   # 64 (res2 on the planes path too) measured neutral: 345.5 vs 345.3 images/s
 
 
-def planes_ok(conv):
+def planes_ok(conv, min_cout=None):
     """Can this convolution READ a planes input (cl4_conv2d_fwd_planes)? bf16x3 arithmetic, 1x1 / 3x3, 32-channel K-tiles, at
-    least PLANES_MIN_COUT output channels (one full 128-row M tile by default)."""
+    least PLANES_MIN_COUT output channels (one full 128-row M tile by default; `min_cout` overrides: the first block of a stage whose
+    identity blocks run fused stays in planes down to 64 channels so that the fused blocks get a planes trunk)."""
+    lim = PLANES_MIN_COUT if min_cout is None else min_cout
     return (CONV_PLANES and ops.CONV_PRECISION == 1 and conv.kernel_size[0] in (1, 3) and conv.kernel_size[0] == conv.kernel_size[1]
-            and conv.in_channels % 32 == 0 and conv.out_channels >= PLANES_MIN_COUT and conv.out_channels % 8 == 0 and conv.groups == 1)
+            and conv.in_channels % 32 == 0 and conv.out_channels >= lim and conv.out_channels % 8 == 0 and conv.groups == 1)
 
 
 def conv_abn_planes(xs, conv, bn, post=None, act2=ops.ACT_NONE, slope2=0.01, pre=None, bn_lo=0, bn_hi=None, want_fp32=False,

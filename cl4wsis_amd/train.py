@@ -432,6 +432,7 @@ class Trainer:
                 for k in ("center", "offset"):
                     old_next[k].copy_(o_next[k])
 
+        self.model.body.f32_images = bs if os.environ.get('CL4_F32_HINT', '1') != '0' else None         # low-level fp32 features are read for the un-flipped half only (feats below)
         if prefetch_old is not None and self._pipe_fork == "body":
             # fork between the new model's body and its DeepLabV3 head (forward_seg = body -> head -> cls, segmentation_module.py:400-426)
             feats_all = self.model.forward_seg(x2, as_feature_extractor=True)
@@ -442,6 +443,7 @@ class Trainer:
             outputs, features = self.model.forward_seg(x2, interpolate=False)
             if prefetch_old is not None:
                 fork_old()
+        self.model.body.f32_images = None
         feats = {k: ops.batch_slice(v, bs) for k, v in features["features"].items()}   # first half = un-flipped images (contiguous views, planes twins kept)
         # train.py:265-272 — trainable instance decoder + heads on the detached features
         if dropout_keep is None:

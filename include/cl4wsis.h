@@ -538,6 +538,24 @@ long cl4_conv_debug_b_launches(void);   /* launches of the big-tile LDS-DMA plan
  * cl4_conv2d_fwd_planes with descriptor precision 4 multiplies such an input with cl4_pack_conv_weight_bf16x6 weights as six bf16 MFMA
  * products = the bf16x6 arithmetic of the differentiated convolutions (train.py:265-272: the trainable ASPP of the instance decoder
  * reads the frozen res5 features). fp32 output only, no planes residual. */
+/* Fused identity bottleneck (r04, csrc/conv_f.hip). Replaces ResidualBlock.forward of modules/residual.py:84-97 for an identity block
+ * (no projection shortcut, stride 1, dilation 1) of a FROZEN network in eval mode — the blocks 2..n of res2 / res3 of models/resnet.py:
+ * 65-99 on the no-grad forwards of train.py:253-263:
+ *     out = leaky( bn3(conv3( leaky(bn2(conv2_3x3( leaky(bn1(conv1(x))) ))) )) + x )
+ * as ONE launch: a workgroup owns a 13 x 13 tile of one image, computes conv1 on the tile's 15 x 15 halo, keeps both cm-channel
+ * intermediates in LDS (planes format), and reads / writes the 4*cm-channel trunk once. xs / ys: planes tensors [n][4*cm/8][hi, lo]
+ * [h*w][8 x bf16] (ys must not alias xs); y: optional fp32 NCHW copy of the output (NULL: none), written for the images [0, n_f32)
+ * only (n_f32 < 0: all — train.py:265-267 reads the low-level features of the un-flipped half of the flip-TTA batch only, the rest of
+ * `y` is left untouched); w1 / w2 / w3: the three weights packed
+ * by cl4_pack_conv_weight_bf16x3; aff: the folded eval-mode ABN affine maps concatenated [scale1 | shift1 | scale2 | shift2] (cm floats
+ * each) [scale3 | shift3] (4*cm each); slope1 / slope2 / slope_out: the leaky-ReLU slopes after bn1, bn2 and after the residual sum
+ * (bn3 has the identity activation, modules/residual.py:82). Same products in the same order as three cl4_conv2d_fwd_planes calls.
+ * cm = 64 (res2) is built. Enqueue-only on `stream`; no workspace. */
+int cl4_bottleneck_fused(const void* xs, void* ys, float* y, int n_f32, const void* w1, const void* w2, const void* w3, const float* aff,
+                         int n, int cm, int h, int w, float slope1, float slope2, float slope_out, void* stream);
+/* Tile of output pixels per workgroup for middle width cm (CL4_EINVAL: not built). */
+int cl4_bottleneck_fused_tile(int cm, int* th, int* tw);
+long cl4_conv_debug_f_launches(void);   /* launches of the fused bottleneck kernel by this process (tests) */
 int cl4_to_planes(const float* x, void* xs, int n, int ctot, int coff, int c, int hw, void* stream);
 int cl4_to_planes3(const float* x, void* xs, int n, int ctot, int coff, int c, int hw, void* stream);
 int cl4_from_planes(const void* xs, float* y, int n, int c, int hw, int out_ctot, int out_coff, void* stream);
