@@ -66,28 +66,35 @@ __device__ __forceinline__ f32x4a mfma3(const bf16x8& ah, const bf16x8& al, cons
   return c;
 }
 
-template <int CM, int NW, int TH, int TW, bool F32OUT>
+// RS = row split of phases 1 and 2: the NW waves form NW / RS column groups x RS row groups; a wave multiplies CM / RS of the CM rows of W1 /
+// W2 with the column blocks of its column group (RS = 2: the 8-wave workgroup of the 128-channel res3 blocks — as 8 column groups its
+// 11 / 15 column blocks would leave 31 % of the matrix pipe's lanes idle, and 128 rows x 4 blocks do not fit one wave's accumulators).
+// The two waves of a column group load the same x chunks in phase 1 (the second request hits the CU's vector cache).
+template <int CM, int NW, int RS, int TH, int TW, bool F32OUT>
 __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs a) {
   constexpr int NT = NW * 64;
+  constexpr int NWC = NW / RS;                             // column groups
   constexpr int C4 = 4 * CM;
   constexpr int HWD = TW + 2;                              // halo width
   constexpr int HP = (TH + 2) * HWD;                       // halo pixels
   constexpr int NP = TH * TW;                              // output pixels
   constexpr int CB1 = (HP + 15) / 16, CB2 = (NP + 15) / 16;   // 16-pixel column blocks of phase 1 / phases 2, 3
-  constexpr int NJ1 = (CB1 + NW - 1) / NW, NJ2 = (CB2 + NW - 1) / NW;   // ... per wave (block index = wave + NW * j)
+  constexpr int NJ1 = (CB1 + NWC - 1) / NWC, NJ2 = (CB2 + NWC - 1) / NWC;   // ... per wave in phases 1, 2 (block index = wcol + NWC * j)
+  constexpr int NJ3 = (CB2 + NW - 1) / NW;                 // ... in phase 3 (32 output channels per step: no row split; block = wave + NW * j)
   constexpr int HPS = (HP + 7) & ~7;                       // chunk stride of one (channel group, plane) row of y1: a multiple of 8 keeps the
                                                            // four k-groups of a fragment read 128 B-aligned against each other (LDS banks)
   constexpr int NPS = CB2 * 16;                            // ... of y2
   static_assert(NPS <= HPS, "y2 reuses y1's LDS");
-  constexpr int RB = CM / 16, RP = CM / 32;                // MFMA row blocks / 32-channel pairs of conv1, conv2
+  constexpr int RB = CM / 16 / RS, RP = CM / 32 / RS;      // MFMA row blocks / 32-channel pairs of conv1, conv2 PER WAVE
+  static_assert(NW % RS == 0 && (CM / 32) % RS == 0, "row split");
   constexpr int KT1 = C4 / 32, KT2 = 9 * CM / 32, KT3 = CM / 32, NM3 = C4 / 32;
   constexpr int G = KT1 + KT2 + NM3;                       // weight tiles of the whole kernel
   constexpr int WCH = 8 * CM;                              // chunks per weight tile (32 k x CM rows, or 32 rows x CM k: two planes)
   constexpr int LW = WCH / NT;                             // weight chunks per thread and tile
   static_assert(WCH % NT == 0 && LW >= 1, "weight staging");
   constexpr int LB = NJ1 * 2;                              // x chunks per thread and K-tile of phase 1
-  constexpr int NR = NJ2 * 2;                              // residual chunks per thread and step of phase 3
-  constexpr int NS = NJ2 * (F32OUT ? 10 : 2);              // stores per thread and step of phase 3
+  constexpr int NR = NJ3 * 2;                              // residual chunks per thread and step of phase 3
+  constexpr int NS = NJ3 * (F32OUT ? 10 : 2);              // stores per thread and step of phase 3
 
   __shared__ u32x4 ybuf[(CM / 8) * 2 * HPS];               // y1, then y2: [channel group][hi, lo][pixel] chunks
   __shared__ u32x4 wst[2][WCH];                            // weight ring
@@ -101,6 +108,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c16 = lane & 15, q = lane >> 4;
+  const int wcol = RS == 1 ? wave : wave % NWC, wrow = RS == 1 ? 0 : wave / NWC;      // wave-uniform
 
   // ---- which tile ------------------------------------------------------------------------------------------------------------------
   const unsigned total = gridDim.x, id = blockIdx.x;
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   int hp1[NJ1];
 #pragma unroll
   for (int j = 0; j < NJ1; ++j) {
-    const int hp = (wave + NW * j) * 16 + c16;
+    const int hp = (wcol + NWC * j) * 16 + c16;
     const int hy = hp / HWD, hx = hp - hy * HWD;
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
     hp1[j] = hp;
@@ -221,14 +229,14 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     bf16x8 ah[RB], al[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      ah[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 0) * CM + i * 16 + c16]);
-      al[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 1) * CM + i * 16 + c16]);
+      ah[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 0) * CM + (wrow * RB + i) * 16 + c16]);
+      al[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 1) * CM + (wrow * RB + i) * 16 + c16]);
     }
     wstore(w_next, g + 1);
     wissue(w_next, g + 3);
 #pragma unroll
     for (int j = 0; j < NJ1; ++j) {
-      if (wave + NW * j < CB1) {                           // wave-uniform
+      if (wcol + NWC * j < CB1) {                          // wave-uniform
         const bf16x8 bh = __builtin_bit_cast(bf16x8, b_cur[j][0]), bl = __builtin_bit_cast(bf16x8, b_cur[j][1]);
 #pragma unroll
         for (int i = 0; i < RB; ++i) acc1[i][j] = mfma3(ah[i], al[i], bh, bl, acc1[i][j]);
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   // epilogue 1: scale / shift / leaky, zero outside the image, split, into LDS
 #pragma unroll
   for (int pr = 0; pr < RP; ++pr) {
-    const int cg = 4 * pr + q;
+    const int cg = 4 * (wrow * RP + pr) + q;
     float sc[8], sh[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) { sc[r] = aff[cg * 8 + r]; sh[r] = aff[CM + cg * 8 + r]; }
@@ -271,17 +279,24 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   }
 
   // ---- geometry of phases 2 and 3: this lane's output pixel in each of the wave's column blocks ---------------------------------------
-  int h0[NJ2];                                             // chunk index of the pixel's top-left tap inside a y1 row
-  unsigned ooff[NJ2];                                      // byte offset of (channel group q, plane 0, pixel) inside a 32-channel block, or OOB
-  unsigned foff[NJ2];                                      // ... of (channel 8 q, pixel) in the fp32 tensor
-  int pcol[NJ2];
+  int h0[NJ2];                                             // phase 2: chunk index of the pixel's top-left tap inside a y1 row
+  int pcol2[NJ2];                                          // ... and the pixel's slot in a y2 row
 #pragma unroll
   for (int j = 0; j < NJ2; ++j) {
+    const int p = (wcol + NWC * j) * 16 + c16;
+    const int oy = p / TW, ox = p - oy * TW;
+    pcol2[j] = (wcol + NWC * j) < CB2 ? p : 0;
+    h0[j] = p < NP ? oy * HWD + ox : 0;
+  }
+  unsigned ooff[NJ3];                                      // phase 3: byte offset of (channel group q, plane 0, pixel) inside a 32-channel block, or OOB
+  unsigned foff[NJ3];                                      // ... of (channel 8 q, pixel) in the fp32 tensor
+  int pcol[NJ3];
+#pragma unroll
+  for (int j = 0; j < NJ3; ++j) {
     const int p = (wave + NW * j) * 16 + c16;
     const int oy = p / TW, ox = p - oy * TW;
     const bool valid = (wave + NW * j) < CB2 && p < NP && y0 + oy < H && x0 + ox < W;
     pcol[j] = (wave + NW * j) < CB2 ? p : 0;
-    h0[j] = p < NP ? oy * HWD + ox : 0;
     ooff[j] = valid ? (unsigned)((q * 2 * HW + (y0 + oy) * W + x0 + ox) * 16) : OOB;
     foff[j] = valid ? (unsigned)((q * 8 * HW + (y0 + oy) * W + x0 + ox) * 4) : OOB;
   }
@@ -308,8 +323,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     bf16x8 ah[RB], al[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      ah[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 0) * CM + i * 16 + c16]);
-      al[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 1) * CM + i * 16 + c16]);
+      ah[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 0) * CM + (wrow * RB + i) * 16 + c16]);
+      al[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 1) * CM + (wrow * RB + i) * 16 + c16]);
     }
     bf16x8 bh[NJ2], bl[NJ2];
 #pragma unroll
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     wissue(w_next, g + 3);
 #pragma unroll
     for (int j = 0; j < NJ2; ++j)
-      if (wave + NW * j < CB2) {
+      if (wcol + NWC * j < CB2) {
 #pragma unroll
         for (int i = 0; i < RB; ++i) acc2[i][j] = mfma3(ah[i], al[i], bh[j], bl[j], acc2[i][j]);
       }
@@ -335,15 +350,15 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   }
   wait_vmcnt<0>();
   // the residual chunks of the first two steps of phase 3 travel under the epilogue of phase 2 (the geometry is known since phase 1)
-  u32x4 rq[2][NJ2][2];                                     // residual chunks of steps m, m + 1
-  auto rissue = [&](u32x4 (&r)[NJ2][2], int m) {
+  u32x4 rq[2][NJ3][2];                                     // residual chunks of steps m, m + 1
+  auto rissue = [&](u32x4 (&r)[NJ3][2], int m) {
 #if CL4_F_DBG & 2
     m = NM3;
 #endif
     const unsigned keep = (unsigned)(-(int)(m < NM3));
     const unsigned so = img_base + (unsigned)(m < NM3 ? m : 0) * 8u * (unsigned)HW * 16u;
 #pragma unroll
-    for (int j = 0; j < NJ2; ++j)
+    for (int j = 0; j < NJ3; ++j)
 #pragma unroll
       for (int p = 0; p < 2; ++p)
         r[j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ((ooff[j] + (unsigned)(p * HW * 16)) & keep) | (OOB & ~keep), so, 0);
@@ -353,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   // every wave has left the K loop (barrier above): y1 is dead, y2 takes its place
 #pragma unroll
   for (int pr = 0; pr < RP; ++pr) {
-    const int cg = 4 * pr + q;
+    const int cg = 4 * (wrow * RP + pr) + q;
     float sc[8], sh[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) { sc[r] = aff[2 * CM + cg * 8 + r]; sh[r] = aff[3 * CM + cg * 8 + r]; }
@@ -369,9 +384,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
       }
       u32x4 hi, lo;
       split8(v, hi, lo);
-      if (wave + NW * j < CB2) {
-        ybuf[(cg * 2 + 0) * NPS + pcol[j]] = hi;
-        ybuf[(cg * 2 + 1) * NPS + pcol[j]] = lo;
+      if (wcol + NWC * j < CB2) {
+        ybuf[(cg * 2 + 0) * NPS + pcol2[j]] = hi;
+        ybuf[(cg * 2 + 1) * NPS + pcol2[j]] = lo;
       }
     }
   }
@@ -386,15 +401,15 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   // first the steps stalled on them, 102 of 428 us). At the start of step m >= 2 everything up to R(m) has to be there; S(m-2) and the whole
   // of step m-1 may be in flight: 2 NS + LW + NR (capped by the 6-bit counter). Step 1 has no S(-1) in front of it, step 0 sees only R(0) R(1).
   constexpr int WAIT3 = (2 * NS + LW + NR) < 63 ? (2 * NS + LW + NR) : 63;
-  auto step3 = [&](u32x4 (&w_next)[LW], u32x4 (&r_cur)[NJ2][2], int m, int which) {
+  auto step3 = [&](u32x4 (&w_next)[LW], u32x4 (&r_cur)[NJ3][2], int m, int which) {
     if (which == 0) wait_vmcnt<NR>(); else if (which == 1) wait_vmcnt<LW + NR + NS>(); else wait_vmcnt<WAIT3>();
     const int g = KT1 + KT2 + m;
     const u32x4* As = wst[g & 1];
-    f32x4a acc3[2][NJ2];
+    f32x4a acc3[2][NJ3];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int j = 0; j < NJ2; ++j) acc3[b][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NJ3; ++j) acc3[b][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < KT3; ++kt) {
       bf16x8 ah[2], al[2];
@@ -405,7 +420,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
       }
       const u32x4* Bs = ybuf + ((kt * 4 + q) * 2) * NPS;
 #pragma unroll
-      for (int j = 0; j < NJ2; ++j)
+      for (int j = 0; j < NJ3; ++j)
         if (wave + NW * j < CB2) {
           const bf16x8 bh = __builtin_bit_cast(bf16x8, Bs[pcol[j]]), bl = __builtin_bit_cast(bf16x8, Bs[NPS + pcol[j]]);
 #pragma unroll
@@ -421,10 +436,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     for (int r = 0; r < 8; ++r) { sc[r] = aff[4 * CM + cg * 8 + r]; sh[r] = aff[4 * CM + C4 + cg * 8 + r]; }
     const unsigned so = img_base + (unsigned)m * 8u * (unsigned)HW * 16u;
     const unsigned fso = ((unsigned)img * (unsigned)C4 + 32u * (unsigned)m) * (unsigned)HW * 4u;
-    float v[NJ2][8];
-    u32x4 ohi[NJ2], olo[NJ2];
+    float v[NJ3][8];
+    u32x4 ohi[NJ3], olo[NJ3];
 #pragma unroll
-    for (int j = 0; j < NJ2; ++j) {
+    for (int j = 0; j < NJ3; ++j) {
       float res[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[j][r] = acc3[0][j][r]; v[j][4 + r] = acc3[1][j][r]; }
@@ -444,9 +459,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     // whatever the next instruction wrote there: FINDINGS.md finding 37; found as 4-pixel groups of wrong channels 8 k, 8 k + 1 in
     // the workgroups of the second round only). Here the stores also keep their whole offset in the VGPR (soffset 0: the form
     // the compiler does guard), and the scheduler may not move anything across the fence in front of them.
-    unsigned ahi[NJ2], alo[NJ2], af32[NJ2];               // ... and every store address
+    unsigned ahi[NJ3], alo[NJ3], af32[NJ3];               // ... and every store address
 #pragma unroll
-    for (int j = 0; j < NJ2; ++j) {
+    for (int j = 0; j < NJ3; ++j) {
 #if CL4_F_DBG & 4
       const unsigned skeep = v[j][0] == 123.456f ? ~0u : 0u;     // keeps the arithmetic alive, drops (practically) every store
 #else
@@ -460,7 +475,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     rissue(r_cur, m + 2);                                  // into the registers the sums above have just consumed
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < NJ2; ++j) {
+    for (int j = 0; j < NJ3; ++j) {
       if constexpr (F32OUT) {                              // dword stores: no multi-cycle data read, the uniform part may stay in the SGPR offset
 #pragma unroll
         for (int r = 0; r < 8; ++r)
@@ -487,18 +502,25 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
 static long g_f_launches = 0;
 extern "C" long cl4_conv_debug_f_launches(void) { return g_f_launches; }
 
+namespace {
+
+// tile of output pixels per workgroup, by middle width: res2 (cm 64, 129 x 129 maps) 13 x 13, two 4-wave workgroups per CU; res3 (cm 128,
+// 65 x 65 maps) one 8-wave workgroup per CU (y1 alone is 116 KB)
+constexpr int F_TH64 = 13, F_TW64 = 13, F_TH128 = 13, F_TW128 = 13;
+
+}  // namespace
+
 extern "C" int cl4_bottleneck_fused_tile(int cm, int* th, int* tw) {
-  if (cm != 64) return CL4_EINVAL;
-  *th = 13;
-  *tw = 13;
-  return CL4_OK;
+  if (cm == 64) { *th = F_TH64; *tw = F_TW64; return CL4_OK; }
+  if (cm == 128) { *th = F_TH128; *tw = F_TW128; return CL4_OK; }
+  return CL4_EINVAL;
 }
 
 extern "C" int cl4_bottleneck_fused(const void* xs, void* ys, float* y, int n_f32, const void* w1, const void* w2, const void* w3, const float* aff,
                                     int n, int cm, int h, int w, float slope1, float slope2, float slope_out, void* stream) {
   CL4_REQUIRE(xs && ys && w1 && w2 && w3 && aff, "bottleneck_fused: null operand");
   CL4_REQUIRE(xs != ys, "bottleneck_fused: the output must not alias the input (tiles read their neighbours' halo)");
-  CL4_REQUIRE(cm == 64, "bottleneck_fused: middle width %d not built (64)", cm);
+  CL4_REQUIRE(cm == 64 || cm == 128, "bottleneck_fused: middle width %d not built (64, 128)", cm);
   CL4_REQUIRE(n > 0 && h > 0 && w > 0, "bottleneck_fused: bad shape");
   CL4_REQUIRE((long)n * 4 * cm * h * w * 4 < (1l << 31), "bottleneck_fused: tensor of %ld bytes exceeds the 2 GiB buffer-descriptor range",
               (long)n * 4 * cm * h * w * 4);
@@ -507,13 +529,19 @@ extern "C" int cl4_bottleneck_fused(const void* xs, void* ys, float* y, int n_f3
   a.neg1 = slope1; a.neg2 = slope2; a.neg3 = 1.f; a.negout = slope_out;
   a.n = n; a.h = h; a.w = w;
   a.n_f32 = y ? (n_f32 < 0 || n_f32 > n ? n : n_f32) : 0;
-  constexpr int TH = 13, TW = 13;
-  a.tiles_x = cl4::cdiv(w, TW);
-  a.tiles_y = cl4::cdiv(h, TH);
+  const int th = cm == 64 ? F_TH64 : F_TH128, tw = cm == 64 ? F_TW64 : F_TW128;
+  a.tiles_x = cl4::cdiv(w, tw);
+  a.tiles_y = cl4::cdiv(h, th);
   a.xcd_remap = 1;
-  const dim3 grid((unsigned)(n * a.tiles_x * a.tiles_y)), block(256);
+  const dim3 grid((unsigned)(n * a.tiles_x * a.tiles_y));
+  hipStream_t st = cl4::as_stream(stream);
   ++g_f_launches;
-  if (y) hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, TH, TW, true>), grid, block, 0, cl4::as_stream(stream), a);
-  else hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, TH, TW, false>), grid, block, 0, cl4::as_stream(stream), a);
+  if (cm == 64) {
+    if (y) hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, 1, F_TH64, F_TW64, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, 1, F_TH64, F_TW64, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (y) hipLaunchKernelGGL((bottleneck_fused_kernel<128, 8, 2, F_TH128, F_TW128, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((bottleneck_fused_kernel<128, 8, 2, F_TH128, F_TW128, false>), grid, dim3(512), 0, st, a);
+  }
   return cl4::launch_status();
 }

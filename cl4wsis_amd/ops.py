@@ -597,8 +597,11 @@ def pack_stem_weight(w):
     return wq
 
 
-FUSED_BLOCK = os.environ.get("CL4_FUSED_BLOCK", "1") != "0"    # r04: identity bottlenecks of res2 as one launch (csrc/conv_f.hip)
-FUSED_CM = (64,)                                                 # middle widths the fused kernel is built for
+FUSED_BLOCK = os.environ.get("CL4_FUSED_BLOCK", "1") != "0"    # r04: identity bottlenecks of res2 / res3 as one launch (csrc/conv_f.hip)
+# Middle widths that run fused (built: 64 = res2, 128 = res3). Default 64 only: the 128-channel variant (one 8-wave workgroup per CU, 116 KB of
+# y1 in LDS, 800 / 400 tiles = 3.1 / 1.6 rounds) is bit-exact but no faster than the three tuned launches — 385 vs 367 us at 32 images, 183 vs
+# 182 us at 16 (tools/probe_f.py, FINDINGS.md finding 38) — so res3 stays on three launches; CL4_FUSED_CM=64,128 selects it for experiments.
+FUSED_CM = tuple(int(v) for v in os.environ.get("CL4_FUSED_CM", "64").split(",") if v)
 
 
 def bottleneck_fused(xs, w1, w2, w3, aff, slope1, slope2, slope_out, want_fp32=False, out_planes=None, f32_images=None):

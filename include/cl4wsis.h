@@ -550,7 +550,7 @@ long cl4_conv_debug_b_launches(void);   /* launches of the big-tile LDS-DMA plan
  * by cl4_pack_conv_weight_bf16x3; aff: the folded eval-mode ABN affine maps concatenated [scale1 | shift1 | scale2 | shift2] (cm floats
  * each) [scale3 | shift3] (4*cm each); slope1 / slope2 / slope_out: the leaky-ReLU slopes after bn1, bn2 and after the residual sum
  * (bn3 has the identity activation, modules/residual.py:82). Same products in the same order as three cl4_conv2d_fwd_planes calls.
- * cm = 64 (res2) is built. Enqueue-only on `stream`; no workspace. */
+ * cm = 64 (res2, 4-wave workgroups, two per CU) and cm = 128 (res3, one 8-wave workgroup per CU) are built. Enqueue-only on `stream`; no workspace. */
 int cl4_bottleneck_fused(const void* xs, void* ys, float* y, int n_f32, const void* w1, const void* w2, const void* w3, const float* aff,
                          int n, int cm, int h, int w, float slope1, float slope2, float slope_out, void* stream);
 /* Tile of output pixels per workgroup for middle width cm (CL4_EINVAL: not built). */

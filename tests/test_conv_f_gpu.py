@@ -31,12 +31,13 @@ def _reference64(x, ws, aff, slope=0.01):
 
 # the last three shapes have more workgroups than the chip holds at once (> 512): the second round runs under memory load, which is
 # what exposed the store-data hazard of FINDINGS.md finding 37 (wrong first dwords of output chunks in those workgroups only)
-@pytest.mark.parametrize("n,h,w,want_fp32", [(2, 33, 33, True), (1, 29, 31, False), (3, 13, 13, True), (1, 40, 17, True),
-                                            (2, 14, 27, False), (1, 129, 129, True), (6, 129, 129, False), (24, 65, 65, True),
-                                            (70, 33, 33, False)])
-def test_fused_bottleneck_matches_three_planes_launches_and_float64(gpu, n, h, w, want_fp32):
+@pytest.mark.parametrize("cm,n,h,w,want_fp32", [(64, 2, 33, 33, True), (64, 1, 29, 31, False), (64, 3, 13, 13, True), (64, 1, 40, 17, True),
+                                               (64, 2, 14, 27, False), (64, 1, 129, 129, True), (64, 6, 129, 129, False),
+                                               (64, 24, 65, 65, True), (64, 70, 33, 33, False),
+                                               (128, 2, 33, 33, True), (128, 1, 29, 31, False), (128, 3, 13, 13, True), (128, 2, 65, 65, True),
+                                               (128, 1, 14, 27, False), (128, 24, 65, 65, False), (128, 40, 33, 33, True)])
+def test_fused_bottleneck_matches_three_planes_launches_and_float64(gpu, cm, n, h, w, want_fp32):
     from cl4wsis_amd import ops
-    cm = 64
     ws, aff = _block(cm, 7 * n + h, gpu)
     g = torch.Generator().manual_seed(h * 100 + w)
     x = torch.randn(n, 4 * cm, h, w, generator=g).to(gpu)
@@ -96,7 +97,7 @@ def test_fused_bottleneck_rejects_what_it_cannot_do(gpu):
         ops.bottleneck_fused(xp, p1, p2, p3, torch.cat(aff), 0.01, 0.01, 0.01, out_planes=xp)        # in place: neighbours read the halo
     with pytest.raises(RuntimeError):
         ops.bottleneck_fused(xp, p1, p3, p2, torch.cat(aff), 0.01, 0.01, 0.01)                       # weights in the wrong roles
-    ws32, aff32 = _block(32, 2, gpu)
+    ws32, aff32 = _block(32, 2, gpu)              # width 32 is not built (64 and 128 are)
     xp32 = ops.to_planes(torch.randn(1, 128, 13, 13, device=gpu))
     with pytest.raises(RuntimeError):
         ops.bottleneck_fused(xp32, *(ops.pack_conv_weight(t, 1) for t in ws32), torch.cat(aff32), 0.01, 0.01, 0.01)   # width not built
@@ -116,13 +117,14 @@ def test_resnet_body_is_unchanged_by_the_fusion(gpu, monkeypatch):
     x = torch.randn(2, 3, 97, 97, generator=torch.Generator().manual_seed(3)).to(gpu)
     lib = ops._hip.load()
     outs = {}
+    monkeypatch.setattr(ops, "FUSED_CM", (64, 128))            # res3 too (off by default: not faster, see ops.FUSED_CM)
     for fused in (False, True):
         monkeypatch.setattr(ops, "FUSED_BLOCK", fused)
         n0 = lib.cl4_conv_debug_f_launches()
         with torch.no_grad():
             outs[fused] = [t.clone() for t in body(x)]
         torch.cuda.synchronize()
-        assert (lib.cl4_conv_debug_f_launches() - n0) == (2 if fused else 0)      # res2 blocks 2 and 3
+        assert (lib.cl4_conv_debug_f_launches() - n0) == (5 if fused else 0)      # res2 blocks 2, 3 and res3 blocks 2, 3, 4
     for a, b in zip(outs[False], outs[True]):
         assert a.shape == b.shape
         err = ((a - b).abs().max() / a.abs().max()).item()
