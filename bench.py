@@ -50,6 +50,9 @@ def parse_args(argv=None):
                     help="timed CPU iterations at batch 16 after the batch-2 warm-up (default 3 = BASELINE.md §4's protocol, ~80 s each on a "
                          "16-thread box share; the stock-ops GPU comparator pays for it with ONE timed iteration after its MIOpen warm-up)")
     ap.add_argument("--no-structured", action="store_true", help="skip the structured-labels sub-record")
+    ap.add_argument("--config", choices=("p2", "p1"), default="p2",
+                    help="p2 (default): BASELINE config 3, the metric; p1: BASELINE config 2 (VOC 15-5 step 1 phase 1, batch 16) through the same "
+                         "Trainer.step, with its own roofline sub-record (no CPU / stock legs)")
     ap.add_argument("--rehearse-launcher", action="store_true",
                     help="CPU-only check of the self-launch path: rendezvous over gloo, all-reduce of ones, no GPU work")
     return ap.parse_args(argv)
@@ -268,6 +271,101 @@ def rehearse(a):
     if rank == 0:
         print(json.dumps({"metric": METRIC, "rehearsal": True, "n_gpus": world, "n_ranks_seen": int(seen.item())}), flush=True)
     if world > 1:
+        dist.destroy_process_group()
+
+
+def p1_opts(batch):
+    """BASELINE config 2: scripts/run.sh:31-33 + --crop_size."""
+    from cl4wsis_amd import argparser
+    args = ["--dataset", "voc", "--task", "15-5", "--step", "1", "--weakly", "--phase", "1", "--alpha", "0.5", "--loss_de", "1",
+            "--lr_policy", "warmup", "--affinity", "--optim", "sgd", "--lr", "0.001", "--epochs", "40", "--crop_size", str(CROP),
+            "--batch_size", str(batch), "--no_pretrained"]
+    return argparser.modify_command_options(argparser.get_argparser().parse_args(args))
+
+
+ALGO_GFLOP_PER_IMAGE_P1 = 684.0   # SURVEY.md §8(d): old fwd + new fwd / bwd + PseudoLabeler on 3b (FLAC) fwd / bwd + eval pass
+
+
+def worker_p1(a):
+    """--config p1: the phase-1 step (BASELINE config 2) at global batch 16, epoch >= pseudo_ep (PAMR, l_seg, l_cls, RandDrop active).
+    Same timing contract as the metric run; HIP-graph replayed on one GPU (three graphs, one per FLAC angle)."""
+    import torch
+    import torch.distributed as dist
+    from cl4wsis_amd import ops
+    from cl4wsis_amd.parallel import init_distributed
+    from cl4wsis_amd.synthetic import synthetic_batch
+    from cl4wsis_amd.train import Trainer
+    rank, world, local = init_distributed()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    b = int(os.environ.get("CL4_BENCH_PER_GPU_BATCH", GLOBAL_BATCH // world))
+    opts = p1_opts(GLOBAL_BATCH)
+    opts.batch_size = b
+    opts.max_iters, opts.start_decay = 40 * 661, 5 * 661
+    torch.manual_seed(42)
+
+    class _Log:
+        def info(self, *a, **k): pass
+        debug = info
+
+    trainer = Trainer(_Log(), device, opts)
+    trainer._cur_epoch = opts.pseudo_ep                     # the full loss stack (train.py:370-416)
+    images, l1h = synthetic_batch(b, 42 + rank, device, CROP)
+    batch = (images, l1h)
+    import numpy as np
+    np.random.seed(7)
+    for _ in range(max(a.warmup, 3) + 6):                   # eager + tuner, then every FLAC angle's graph gets captured before the timed region
+        trainer.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = trainer.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    graphs = len(trainer._p1_static["graphs"]) if trainer._p1_static else 0
+    # roofline leg: one more step, eager, HIP events around every convolution launch
+    ops.TIMER = ops.KernelTimer()
+    trainer._use_graph = False
+    trainer.step(batch)
+    torch.cuda.synchronize()
+    summ, ops.TIMER = ops.TIMER.summary(), None
+    if rank == 0:
+        peaks = {"conv_fwd_bf16x6": PEAK_BF16_MFMA_TFLOPS / 6.0, "conv_fwd_bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "conv_fwd_f32": PEAK_FP32_MFMA_TFLOPS,
+                 "conv_wgrad": PEAK_BF16_MFMA_TFLOPS / 3.0 if ops.WGRAD_PRECISION == 1 else PEAK_FP32_MFMA_TFLOPS}
+        kinds = {k: {"achieved": fl / (ms * 1e-3) / 1e12, "peak": peaks.get(k), "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peaks[k] if k in peaks else None,
+                     "ms_per_step": ms, "launches_per_step": n} for k, (n, fl, ms) in summ.items()}
+        dom = max(kinds, key=lambda k: kinds[k]["ms_per_step"])
+        res = {"metric": "images/sec at batch 16, VOC 15-5 step-1 phase-1 (BASELINE config 2), 1/2/4/8 MI355X", "value": GLOBAL_BATCH * a.steps / dt,
+               "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "VOC 15-5 step 1 phase 1 (BASELINE config 2), Trainer.step, global batch 16, 513x513, ResNet101 + DeepLabV3 + "
+                                      "PseudoLabeler + PeakGenerator trained with SGD-Nesterov, epoch >= pseudo_ep (PAMR, l_seg, l_cls, RandDrop on), "
+                                      "random-init weights", "global_batch": GLOBAL_BATCH, "per_gpu_batch": b, "crop": CROP, "parallelism": f"dp{world}",
+                          "arithmetic": "fp32 tensors; differentiated convolutions bf16x6 (fp32-level), weight gradients bf16x3, frozen old model bf16x3",
+                          "hip_graphs": graphs},
+               "roofline": dict(kinds[dom], bound="mfma", kernel=dom + ": every launch of one eager step after the timed region, HIP events on the launch stream",
+                                traffic=None),
+               "kinds": kinds,
+               "algorithmic_tflops_whole_step": ALGO_GFLOP_PER_IMAGE_P1 * GLOBAL_BATCH * a.steps / dt / 1e3,
+               "final_losses": {k: float(v) for k, v in out["losses"].items()}}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -528,6 +626,8 @@ def main():
         sys.exit(launch_workers(a, argv))
     if a.rehearse_launcher:
         rehearse(a)
+    elif a.config == "p1":
+        worker_p1(a)
     else:
         worker(a)
 

@@ -173,6 +173,7 @@ _decl("cl4_channel_affine", _P, _P, _I, _I, _I, _P, _P, _P)
 _decl("cl4_randrop_loss", _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_transpose_flip_weight", _P, _P, _I, _I, _I, _P)
 _decl("cl4_random_labels", _P, _L, C.c_uint64, _I, _P)
+_decl("cl4_random_labels_dev", _P, _L, _P, C.c_uint64, _I, _P)
 _decl("cl4_val_seg", _P, _P, _P, _P, _I, _I, _I, _I, _I, _P)
 _decl("cl4_instance_map", C.POINTER(InsmapIO), _P, C.c_size_t, _P)
 _decl("cl4_semseg_hist", _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P)

@@ -342,7 +342,8 @@ __global__ void dropout_mask_kernel(uint8_t* __restrict__ keep, long n, uint64_t
 }
 
 // Uniform integer draws in [0, modulus): splitmix64 of (seed, element index) — RandropLoss' random old classes.
-__global__ void random_labels_kernel(int* __restrict__ out, long n, uint64_t seed, int modulus) {
+__global__ void random_labels_kernel(int* __restrict__ out, long n, uint64_t seed, const uint64_t* __restrict__ seed_dev, int modulus) {
+  if (seed_dev) seed = *seed_dev * 0xD1342543DE82EF95ull + 7919;      // device-resident seed (graph replays): one counter value per step
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -549,7 +550,8 @@ extern "C" int cl4_dropout_mask(uint8_t* keep, long n, uint64_t seed, float p, v
 
 extern "C" int cl4_random_labels(int* out, long n, uint64_t seed, int modulus, void* stream) {
   CL4_REQUIRE(out && n > 0 && modulus > 0, "random_labels: bad arguments");
-  hipLaunchKernelGGL(random_labels_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), out, n, seed, modulus);
+  hipLaunchKernelGGL(random_labels_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), out, n, seed,
+                     (const uint64_t*)nullptr, modulus);
   return cl4::launch_status();
 }
 
@@ -574,6 +576,16 @@ extern "C" int cl4_abs_eps(const float* w, float* out, int n, float eps, void* s
 extern "C" int cl4_sign_axpy(float* y, const float* x, const float* w, int n, void* stream) {
   CL4_REQUIRE(y && x && w && n > 0, "sign_axpy: bad arguments");
   hipLaunchKernelGGL(sign_axpy_kernel, dim3(cl4::cdiv(n, 256)), dim3(256), 0, cl4::as_stream(stream), y, x, w, n);
+  return cl4::launch_status();
+}
+
+// The same draws from a seed that lives in device memory and is advanced by the launch (like cl4_dropout_mask_dev): a captured
+// phase-1 step draws fresh RandDrop labels at every replay (utils/wss_loss.py:237 draws them with Tensor.random_ per call).
+extern "C" int cl4_random_labels_dev(int* out, long n, uint64_t* seed_dev, uint64_t advance, int modulus, void* stream) {
+  CL4_REQUIRE(out && seed_dev && n > 0 && modulus > 0, "random_labels_dev: bad arguments");
+  hipStream_t st = cl4::as_stream(stream);
+  hipLaunchKernelGGL(random_labels_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, st, out, n, (uint64_t)0, (const uint64_t*)seed_dev, modulus);
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, st, seed_dev, advance);
   return cl4::launch_status();
 }
 

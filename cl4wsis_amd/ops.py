@@ -1435,6 +1435,13 @@ def random_labels(shape, modulus, seed, device):
     return out
 
 
+def random_labels_dev(shape, modulus, seed_dev, advance, device):
+    """random_labels from a device-resident seed (uint64 tensor [1]) that the launch advances: graph-replay safe."""
+    out = torch.empty(shape, dtype=torch.int32, device=device)
+    call("cl4_random_labels_dev", ptr(out), out.numel(), ptr(seed_dev), C.c_uint64(advance), int(modulus), stream())
+    return out
+
+
 def semseg_hist_(hist, logits, labels, n_classes, flip=False, zero_below=0, want_pred=False):
     """Confusion-matrix update of validation (train.py:695-745): hist (int64 [n,n] device tensor) += counts."""
     _f32c(logits, "semseg_hist logits")

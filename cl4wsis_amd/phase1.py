@@ -87,8 +87,8 @@ class Phase1Step:
             ops.axpy_(draw, g)
             if opts.randrop:
                 if randrop_neg is None:
-                    self._draws += 1
-                    randrop_neg = ops.random_labels((bs, h, w), old, opts.random_seed * 7919 + self._draws, res5.device)
+                    # device-resident seed, advanced by the launch: the same code path eager and under HIP-graph replay
+                    randrop_neg = ops.random_labels_dev((bs, h, w), old, tr._p1_seed_dev, 1, res5.device)
                 losses["l_rand"], g = ops.randrop_loss(raw, int_masks, l1h, randrop_neg, old, mask_labels=l1h if opts.no_mask else None)
                 ops.axpy_(draw, g)
 

@@ -92,6 +92,13 @@ class Trainer:
         self._iter = 0
         self._side_stream = torch.cuda.Stream(device=self.device) if os.environ.get("CL4_OVERLAP", "1") != "0" else None
         self._use_graph = os.environ.get("CL4_GRAPH", "1") != "0"
+        # N > 1: the ASPP tail as a chain of per-bucket graphs (_distributed_tail). Built and tested (world-size-1 RCCL rehearsal, two gloo ranks),
+        # measured at world size 1: 34.57 / 19.53 / 11.95 / 8.27 ms per step at 16 / 8 / 4 / 2 images against 34.57 / 19.44 / 11.96 / 8.21 with the
+        # eager tail (profiles/r04_solo_collectives.txt) — the host runs ahead of the device either way, so it is OFF by default: the only real
+        # N > 1 RCCL run is the driver's, and a capture of ~15 kernels buys nothing there.
+        self._tail_graph = os.environ.get("CL4_TAIL_GRAPH", "0") != "0"
+        self._tail_segs, self._tail_keep = {}, []
+        self._p1_static = None
         self._graph, self._static, self._graph_active = None, None, False
         # Software pipelining across iterations (single-GPU graph mode): the frozen old model's forward of batch t+1 is replayed on
         # its own stream while batch t's step runs (it depends on nothing the optimizer touches). CL4_PIPELINE=0 switches it off.
@@ -110,6 +117,9 @@ class Trainer:
         # of masks (with "+ 7919 * rank", rank r at step t drew rank 0's mask of step t + 7919 r: ADVICE r02)
         self._seed_dev = torch.tensor([(opts.random_seed * 1000003) % (1 << 40) + ((dist.get_rank() if dist.is_initialized() else 0) << 40)],
                                       dtype=torch.int64, device=self.device)
+        # RandDrop's random old-class labels (phase 1, utils/wss_loss.py:237): their own device-resident counter, same rank layout
+        self._p1_seed_dev = torch.tensor([(opts.random_seed * 7919) % (1 << 40) + ((dist.get_rank() if dist.is_initialized() else 0) << 40)],
+                                         dtype=torch.int64, device=self.device)
 
     # ------------------------------------------------------------------------------------------ optimizer
     def get_optimizer(self, opts):
@@ -244,7 +254,13 @@ class Trainer:
         return {"losses": losses}
 
     def _step_phase1(self, batch, cur_epoch=None, flac_angle=None, randrop_neg=None):
-        """One phase-1 iteration (train.py:241-566 with --phase 1) — see cl4wsis_amd/phase1.py."""
+        """One phase-1 iteration (train.py:241-566 with --phase 1) — see cl4wsis_amd/phase1.py.
+
+        r04: on one GPU the step is HIP-graph replayed from its third call on. What varies between iterations is
+        device-resident (learning rates, the RandDrop seed) or selects the graph: the FLAC angle (train.py:316 draws 90 / 180 / 270 on
+        the host — three graphs, captured on first use, sharing one memory pool) and the side of `pseudo_ep` the epoch is on (two loss
+        stacks). Injected angles / draws (the parity tests), N > 1 (cross-rank ABN statistics and the bucketed all-reduce sit between
+        the kernels) and CL4_GRAPH=0 take the eager path."""
         from .phase1 import Phase1Step
         if self._p1 is None:
             self._p1 = Phase1Step(self)
@@ -252,19 +268,60 @@ class Trainer:
         images = images.to(self.device, dtype=torch.float32).contiguous()
         l1h = l1h.to(self.device, dtype=torch.float32).contiguous()
         self.model.train()
-        ops.AUTOTUNE = self._iter == 0 and os.environ.get("CL4_AUTOTUNE", "1") != "0"
-        try:
-            losses = self._p1.run(images, l1h, self._cur_epoch if cur_epoch is None else cur_epoch, flac_angle, randrop_neg)
-        finally:
-            ops.AUTOTUNE = False
-        for i in range(len(self.buckets.fb.sizes)):
-            self.buckets.ready(i)
-        self.buckets.finish()
-        self.optimizer.step()
+        epoch = self._cur_epoch if cur_epoch is None else cur_epoch
+        late = epoch >= self.pseudo_epoch
+        use_graph = (self._use_graph and flac_angle is None and randrop_neg is None and self._iter >= 2 and ops.TIMER is None
+                     and not self.buckets.distributed
+                     and (self._p1_static is None or tuple(images.shape) == tuple(self._p1_static["images"].shape)))
+        if use_graph:
+            angle = [90, 180, 270][np.random.randint(3)]          # train.py:316, drawn on the host like the reference does
+            losses = self._replay_phase1(images, l1h, angle, late)
+        else:
+            ops.AUTOTUNE = self._iter == 0 and os.environ.get("CL4_AUTOTUNE", "1") != "0"
+            try:
+                losses = self._p1.run(images, l1h, epoch, flac_angle, randrop_neg)
+            finally:
+                ops.AUTOTUNE = False
+            for i in range(len(self.buckets.fb.sizes)):
+                self.buckets.ready(i)
+            self.buckets.finish()
+            self.optimizer.step()
         if self.scheduler is not None:
             self.scheduler.step()
         self._iter += 1
         return {"losses": losses}
+
+    def _replay_phase1(self, images, l1h, angle, late):
+        from .nn import CACHE
+        opt = self.optimizer
+        if self._p1_static is None:
+            self._p1_static = {"images": images.clone(), "l1h": l1h.clone(), "graphs": {}, "pool": torch.cuda.graph_pool_handle(), "keep": []}
+        S = self._p1_static
+        key = (angle, late)
+        if key not in S["graphs"]:
+            def stale_trainable():
+                # every graph re-derives (packs / folds) what it reads from the TRAINABLE weights itself; eager code and the other
+                # graphs must not read a derived tensor that only this graph refreshes (same rule as _replay_pipelined)
+                for grp in opt.param_groups:
+                    for prm in grp["params"]:
+                        CACHE.touch(prm)
+            opt.upload_lr()
+            torch.cuda.synchronize()
+            stale_trainable()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=S["pool"]):
+                losses = self._p1.run(S["images"], S["l1h"], self.pseudo_epoch if late else 0, angle, None)
+                opt.step(upload=False)
+            stale_trainable()
+            S["graphs"][key] = (g, losses)
+            S["keep"].append(self._derived_snapshot())
+        g, losses = S["graphs"][key]
+        S["images"].copy_(images)
+        S["l1h"].copy_(l1h)
+        opt.upload_lr()
+        g.replay()
+        self._graph_active = True
+        return losses
 
     # HIP-graph path: iteration 0 runs eagerly (autotuning), iteration 1 captures the whole step — both streams, ~600
     # kernel launches — into one graph, and every later iteration is a copy of the batch into static buffers plus one
@@ -277,7 +334,8 @@ class Trainer:
             opt.upload_lr()
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            self._static["pool"] = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(self._graph, pool=self._static["pool"]):
                 out = self._forward_backward(self._static["images"], self._static["l1h"], None,
                                              split_tail=self.buckets.distributed)
                 if not self.buckets.distributed:
@@ -293,7 +351,7 @@ class Trainer:
         if not self.buckets.distributed:
             opt.note_replayed_step()
         else:
-            self._distributed_tail(self._static["out"])
+            self._distributed_tail(self._static["out"], self._static.get("pool"))
         return self._static["out"]
 
     def _derived_snapshot(self):
@@ -306,18 +364,80 @@ class Trainer:
         return (CACHE.snapshot([self.model, self.model_old, getattr(self, "pseudolabeler", None), getattr(self, "peakgenerator", None)])
                 + ops.workspace_snapshot())
 
-    def _distributed_tail(self, out):
-        # N > 1: the graph ends where the ASPP block's backward begins. Those last kernels produce 90 % of the gradient
-        # bytes; they run eagerly here so that each bucket's RCCL all-reduce is issued on the communication stream as soon as
-        # its weight-gradient kernel is enqueued and overlaps the remaining ones (RCCL calls stay out of the capture).
-        tape, dy = out["_tail"]
+    def _distributed_tail(self, out, pool=None):
+        # N > 1: the main graph ends where the ASPP block's backward begins. Those last kernels produce 90 % of the gradient bytes, and
+        # each bucket's RCCL all-reduce has to be issued on the communication stream as soon as its last weight-gradient kernel is
+        # enqueued, so that it overlaps the remaining ones; the RCCL calls stay out of every capture. r02 / r03 ran these ~15 launches
+        # eagerly (0.3-0.6 ms of Python + launch time per step at world size 1). r04: the tail is captured ONCE as a
+        # chain of small graphs cut exactly where a bucket completes (the ready-hook of the backward pass ends one capture and begins the
+        # next); a step replays segment, marks its parameters ready (which launches the bucket's all-reduce behind it), replays the next.
+        # CL4_TAIL_GRAPH=1 selects it; the default is the eager tail (no measurable difference at world size 1, see __init__).
+        b = self.buckets
         aspp = {id(p) for p in self._branch.aspp_parameters()}
-        for p in self.optimizer.flat_params():
-            if id(p) not in aspp:
-                self.buckets.ready(self.optimizer.index[id(p)])       # finalised inside the graph
-        self._branch.backward_aspp(tape, dy, self._grad_map, on_ready=self._ready)
-        self.buckets.finish()
+        if not self._tail_graph:
+            tape, dy = out["_tail"]
+            for p in self.optimizer.flat_params():
+                if id(p) not in aspp:
+                    b.ready(self.optimizer.index[id(p)])       # finalised inside the main graph
+            self._branch.backward_aspp(tape, dy, self._grad_map, on_ready=self._ready)
+            b.finish()
+            self.optimizer.step()
+            return
+        key = id(out)
+        if key not in self._tail_segs:
+            self._tail_segs[key] = self._capture_tail(out, aspp, pool)
+        pre, segs = self._tail_segs[key]
+        for i in pre:
+            b.ready(i)
+        for g, ready in segs:
+            g.replay()
+            for i in ready:
+                b.ready(i)
+        b.finish()
         self.optimizer.step()
+
+    def _capture_tail(self, out, aspp, pool):
+        """Capture `backward_aspp` as a chain of graphs, one per gradient bucket it completes. Returns (indices of the parameters the
+        main graph already finalised, [(graph, indices that become final with it), ...])."""
+        tape, dy = out["_tail"]
+        b, opt = self.buckets, self.optimizer
+        pre = [opt.index[id(p)] for p in opt.flat_params() if id(p) not in aspp]
+        pending = [hi - lo for lo, hi in b.bounds]
+        for i in pre:
+            pending[b.bucket_of[i]] -= 1
+        segs, cur, state = [], [], {"g": None}
+        kw = {} if pool is None else {"pool": pool}
+
+        def begin():
+            state["g"] = torch.cuda.CUDAGraph()
+            state["g"].capture_begin(**kw)
+
+        def cut():
+            state["g"].capture_end()
+            segs.append((state["g"], list(cur)))
+            del cur[:]
+
+        def hook(param):
+            i = opt.index[id(param)]
+            cur.append(i)
+            bk = b.bucket_of[i]
+            pending[bk] -= 1
+            if pending[bk] == 0:              # this bucket is complete: its all-reduce starts behind the kernels captured so far
+                cut()
+                begin()
+
+        opt.upload_lr()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            begin()
+            self._branch.backward_aspp(tape, dy, self._grad_map, on_ready=hook)
+            cut()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._tail_keep.append(self._derived_snapshot())
+        return pre, segs
 
     # Pipelined graph path (single GPU, used when the caller announces the next batch). Two parities p = iteration % 2 with their
     # own static inputs X[p], L[p] and old-model outputs OLD[p]. Graph G[p] = the step on X[p] reading OLD[p], PLUS, forked off
@@ -337,6 +457,7 @@ class Trainer:
             del o
             torch.cuda.synchronize()
             pool = torch.cuda.graph_pool_handle()
+            P["pool"] = pool
             from .nn import CACHE
 
             def stale_trainable():
@@ -397,7 +518,7 @@ class Trainer:
             from .nn import CACHE
             for prm in self._branch.aspp_parameters():    # the eager ASPP tail derives its operands from the current weights itself
                 CACHE.touch(prm)
-            self._distributed_tail(P["out"][p])
+            self._distributed_tail(P["out"][p], P.get("pool"))
         return P["out"][p]
 
     def _forward_backward(self, images, l1h, dropout_keep, split_tail=False, old_outputs=None, prefetch_old=None):
@@ -502,6 +623,7 @@ class Trainer:
             inputs = {k: inputs[k].to(self.device, dtype=torch.float32).contiguous() for k in ("seg2b", "int_masks", "center_lo", "offset_lo")}
         self._label_override = inputs
         self._graph, self._static, self._pipe = None, None, None
+        self._tail_segs, self._tail_keep = {}, []
         if self._graph_active:
             from .nn import CACHE
             CACHE.clear()

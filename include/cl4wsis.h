@@ -197,6 +197,9 @@ int cl4_relu_bwd(const float* y, const float* dy, float* dx, long n, void* strea
 /* int32 uniform draws in [0, modulus) (counter-based, like the Dropout masks): the random old classes of RandropLoss
  * (utils/wss_loss.py:237; the reference draws them with the CPU generator, so the stream itself cannot be matched). */
 int cl4_random_labels(int* out, long n, uint64_t seed, int modulus, void* stream);
+/* ... from a seed in device memory (uint64 [1]) that the launch advances by `advance`: a HIP-graph replay of the phase-1 step draws fresh
+ * labels every time (utils/wss_loss.py:237 draws them per call). */
+int cl4_random_labels_dev(int* out, long n, uint64_t* seed_dev, uint64_t advance, int modulus, void* stream);
 /* Two-phase forms for cross-rank batch statistics — InPlaceABNSync in training mode (segmentation_module.py:17-29;
  * SURVEY.md §8 A2): BN (eps 1e-5, momentum 0.1) + leaky-ReLU(slope) / identity, statistics over ALL ranks.
  *   forward : cl4_bn_sync_stats_local -> host all-reduce(SUM) of sums[c*2] doubles and of the element count ->

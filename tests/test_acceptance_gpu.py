@@ -117,10 +117,25 @@ def test_phase2_gradients_well_conditioned(gpu, monkeypatch, frozen_precision):
     for i in sorted(range(len(errs)), key=lambda i: -errs[i])[:6]:      # the per-tensor table of the outliers
         print(f"WELLCOND   worst: {keys[i]:58s} HIP {errs[i]:.2e}  CPU-fp32 {cpu[i]:.2e}  |g64| {float(r64['grads'][keys[i]].norm()):.3e}")
     assert len(errs) >= 55
-    if frozen_precision == 0:
-        assert e.median() <= 3 * c.median() and e.max() < 0.05, (e.median(), e.max(), c.median(), c.max())
-    else:
-        assert e.max() < 0.1 and e.median() < 2.5e-2, (e.median(), e.max(), c.max())
+    # The bar of EVERY arithmetic setting is a stated multiple of the reference arithmetic's own distance from float64 (c = CPU fp32 oracle),
+    # median and maximum; the one cancellation-dominated tensor (FINDINGS.md finding 29: the pooling branch's weight,
+    # exact kernels on operands whose 1e-6 noise the pixel / image sums amplify) is taken out of the maximum and bounded on its own.
+    # The oracle's own distance depends on the host CPU it runs on (oneDNN kernels, thread count: median 1.43e-3 on the r03 boxes, 9.7e-4 on
+    # an r04 box), so the multiples carry that spread:
+    #   0  exact fp32 products everywhere: 4x (measured 2.3x-2.7x median, 1.9x-2.1x maximum)
+    #   2  bf16x6 frozen networks (fp32-level per convolution, tools/dbg_x6.py) + bf16x3 weight gradients: 7x (3.5x-5.0x, 2.9x-3x)
+    #   1  the DEFAULT, bf16x3 frozen networks: 20x (8.3x-13.9x, 6.6x-7x). Their features are 1e-4 off through ~100 layers (bar: 1e-3), which batch-
+    #      statistics BN + ReLU turn into percent-level gradient differences. What that costs where it matters is measured below in mAP
+    #      points (test_map_...: HIP at both settings inside the reference runs' distribution); the reference itself trains under fp16
+    #      autocast (train.py:252: 5e-4 per operand, 100x coarser than these products).
+    mult = {0: 4.0, 2: 7.0, 1: 20.0}[frozen_precision]
+    pool = [i for i, k in enumerate(keys) if k.endswith("aspp_pooling.1.weight")]
+    rest = torch.tensor([i for i in range(len(keys)) if i not in pool])
+    print(f"WELLCOND bars precision {frozen_precision}: median ratio {float(e.median() / c.median()):.2f} (bar {mult}), max ratio without the pooling "
+          f"weight {float(e[rest].max() / c[rest].max()):.2f} (bar {mult}), pooling weight {[float(e[i]) for i in pool]} (bar 0.05)")
+    assert e.median() <= mult * c.median(), (float(e.median()), float(c.median()))
+    assert e[rest].max() <= mult * c[rest].max(), (float(e[rest].max()), float(c[rest].max()))
+    assert all(float(e[i]) < 0.05 for i in pool)
 
 
 def test_phase1_gradients_well_conditioned(gpu):
@@ -176,32 +191,36 @@ def _oracle_predict(sd, img, target, opts):
     return lab, msk, sc
 
 
-def test_map_after_training_inside_the_reference_arithmetics_own_spread(gpu, tmp_path):
-    """North star: "<= 0.2 mAP delta vs reference after one epoch on fixed seeds". No dataset and no trained checkpoint exist
-    offline, so the statement is tested in the form that CAN be decided here:
+def test_map_after_training_is_an_unremarkable_draw_from_the_reference_distribution(gpu, tmp_path, monkeypatch):
+    """North star: "<= 0.2 mAP delta vs reference after one epoch on fixed seeds". No dataset and no trained checkpoint exist offline, so
+    the statement is tested in the form that CAN be decided here:
 
-    * a common, CONDITIONED start: K0 = 30 phase-2 iterations (HIP path) from the seeded weights — the decoder has left its
-      initialisation, Adam's first sign-like steps are behind it;
-    * from that state K = 5 iterations on identical batches / Dropout masks along SEVEN trajectories: the HIP path, the CPU oracle
-      (A), and five more runs of the CPU oracle whose input images are perturbed by 3e-5 relative (B1..B5). The size is chosen to
-      make the B runs START where the HIP path starts: its frozen networks (bf16x3 products) agree with the fp32 oracle to ~1e-4 in
-      their outputs (bar: 1e-3), which moves the first iteration's loss by a few 1e-6 — what a 3e-5 input perturbation does to the
-      oracle (a 1e-6 perturbation, r03's first version, starts 15x closer and sometimes has not left the linear regime after five
-      iterations, so that it calibrated nothing: measured 6e-4 vs 1e-2 envelope maxima on two boxes). It is still 30x inside the
-      1e-3 bar and far inside the fp16 autocast the reference itself trains under (train.py:252). Adam turns any gradient
-      difference on weights with near-zero gradients into +-lr steps, so the B runs do NOT stay within 1e-3 of A; they measure
-      the reference arithmetic's own spread under admissible perturbations, with five samples instead of the single one of r02;
-    * iteration 1 (identical weights) must meet the 1e-3 bar outright; afterwards the HIP path's loss deviation and weight distance
-      from A must stay inside the envelope of the five B runs;
-    * validation (train.py:588-651) of all seven weight sets against ONE ground truth that favours none of them — the instances the
-      COMMON start state predicts on 12 held-out images, degraded (first instance shifted by 3 px, last one dropped) — through ONE
-      evaluation path (Trainer.validate on the GPU), plus A through the oracle's own evaluation as a check of that path. The HIP
-      path's mAP must lie inside the reference runs' range widened by its own width; |mAP(HIP) - mAP(A)| is reported next to the spread."""
-    from cl4wsis_amd import metrics as MT
+    * a common, CONDITIONED start: K0 = 30 phase-2 iterations (HIP path) from the seeded weights;
+    * from that state K = 20 iterations on identical batches / Dropout masks along 23 trajectories: the CPU oracle (A), TWENTY more runs of
+      the CPU oracle whose input images are perturbed by 3e-5 relative (B1..B20: the reference arithmetic's own distribution under
+      admissible perturbations — 30x inside the 1e-3 output bar, far inside the fp16 autocast the reference trains under, train.py:252 —
+      which is where a path whose frozen networks agree with fp32 to ~1e-4 starts), the HIP path at its defaults (bf16x3 frozen networks)
+      and the HIP path with bf16x6 frozen networks (CL4_CONV_PRECISION=2: fp32-level products everywhere), so that the price of the default
+      arithmetic is a number in mAP points;
+    * iteration 1 (identical weights) must meet the 1e-3 bar outright;
+    * validation (train.py:588-651) of all 24 weight sets against ONE ground truth that favours none of them — the instances the COMMON
+      start state predicts on 12 held-out images, degraded (first instance shifted by 3 px, last one dropped) — through ONE evaluation
+      path (Trainer.validate on the GPU), plus A through the oracle's own evaluation as a check of that path.
+
+    Decision: A and the twenty B runs form the reference ENSEMBLE (21 draws of the reference arithmetic); with d(X) = |mAP(X) - median of
+    the ensemble|, the HIP path is placed at its PERCENTILE of the ensemble's own d and must satisfy the hard cap d(HIP) <= max(0.2, 2 x the
+    75th percentile of d) — 0.2 = the stated bar, and a fair draw exceeds twice the upper quartile of its own distribution about one time
+    in fifty (a min-max band widened by itself, r03, let a 2-point spread pass a 4-point difference). The ensemble itself is sanity-capped
+    (upper quartile <= 6 points, loss envelope <= 0.25): a noisy reference cannot widen the gate without limit. Whether d(HIP) <= 0.2
+    holds outright is printed as a verdict of its own, next to how many reference runs meet it. Measured (r04): after 20 iterations the
+    reference runs spread by 2-3 points around their median and A itself sat 8 points below all of them — distances from A alone (r03)
+    measure A's luck. The loss trajectories and the distance between the trained weights are compared with A (iteration-wise identical
+    inputs) against the same kind of quartile cap."""
+    from cl4wsis_amd import metrics as MT, ops
     from cl4wsis_amd.dataset import DeviceLoader, get_dataset
     from cl4wsis_amd.train import Trainer
     from oracle import step as ostep
-    K0, K, NB, crop = 30, 5, 5, 65
+    K0, K, NB, crop = 30, 20, 20, 65
     NOISE = 3e-5      # relative input perturbation of the B runs, see the docstring
     make_mini_voc(tmp_path, n_train=9, n_val=12)
     opts = p2_opts(crop, extra=["--data_root", str(tmp_path), "--crop_size_val", str(crop), "--batch_size", "2"])
@@ -230,51 +249,70 @@ def test_map_after_training_inside_the_reference_arithmetics_own_spread(gpu, tmp
     start = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
              for m in (tr0.model, tr0.model_old, tr0.pseudolabeler, tr0.peakgenerator)]
     del tr0
-    torch.manual_seed(0)
-    tr = Trainer(QuietLogger(), gpu, opts)                   # fresh optimiser state, like the oracle trajectories
-    for m, sd in zip((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator), start):
-        m.load_state_dict(sd)
-    tr._realias()
-    cp = lambda sds: [{k: v.clone() for k, v in d.items()} for d in sds]
-    A, Bs = cp(start), [cp(start) for _ in range(NB)]
     names = ("center_old", "offset_old", "center_new", "offset_new")
-    state_a, state_b = None, [None] * NB
+    work = batches(K, 12)
+
+    def hip_trajectory(frozen_precision):
+        """K iterations of the HIP path from the common start; returns (per-iteration losses, trained state dicts)."""
+        with monkeypatch.context() as mp:
+            mp.setattr(ops, "CONV_PRECISION", frozen_precision)
+            torch.manual_seed(0)
+            tr = Trainer(QuietLogger(), gpu, opts)               # fresh optimiser state, like the oracle trajectories
+            for m, sd in zip((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator), start):
+                m.load_state_dict(sd)
+            tr._realias()
+            losses = [tr.step((images, l1h), dropout_keep=keep.to(torch.uint8).to(gpu))["losses"].cpu().tolist() for images, l1h, keep in work]
+            torch.cuda.synchronize()
+            sds = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+                   for m in (tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)]
+        return losses, sds
+
+    cp = lambda sds: [{k: v.clone() for k, v in d.items()} for d in sds]
+
+    def oracle_trajectory(noise_gen):
+        sds, state, losses = cp(start), None, []
+        for it, (images, l1h, keep) in enumerate(work):
+            x = images.cpu()
+            if noise_gen is not None:
+                x = x * (1.0 + NOISE * torch.randn(x.shape, generator=noise_gen))
+            r = ostep.p2_step(*sds, x, l1h.cpu(), 16, adam_state=state, pooling=opts.pooling, dropout_mask=keep.float(),
+                              lr=opts.lr * opts.lr_head, step=it + 1)
+            state = r["adam_state"]
+            losses.append([float(r[k].detach()) for k in names])
+        return losses, sds
+
+    loss_h, sd_h = hip_trajectory(1)
+    loss_h6, sd_h6 = hip_trajectory(2)
+    loss_a, A = oracle_trajectory(None)
     gn = torch.Generator().manual_seed(13)
-    traj = {"hip": [], "a": [], "b": [[] for _ in range(NB)]}
-    for it, (images, l1h, keep) in enumerate(batches(K, 12)):
-        out = tr.step((images, l1h), dropout_keep=keep.to(torch.uint8).to(gpu))
-        traj["hip"].append(out["losses"].cpu().tolist())
-        kw = dict(pooling=opts.pooling, dropout_mask=keep.float(), lr=opts.lr * opts.lr_head, step=it + 1)
-        ra = ostep.p2_step(*A, images.cpu(), l1h.cpu(), 16, adam_state=state_a, **kw)
-        state_a = ra["adam_state"]
-        traj["a"].append([float(ra[k].detach()) for k in names])
-        for i in range(NB):
-            noise = 1.0 + NOISE * torch.randn(images.shape, generator=gn)
-            rb = ostep.p2_step(*Bs[i], images.cpu() * noise, l1h.cpu(), 16, adam_state=state_b[i], **kw)
-            state_b[i] = rb["adam_state"]
-            traj["b"][i].append([float(rb[k].detach()) for k in names])
-    torch.cuda.synchronize()
+    runs_b = [oracle_trajectory(gn) for _ in range(NB)]
     tot = lambda t: torch.tensor(t, dtype=torch.float64).sum(1)
-    ta = tot(traj["a"])
-    dev_h = ((tot(traj["hip"]) - ta).abs() / ta).tolist()
-    dev_b = [((tot(t) - ta).abs() / ta).tolist() for t in traj["b"]]
-    env = [max(d[it] for d in dev_b) for it in range(K)]
-    print("MAPPROXY total loss per iteration, oracle A:", [round(v, 3) for v in ta.tolist()])
-    print("MAPPROXY relative loss deviation from A — HIP          :", ["%.1e" % v for v in dev_h])
-    print("MAPPROXY relative loss deviation from A — max of B1..B5:", ["%.1e" % v for v in env])
-    params = dict(tr.model.named_parameters())
+    ta = tot(loss_a)
+    dev = lambda t: ((tot(t) - ta).abs() / ta)
+    dev_h, dev_h6 = dev(loss_h), dev(loss_h6)
+    dev_b = torch.stack([dev(l) for l, _ in runs_b])                  # [NB, K]
+    q75 = lambda v: float(torch.quantile(torch.as_tensor(v, dtype=torch.float64), 0.75))
+    pct = lambda x, ref: float((torch.as_tensor(ref, dtype=torch.float64) < x).double().mean())
+    print("MAPPROXY total loss per iteration, oracle A:", [round(v, 2) for v in ta.tolist()])
+    print("MAPPROXY relative loss deviation from A, max over the 20 iterations — HIP default %.2e (percentile %.2f of the B runs), HIP bf16x6 "
+          "frozen nets %.2e (%.2f); B runs: median %.2e, upper quartile %.2e, max %.2e"
+          % (dev_h.max(), pct(dev_h.max(), dev_b.max(1).values), dev_h6.max(), pct(dev_h6.max(), dev_b.max(1).values),
+             dev_b.max(1).values.median(), q75(dev_b.max(1).values), dev_b.max()))
     tn = ostep.trainable_names(A[0])
     den = sum(float((A[0][k] - start[0][k]).double().pow(2).sum()) for k in tn) ** 0.5      # how far A itself moved
-    dist_h = sum(float((params[k].detach().cpu() - A[0][k]).double().pow(2).sum()) for k in tn) ** 0.5 / den
-    dist_b = [sum(float((B[0][k] - A[0][k]).double().pow(2).sum()) for k in tn) ** 0.5 / den for B in Bs]
-    print(f"MAPPROXY distance to A after {K} iterations, relative to the distance A moved: HIP {dist_h:.3e}, B1..B5 {['%.3e' % v for v in dist_b]}")
-    assert dev_h[0] < 1e-3                                        # first iteration: identical weights, the 1e-3 bar itself
-    # If the HIP path is one more draw from the distribution the five B runs sample, it exceeds their maximum one time in six; a factor
-    # of 3 on a heavy-tailed quantity leaves room for that, a wrong gradient (tens of per cent from the second iteration on) does not fit
-    assert max(dev_h) <= 3 * max(env) + 2e-3, (dev_h, env)
-    assert dist_h <= 2 * max(dist_b) + 1e-3, (dist_h, dist_b)
+    wdist = lambda sd: sum(float((sd[0][k] - A[0][k]).double().pow(2).sum()) for k in tn) ** 0.5 / den
+    dist_h, dist_h6, dist_b = wdist(sd_h), wdist(sd_h6), [wdist(sd) for _, sd in runs_b]
+    print(f"MAPPROXY distance to A after {K} iterations, relative to the distance A moved: HIP default {dist_h:.3e} (percentile "
+          f"{pct(dist_h, dist_b):.2f}), HIP bf16x6 frozen nets {dist_h6:.3e} ({pct(dist_h6, dist_b):.2f}); B runs median "
+          f"{float(torch.tensor(dist_b).median()):.3e}, upper quartile {q75(dist_b):.3e}, max {max(dist_b):.3e}")
+    assert float(dev_h[0]) < 1e-3 and float(dev_h6[0]) < 1e-3        # first iteration: identical weights, the 1e-3 bar itself
+    assert float(dev_b.max()) < 0.25, float(dev_b.max())              # sanity ceiling: the reference distribution itself (measured: 0.10 —
+    # after 20 Adam iterations the perturbed reference runs sit 0.58 of the distance A moved away from A: the trajectories decorrelate)
+    for d, w in ((dev_h, dist_h), (dev_h6, dist_h6)):
+        assert float(d.max()) <= 2 * q75(dev_b.max(1).values) + 2e-3, (d.tolist(), dev_b.max(1).values.tolist())
+        assert w <= 2 * q75(dist_b) + 1e-3, (w, dist_b)
 
-    # ---- validation: one ground truth (from the common start state), one evaluation path, seven weight sets --------------------------
+    # ---- validation: one ground truth (from the common start state), one evaluation path, 24 weight sets -----------------------------
     val_loader = DeviceLoader(val_dst, 1, gpu)
     images = [img.cpu() for img, seg, mask, mask_label, fname in val_loader]
     ev = Trainer(QuietLogger(), gpu, opts)
@@ -324,19 +362,30 @@ def test_map_after_training_inside_the_reference_arithmetics_own_spread(gpu, tmp
             warnings.simplefilter("ignore", RuntimeWarning)
             return 100.0 * float(np.nanmean(np.nanmean(ap, axis=0)))
 
-    trained_h = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-                 for m in (tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)]
     map_start = hip_map(start)
-    map_h, map_a = hip_map(trained_h), hip_map(A)
-    map_b = [hip_map(B) for B in Bs]
+    map_h, map_h6, map_a = hip_map(sd_h), hip_map(sd_h6), hip_map(A)
+    map_b = [hip_map(sd) for _, sd in runs_b]
     map_a_oracle = oracle_map(A[0])
-    lo, hi = min(map_b + [map_a]), max(map_b + [map_a])
-    print(f"MAPPROXY mAP (points) against the start state's degraded predictions, {n_inst} instances on {len(images)} images: "
-          f"start {map_start:.2f}; after {K} iterations HIP {map_h:.2f}, oracle A {map_a:.2f} (A through the oracle's own evaluation: "
-          f"{map_a_oracle:.2f}), B1..B5 {['%.2f' % v for v in map_b]}; |HIP - A| = {abs(map_h - map_a):.2f}, reference spread {hi - lo:.2f}")
+    # The reference ensemble: A and the twenty perturbed runs are 21 draws of the reference arithmetic (A is not special: measured, it can
+    # sit 8 points below every B run after 20 iterations); distances are taken from the ensemble's median.
+    ens = [map_a] + map_b
+    centre = float(np.median(ens))
+    d_r = [abs(v - centre) for v in ens]
+    d_h, d_h6 = abs(map_h - centre), abs(map_h6 - centre)
+    cap = max(0.2, 2 * q75(d_r))
+    print(f"MAPPROXY mAP (points) against the start state's degraded predictions, {n_inst} instances on {len(images)} images: start "
+          f"{map_start:.2f}; after {K} iterations oracle A {map_a:.2f} (through the oracle's own evaluation: {map_a_oracle:.2f}), HIP default "
+          f"{map_h:.2f}, HIP bf16x6 frozen nets {map_h6:.2f}, B1..B{NB} {['%.2f' % v for v in map_b]}")
+    print(f"MAPPROXY reference ensemble (A + {NB} perturbed runs): median {centre:.2f}, |mAP - median|: median {float(np.median(d_r)):.2f}, upper "
+          f"quartile {q75(d_r):.2f}, max {max(d_r):.2f}; HIP default {d_h:.2f} = percentile {pct(d_h, d_r):.2f} of the ensemble, HIP bf16x6 frozen "
+          f"nets {d_h6:.2f} = percentile {pct(d_h6, d_r):.2f}; hard cap max(0.2, 2 x upper quartile) = {cap:.2f}; price of the bf16x3 frozen "
+          f"networks: mAP(default) - mAP(bf16x6) = {map_h - map_h6:+.2f} (the ensemble's own upper-quartile distance is {q75(d_r):.2f})")
+    print(f"MAPPROXY VERDICT against the stated bar: HIP within 0.2 points of the reference ensemble's median: {'yes' if d_h <= 0.2 else 'NO'} "
+          f"({d_h:.2f}); of the {len(ens)} reference runs themselves {sum(v <= 0.2 for v in d_r)} are — after {K} iterations from this start the "
+          f"reference arithmetic does not reproduce its own mAP to 0.2 points under a 3e-5 input perturbation, so the bar is decidable here "
+          f"only as 'indistinguishable from the reference runs' (the percentile above)")
     assert n_inst >= 40 and 20.0 < map_start < 100.0      # non-vacuous: the start state scores high but not 100 against its own degraded predictions
     assert abs(map_a - map_a_oracle) <= 1.0, (map_a, map_a_oracle)          # the evaluation path itself
-    # an exchangeable seventh run is the minimum or the maximum of seven two times in seven: the band is the reference runs' range widened by
-    # its own width (at least 0.5 points) on either side
-    margin = max(hi - lo, 0.5)
-    assert lo - margin <= map_h <= hi + margin, (map_h, map_a, map_b)
+    assert q75(d_r) <= 6.0, d_r                                         # sanity ceiling on the reference distribution (measured: 2-3 points)
+    assert d_h <= cap, (map_h, centre, d_r)
+    assert d_h6 <= cap, (map_h6, centre, d_r)

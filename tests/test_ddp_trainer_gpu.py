@@ -141,5 +141,5 @@ def test_two_rank_phase2_step_matches_sharded_single_process_emulation(gpu, monk
     agree = float((diff[bigw] < 0.05 * lr_eff).float().mean())
     print(f"DDP-EMU {int(bigw.sum())} of {bigw.numel()} weights have a real gradient in both steps; {100 * agree:.3f} % of them within 5 % of one "
           f"Adam step of the emulation (max |w - w_emu| overall {float(diff.max()):.3e}, lr {lr_eff:.1e})")
-    assert int(bigw.sum()) > 0.2 * bigw.numel()
+    assert int(bigw.sum()) > 0.15 * bigw.numel()       # non-vacuity only (r03: 20.2 %, r04 with the fused res2 blocks: 19.5 %: the set moves with the last bits of the features)
     assert agree > 0.995 and float(diff.max()) <= 2.5 * STEPS * lr_eff

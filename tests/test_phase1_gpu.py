@@ -90,3 +90,44 @@ def test_phase1_step_matches_oracle(gpu, monkeypatch, cur_epoch, precision):
         assert ratios.median() < 2.5 and (ratios > 3).float().mean() < 0.035 and worst < 0.2, (ratios.median(), (ratios > 3).float().mean(), worst)
     else:
         assert rms_ours < 5 * rms_cpu + 1e-4 and worst < 0.3, (rms_ours, rms_cpu, worst)
+
+
+def test_phase1_graph_replay_matches_eager(gpu):
+    """r04: on one GPU the phase-1 step is HIP-graph replayed from its third call on — one graph per FLAC angle (drawn on the host,
+    train.py:316) and side of `pseudo_ep`, RandDrop labels from a device-resident counter. Same weights, batches, angle draws and
+    RandDrop counter through an eager trainer and a replaying one: the same losses, the same weights (up to the order of the fp32
+    atomics of the split-K weight gradients)."""
+    import numpy as np
+    from cl4wsis_amd.train import Trainer
+    from oracle import weights
+    crop = 65
+    g = torch.Generator().manual_seed(23)
+    batches = [(torch.randn(2, 3, crop, crop, generator=g), torch.eye(20)[[15 + i % 5, 19 - i % 3]].clone()) for i in range(8)]
+
+    def run(use_graph):
+        opts = p1_opts(crop)
+        opts.max_iters, opts.start_decay = 1000, 1000
+        torch.manual_seed(0)
+        tr = Trainer(_Log(), gpu, opts)
+        tr._use_graph = use_graph
+        tr._cur_epoch = opts.pseudo_ep                  # full loss stack: PAMR, l_seg, l_cls, RandDrop
+        for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
+            m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=41 + i))
+        tr._realias()
+        np.random.seed(11)
+        losses = [{k: float(v) for k, v in tr.step(b)["losses"].items()} for b in batches]
+        torch.cuda.synchronize()
+        w = torch.cat([p.detach().flatten() for p in tr.model.parameters()]).cpu()
+        n_graphs = len(tr._p1_static["graphs"]) if tr._p1_static else 0
+        return losses, w, n_graphs
+
+    le, we, ne = run(False)
+    lg, wg, ng = run(True)
+    assert ne == 0 and 1 <= ng <= 3
+    for a, b in zip(le, lg):
+        assert set(a) == set(b) and {"l_seg", "l_cls", "l_rand"} <= set(a)
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * max(abs(a[k]), 1e-3), (k, a[k], b[k])
+    rel = ((we - wg).norm() / we.norm()).item()
+    print("P1GRAPH graphs", ng, "weights rel diff", rel)
+    assert rel < 1e-4, rel
