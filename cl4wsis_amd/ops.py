@@ -828,8 +828,8 @@ def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momen
     sums = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
     ws = _workspace(x.device, bn_workspace_bytes(c))
     call("cl4_bn_sync_stats_local", ptr(x), n, c, h * w, c, 0, ptr(sums), ptr(ws), ws.numel(), stream())
-    sums[2 * c] = float(n * h * w)
-    if extra_sums is not None:
+    if extra_sums is not None:      # (a host scalar written into a device tensor is a synchronous copy: not inside a HIP-graph capture)
+        sums[2 * c] = float(n * h * w)
         sums += extra_sums
     _allreduce_sum(sums, group)
     # equal shards on every rank (run.py:66 splits the batch evenly): the global count needs no host round trip

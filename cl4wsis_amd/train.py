@@ -301,10 +301,16 @@ class Trainer:
         if key not in S["graphs"]:
             def stale_trainable():
                 # every graph re-derives (packs / folds) what it reads from the TRAINABLE weights itself; eager code and the other
-                # graphs must not read a derived tensor that only this graph refreshes (same rule as _replay_pipelined)
+                # graphs must not read a derived tensor that only this graph refreshes (same rule as _replay_pipelined). In phase 1
+                # that includes the running statistics: the PseudoLabeler's eval pass (train.py:304-311) folds the statistics its own
+                # training pass updated in the previous iteration.
                 for grp in opt.param_groups:
                     for prm in grp["params"]:
                         CACHE.touch(prm)
+                for mod in (self.model, self.pseudolabeler, self.peakgenerator):
+                    if mod is not None:
+                        for buf in mod.buffers():
+                            CACHE.touch(buf)
             opt.upload_lr()
             torch.cuda.synchronize()
             stale_trainable()

@@ -94,40 +94,63 @@ def test_phase1_step_matches_oracle(gpu, monkeypatch, cur_epoch, precision):
 
 def test_phase1_graph_replay_matches_eager(gpu):
     """r04: on one GPU the phase-1 step is HIP-graph replayed from its third call on — one graph per FLAC angle (drawn on the host,
-    train.py:316) and side of `pseudo_ep`, RandDrop labels from a device-resident counter. Same weights, batches, angle draws and
-    RandDrop counter through an eager trainer and a replaying one: the same losses, the same weights (up to the order of the fp32
-    atomics of the split-K weight gradients)."""
+    train.py:316) and side of `pseudo_ep`, RandDrop labels from a device-resident counter. Two eager runs of this tiny configuration
+    (crop 65, batch 2, SGD at lr 1e-2 on the heads) already differ by several per cent in every loss from the third iteration on
+    (tests/tools/dbg_p1_graph.py: the fp32 atomics of one step are amplified by the next), so trajectories cannot be compared; what is
+    compared is ONE step from ONE state: a replay of the captured graph, then — weights, momentum buffers, running statistics and the
+    RandDrop counter restored — the eager step with the same angle. Same losses to 1e-4, same updated weights."""
     import numpy as np
     from cl4wsis_amd.train import Trainer
     from oracle import weights
     crop = 65
     g = torch.Generator().manual_seed(23)
-    batches = [(torch.randn(2, 3, crop, crop, generator=g), torch.eye(20)[[15 + i % 5, 19 - i % 3]].clone()) for i in range(8)]
+    batches = [(torch.randn(2, 3, crop, crop, generator=g), torch.eye(20)[[15 + i % 5, 19 - i % 3]].clone()) for i in range(5)]
+    opts = p1_opts(crop)
+    opts.max_iters, opts.start_decay = 1000, 1000
+    torch.manual_seed(0)
+    tr = Trainer(_Log(), gpu, opts)
+    tr._cur_epoch = opts.pseudo_ep                  # full loss stack: PAMR, l_seg, l_cls, RandDrop
+    mods = (tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)
+    for i, m in enumerate(mods):
+        m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=41 + i))
+    tr._realias()
+    np.random.seed(11)
+    for b in batches[:4]:
+        out = tr.step(b)
+        assert all(np.isfinite(float(v)) for v in out["losses"].values())
+    assert tr._p1_static is not None and 1 <= len(tr._p1_static["graphs"]) <= 2      # iterations 2 and 3 replayed
+    torch.cuda.synchronize()
+    snap = [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in mods]
+    opt_snap = {k: v.clone() for k, v in enumerate(tr.optimizer.buf_fb.views)}
+    seed = tr._p1_seed_dev.clone()
+    x, l = batches[4][0].to(gpu), batches[4][1].to(gpu).float()
+    flat = lambda: torch.cat([p.detach().flatten() for m in (tr.model, tr.pseudolabeler, tr.peakgenerator) for p in m.parameters()]).clone()
 
-    def run(use_graph):
-        opts = p1_opts(crop)
-        opts.max_iters, opts.start_decay = 1000, 1000
-        torch.manual_seed(0)
-        tr = Trainer(_Log(), gpu, opts)
-        tr._use_graph = use_graph
-        tr._cur_epoch = opts.pseudo_ep                  # full loss stack: PAMR, l_seg, l_cls, RandDrop
-        for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
-            m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=41 + i))
+    def restore():
+        for m, sd in zip(mods, snap):
+            m.load_state_dict(sd)
         tr._realias()
-        np.random.seed(11)
-        losses = [{k: float(v) for k, v in tr.step(b)["losses"].items()} for b in batches]
-        torch.cuda.synchronize()
-        w = torch.cat([p.detach().flatten() for p in tr.model.parameters()]).cpu()
-        n_graphs = len(tr._p1_static["graphs"]) if tr._p1_static else 0
-        return losses, w, n_graphs
+        for k, v in opt_snap.items():
+            tr.optimizer.buf_fb.views[k].copy_(v)
+        tr._p1_seed_dev.copy_(seed)
 
-    le, we, ne = run(False)
-    lg, wg, ng = run(True)
-    assert ne == 0 and 1 <= ng <= 3
-    for a, b in zip(le, lg):
-        assert set(a) == set(b) and {"l_seg", "l_cls", "l_rand"} <= set(a)
-        for k in a:
-            assert abs(a[k] - b[k]) <= 2e-3 * max(abs(a[k]), 1e-3), (k, a[k], b[k])
-    rel = ((we - wg).norm() / we.norm()).item()
-    print("P1GRAPH graphs", ng, "weights rel diff", rel)
-    assert rel < 1e-4, rel
+    for angle in (90, 270):
+        restore()
+        lg = {k: float(v) for k, v in tr._replay_phase1(x, l, angle, True).items()}        # forward + backward + SGD, one replay
+        torch.cuda.synchronize()
+        wg = flat()
+        restore()
+        le = {k: float(v) for k, v in tr._p1.run(x, l, opts.pseudo_ep, flac_angle=angle).items()}
+        for i in range(len(tr.buckets.fb.sizes)):
+            tr.buckets.ready(i)
+        tr.buckets.finish()
+        tr.optimizer.step()
+        torch.cuda.synchronize()
+        we = flat()
+        assert {"l_seg", "l_cls", "l_rand", "flac"} <= set(lg) and set(lg) == set(le)
+        for k in le:
+            assert abs(le[k] - lg[k]) <= 1e-4 * max(abs(le[k]), 1e-3), (angle, k, le[k], lg[k])
+        rel = ((we - wg).norm() / (we - torch.cat([v.flatten() for m, sd in zip(mods, snap) if m is not tr.model_old
+                                                   for k, v in sd.items() if k in dict(m.named_parameters())])).norm()).item()
+        print("P1GRAPH angle", angle, "graphs", len(tr._p1_static["graphs"]), "update difference relative to the update", rel)
+        assert rel < 2e-2, rel
