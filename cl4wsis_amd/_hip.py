@@ -125,6 +125,7 @@ _decl("cl4_dwconv5_wgrad", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_cam_smooth", _P, _I, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P, C.c_size_t, _P)
 _decl("cl4_conv_debug_timeline", _P)
 _decl("cl4_bottleneck_fused", _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P)
+_decl("cl4_bottleneck_fused_proj", _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P)
 _decl("cl4_bottleneck_fused_tile", _I, _P, _P)
 _decl("cl4_to_planes", _P, _P, _I, _I, _I, _I, _I, _P)
 _decl("cl4_to_planes3", _P, _P, _I, _I, _I, _I, _I, _P)

@@ -68,27 +68,38 @@ class ResidualBlock(nn.Module):
                 and (not hasattr(self, "proj_conv") or planes_ok(self.proj_conv, min_cout)))
 
     def fusable(self):
-        """Identity block that csrc/conv_f.hip runs as ONE launch (frozen networks, planes trunk): 4 cm -> cm -> cm (3x3, stride 1,
-        dilation 1) -> 4 cm with leaky-ReLU ABNs after conv1 / conv2, an identity-activation ABN after conv3 and leaky-ReLU on the sum."""
+        """Block that csrc/conv_f.hip runs as ONE launch (frozen networks, planes trunk): c_in -> cm -> cm (3x3, stride 1, dilation 1)
+        -> 4 cm with leaky-ReLU ABNs after conv1 / conv2, an identity-activation ABN after conv3 and leaky-ReLU on the sum; either an identity
+        block (c_in = 4 cm) or — width 64 only — a stage's first block with a stride-1 projection shortcut from c_in = cm channels (res2's
+        block 1, models/resnet.py:68-77)."""
         c = self.convs
         cm = c.conv1.out_channels
-        return (ops.FUSED_BLOCK and not hasattr(self, "proj_conv") and cm in ops.FUSED_CM and planes_ok(c.conv3)
-                and c.conv1.kernel_size == (1, 1) and c.conv3.kernel_size == (1, 1) and c.conv2.kernel_size == (3, 3)
-                and c.conv2.stride == (1, 1) and c.conv2.dilation == (1, 1) and c.conv2.padding == (1, 1) and c.conv2.in_channels == cm
-                and c.conv2.out_channels == cm and c.conv1.in_channels == 4 * cm and c.conv3.out_channels == 4 * cm
-                and all(isinstance(b, ABN) for b in (c.bn1, c.bn2, c.bn3))
-                and c.bn1.activation == "leaky_relu" and c.bn2.activation == "leaky_relu" and c.bn3.activation == "identity")
+        ok = (ops.FUSED_BLOCK and cm in ops.FUSED_CM and planes_ok(c.conv3)
+              and c.conv1.kernel_size == (1, 1) and c.conv3.kernel_size == (1, 1) and c.conv2.kernel_size == (3, 3)
+              and c.conv2.stride == (1, 1) and c.conv2.dilation == (1, 1) and c.conv2.padding == (1, 1) and c.conv2.in_channels == cm
+              and c.conv2.out_channels == cm and c.conv3.out_channels == 4 * cm
+              and all(isinstance(b, ABN) for b in (c.bn1, c.bn2, c.bn3))
+              and c.bn1.activation == "leaky_relu" and c.bn2.activation == "leaky_relu" and c.bn3.activation == "identity")
+        if not ok:
+            return False
+        if not hasattr(self, "proj_conv"):
+            return c.conv1.in_channels == 4 * cm
+        pc, pb = self.proj_conv, self.proj_bn
+        return (ops.FUSED_PROJ and cm == 64 and c.conv1.in_channels == cm and pc.in_channels == cm and pc.out_channels == 4 * cm and pc.kernel_size == (1, 1)
+                and pc.stride == (1, 1) and isinstance(pb, ABN) and pb.activation == "identity")
 
     def forward_fused(self, xp, want_fp32, f32_images=None):
-        """Eval forward of a fusable block on a planes trunk: (fp32 output or None, planes output), one launch."""
+        """Eval forward of a fusable block on a planes input: (fp32 output or None, planes output), one launch."""
         import torch
         from .nn import CACHE, folded_bn
         c = self.convs
-        srcs = tuple(t for b in (c.bn1, c.bn2, c.bn3) for t in (b.weight, b.bias, b.running_mean, b.running_var))
-        aff = CACHE.get(self, "faff", srcs, lambda: torch.cat([t for b in (c.bn1, c.bn2, c.bn3) for t in folded_bn(b)]).contiguous())
+        bns = (c.bn1, c.bn2, c.bn3) + ((self.proj_bn,) if hasattr(self, "proj_conv") else ())
+        srcs = tuple(t for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var))
+        aff = CACHE.get(self, "faff", srcs, lambda: torch.cat([t for b in bns for t in folded_bn(b)]).contiguous())
         return ops.bottleneck_fused(xp, packed_weight(c.conv1, 1), packed_weight(c.conv2, 1), packed_weight(c.conv3, 1), aff,
                                     float(c.bn1.activation_param), float(c.bn2.activation_param), float(c.bn1.activation_param),
-                                    want_fp32=want_fp32, f32_images=f32_images)
+                                    want_fp32=want_fp32, f32_images=f32_images,
+                                    wp=packed_weight(self.proj_conv, 1) if hasattr(self, "proj_conv") else None)
 
     def forward_planes(self, x, xp, want_fp32, own_input=False):
         """Eval forward with planes activations (frozen networks only). `x`: fp32 input or None, `xp`: its planes twin or None (at

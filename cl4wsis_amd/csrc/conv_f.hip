@@ -41,7 +41,8 @@ struct FusedArgs {
   const void* w1;      // packed bf16x3 weights (cl4_pack_conv_weight_bf16x3): [K/8][hi, lo][cout][8]
   const void* w2;
   const void* w3;
-  const float* aff;    // [sc1 | sh1 | sc2 | sh2] (CM each), [sc3 | sh3] (C4 each): folded eval-mode ABN
+  const void* wp;      // PROJ only: the projection shortcut's weight (cin = CM -> C4), packed like w3
+  const float* aff;    // [sc1 | sh1 | sc2 | sh2] (CM each), [sc3 | sh3] (C4 each) (, PROJ: [scp | shp] (C4 each)): folded eval-mode ABN
   float neg1, neg2, neg3, negout;   // branch-free activations act(v) = v > 0 ? v : v * neg of bn1, bn2, bn3 (identity: 1) and of the sum
   int n, h, w, tiles_x, tiles_y, xcd_remap;
   int n_f32;           // the fp32 copy is written for images [0, n_f32) only (the others' stores are dropped by the descriptor)
@@ -70,9 +71,32 @@ __device__ __forceinline__ f32x4a mfma3(const bf16x8& ah, const bf16x8& al, cons
 // W2 with the column blocks of its column group (RS = 2: the 8-wave workgroup of the 128-channel res3 blocks — as 8 column groups its
 // 11 / 15 column blocks would leave 31 % of the matrix pipe's lanes idle, and 128 rows x 4 blocks do not fit one wave's accumulators).
 // The two waves of a column group load the same x chunks in phase 1 (the second request hits the CU's vector cache).
-template <int CM, int NW, int RS, int TH, int TW, bool F32OUT>
+// PROJ = the stage's FIRST block (modules/residual.py:79-82: projection shortcut): the input has CM channels (res2: the pooled stem output),
+// conv1 is CM -> CM, and the residual operand is bn_p(Wp . x) — a second 32-row slab GEMM per step of phase 3 (K = CM, the B fragments are
+// the tile's own x chunks, fetched once and held in registers), rounded through the planes split like the stored shortcut of the
+// three-launch path. The weight stream of phase 3 then alternates slabs of W3 and Wp.
+// Every 16-byte buffer load lands in a FLOAT vector. hipcc (ROCm 7.2) mishandles the builtin's own <4 x i32> result in this kernel: in the
+// projection variant it reused the FIRST register of a loaded weight chunk as an address temporary between the load and the ds_write_b128
+// that stores the chunk (v_lshl_add_u32 v30, ... ; ds_write_b128 v171, v[30:33]), so every weight row reached LDS with a wrong first dword —
+// the same family as FINDINGS.md finding 15 (element 0 of a raw_buffer_load_b128 result). A real bitcast to <4 x float> at the load keeps
+// the four registers together (conv_u.hip's workaround); the values go back to integer vectors only where they are consumed.
+typedef float ldv_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ldv_t bload16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(ldv_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+// ... and where a loaded chunk is consumed, an empty asm takes all four registers as an in/out operand: the bitcast alone did not stop the
+// allocator (same ISA), this does (the address temporaries moved to another register).
+__device__ __forceinline__ u32x4 as_u32x4(const ldv_t& v) {
+  u32x4 t = __builtin_bit_cast(u32x4, v);
+  asm volatile("" : "+v"(t));
+  return t;
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const ldv_t& v) { return __builtin_bit_cast(bf16x8, as_u32x4(v)); }
+
+template <int CM, int NW, int RS, int TH, int TW, bool F32OUT, bool PROJ>
 __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs a) {
   constexpr int NT = NW * 64;
+  constexpr int CIN = PROJ ? CM : 4 * CM;                  // channels of the block's input
   constexpr int NWC = NW / RS;                             // column groups
   constexpr int C4 = 4 * CM;
   constexpr int HWD = TW + 2;                              // halo width
@@ -87,8 +111,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   static_assert(NPS <= HPS, "y2 reuses y1's LDS");
   constexpr int RB = CM / 16 / RS, RP = CM / 32 / RS;      // MFMA row blocks / 32-channel pairs of conv1, conv2 PER WAVE
   static_assert(NW % RS == 0 && (CM / 32) % RS == 0, "row split");
-  constexpr int KT1 = C4 / 32, KT2 = 9 * CM / 32, KT3 = CM / 32, NM3 = C4 / 32;
-  constexpr int G = KT1 + KT2 + NM3;                       // weight tiles of the whole kernel
+  constexpr int KT1 = CIN / 32, KT2 = 9 * CM / 32, KT3 = CM / 32, NM3 = C4 / 32;
+  constexpr int T3 = PROJ ? 2 * NM3 : NM3;                 // weight tiles of phase 3
+  constexpr int G = KT1 + KT2 + T3;                        // weight tiles of the whole kernel
   constexpr int WCH = 8 * CM;                              // chunks per weight tile (32 k x CM rows, or 32 rows x CM k: two planes)
   constexpr int LW = WCH / NT;                             // weight chunks per thread and tile
   static_assert(WCH % NT == 0 && LW >= 1, "weight staging");
@@ -98,7 +123,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
 
   __shared__ u32x4 ybuf[(CM / 8) * 2 * HPS];               // y1, then y2: [channel group][hi, lo][pixel] chunks
   __shared__ u32x4 wst[2][WCH];                            // weight ring
-  __shared__ float aff[4 * CM + 2 * C4];
+  constexpr int NAFF = 4 * CM + 2 * C4 + (PROJ ? 2 * C4 : 0);
+  __shared__ float aff[NAFF];
 #ifdef CL4_F_PAD
   __shared__ float lds_pad[CL4_F_PAD];                     // experiments: force one workgroup per CU
   if (a.n < 0) lds_pad[threadIdx.x] = 1.f;
@@ -120,15 +146,16 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   const int y0 = ty * TH, x0 = tx * TW;
   const int H = a.h, W = a.w, HW = H * W;
 
-  for (int i = tid; i < 4 * CM + 2 * C4; i += NT) aff[i] = a.aff[i];
+  for (int i = tid; i < NAFF; i += NT) aff[i] = a.aff[i];
 
   const unsigned act_bytes = (unsigned)((long)a.n * C4 * HW * 4);      // < 2^31: checked on the host
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, act_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, (unsigned)((long)a.n * CIN * HW * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.ys, 0, act_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (F32OUT && img < a.n_f32) ? act_bytes : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1, 0, (unsigned)(C4 * CM * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1, 0, (unsigned)(CIN * CM * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, (unsigned)(9 * CM * CM * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t w3rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w3, 0, (unsigned)(CM * C4 * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wprsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, PROJ ? (unsigned)(CIN * C4 * 4) : 0u, 0x00020000);
 
   // ---- weight stream: tile g -> registers (set g & 1) -> LDS stage g & 1 -------------------------------------------------------------
   // K-tiles of W1 / W2 (rows = CM): chunk e = r * CM + s, r = 2 * k-group + plane, LDS slot s holds weight row pair * 32 + q * 8 + b * 4 + i
@@ -145,7 +172,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     const int kt = rr >> 3, r3 = rr & 7;
     w3_off[i] = (unsigned)((((kt * 8 + r3) * C4) + unperm(s3)) * 16);
   }
-  auto wissue = [&](u32x4 (&wr)[LW], int g) {
+  auto wissue = [&](ldv_t (&wr)[LW], int g) {
 #if CL4_F_DBG & 16
     g = G;
 #endif
@@ -153,22 +180,28 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     if (g < KT1) {
       const unsigned so = (unsigned)g * (unsigned)(WCH * 16);
 #pragma unroll
-      for (int i = 0; i < LW; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(w1rsrc, w12_off[i], so, 0);
+      for (int i = 0; i < LW; ++i) wr[i] = bload16(w1rsrc, w12_off[i], so);
     } else if (g < KT1 + KT2) {
       const unsigned so = (unsigned)(g - KT1) * (unsigned)(WCH * 16);
 #pragma unroll
-      for (int i = 0; i < LW; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(w2rsrc, w12_off[i], so, 0);
+      for (int i = 0; i < LW; ++i) wr[i] = bload16(w2rsrc, w12_off[i], so);
     } else {
-      const unsigned so = g < G ? (unsigned)(g - KT1 - KT2) * 32u * 16u : 0u;
+      const int t3 = g - KT1 - KT2;
+      const unsigned so = g < G ? (unsigned)(PROJ ? t3 >> 1 : t3) * 32u * 16u : 0u;
       const unsigned keep = (unsigned)(-(int)(g < G));
+      if (PROJ && (t3 & 1)) {
 #pragma unroll
-      for (int i = 0; i < LW; ++i) wr[i] = __builtin_amdgcn_raw_buffer_load_b128(w3rsrc, (w3_off[i] & keep) | (OOB & ~keep), so, 0);
+        for (int i = 0; i < LW; ++i) wr[i] = bload16(wprsrc, (w3_off[i] & keep) | (OOB & ~keep), so);
+      } else {
+#pragma unroll
+        for (int i = 0; i < LW; ++i) wr[i] = bload16(w3rsrc, (w3_off[i] & keep) | (OOB & ~keep), so);
+      }
     }
   };
-  auto wstore = [&](const u32x4 (&wr)[LW], int g) {
+  auto wstore = [&](const ldv_t (&wr)[LW], int g) {
     u32x4* st = wst[g & 1];
 #pragma unroll
-    for (int i = 0; i < LW; ++i) st[tid + NT * i] = wr[i];
+    for (int i = 0; i < LW; ++i) st[tid + NT * i] = as_u32x4(wr[i]);
   };
 
   // ---- phase-1 geometry: this lane's halo pixel in each of the wave's column blocks -------------------------------------------------------
@@ -184,8 +217,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     inimg[j] = hp < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     xoff[j] = inimg[j] ? (unsigned)((q * 2 * HW + iy * W + ix) * 16) : OOB;
   }
-  const unsigned img_base = (unsigned)img * (unsigned)(C4 / 8) * 2u * (unsigned)HW * 16u;     // byte offset of the image in a planes tensor
-  auto bissue = [&](u32x4 (&bq)[NJ1][2], int kt) {
+  const unsigned img_base = (unsigned)img * (unsigned)(CIN / 8) * 2u * (unsigned)HW * 16u;    // byte offset of the image in the INPUT planes tensor
+  const unsigned oimg_base = (unsigned)img * (unsigned)(C4 / 8) * 2u * (unsigned)HW * 16u;    // ... in the output planes tensor
+  auto bissue = [&](ldv_t (&bq)[NJ1][2], int kt) {
 #if CL4_F_DBG & 1
     kt = KT1;
 #endif
@@ -195,14 +229,14 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     for (int j = 0; j < NJ1; ++j)
 #pragma unroll
       for (int p = 0; p < 2; ++p)
-        bq[j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ((xoff[j] + (unsigned)(p * HW * 16)) & keep) | (OOB & ~keep), so, 0);
+        bq[j][p] = bload16(xrsrc, ((xoff[j] + (unsigned)(p * HW * 16)) & keep) | (OOB & ~keep), so);
   };
 
   // ===================================================================================================================================
   // phase 1: y1 = leaky(bn1(W1 . x)) on the halo
   // ===================================================================================================================================
-  u32x4 wr[2][LW];
-  u32x4 bq[3][NJ1][2];                                     // x chunks of K-tiles g, g + 1, g + 2 (mod 3)
+  ldv_t wr[2][LW];
+  ldv_t bq[3][NJ1][2];                                     // x chunks of K-tiles g, g + 1, g + 2 (mod 3)
   // issue stream of phase 1: W0 B0 | W1 B1 | W2 B2 | then iteration g adds W(g+3) B(g+3)
   wissue(wr[0], 0);
   bissue(bq[0], 0);
@@ -223,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   // iteration g of phase 1 (K-tile g of conv1). In flight at its start, oldest first: W(g+1) B(g+1) | W(g+2) B(g+2) behind B(g). It needs W(g)
   // in LDS (stored by the previous iteration), B(g) in registers and W(g+1) in registers (to store it): everything but the last
   // LB + LW + LB operations.
-  auto step1 = [&](u32x4 (&w_next)[LW], u32x4 (&b_cur)[NJ1][2], int g) {
+  auto step1 = [&](ldv_t (&w_next)[LW], ldv_t (&b_cur)[NJ1][2], int g) {
     wait_vmcnt<LW + 2 * LB>();
     const u32x4* As = wst[g & 1];
     bf16x8 ah[RB], al[RB];
@@ -237,7 +271,9 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
 #pragma unroll
     for (int j = 0; j < NJ1; ++j) {
       if (wcol + NWC * j < CB1) {                          // wave-uniform
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, b_cur[j][0]), bl = __builtin_bit_cast(bf16x8, b_cur[j][1]);
+        // (128-channel variant: 256 registers without the liveness marker, a spill with it; its fragments feed MFMAs directly)
+        const bf16x8 bh = CM == 128 ? __builtin_bit_cast(bf16x8, b_cur[j][0]) : as_bf16x8(b_cur[j][0]);
+        const bf16x8 bl = CM == 128 ? __builtin_bit_cast(bf16x8, b_cur[j][1]) : as_bf16x8(b_cur[j][1]);
 #pragma unroll
         for (int i = 0; i < RB; ++i) acc1[i][j] = mfma3(ah[i], al[i], bh, bl, acc1[i][j]);
       }
@@ -312,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
 #pragma unroll
     for (int j = 0; j < NJ2; ++j) acc2[i][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
   // iteration g: W(g) in LDS, W(g+1) and W(g+2) requested; in flight at most W(g+2) when W(g+1) is needed
-  auto step2 = [&](u32x4 (&w_next)[LW], int g) {
+  auto step2 = [&](ldv_t (&w_next)[LW], int g) {
     wait_vmcnt<LW>();
     const int t2 = g - KT1;
     const int cb = t2 / 9, tap = t2 - cb * 9;
@@ -350,8 +386,8 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   }
   wait_vmcnt<0>();
   // the residual chunks of the first two steps of phase 3 travel under the epilogue of phase 2 (the geometry is known since phase 1)
-  u32x4 rq[2][NJ3][2];                                     // residual chunks of steps m, m + 1
-  auto rissue = [&](u32x4 (&r)[NJ3][2], int m) {
+  ldv_t rq[2][NJ3][2];                                     // residual chunks of steps m, m + 1
+  auto rissue = [&](ldv_t (&r)[NJ3][2], int m) {
 #if CL4_F_DBG & 2
     m = NM3;
 #endif
@@ -361,10 +397,25 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     for (int j = 0; j < NJ3; ++j)
 #pragma unroll
       for (int p = 0; p < 2; ++p)
-        r[j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ((ooff[j] + (unsigned)(p * HW * 16)) & keep) | (OOB & ~keep), so, 0);
+        r[j][p] = bload16(xrsrc, ((ooff[j] + (unsigned)(p * HW * 16)) & keep) | (OOB & ~keep), so);
   };
-  rissue(rq[0], 0);
-  rissue(rq[1], 1);
+  constexpr int KTP = PROJ ? CIN / 32 : 1;
+  ldv_t xr[KTP][NJ3][2];                                   // PROJ: the tile's own x chunks = B fragments of the shortcut GEMM, all K-tiles
+#if !(CL4_F_DBG & 1024)
+  if constexpr (PROJ) {
+#pragma unroll
+    for (int kt = 0; kt < KTP; ++kt)
+#pragma unroll
+      for (int j = 0; j < NJ3; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          xr[kt][j][p] = bload16(xrsrc, ooff[j] == OOB ? OOB : ooff[j] + (unsigned)(p * HW * 16), img_base + (unsigned)kt * 8u * (unsigned)HW * 16u);
+  } else
+#endif
+  if constexpr (!PROJ) {
+    rissue(rq[0], 0);
+    rissue(rq[1], 1);
+  }
   // every wave has left the K loop (barrier above): y1 is dead, y2 takes its place
 #pragma unroll
   for (int pr = 0; pr < RP; ++pr) {
@@ -372,6 +423,10 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     float sc[8], sh[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) { sc[r] = aff[2 * CM + cg * 8 + r]; sh[r] = aff[3 * CM + cg * 8 + r]; }
+#if CL4_F_DBG & 128
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { sc[r] = 1.f; sh[r] = 0.5f; }
+#endif
 #pragma unroll
     for (int j = 0; j < NJ2; ++j) {
       float v[8];
@@ -396,20 +451,28 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   // ===================================================================================================================================
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                            // y2 is complete
+#if CL4_F_DBG & 1024
+  if constexpr (PROJ) {
+#pragma unroll
+    for (int kt = 0; kt < KTP; ++kt)
+#pragma unroll
+      for (int j = 0; j < NJ3; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          xr[kt][j][p] = bload16(xrsrc, ooff[j] == OOB ? OOB : ooff[j] + (unsigned)(p * HW * 16), img_base + (unsigned)kt * 8u * (unsigned)HW * 16u);
+  }
+#endif
   // step m (weight tile g = KT1 + KT2 + m). Issue order of a step: W(g+3), residual R(m+2), stores S(m) — the loads in FRONT of the stores,
   // because vmcnt retires in order: a wait for a load also waits for every older store's acknowledgement (measured: with the stores
   // first the steps stalled on them, 102 of 428 us). At the start of step m >= 2 everything up to R(m) has to be there; S(m-2) and the whole
   // of step m-1 may be in flight: 2 NS + LW + NR (capped by the 6-bit counter). Step 1 has no S(-1) in front of it, step 0 sees only R(0) R(1).
   constexpr int WAIT3 = (2 * NS + LW + NR) < 63 ? (2 * NS + LW + NR) : 63;
-  auto step3 = [&](u32x4 (&w_next)[LW], u32x4 (&r_cur)[NJ3][2], int m, int which) {
-    if (which == 0) wait_vmcnt<NR>(); else if (which == 1) wait_vmcnt<LW + NR + NS>(); else wait_vmcnt<WAIT3>();
-    const int g = KT1 + KT2 + m;
-    const u32x4* As = wst[g & 1];
-    f32x4a acc3[2][NJ3];
+  // one 32-row slab (weight tile in `As`: 32 rows x CM k) against B fragments handed out by `bfrag(kt, j, plane)`
+  auto slab3 = [&](const u32x4* As, f32x4a (&acc)[2][NJ3], auto bfrag) {
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int j = 0; j < NJ3; ++j) acc3[b][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NJ3; ++j) acc[b][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < KT3; ++kt) {
       bf16x8 ah[2], al[2];
@@ -417,38 +480,45 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
       for (int b = 0; b < 2; ++b) {
         ah[b] = __builtin_bit_cast(bf16x8, As[(kt * 8 + q * 2 + 0) * 32 + b * 16 + c16]);
         al[b] = __builtin_bit_cast(bf16x8, As[(kt * 8 + q * 2 + 1) * 32 + b * 16 + c16]);
+#if CL4_F_DBG & 256
+        ah[b] = __builtin_bit_cast(bf16x8, u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u});
+        al[b] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+#endif
       }
-      const u32x4* Bs = ybuf + ((kt * 4 + q) * 2) * NPS;
 #pragma unroll
       for (int j = 0; j < NJ3; ++j)
         if (wave + NW * j < CB2) {
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, Bs[pcol[j]]), bl = __builtin_bit_cast(bf16x8, Bs[NPS + pcol[j]]);
+#if CL4_F_DBG & 512
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}), bl = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+#else
+          const bf16x8 bh = bfrag(kt, j, 0), bl = bfrag(kt, j, 1);
+#endif
 #pragma unroll
-          for (int b = 0; b < 2; ++b) acc3[b][j] = mfma3(ah[b], al[b], bh, bl, acc3[b][j]);
+          for (int b = 0; b < 2; ++b) acc[b][j] = mfma3(ah[b], al[b], bh, bl, acc[b][j]);
         }
     }
-    wstore(w_next, g + 1);
-    wissue(w_next, g + 3);
-    // epilogue of the step: channels 32 m + 8 q .. + 7 of this lane's pixels
+  };
+  auto y2frag = [&](int kt, int j, int pl) { return __builtin_bit_cast(bf16x8, ybuf[((kt * 4 + q) * 2 + pl) * NPS + pcol[j]]); };
+  // epilogue of step m: channels 32 m + 8 q .. + 7 of this lane's pixels = bn3(acc) [+ res] -> leaky -> chunks -> stores.
+  // `between()` runs after the last use of `res` and before the stores (the residual loads of a later step go there).
+  auto epi3 = [&](int m, const f32x4a (&acc3)[2][NJ3], const float (&res)[NJ3][8], auto between) {
     const int cg = 4 * m + q;
     float sc[8], sh[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) { sc[r] = aff[4 * CM + cg * 8 + r]; sh[r] = aff[4 * CM + C4 + cg * 8 + r]; }
-    const unsigned so = img_base + (unsigned)m * 8u * (unsigned)HW * 16u;
+    const unsigned so = oimg_base + (unsigned)m * 8u * (unsigned)HW * 16u;
     const unsigned fso = ((unsigned)img * (unsigned)C4 + 32u * (unsigned)m) * (unsigned)HW * 4u;
     float v[NJ3][8];
     u32x4 ohi[NJ3], olo[NJ3];
 #pragma unroll
     for (int j = 0; j < NJ3; ++j) {
-      float res[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) { v[j][r] = acc3[0][j][r]; v[j][4 + r] = acc3[1][j][r]; }
-      join8(r_cur[j][0], r_cur[j][1], res);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const float u = v[j][r] * sc[r] + sh[r];
         float t = u > 0.f ? u : u * a.neg3;
-        t += res[r];
+        t += res[j][r];
         v[j][r] = t > 0.f ? t : t * a.negout;
       }
       split8(v[j], ohi[j], olo[j]);
@@ -472,7 +542,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
       alo[j] = o0 == OOB ? OOB : o0 + so + (unsigned)(HW * 16);
       af32[j] = (foff[j] & skeep) | (OOB & ~skeep);
     }
-    rissue(r_cur, m + 2);                                  // into the registers the sums above have just consumed
+    between();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NJ3; ++j) {
@@ -485,15 +555,81 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
       __builtin_amdgcn_raw_buffer_store_b128(olo[j], yrsrc, alo[j], 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
   };
   static_assert(NM3 % 2 == 0 && (KT1 + KT2) % 2 == 0, "phase 3 is unrolled by two and starts on an even tile");
-  step3(wr[1], rq[0], 0, 0);
-  step3(wr[0], rq[1], 1, 1);
-  for (int m = 2; m < NM3; m += 2) {
-    step3(wr[1], rq[0], m, 2);
-    step3(wr[0], rq[1], m + 1, 2);
+  if constexpr (!PROJ) {
+    auto step3 = [&](ldv_t (&w_next)[LW], ldv_t (&r_cur)[NJ3][2], int m, int which) {
+      if (which == 0) wait_vmcnt<NR>(); else if (which == 1) wait_vmcnt<LW + NR + NS>(); else wait_vmcnt<WAIT3>();
+      const int g = KT1 + KT2 + m;
+      f32x4a acc3[2][NJ3];
+      slab3(wst[g & 1], acc3, y2frag);
+      wstore(w_next, g + 1);
+      wissue(w_next, g + 3);
+      float res[NJ3][8];
+#pragma unroll
+      for (int j = 0; j < NJ3; ++j) join8(as_u32x4(r_cur[j][0]), as_u32x4(r_cur[j][1]), res[j]);
+      epi3(m, acc3, res, [&] { rissue(r_cur, m + 2); });    // into the registers the sums above have just consumed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    step3(wr[1], rq[0], 0, 0);
+    step3(wr[0], rq[1], 1, 1);
+    for (int m = 2; m < NM3; m += 2) {
+      step3(wr[1], rq[0], m, 2);
+      step3(wr[0], rq[1], m + 1, 2);
+    }
+  } else {
+    // two ring tiles per step: the slab of W3 (against y2), then the slab of Wp (against the tile's x chunks). Issue stream per step: W | W S(m);
+    // a tile is needed two iterations after its request, with at most W + S(m-1) issued behind it.
+    constexpr int WAIT3P = (LW + NS) < 63 ? (LW + NS) : 63;
+    auto xfrag = [&](int kt, int j, int pl) { return as_bf16x8(xr[kt < KTP ? kt : 0][j][pl]); };
+    for (int m = 0; m < NM3; ++m) {
+      const int g = KT1 + KT2 + 2 * m;                     // even: W3's slab sits in stage 0, Wp's in stage 1
+      f32x4a acc3[2][NJ3], accp[2][NJ3];
+      wait_vmcnt<WAIT3P>();
+      slab3(wst[0], acc3, y2frag);
+      wstore(wr[1], g + 1);
+      wissue(wr[1], g + 3);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      wait_vmcnt<WAIT3P>();
+#if CL4_F_DBG & 32
+      slab3(wst[1], accp, y2frag);
+#else
+      slab3(wst[1], accp, xfrag);
+#endif
+      wstore(wr[0], g + 2);
+      wissue(wr[0], g + 4);
+      // the shortcut bn_p(Wp . x), rounded through the planes split exactly like the stored shortcut of the three-launch path
+      const int cg = 4 * m + q;
+      float res[NJ3][8];
+#pragma unroll
+      for (int j = 0; j < NJ3; ++j) {
+        float pv[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pv[r] = accp[0][j][r]; pv[4 + r] = accp[1][j][r]; }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pv[r] = pv[r] * aff[4 * CM + 2 * C4 + cg * 8 + r] + aff[4 * CM + 3 * C4 + cg * 8 + r];
+        u32x4 ph, pl;
+        split8(pv, ph, pl);
+        join8(ph, pl, res[j]);
+      }
+#if CL4_F_DBG & 2048
+#pragma unroll
+      for (int j = 0; j < NJ3; ++j) {
+        join8(ybuf[(((m & 1) * 4 + q) * 2 + 0) * NPS + pcol[j]], ybuf[(((m & 1) * 4 + q) * 2 + 1) * NPS + pcol[j]], res[j]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc3[b][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
+      }
+#endif
+#if CL4_F_DBG & 64
+      epi3(m, accp, res, [] {});
+#else
+      epi3(m, acc3, res, [] {});
+#endif
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
 }
 
@@ -516,16 +652,16 @@ extern "C" int cl4_bottleneck_fused_tile(int cm, int* th, int* tw) {
   return CL4_EINVAL;
 }
 
-extern "C" int cl4_bottleneck_fused(const void* xs, void* ys, float* y, int n_f32, const void* w1, const void* w2, const void* w3, const float* aff,
-                                    int n, int cm, int h, int w, float slope1, float slope2, float slope_out, void* stream) {
+static int fused_launch(const void* xs, void* ys, float* y, int n_f32, const void* w1, const void* w2, const void* w3, const void* wp,
+                        const float* aff, int n, int cm, int h, int w, float slope1, float slope2, float slope_out, void* stream) {
   CL4_REQUIRE(xs && ys && w1 && w2 && w3 && aff, "bottleneck_fused: null operand");
   CL4_REQUIRE(xs != ys, "bottleneck_fused: the output must not alias the input (tiles read their neighbours' halo)");
-  CL4_REQUIRE(cm == 64 || cm == 128, "bottleneck_fused: middle width %d not built (64, 128)", cm);
+  CL4_REQUIRE(cm == 64 || (cm == 128 && !wp), "bottleneck_fused: middle width %d not built (64; 128 without projection shortcut)", cm);
   CL4_REQUIRE(n > 0 && h > 0 && w > 0, "bottleneck_fused: bad shape");
   CL4_REQUIRE((long)n * 4 * cm * h * w * 4 < (1l << 31), "bottleneck_fused: tensor of %ld bytes exceeds the 2 GiB buffer-descriptor range",
               (long)n * 4 * cm * h * w * 4);
   cl4::FusedArgs a;
-  a.xs = xs; a.ys = ys; a.y = y; a.w1 = w1; a.w2 = w2; a.w3 = w3; a.aff = aff;
+  a.xs = xs; a.ys = ys; a.y = y; a.w1 = w1; a.w2 = w2; a.w3 = w3; a.wp = wp; a.aff = aff;
   a.neg1 = slope1; a.neg2 = slope2; a.neg3 = 1.f; a.negout = slope_out;
   a.n = n; a.h = h; a.w = w;
   a.n_f32 = y ? (n_f32 < 0 || n_f32 > n ? n : n_f32) : 0;
@@ -536,12 +672,26 @@ extern "C" int cl4_bottleneck_fused(const void* xs, void* ys, float* y, int n_f3
   const dim3 grid((unsigned)(n * a.tiles_x * a.tiles_y));
   hipStream_t st = cl4::as_stream(stream);
   ++g_f_launches;
-  if (cm == 64) {
-    if (y) hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, 1, F_TH64, F_TW64, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, 1, F_TH64, F_TW64, false>), grid, dim3(256), 0, st, a);
+  if (cm == 64 && wp) {
+    if (y) hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, 1, F_TH64, F_TW64, true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, 1, F_TH64, F_TW64, false, true>), grid, dim3(256), 0, st, a);
+  } else if (cm == 64) {
+    if (y) hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, 1, F_TH64, F_TW64, true, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bottleneck_fused_kernel<64, 4, 1, F_TH64, F_TW64, false, false>), grid, dim3(256), 0, st, a);
   } else {
-    if (y) hipLaunchKernelGGL((bottleneck_fused_kernel<128, 8, 2, F_TH128, F_TW128, true>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((bottleneck_fused_kernel<128, 8, 2, F_TH128, F_TW128, false>), grid, dim3(512), 0, st, a);
+    if (y) hipLaunchKernelGGL((bottleneck_fused_kernel<128, 8, 2, F_TH128, F_TW128, true, false>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((bottleneck_fused_kernel<128, 8, 2, F_TH128, F_TW128, false, false>), grid, dim3(512), 0, st, a);
   }
   return cl4::launch_status();
+}
+
+extern "C" int cl4_bottleneck_fused(const void* xs, void* ys, float* y, int n_f32, const void* w1, const void* w2, const void* w3, const float* aff,
+                                    int n, int cm, int h, int w, float slope1, float slope2, float slope_out, void* stream) {
+  return fused_launch(xs, ys, y, n_f32, w1, w2, w3, nullptr, aff, n, cm, h, w, slope1, slope2, slope_out, stream);
+}
+
+extern "C" int cl4_bottleneck_fused_proj(const void* xs, void* ys, float* y, int n_f32, const void* w1, const void* w2, const void* w3, const void* wp,
+                                         const float* aff, int n, int cm, int h, int w, float slope1, float slope2, float slope_out, void* stream) {
+  CL4_REQUIRE(wp, "bottleneck_fused_proj: null projection weight");
+  return fused_launch(xs, ys, y, n_f32, w1, w2, w3, wp, aff, n, cm, h, w, slope1, slope2, slope_out, stream);
 }

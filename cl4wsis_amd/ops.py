@@ -602,33 +602,41 @@ FUSED_BLOCK = os.environ.get("CL4_FUSED_BLOCK", "1") != "0"    # r04: identity b
 # y1 in LDS, 800 / 400 tiles = 3.1 / 1.6 rounds) is bit-exact but no faster than the three tuned launches — 385 vs 367 us at 32 images, 183 vs
 # 182 us at 16 (tools/probe_f.py, FINDINGS.md finding 38) — so res3 stays on three launches; CL4_FUSED_CM=64,128 selects it for experiments.
 FUSED_CM = tuple(int(v) for v in os.environ.get("CL4_FUSED_CM", "64").split(",") if v)
+FUSED_PROJ = os.environ.get("CL4_FUSED_PROJ", "1") != "0"      # the stage's first block (projection shortcut, width 64) fused as well
 
 
-def bottleneck_fused(xs, w1, w2, w3, aff, slope1, slope2, slope_out, want_fp32=False, out_planes=None, f32_images=None):
-    """One identity ResidualBlock of a frozen network (modules/residual.py:84-97) as ONE launch (csrc/conv_f.hip): `xs` planes input
-    [n, 4 cm, h, w]; w1 / w2 / w3 bf16x3 packed weights of conv1 (1x1), conv2 (3x3, stride 1, dilation 1), conv3 (1x1); `aff` the folded
-    ABN maps [scale1 | shift1 | scale2 | shift2 | scale3 | shift3]. Returns (fp32 output or None, planes output). `f32_images`: the fp32
-    copy is written for the first so many images only (the rest of the returned tensor is uninitialised memory)."""
+def bottleneck_fused(xs, w1, w2, w3, aff, slope1, slope2, slope_out, want_fp32=False, out_planes=None, f32_images=None, wp=None):
+    """One ResidualBlock of a frozen network (modules/residual.py:84-97) as ONE launch (csrc/conv_f.hip). Identity block (`wp` None): `xs`
+    planes input [n, 4 cm, h, w]; w1 / w2 / w3 bf16x3 packed weights of conv1 (1x1), conv2 (3x3, stride 1, dilation 1), conv3 (1x1); `aff`
+    the folded ABN maps [scale1 | shift1 | scale2 | shift2 | scale3 | shift3]. Block with a projection shortcut (`wp`: its packed weight,
+    cm -> 4 cm, stride 1): `xs` has cm channels, `aff` carries [scale_p | shift_p] behind the others. Returns (fp32 output or None, planes
+    output). `f32_images`: the fp32 copy is written for the first so many images only (the rest of the returned tensor is uninitialised)."""
     if not isinstance(xs, Planes) or xs.planes != 2:
         raise RuntimeError("bottleneck_fused: two-plane Planes input expected")
-    n, c4, h, w = xs.shape
-    cm = c4 // 4
-    for wp, K, co in ((w1, c4, cm), (w2, 9 * cm, cm), (w3, cm, c4)):
-        if not isinstance(wp, PackedWeight) or wp.precision != 1 or wp.K != K or wp.cout != co:
-            raise RuntimeError("bottleneck_fused: bf16x3 packed weights of a [4 cm -> cm -> cm (3x3) -> 4 cm] bottleneck expected")
-    if aff.numel() != 4 * cm + 2 * c4:
-        raise RuntimeError("bottleneck_fused: aff must hold 4 cm + 8 cm floats")
+    n, cin, h, w = xs.shape
+    cm = cin if wp is not None else cin // 4
+    c4 = 4 * cm
+    for pw, K, co in ((w1, cin, cm), (w2, 9 * cm, cm), (w3, cm, c4)) + (((wp, cin, c4),) if wp is not None else ()):
+        if not isinstance(pw, PackedWeight) or pw.precision != 1 or pw.K != K or pw.cout != co:
+            raise RuntimeError("bottleneck_fused: bf16x3 packed weights of a [c_in -> cm -> cm (3x3) -> 4 cm] bottleneck (+ c_in -> 4 cm shortcut) expected")
+    if aff.numel() != 4 * cm + 2 * c4 + (2 * c4 if wp is not None else 0):
+        raise RuntimeError("bottleneck_fused: aff must hold 4 cm + 8 cm (+ 8 cm with a projection shortcut) floats")
     dev = xs.data.device
     ys = Planes(n, c4, h, w, dev) if out_planes is None else out_planes
     if ys.data.data_ptr() == xs.data.data_ptr():
         raise RuntimeError("bottleneck_fused: the output must not alias the input")
     y = torch.empty((n, c4, h, w), dtype=torch.float32, device=dev) if want_fp32 else None
-    if TIMER is not None:     # the three convolutions' algorithmic FLOPs, one span (shape key: the 3x3 layer with k = 0 marking the fusion)
-        e0, e1 = TIMER.span("conv_fwd_bf16x3", 2.0 * n * h * w * (2 * c4 * cm + 9 * cm * cm), (n, c4, h, c4, 0, 1, 1), 0)
+    if TIMER is not None:     # the block's convolutions' algorithmic FLOPs, one span (shape key: k = 0 marks the fusion)
+        e0, e1 = TIMER.span("conv_fwd_bf16x3", 2.0 * n * h * w * (cin * cm + 9 * cm * cm + cm * c4 + (cin * c4 if wp is not None else 0)),
+                            (n, cin, h, c4, 0, 1, 1), 0)
         e0.record()
-    call("cl4_bottleneck_fused", ptr(xs.data), ptr(ys.data), ptr(y), -1 if f32_images is None else int(f32_images), ptr(w1.data), ptr(w2.data),
-         ptr(w3.data), ptr(aff), n, cm, h, w,
-         C.c_float(slope1), C.c_float(slope2), C.c_float(slope_out), stream())
+    f32n = -1 if f32_images is None else int(f32_images)
+    if wp is None:
+        call("cl4_bottleneck_fused", ptr(xs.data), ptr(ys.data), ptr(y), f32n, ptr(w1.data), ptr(w2.data), ptr(w3.data), ptr(aff), n, cm, h, w,
+             C.c_float(slope1), C.c_float(slope2), C.c_float(slope_out), stream())
+    else:
+        call("cl4_bottleneck_fused_proj", ptr(xs.data), ptr(ys.data), ptr(y), f32n, ptr(w1.data), ptr(w2.data), ptr(w3.data), ptr(wp.data),
+             ptr(aff), n, cm, h, w, C.c_float(slope1), C.c_float(slope2), C.c_float(slope_out), stream())
     if TIMER is not None:
         e1.record()
     return y, ys

@@ -556,6 +556,13 @@ long cl4_conv_debug_b_launches(void);   /* launches of the big-tile LDS-DMA plan
  * cm = 64 (res2, 4-wave workgroups, two per CU) and cm = 128 (res3, one 8-wave workgroup per CU) are built. Enqueue-only on `stream`; no workspace. */
 int cl4_bottleneck_fused(const void* xs, void* ys, float* y, int n_f32, const void* w1, const void* w2, const void* w3, const float* aff,
                          int n, int cm, int h, int w, float slope1, float slope2, float slope_out, void* stream);
+/* The same for the FIRST block of a stage, the one with a projection shortcut (modules/residual.py:79-82, 90-91; stride 1: res2's block 1,
+ * models/resnet.py:68-77): xs holds cm channels, conv1 is cm -> cm, and
+ *     out = leaky( bn3(conv3(...)) + bn_p(conv_p(x)) ),      conv_p: 1x1, cm -> 4*cm, weight `wp` (packed like w3),
+ * with `aff` = [scale1 | shift1 | scale2 | shift2] (cm each) [scale3 | shift3] [scale_p | shift_p] (4*cm each). The shortcut is rounded through
+ * the planes split (hi + lo) before it is added, exactly like the stored shortcut of the cl4_conv2d_fwd_planes path. cm = 64 is built. */
+int cl4_bottleneck_fused_proj(const void* xs, void* ys, float* y, int n_f32, const void* w1, const void* w2, const void* w3, const void* wp,
+                              const float* aff, int n, int cm, int h, int w, float slope1, float slope2, float slope_out, void* stream);
 /* Tile of output pixels per workgroup for middle width cm (CL4_EINVAL: not built). */
 int cl4_bottleneck_fused_tile(int cm, int* th, int* tw);
 long cl4_conv_debug_f_launches(void);   /* launches of the fused bottleneck kernel by this process (tests) */

@@ -72,6 +72,48 @@ def test_fused_bottleneck_matches_three_planes_launches_and_float64(gpu, cm, n, 
     assert err < 2e-5, err                                       # three bf16x3 layers: ~4e-6 each
 
 
+@pytest.mark.parametrize("n,h,w,want_fp32", [(2, 33, 33, True), (1, 29, 31, False), (3, 13, 13, True), (1, 129, 129, True), (7, 129, 129, False),
+                                            (40, 40, 37, True)])
+def test_fused_first_block_with_projection_shortcut(gpu, n, h, w, want_fp32):
+    """The stage's first block (modules/residual.py:79-82, 90-91: conv -> bn shortcut from the cm-channel input; res2 block 1) as one launch
+    against the four planes launches (shortcut, conv1, conv2, conv3 + shortcut), bit for bit, and against float64."""
+    import ctypes as C
+    from cl4wsis_amd import ops
+    cm = 64
+    g = torch.Generator().manual_seed(1000 * n + h)
+    w1 = (torch.randn(cm, cm, 1, 1, generator=g) / cm ** 0.5).to(gpu)
+    w2 = (torch.randn(cm, cm, 3, 3, generator=g) / (9 * cm) ** 0.5).to(gpu)
+    w3 = (torch.randn(4 * cm, cm, 1, 1, generator=g) / cm ** 0.5).to(gpu)
+    wp = (torch.randn(4 * cm, cm, 1, 1, generator=g) / cm ** 0.5).to(gpu)
+    aff = [(torch.rand(c, generator=g) * 1.5 + 0.25 if i % 2 == 0 else torch.randn(c, generator=g) * 0.3).to(gpu)
+           for i, c in enumerate((cm, cm, cm, cm, 4 * cm, 4 * cm, 4 * cm, 4 * cm))]
+    s1, b1, s2, b2, s3, b3, sp, bp = aff
+    x = torch.randn(n, cm, h, w, generator=g).to(gpu)
+    xp = ops.to_planes(x)
+    p1, p2, p3, pp = (ops.pack_conv_weight(t, 1) for t in (w1, w2, w3, wp))
+    for cin, cout, k, pad in ((cm, cm, 1, 0), (cm, cm, 3, 1), (cm, 4 * cm, 1, 0)):
+        d = ops.ConvDescFor(n, cin, h, w, cin, 0, cout, k, 1, pad, 1, cout, 0, ops.ACT_LEAKY, 0.01, ops.ACT_NONE, 0.01, 3)
+        ops.call("cl4_conv2d_fwd_set_plan", C.byref(d), 2, 128, 1)
+    _, rp = ops.conv2d_planes(xp, pp, 1, scale=sp, shift=bp, want_fp32=False, want_planes=True)
+    _, y1 = ops.conv2d_planes(xp, p1, 1, scale=s1, shift=b1, act1=ops.ACT_LEAKY, slope1=0.01, want_fp32=False, want_planes=True)
+    _, y2 = ops.conv2d_planes(y1, p2, 3, pad=1, scale=s2, shift=b2, act1=ops.ACT_LEAKY, slope1=0.01, want_fp32=False, want_planes=True)
+    ref_f, ref_p = ops.conv2d_planes(y2, p3, 1, scale=s3, shift=b3, post=rp, act2=ops.ACT_LEAKY, slope2=0.01, want_fp32=True, want_planes=True)
+    out_f, out_p = ops.bottleneck_fused(xp, p1, p2, p3, torch.cat(aff).contiguous(), 0.01, 0.01, 0.01, want_fp32=want_fp32, wp=pp)
+    torch.cuda.synchronize()
+    got, want = ops.from_planes(out_p), ops.from_planes(ref_p)
+    assert torch.equal(out_p.data, ref_p.data), f"planes output differs from the four-launch path: max |d| {(got - want).abs().max().item():.3e}"
+    if want_fp32:
+        assert torch.equal(out_f, ref_f)
+    xs64 = ops.from_planes(xp).double().cpu()
+    c = lambda t: t.double().cpu()
+    v = lambda t: t.double().cpu()[None, :, None, None]
+    y = F.leaky_relu(F.conv2d(xs64, c(w1)) * v(s1) + v(b1), 0.01)
+    y = F.leaky_relu(F.conv2d(y, c(w2), padding=1) * v(s2) + v(b2), 0.01)
+    r64 = F.leaky_relu(F.conv2d(y, c(w3)) * v(s3) + v(b3) + F.conv2d(xs64, c(wp)) * v(sp) + v(bp), 0.01)
+    err = ((got.double().cpu() - r64).abs().max() / r64.abs().max()).item()
+    assert err < 3e-5, err
+
+
 def test_fused_bottleneck_fp32_copy_can_be_limited_to_the_first_images(gpu):
     """train.py:265-267 reads the low-level features of the un-flipped half of the flip-TTA batch only: the fp32 copy of a stage output is
     written for images [0, f32_images); the planes output always covers the whole batch."""
@@ -124,7 +166,7 @@ def test_resnet_body_is_unchanged_by_the_fusion(gpu, monkeypatch):
         with torch.no_grad():
             outs[fused] = [t.clone() for t in body(x)]
         torch.cuda.synchronize()
-        assert (lib.cl4_conv_debug_f_launches() - n0) == (5 if fused else 0)      # res2 blocks 2, 3 and res3 blocks 2, 3, 4
+        assert (lib.cl4_conv_debug_f_launches() - n0) == (6 if fused else 0)      # res2 blocks 1 (projection), 2, 3 and res3 blocks 2, 3, 4
     for a, b in zip(outs[False], outs[True]):
         assert a.shape == b.shape
         err = ((a - b).abs().max() / a.abs().max()).item()

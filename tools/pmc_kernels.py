@@ -23,7 +23,7 @@ def is_x3(name):
     if "conv_b_bf16x3" in name:                          # conv_b<KS, BMB, NW, PB, GEMM, NSTG>: PB = 3 is bf16x6, GEMM = true the weight-gradient GEMM
         t = [v.strip() for v in re.search(r"conv_b_bf16x3<([^>]*)>", name).group(1).split(",")]
         return t[3] == "2" and (len(t) < 5 or t[4] == "false")
-    if "conv_u_bf16x3" in name or "conv_p_bf16x3" in name or "stem_fused" in name:
+    if "conv_u_bf16x3" in name or "conv_p_bf16x3" in name or "stem_fused" in name or "bottleneck_fused" in name:
         return True
     m = re.search(r"conv_igemm_bf16x3<([^>]*)>", name)
     return bool(m) and m.group(1).split(",")[5].strip() == "2"

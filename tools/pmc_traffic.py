@@ -24,7 +24,7 @@ def is_x3(name):
     if "conv_b_bf16x3" in name:                          # conv_b<KS, BMB, NW, PB, GEMM, NSTG>: PB = 3 is bf16x6, GEMM = true the weight-gradient GEMM
         t = [v.strip() for v in re.search(r"conv_b_bf16x3<([^>]*)>", name).group(1).split(",")]
         return t[3] == "2" and (len(t) < 5 or t[4] == "false")
-    if "conv_u_bf16x3" in name or "conv_p_bf16x3" in name or "stem_fused" in name:
+    if "conv_u_bf16x3" in name or "conv_p_bf16x3" in name or "stem_fused" in name or "bottleneck_fused" in name:
         return True
     m = re.search(r"conv_igemm_bf16x3<([^>]*)>", name)
     return bool(m) and m.group(1).split(",")[5].strip() == "2"
@@ -69,7 +69,7 @@ for k in sorted(fetch, key=lambda k: -fetch[k][1]):
     if is_x3(k):
         m = re.search(r"<([^>]*)>", k)
         args = m.group(1).split(",") if m else []
-        vec = "conv_u_bf16x3" in k or "conv_s_bf16x3" in k or "conv_b_bf16x3" in k or "conv_p_bf16x3" in k or "stem_fused" in k or (len(args) > 9 and args[9].strip() == "true")   # 16-byte-per-lane activation loads
+        vec = "conv_u_bf16x3" in k or "conv_s_bf16x3" in k or "conv_b_bf16x3" in k or "conv_p_bf16x3" in k or "stem_fused" in k or "bottleneck_fused" in k or (len(args) > 9 and args[9].strip() == "true")   # 16-byte-per-lane activation loads
         fac = f_fac if vec else f_fac0
         out["kernels"][k]["fetch_factor_used"] = fac
         tot_l += l

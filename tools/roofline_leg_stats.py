@@ -25,7 +25,7 @@ def is_x3(name):
     if "conv_b_bf16x3" in name:                          # conv_b<KS, BMB, NW, PB, GEMM, NSTG>: PB = 3 is bf16x6, GEMM = true the weight-gradient GEMM
         t = [v.strip() for v in re.search(r"conv_b_bf16x3<([^>]*)>", name).group(1).split(",")]
         return t[3] == "2" and (len(t) < 5 or t[4] == "false")
-    if "conv_u_bf16x3" in name or "conv_p_bf16x3" in name or "stem_fused" in name:
+    if "conv_u_bf16x3" in name or "conv_p_bf16x3" in name or "stem_fused" in name or "bottleneck_fused" in name:
         return True
     m = re.search(r"conv_igemm_bf16x3<([^>]*)>", name)
     return bool(m) and m.group(1).split(",")[5].strip() == "2"
@@ -56,7 +56,7 @@ def main():
         if is_x3(k):
             x3_n += c
             x3_ms += t
-    print(f"bf16x3 forward family (conv_igemm_bf16x3 P=2, conv_u / conv_s / conv_b / conv_p _bf16x3, stem_fused): {x3_n / n:.1f} launches/step, {x3_ms / n:.3f} ms/step, "
+    print(f"bf16x3 forward family (conv_igemm_bf16x3 P=2, conv_u / conv_s / conv_b / conv_p _bf16x3, stem_fused, bottleneck_fused): {x3_n / n:.1f} launches/step, {x3_ms / n:.3f} ms/step, "
           f"avg launch {x3_ms / max(x3_n, 1):.5f} ms")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"{k[:80]:80s} calls/step {c / n:7.1f}  ms/step {t / n:8.3f}  {100 * t / tot:5.1f}%")
