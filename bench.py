@@ -343,7 +343,15 @@ def worker_p1(a):
     trainer._use_graph = False
     trainer.step(batch)
     torch.cuda.synchronize()
+    timer_p1 = ops.TIMER
     summ, ops.TIMER = ops.TIMER.summary(), None
+    if rank == 0 and os.environ.get("CL4_BENCH_LAYER_TABLE"):
+        rows = sorted(timer_p1.by_shape().items(), key=lambda kv: -kv[1][2])
+        tot = sum(v[2] for _, v in rows)
+        with open(os.environ["CL4_BENCH_LAYER_TABLE"], "w") as f:
+            f.write("kind (n,cin,hin,cout,k,stride,dil) launches/step ms/step TFLOP/s share\n")
+            for (kind, shp), (n_, fl_, ms_) in rows:
+                f.write(f"{kind:16s} {str(shp):36s} {n_:5d} {ms_:8.3f} {fl_ / ms_ / 1e9:8.1f} {100 * ms_ / tot:5.1f}%\n")
     if rank == 0:
         peaks = {"conv_fwd_bf16x6": PEAK_BF16_MFMA_TFLOPS / 6.0, "conv_fwd_bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "conv_fwd_f32": PEAK_FP32_MFMA_TFLOPS,
                  "conv_wgrad": PEAK_BF16_MFMA_TFLOPS / 3.0 if ops.WGRAD_PRECISION == 1 else PEAK_FP32_MFMA_TFLOPS}

@@ -642,7 +642,7 @@ namespace {
 
 // tile of output pixels per workgroup, by middle width: res2 (cm 64, 129 x 129 maps) 13 x 13, two 4-wave workgroups per CU; res3 (cm 128,
 // 65 x 65 maps) one 8-wave workgroup per CU (y1 alone is 116 KB)
-constexpr int F_TH64 = 13, F_TW64 = 13, F_TH128 = 13, F_TW128 = 13;
+constexpr int F_TH64 = 13, F_TW64 = 13, F_TH128 = 11, F_TW128 = 13;
 
 }  // namespace
 
