@@ -348,26 +348,30 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
 #pragma unroll
     for (int j = 0; j < NJ2; ++j) acc2[i][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
   // iteration g: W(g) in LDS, W(g+1) and W(g+2) requested; in flight at most W(g+2) when W(g+1) is needed
-  auto step2 = [&](ldv_t (&w_next)[LW], int g) {
-    wait_vmcnt<LW>();
-    const int t2 = g - KT1;
+  // B fragments (y1, static in LDS for the whole phase) are read ONE ITERATION AHEAD: their LDS latency runs under the current tile's MFMAs,
+  // only the weight fragments (which need the ring's barrier) are read at the head of an iteration.
+  auto bread2 = [&](bf16x8 (&bh)[NJ2], bf16x8 (&bl)[NJ2], int g) {
+    const int t2 = (g < KT1 + KT2 ? g : KT1 + KT2 - 1) - KT1;
     const int cb = t2 / 9, tap = t2 - cb * 9;
     const int ky = tap / 3, kx = tap - ky * 3;
     const int toff = __builtin_amdgcn_readfirstlane(ky * HWD + kx);
-    const u32x4* As = wst[g & 1];
     const u32x4* Bs = ybuf + ((cb * 4 + q) * 2) * HPS + toff;
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) {
+      bh[j] = __builtin_bit_cast(bf16x8, Bs[h0[j]]);
+      bl[j] = __builtin_bit_cast(bf16x8, Bs[HPS + h0[j]]);
+    }
+  };
+  auto step2 = [&](ldv_t (&w_next)[LW], bf16x8 (&bh)[NJ2], bf16x8 (&bl)[NJ2], bf16x8 (&bh_n)[NJ2], bf16x8 (&bl_n)[NJ2], int g) {
+    wait_vmcnt<LW>();
+    const u32x4* As = wst[g & 1];
     bf16x8 ah[RB], al[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       ah[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 0) * CM + (wrow * RB + i) * 16 + c16]);
       al[i] = __builtin_bit_cast(bf16x8, As[(q * 2 + 1) * CM + (wrow * RB + i) * 16 + c16]);
     }
-    bf16x8 bh[NJ2], bl[NJ2];
-#pragma unroll
-    for (int j = 0; j < NJ2; ++j) {
-      bh[j] = __builtin_bit_cast(bf16x8, Bs[h0[j]]);
-      bl[j] = __builtin_bit_cast(bf16x8, Bs[HPS + h0[j]]);
-    }
+    bread2(bh_n, bl_n, g + 1);
     wstore(w_next, g + 1);
     wissue(w_next, g + 3);
 #pragma unroll
@@ -380,9 +384,13 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     __builtin_amdgcn_s_barrier();
   };
   static_assert(KT2 % 2 == 0 && KT1 % 2 == 0, "phase 2 is unrolled by two and starts on an even tile");
-  for (int g = KT1; g < KT1 + KT2; g += 2) {
-    step2(wr[1], g);
-    step2(wr[0], g + 1);
+  {
+    bf16x8 bh0[NJ2], bl0[NJ2], bh1[NJ2], bl1[NJ2];
+    bread2(bh0, bl0, KT1);
+    for (int g = KT1; g < KT1 + KT2; g += 2) {
+      step2(wr[1], bh0, bl0, bh1, bl1, g);
+      step2(wr[0], bh1, bl1, bh0, bl0, g + 1);
+    }
   }
   wait_vmcnt<0>();
   // the residual chunks of the first two steps of phase 3 travel under the epilogue of phase 2 (the geometry is known since phase 1)
@@ -499,6 +507,19 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
     }
   };
   auto y2frag = [&](int kt, int j, int pl) { return __builtin_bit_cast(bf16x8, ybuf[((kt * 4 + q) * 2 + pl) * NPS + pcol[j]]); };
+  // identity blocks: the y2 fragments of a lane are the same for all NM3 steps — read them once (KT3 x NJ3 x 2 chunks: 48 registers at
+  // 64 channels). The projection variant keeps reading them per step (its registers hold the x chunks of the shortcut GEMM).
+  constexpr bool HOIST_Y2 = !PROJ && CM == 64;
+  bf16x8 y2r[HOIST_Y2 ? KT3 : 1][HOIST_Y2 ? NJ3 : 1][2];
+  if constexpr (HOIST_Y2) {
+#pragma unroll
+    for (int kt = 0; kt < KT3; ++kt)
+#pragma unroll
+      for (int j = 0; j < NJ3; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) y2r[kt][j][pl] = y2frag(kt, j, pl);
+  }
+  auto y2reg = [&](int kt, int j, int pl) { return y2r[HOIST_Y2 ? kt : 0][HOIST_Y2 ? j : 0][pl]; };
   // epilogue of step m: channels 32 m + 8 q .. + 7 of this lane's pixels = bn3(acc) [+ res] -> leaky -> chunks -> stores.
   // `between()` runs after the last use of `res` and before the stores (the residual loads of a later step go there).
   auto epi3 = [&](int m, const f32x4a (&acc3)[2][NJ3], const float (&res)[NJ3][8], auto between) {
@@ -562,7 +583,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
       if (which == 0) wait_vmcnt<NR>(); else if (which == 1) wait_vmcnt<LW + NR + NS>(); else wait_vmcnt<WAIT3>();
       const int g = KT1 + KT2 + m;
       f32x4a acc3[2][NJ3];
-      slab3(wst[g & 1], acc3, y2frag);
+      if constexpr (HOIST_Y2) slab3(wst[g & 1], acc3, y2reg); else slab3(wst[g & 1], acc3, y2frag);
       wstore(w_next, g + 1);
       wissue(w_next, g + 3);
       float res[NJ3][8];
