@@ -104,6 +104,7 @@ _decl("cl4_stem_fused", _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P)
 _decl("cl4_avgpool_s1", _P, _P, _L, _I, _I, _I, _I, _P)
 _decl("cl4_replicate_pad", _P, _P, _L, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_global_mean", _P, _P, _L, _I, _P)
+_decl("cl4_plane_sum", _P, _P, _L, _I, _P)
 _decl("cl4_resize_bilinear_fwd", _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_resize_bilinear_bwd", _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P)
 _decl("cl4_flip_w", _P, _P, _L, _I, _P)

@@ -460,6 +460,24 @@ extern "C" int cl4_replicate_pad(const float* x, float* y, long planes, int hin,
   return cl4::launch_status();
 }
 
+// Sum over H*W per plane with fp64 partial sums, one wave per plane (r04: the pooling branch of the ASPP backward sums the gradient of the
+// projection's pre-activation per plane BEFORE the 1x1 input-gradient product instead of after it — see heads.py, FINDINGS.md finding 41).
+__global__ __launch_bounds__(256) void plane_sum_d_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int hw) {
+  const long pl = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pl >= planes) return;
+  const float* xp = x + pl * hw;
+  double s = 0.0;
+  for (int i = threadIdx.x & 63; i < hw; i += 64) s += (double)xp[i];
+  s = cl4::wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) y[pl] = (float)s;
+}
+
+extern "C" int cl4_plane_sum(const float* x, float* y, long planes, int hw, void* stream) {
+  CL4_REQUIRE(x && y && planes > 0 && hw > 0, "plane_sum: bad arguments");
+  hipLaunchKernelGGL(plane_sum_d_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, cl4::as_stream(stream), x, y, planes, hw);
+  return cl4::launch_status();
+}
+
 extern "C" int cl4_global_mean(const float* x, float* y, long planes, int hw, void* stream) {
   CL4_REQUIRE(x && y && planes > 0 && hw > 0, "global_mean: bad arguments");
   if (hw <= 8192) {

@@ -31,6 +31,7 @@ TRAIN_PRECISION = int(__import__("os").environ.get("CL4_TRAIN_PRECISION", "2"))
 # The trainable ASPP reads a three-plane (hi, mid, lo) copy of the frozen res5 features through the LDS-DMA planes kernel (conv_b.hip,
 # plan impl 6): 0.82 -> 0.61 ms per dilated branch (r03); 0 = the role-split bf16x6 kernel on the fp32 features.
 X6_PLANES = __import__("os").environ.get("CL4_X6_PLANES", "1") == "1"
+POOL_GRAD_COMMUTED = __import__("os").environ.get("CL4_POOL_GRAD", "1") != "0"
 
 
 def _dx_1x1(dz, conv):
@@ -560,6 +561,19 @@ class InstanceBranch:
         assert i == 0
         return dy
 
+    @staticmethod
+    def _pool_branch_grad(dpz, dcat5, pconv0, cout):
+        """Gradient of the image-pooling branch's [n, cout, 1, 1] output: the sum over the plane of the projection's input gradient in
+        that branch's channels (the backward of `x.repeat(1, 1, h, w)`, modules/panoptic_deeplab.py:84-89). r04:
+        sum_px (W^T dpz)[px] = W^T (sum_px dpz[px]) — the plane sum is taken FIRST, in fp64, on the projection's pre-activation gradient,
+        and the 1x1 input-gradient product runs on the [n, 256, 1, 1] sums. Autograd (and the oracle) sum 1089 products that each carry the
+        rounding of a 256-term fp32 dot product; the sums nearly cancel (the BatchNorm backward made dpz zero-mean per channel), so that
+        noise was this tensor's whole 1.4e-2 distance at exact fp32. CL4_POOL_GRAD=0 restores the literal order."""
+        if not POOL_GRAD_COMMUTED:
+            return ops.resize_bilinear_bwd(dcat5, (1, 1), True, dy_coff=4 * cout, c=cout)
+        ds = _dx_1x1(ops.plane_sum(dpz), pconv0)               # [n, 5 * cout, 1, 1]
+        return ops.resize_bilinear_bwd(ds, (1, 1), True, dy_coff=4 * cout, c=cout)
+
     def _decoder_backward_aspp(self, rec, dy, grads, feature_grads=None):
         G = lambda p: self._grad(p, grads)
         d = self.dec
@@ -579,7 +593,7 @@ class InstanceBranch:
             # parameter order in the flat gradient buffer is convs.0 .. convs.4, project: finishing the small pooling branch
             # first and the four conv branches from the last to the first lets every bucket but the smallest (the 1x1 branch)
             # be all-reduced under the remaining weight-gradient kernels. The tensors are independent: same values.
-            dgp = ops.relu_bwd(gp, ops.resize_bilinear_bwd(dcat5, (1, 1), True, dy_coff=4 * cout, c=cout))
+            dgp = ops.relu_bwd(gp, self._pool_branch_grad(dpz, dcat5, pconv0, cout))
             ops.conv2d_wgrad(g, dgp, G(pconv.weight), 1)
         kcache = {}       # the three dilated branches share one pixel-major pack of x on the GEMM path of the weight gradient (ops._wgrad_gemm)
         for j in (range(4) if feature_grads is not None else (3, 2, 1, 0)):
@@ -594,8 +608,7 @@ class InstanceBranch:
                 part = ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(x.shape[2:]), k, pad=pad, dil=dil)
                 dx = part if dx is None else ops.axpy_(dx, part)
         if feature_grads is not None:
-            dgp = ops.resize_bilinear_bwd(dcat5, (1, 1), True, dy_coff=4 * cout, c=cout)
-            dgp = ops.relu_bwd(gp, dgp)
+            dgp = ops.relu_bwd(gp, self._pool_branch_grad(dpz, dcat5, pconv0, cout))
             ops.conv2d_wgrad(g, dgp, G(pconv.weight), 1)
             dg = _dx_1x1(dgp, pconv)
             feature_grads[d.feature_key] = ops.add_per_plane_(dx, dg, 1.0 / (h * w))

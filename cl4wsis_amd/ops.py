@@ -66,6 +66,27 @@ def conv_out_size(h, k, stride, pad, dil):
 # hi + lo, three bf16 MFMA products with fp32 accumulation; ~4e-6 relative error per layer, 3/16 of the MFMA cycles),
 # 2 = "bf16x6" (hi + mid + lo, six products: fp32-level accuracy at 6/16 of the fp32 MFMA cycles).
 CONV_PRECISION = int(os.environ.get("CL4_CONV_PRECISION", "1"))
+# r04: plain bf16x6 convolutions with a long K loop via cl4_to_planes3 + the three-plane LDS-DMA kernel; thresholds
+# from tools/probe_x6_planes.py (the extra pass over the input has to be paid back by the kernel)
+# Scope: the steps that differentiate the body (phase 1, step 0) switch it on around their run (`x6_route_scope`); in phase 2 the precision-2
+# convolutions of the instance branch share the chip with the frozen networks' stream and the extra pass costs more than it returns
+# (measured 464.0 -> 459.2 images/s with the route on everywhere; phase 1: 88.8 -> 85.6 ms per step).
+X6_ROUTE = os.environ.get("CL4_X6_ROUTE", "1") != "0"
+_x6_scope = 0
+X6_ROUTE_MIN_K3 = int(os.environ.get("CL4_X6_ROUTE_MIN_K3", "1152"))     # 3x3: from 128 input channels (measured gain 1.07-1.27)
+X6_ROUTE_MIN_K1 = int(os.environ.get("CL4_X6_ROUTE_MIN_K1", "256"))      # 1x1: widening ones only, cout >= cin (1.11-1.25; narrowing 0.65-0.96)
+
+
+class x6_route_scope:
+    """with ops.x6_route_scope(): plain bf16x6 convolutions inside take the three-plane route (see X6_ROUTE)."""
+
+    def __enter__(self):
+        global _x6_scope
+        _x6_scope += 1
+
+    def __exit__(self, *exc):
+        global _x6_scope
+        _x6_scope -= 1
 
 
 class PackedWeight:
@@ -359,6 +380,14 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     K, cout = wp.K, wp.cout
     if K != cin * k * k:
         raise RuntimeError(f"conv2d: packed weight K={K} does not match cin*k*k={cin * k * k}")
+    if (X6_ROUTE and _x6_scope and wp.precision == 2 and stride == 1 and in_coff == 0 and cin == in_ctot and cin % 32 == 0 and cout % 8 == 0
+            and cout >= 128 and scale is None and shift is None and pre is None and post is None and x.is_contiguous()
+            and ((k == 3 and K >= X6_ROUTE_MIN_K3) or (k == 1 and K >= X6_ROUTE_MIN_K1 and cout >= cin))):
+        # r04: a plain bf16x6 convolution of the differentiated networks (phase 1 / step 0: body, DeepLabV3 head, PseudoLabeler, forward and
+        # input gradient) whose K loop is long enough goes through a three-plane copy of its input and the LDS-DMA kernel (conv_b, FINDINGS.md
+        # finding 32: 0.65 of the bf16x6 ceiling against 0.3-0.45 for the role-split kernel); same six products per MAC, fp32 accumulation.
+        x3 = to_planes(x, planes=3)
+        return conv2d_planes(x3, wp, k, stride=1, pad=pad, dil=dil, out=out, out_coff=out_coff, want_fp32=True)[0]
     hout = conv_out_size(hin, k, stride, pad, dil)
     wout = conv_out_size(win, k, stride, pad, dil)
     if out is None:
@@ -681,6 +710,14 @@ def global_mean(x):
     n, c, h, w = x.shape
     y = torch.empty((n, c, 1, 1), dtype=torch.float32, device=x.device)
     call("cl4_global_mean", ptr(x), ptr(y), n * c, h * w, stream())
+    return y
+
+
+def plane_sum(x):
+    """[n, c, h, w] -> [n, c, 1, 1] sums (fp64 partial sums)."""
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, 1, 1), dtype=torch.float32, device=x.device)
+    call("cl4_plane_sum", ptr(x), ptr(y), n * c, h * w, stream())
     return y
 
 

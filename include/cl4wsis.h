@@ -154,6 +154,10 @@ int cl4_avgpool_s1(const float* x, float* y, long planes, int h, int w, int kh, 
 int cl4_replicate_pad(const float* x, float* y, long planes, int hin, int win, int pad_t, int pad_l, int hout, int wout, void* stream);
 /* mean over H*W per plane — AdaptiveAvgPool2d(1), modules/panoptic_deeplab.py:84; deeplab.py:75-76. */
 int cl4_global_mean(const float* x, float* y, long planes, int hw, void* stream);
+/* sum over H*W per plane, fp64 partial sums — the reduction of `x.repeat(1, 1, h, w)`'s backward in the image-pooling branch
+   (modules/panoptic_deeplab.py:84-89 through autograd), taken on the projection's pre-activation gradient before the 1x1 input-gradient
+   product instead of on its 1280-channel result (same sum, 256 instead of 256 x 1089 rounded terms per output). */
+int cl4_plane_sum(const float* x, float* y, long planes, int hw, void* stream);
 /* F.interpolate(mode="bilinear") in both align_corners conventions; x and y may be
  * channel slices. Backward is a deterministic gather (no atomics); accumulate!=0 adds into dx. */
 int cl4_resize_bilinear_fwd(const float* x, float* y, int n, int c, int hin, int win, int hout, int wout,

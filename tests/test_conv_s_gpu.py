@@ -343,3 +343,27 @@ def test_three_plane_split_is_exact_to_24_bits(gpu):
     want = [t.view(2, 2, 8, 35).permute(0, 1, 3, 2) for t in (hi, mid, lo)]
     for p in range(3):
         assert torch.equal(parts[p], want[p].contiguous())
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 17, 19, 128, 3, 1), (2, 256, 9, 9, 512, 1, 1), (1, 160, 12, 11, 136, 3, 2), (2, 512, 9, 9, 256, 1, 1)])
+def test_x6_route_scope_sends_plain_bf16x6_convolutions_through_three_planes(gpu, shape):
+    """ops.x6_route_scope (phase 1 / step 0): a plain precision-2 convolution with a long K loop runs as cl4_to_planes3 + the three-plane
+    LDS-DMA kernel — same six bf16 products per MAC, so fp32-level against float64 (2e-6 of the output scale) and against the role-split
+    kernel it replaces; the narrowing 1x1 (last shape) and everything outside the scope stay on the role-split kernel."""
+    from cl4wsis_amd import _hip, ops
+    n, cin, h, w, cout, k, dil = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    pad = dil * (k - 1) // 2
+    ref = F.conv2d(x.double(), wt.double(), padding=pad, dilation=dil).float()
+    wp = ops.pack_conv_weight(wt.to(gpu), 2)
+    lib = _hip.load()
+    y0 = ops.conv2d(x.to(gpu), wp, k, pad=pad, dil=dil)
+    b0 = lib.cl4_conv_debug_b_launches() + lib.cl4_conv_debug_s_launches()
+    with ops.x6_route_scope():
+        y1 = ops.conv2d(x.to(gpu), wp, k, pad=pad, dil=dil)
+    routed = lib.cl4_conv_debug_b_launches() + lib.cl4_conv_debug_s_launches() - b0
+    assert routed == (0 if (k == 1 and cout < cin) else 1)
+    assert _rel_err(y1.cpu(), ref) < 2e-6 and _rel_err(y0.cpu(), ref) < 2e-6
+    assert ops._x6_scope == 0

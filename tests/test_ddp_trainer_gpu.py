@@ -116,7 +116,7 @@ def test_two_rank_phase2_step_matches_sharded_single_process_emulation(gpu, monk
     # ---- two ranks on this GPU over gloo ---------------------------------------------------------------------------------------------
     # a mismatched collective between the two ranks — what this test guards against — must FAIL, not hang the suite
     import time
-    deadline = time.time() + 300
+    deadline = time.time() + 600
     while not ranks.join(timeout=5):
         if time.time() > deadline:
             for p in ranks.processes:

@@ -360,10 +360,15 @@ def test_pipelined_replay_matches_plain_graph_replay(gpu, monkeypatch):
     l1, w1 = results["1"]
     assert torch.isfinite(l1).all()
     dev = ((l0 - l1).abs() / l0.abs().clamp_min(1e-6)).max(1).values      # per step
-    # the reordered fp32 atomics of the weight gradients grow through the discrete label stage step by step (measured: 0, 0, 1e-7,
-    # 4e-7, 2e-5, 8e-4, 2e-3, 4e-3); a wrong old-model map at step 3 would show there, as a deviation of order one
-    assert torch.allclose(l0[:6], l1[:6], rtol=2e-3, atol=1e-6) and (dev[6:] < 3e-2).all(), (dev, l0, l1)
+    # the reordered fp32 atomics of the weight gradients grow through the discrete label stage step by step, differently from run to run
+    # (measured on two boxes: 0, 0, 1e-7, 4e-7, 2e-5, 8e-4, 2e-3, 4e-3 and 0, 1e-7, 2e-7, 2e-4, 5e-4, 3e-3, 8e-3, 1e-2); a wrong old-model
+    # map at step 3 (the step after the unannounced one) would show there as a deviation of order one
+    assert (dev[:3] < 1e-5).all() and dev[3] < 5e-3 and (dev[4:] < 5e-2).all(), (dev, l0, l1)
     lr = opts.lr * opts.lr_head
     for k in w0:
-        if w0[k].is_floating_point():                      # Adam: up to +-lr per step where a gradient is numerically zero
+        if not w0[k].is_floating_point():
+            continue
+        if "running_" in k:                                # batch statistics of activations whose weights moved apart by up to +-lr per step
+            assert (w0[k] - w1[k]).abs().max() <= 5e-2 * w0[k].abs().max(), k
+        else:                                              # Adam: up to +-lr per step where a gradient is numerically zero
             assert (w0[k] - w1[k]).abs().max() <= 3.2 * lr * 8 + 1e-6 * w0[k].abs().max(), k
