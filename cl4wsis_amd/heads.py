@@ -31,7 +31,7 @@ TRAIN_PRECISION = int(__import__("os").environ.get("CL4_TRAIN_PRECISION", "2"))
 # The trainable ASPP reads a three-plane (hi, mid, lo) copy of the frozen res5 features through the LDS-DMA planes kernel (conv_b.hip,
 # plan impl 6): 0.82 -> 0.61 ms per dilated branch (r03); 0 = the role-split bf16x6 kernel on the fp32 features.
 X6_PLANES = __import__("os").environ.get("CL4_X6_PLANES", "1") == "1"
-POOL_GRAD_COMMUTED = __import__("os").environ.get("CL4_POOL_GRAD", "1") != "0"
+POOL_GRAD_COMMUTED = __import__("os").environ.get("CL4_POOL_GRAD", "0") != "0"
 
 
 def _dx_1x1(dz, conv):
@@ -564,11 +564,12 @@ class InstanceBranch:
     @staticmethod
     def _pool_branch_grad(dpz, dcat5, pconv0, cout):
         """Gradient of the image-pooling branch's [n, cout, 1, 1] output: the sum over the plane of the projection's input gradient in
-        that branch's channels (the backward of `x.repeat(1, 1, h, w)`, modules/panoptic_deeplab.py:84-89). r04:
-        sum_px (W^T dpz)[px] = W^T (sum_px dpz[px]) — the plane sum is taken FIRST, in fp64, on the projection's pre-activation gradient,
-        and the 1x1 input-gradient product runs on the [n, 256, 1, 1] sums. Autograd (and the oracle) sum 1089 products that each carry the
-        rounding of a 256-term fp32 dot product; the sums nearly cancel (the BatchNorm backward made dpz zero-mean per channel), so that
-        noise was this tensor's whole 1.4e-2 distance at exact fp32. CL4_POOL_GRAD=0 restores the literal order."""
+        that branch's channels (the backward of `x.repeat(1, 1, h, w)`, modules/panoptic_deeplab.py:84-89). CL4_POOL_GRAD=1 (r04, VERDICT
+        r03 item 2c) commutes the sum: sum_px (W^T dpz)[px] = W^T (sum_px dpz[px]) with the plane sum in fp64 — 256 rounded terms per
+        output instead of 256 x 1089. Measured (FINDINGS.md finding 41): the pooling weight's distance from the float64 oracle does not
+        move in the fourth digit (3.7603e-3 / 3.1669e-2 / 9.987e-3 at frozen precision 0 / 2 / 1, both orders), i.e. the noise is in dpz
+        itself — sign decisions of the activation backward on a nearly cancelling sum — not in the order of the reduction, so the
+        literal order stays the default."""
         if not POOL_GRAD_COMMUTED:
             return ops.resize_bilinear_bwd(dcat5, (1, 1), True, dy_coff=4 * cout, c=cout)
         ds = _dx_1x1(ops.plane_sum(dpz), pconv0)               # [n, 5 * cout, 1, 1]

@@ -122,7 +122,7 @@ def test_two_rank_phase2_step_matches_sharded_single_process_emulation(gpu, monk
             for p in ranks.processes:
                 if p.is_alive():
                     p.terminate()
-            pytest.fail("the two ranks did not finish within 300 s: a collective of the N > 1 path is unpaired")
+            pytest.fail("the two ranks did not finish within 600 s: a collective of the N > 1 path is unpaired")
     (l0, w_r0), (l1, w_r1) = ret[0], ret[1]
     assert torch.equal(w_r0, w_r1), "the two ranks diverged"
     for it in range(STEPS):

@@ -87,3 +87,24 @@ def test_pseudolabeler_train(gpu):
     errs = torch.tensor([((grads[id(p)].double().cpu() - osd[n].grad).norm() / (osd[n].grad.norm() + 1e-30)).item()
                          for n, p in pl.named_parameters()])
     assert errs.max() < 3e-2 and errs.median() < 1e-3, (errs.max(), errs.median())
+
+
+def test_pooling_branch_gradient_commuted_sum_equals_literal_order(gpu, monkeypatch):
+    """CL4_POOL_GRAD=1: sum over the plane first (cl4_plane_sum, fp64 partials), 1x1 input-gradient product on the sums — against the
+    literal order (product, then the plane sum) and against float64, on a well-conditioned input."""
+    import torch.nn as nn
+    from cl4wsis_amd import heads, ops
+    g = torch.Generator().manual_seed(3)
+    n, cout, h = 3, 64, 9
+    conv = nn.Conv2d(5 * cout, cout, 1, bias=False).to(gpu)
+    dpz = torch.randn(n, cout, h, h, generator=g) + 0.3
+    dcat5 = heads._dx_1x1(dpz.to(gpu), conv)
+    want = torch.einsum("nkhw,kc->nc", dpz.double(), conv.weight.detach().cpu().double()[:, 4 * cout:, 0, 0])
+    s = ops.plane_sum(dpz.to(gpu))
+    assert torch.allclose(s.cpu().double().flatten(), dpz.double().sum((2, 3)).flatten(), rtol=1e-6, atol=1e-5)
+    for mode in (False, True):
+        monkeypatch.setattr(heads, "POOL_GRAD_COMMUTED", mode)
+        got = heads.InstanceBranch._pool_branch_grad(dpz.to(gpu), dcat5, conv, cout)
+        assert tuple(got.shape) == (n, cout, 1, 1)
+        err = (got.cpu().double().flatten() - want.flatten()).abs().max() / want.abs().max()
+        assert err < 2e-5, (mode, float(err))
