@@ -42,7 +42,7 @@ def conv_abn_train(x, conv, bn, group=None):
     k = conv.kernel_size[0]
     r = _Rec()
     r.x = x
-    r.z = ops.conv2d(x, packed_weight(conv, PRECISION), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0])
+    r.z = ops.conv2d(x, packed_weight(conv, PRECISION), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], x6=True)
     act, slope = bn.act_code()
     r.y, r.mean, r.var, r.count = ops.abn_train_forward(r.z, gamma_of(bn), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                         bn.momentum, bn.eps, act, slope, group)
@@ -63,7 +63,7 @@ def conv_abn_backward(r, conv, bn, dy, grad_of, need_dx=True, group=None):
     if not need_dx:
         return None
     return ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(r.x.shape[2:]), k, stride=conv.stride[0], pad=conv.padding[0],
-                            dil=conv.dilation[0])
+                            dil=conv.dilation[0], x6=True)
 
 
 def block_forward(blk, x, group=None):
@@ -169,7 +169,7 @@ def _abn_backward(r, bn, dy, grad_of, group=None):
 
 def _conv_train(x, conv):
     k = conv.kernel_size[0]
-    return ops.conv2d(x, packed_weight(conv, PRECISION), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0])
+    return ops.conv2d(x, packed_weight(conv, PRECISION), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], x6=True)
 
 
 def _conv_backward(x, conv, dz, grad_of, need_dx=True):
@@ -177,7 +177,7 @@ def _conv_backward(x, conv, dz, grad_of, need_dx=True):
     ops.conv2d_wgrad(x, dz, grad_of(conv.weight), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], precision=WGRAD_PRECISION)
     if not need_dx:
         return None
-    return ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(x.shape[2:]), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0])
+    return ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(x.shape[2:]), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], x6=True)
 
 
 def identity_block_forward(blk, x, group=None, drop_p=None, keep=None, seed=0):

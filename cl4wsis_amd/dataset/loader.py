@@ -8,6 +8,8 @@ training step runs. Yields the reference's batch tuples (dataset/dataset.py:199,
   train: (images f32 [b,3,S,S], seg_map int64 [b,S,S], center [b,C,S,S], offset [b,2,S,S], weight [b,1,S,S], l1h f64 [b,C])
   val:   (images f32 [1,3,h,w], seg int64 [1,h,w], masks [1,R,H,W], mask_label [1,R], [path])
 In weakly supervised phases the dense targets are not read by the step (train.py:243-248) and are skipped (zero placeholders)."""
+import os
+
 import numpy as np
 import torch
 import torch.utils.data as data
@@ -41,15 +43,25 @@ def collate_raw(samples):
     return pb
 
 
+def worker_options(num_workers):
+    """DataLoader keywords for `num_workers` host-side worker processes next to a GPU-initialised parent: spawn, persistent."""
+    if not num_workers:
+        return {}
+    return {"multiprocessing_context": os.environ.get("CL4_WORKER_START", "spawn"), "persistent_workers": True}
+
+
 class DeviceLoader:
     """DataLoader whose batches are finished on the GPU. `supervised` = build centre / offset / weight targets (step 0)."""
 
     def __init__(self, dataset, batch_size, device, sampler=None, shuffle=False, num_workers=0, drop_last=False,
                  supervised=False):
         self.dataset, self.device, self.supervised = dataset, device, supervised
+        # Worker processes are SPAWNED and kept for the life of the loader. The default (fork, again at every epoch) copies the page
+        # tables of a process that has the HIP runtime's device mappings in its address space: measured ~190 s per fork on an MI355X box
+        # once a few models had lived in the parent (FINDINGS.md finding 42), against ~3 s for a fresh interpreter.
         self.loader = data.DataLoader(dataset, batch_size=batch_size, sampler=sampler, shuffle=shuffle and sampler is None,
                                       num_workers=num_workers, drop_last=drop_last, collate_fn=collate_raw,
-                                      pin_memory=False)
+                                      pin_memory=False, **worker_options(num_workers))
         self.sampler = sampler if sampler is not None else self.loader.sampler
         self.side = torch.cuda.Stream(device=device)
         self.lut = torch.from_numpy(dataset.lut).to(device)

@@ -33,7 +33,7 @@ def _conv1x1_bwd(x, conv, dz, grad_of, need_dx=True):
     if not need_dx:
         return None
     if BT.PRECISION:
-        return ops.conv2d(dz, _dgrad_weight(conv), 1)
+        return ops.conv2d(dz, _dgrad_weight(conv), 1, x6=True)
     return ops.conv2d(dz, conv.weight.detach().reshape(conv.out_channels, conv.in_channels), 1)
 
 
@@ -45,9 +45,9 @@ def deeplab_forward(head, x, group=None):
     hid = head.hidden
     cat = torch.empty((n, 4 * hid, h, w), dtype=torch.float32, device=x.device)
     for i, conv in enumerate(head.map_convs):
-        ops.conv2d(x, packed_weight(conv, BT.PRECISION), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0], out=cat, out_coff=i * hid)
+        ops.conv2d(x, packed_weight(conv, BT.PRECISION), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0], out=cat, out_coff=i * hid, x6=True)
     a, r_map = _abn_fwd(cat, head.map_bn, group)
-    out = ops.conv2d(a, packed_weight(head.red_conv, BT.PRECISION), 1)
+    out = ops.conv2d(a, packed_weight(head.red_conv, BT.PRECISION), 1, x6=True)
     g = ops.global_mean(x)                                            # [n, cin, 1, 1]
     pz = ops.conv2d(g, packed_weight(head.global_pooling_conv, BT.PRECISION), 1)
     pa, r_pool = _abn_fwd(pz, head.global_pooling_bn, group)

@@ -68,9 +68,10 @@ def conv_out_size(h, k, stride, pad, dil):
 CONV_PRECISION = int(os.environ.get("CL4_CONV_PRECISION", "1"))
 # r04: plain bf16x6 convolutions with a long K loop via cl4_to_planes3 + the three-plane LDS-DMA kernel; thresholds
 # from tools/probe_x6_planes.py (the extra pass over the input has to be paid back by the kernel)
-# Scope: the steps that differentiate the body (phase 1, step 0) switch it on around their run (`x6_route_scope`); in phase 2 the precision-2
-# convolutions of the instance branch share the chip with the frozen networks' stream and the extra pass costs more than it returns
-# (measured 464.0 -> 459.2 images/s with the route on everywhere; phase 1: 88.8 -> 85.6 ms per step).
+# Scope: the call sites of the differentiated body / DeepLabV3 head / PseudoLabeler (body_train.py, heads_train.py: phase 1, step 0 and the
+# autograd module surface) ask for it with `x6=True`; `x6_route_scope` switches it on for everything inside a `with`. Phase 2's instance
+# branch does not: its precision-2 convolutions share the chip with the frozen networks' stream and the extra pass costs more than it
+# returns (measured 464.0 -> 459.2 images/s with the route on everywhere; phase 1: 88.8 -> 83.7-85.6 ms per step).
 X6_ROUTE = os.environ.get("CL4_X6_ROUTE", "1") != "0"
 _x6_scope = 0
 X6_ROUTE_MIN_K3 = int(os.environ.get("CL4_X6_ROUTE_MIN_K3", "1152"))     # 3x3: from 128 input channels (measured gain 1.07-1.27)
@@ -365,8 +366,8 @@ def _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, a
 
 def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, post=None,
            act1=ACT_NONE, slope1=0.01, act2=ACT_NONE, slope2=0.01,
-           out=None, out_coff=0, in_coff=0, cin=None):
-    """Fused conv (+affine +act +residual +act). `wp` comes from pack_conv_weight.
+           out=None, out_coff=0, in_coff=0, cin=None, x6=False):
+    """Fused conv (+affine +act +residual +act). `wp` comes from pack_conv_weight. `x6`: see X6_ROUTE.
 
     `out`/`out_coff` write into a channel slice of a wider tensor (replaces torch.cat);
     `in_coff`/`cin` read a channel slice of `x`.
@@ -380,7 +381,7 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     K, cout = wp.K, wp.cout
     if K != cin * k * k:
         raise RuntimeError(f"conv2d: packed weight K={K} does not match cin*k*k={cin * k * k}")
-    if (X6_ROUTE and _x6_scope and wp.precision == 2 and stride == 1 and in_coff == 0 and cin == in_ctot and cin % 32 == 0 and cout % 8 == 0
+    if (X6_ROUTE and (x6 or _x6_scope) and wp.precision == 2 and stride == 1 and in_coff == 0 and cin == in_ctot and cin % 32 == 0 and cout % 8 == 0
             and cout >= 128 and scale is None and shift is None and pre is None and post is None and x.is_contiguous()
             and ((k == 3 and K >= X6_ROUTE_MIN_K3) or (k == 1 and K >= X6_ROUTE_MIN_K1 and cout >= cin))):
         # r04: a plain bf16x6 convolution of the differentiated networks (phase 1 / step 0: body, DeepLabV3 head, PseudoLabeler, forward and
@@ -1426,14 +1427,14 @@ def dgrad_weight(w, precision=0):
     return pack_conv_weight(wt, precision if bf16x3_ok(cin) else 0)
 
 
-def conv2d_dgrad(dy, wd, in_size, k, stride=1, pad=0, dil=1):
+def conv2d_dgrad(dy, wd, in_size, k, stride=1, pad=0, dil=1, x6=False):
     """Input gradient of conv2d(x, w, stride, pad, dil): `wd` = dgrad_weight(w); in_size = (hin, win) of x."""
     hin, win = in_size
     if k == 1 and pad == 0:
-        dx = conv2d(dy, wd, 1)
+        dx = conv2d(dy, wd, 1, x6=x6)
         return dx if stride == 1 else zero_insert(dx, stride, (hin, win))
     up = dy if stride == 1 else zero_insert(dy, stride, (hin + 2 * pad - dil * (k - 1), win + 2 * pad - dil * (k - 1)))
-    return conv2d(up, wd, k, stride=1, pad=dil * (k - 1) - pad, dil=dil)
+    return conv2d(up, wd, k, stride=1, pad=dil * (k - 1) - pad, dil=dil, x6=x6)
 
 
 def rot90(x, k, out=None):

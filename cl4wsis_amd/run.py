@@ -138,8 +138,9 @@ def main(opts):
         n_img = int(os.environ.get("CL4_SYNTH_LEN", "10582"))        # VOC 2012 aug train size
         train_dst = SyntheticVOC(n_img, opts.crop_size, opts.random_seed, supervised=supervised)
         sampler = DistributedSampler(train_dst, num_replicas=world, rank=rank) if world > 1 else None
+        from .dataset.loader import worker_options
         loader = data.DataLoader(train_dst, batch_size=opts.batch_size, sampler=sampler, shuffle=sampler is None,
-                                 num_workers=opts.num_workers, drop_last=True)
+                                 num_workers=opts.num_workers, drop_last=True, **worker_options(opts.num_workers))
         n_classes = 21
         logger.info(f"no dataset under {opts.data_root!r}: synthetic VOC-shaped batches ({n_img} images); validation / test are skipped")
     logger.info(f"Total batch size is {opts.batch_size * world}")

@@ -240,9 +240,8 @@ class Trainer:
         self.model.train()
         ops.AUTOTUNE = self._iter == 0 and os.environ.get("CL4_AUTOTUNE", "1") != "0"
         try:
-            with ops.x6_route_scope():
-                losses = self._s0.run(f32(images), seg_maps.to(self.device, dtype=torch.long).contiguous(), f32(center_maps),
-                                      f32(offset_maps), f32(weights), dropout_keep)
+            losses = self._s0.run(f32(images), seg_maps.to(self.device, dtype=torch.long).contiguous(), f32(center_maps),
+                                  f32(offset_maps), f32(weights), dropout_keep)
         finally:
             ops.AUTOTUNE = False
         for i in range(len(self.buckets.fb.sizes)):
@@ -280,8 +279,7 @@ class Trainer:
         else:
             ops.AUTOTUNE = self._iter == 0 and os.environ.get("CL4_AUTOTUNE", "1") != "0"
             try:
-                with ops.x6_route_scope():
-                    losses = self._p1.run(images, l1h, epoch, flac_angle, randrop_neg)
+                losses = self._p1.run(images, l1h, epoch, flac_angle, randrop_neg)
             finally:
                 ops.AUTOTUNE = False
             for i in range(len(self.buckets.fb.sizes)):
@@ -317,7 +315,7 @@ class Trainer:
             torch.cuda.synchronize()
             stale_trainable()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=S["pool"]), ops.x6_route_scope():
+            with torch.cuda.graph(g, pool=S["pool"]):
                 losses = self._p1.run(S["images"], S["l1h"], self.pseudo_epoch if late else 0, angle, None)
                 opt.step(upload=False)
             stale_trainable()

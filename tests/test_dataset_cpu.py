@@ -194,3 +194,23 @@ def test_coco_voc_step1_reads_the_as_coco_voc_tree(tmp_path):
     img, seg_coco, inst, lab = truth["val"][1]
     assert np.array_equal(v.label[:, :, 0], seg_coco) and v.masks.shape[0] == len(v.mask_label) == len(np.unique(inst)) - 1
     assert v.path == "val_01"
+
+
+def test_loader_workers_are_spawned_and_the_dataset_travels_to_them(tmp_path):
+    """cl4wsis_amd.dataset.loader.worker_options: worker processes are spawned (never forked from the GPU-initialised trainer process) and
+    persistent, so the dataset object and the collate function must pickle; one epoch through one spawned worker yields the same packed
+    batches (photo bytes, labels, image-level labels) as the in-process loader."""
+    import torch.utils.data as data
+    from cl4wsis_amd.dataset import get_dataset
+    from cl4wsis_amd.dataset.loader import collate_raw, worker_options
+    make_mini_voc(tmp_path)
+    train = get_dataset(_opts(tmp_path))[0]
+    opt = worker_options(1)
+    assert opt == {"multiprocessing_context": "spawn", "persistent_workers": True} and worker_options(0) == {}
+    got = {}
+    for tag, kw in (("main", {}), ("worker", opt)):
+        loader = data.DataLoader(train, batch_size=2, shuffle=False, num_workers=1 if kw else 0, collate_fn=collate_raw, **kw)
+        got[tag] = [(pb.paths, pb.l1h.clone()) for pb in loader]
+        del loader
+    assert len(got["main"]) == 2 and [p for p, _ in got["main"]] == [p for p, _ in got["worker"]]
+    assert all((a == b).all() for (_, a), (_, b) in zip(got["main"], got["worker"]))

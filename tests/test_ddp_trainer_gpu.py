@@ -87,7 +87,9 @@ def _rank(rank, world, port, ret):
 def test_two_rank_phase2_step_matches_sharded_single_process_emulation(gpu, monkeypatch):
     monkeypatch.setenv("CL4_AUTOTUNE", "0")
     # the two ranks start first: their start-up (interpreter, torch, HIP context, rendezvous: most of this test's time) runs beside the emulation
-    mgr = mp.Manager()
+    # (everything here is SPAWNED: a fork of this process — what mp.Manager() does by default — copies the page tables of an address space that
+    # holds the HIP runtime's device mappings and took 190 s of this test's 200 once the acceptance tests had run before it)
+    mgr = mp.get_context("spawn").Manager()
     ret = mgr.dict()
     ranks = mp.spawn(_rank, args=(2, _free_port(), ret), nprocs=2, join=False)
     # ---- the emulation: one trainer, two shards per iteration, averaged gradients, one Adam step -------------------------------------
