@@ -595,7 +595,7 @@ def conv2d_wgrad(x, dy, dw, k, stride=1, pad=0, dil=1, in_coff=0, cin=None, dy_c
     if tuple(dy.shape[2:]) != (d.hout, d.wout) or dy.shape[0] != n:
         raise RuntimeError("conv2d_wgrad: dy spatial shape does not match the convolution geometry")
     if TIMER is not None:
-        e0, e1 = TIMER.span("conv_wgrad", 2.0 * n * d.hout * d.wout * cout * cin * k * k)
+        e0, e1 = TIMER.span("conv_wgrad", 2.0 * n * d.hout * d.wout * cout * cin * k * k, (n, cin, hin, cout, k, stride, dil))
         e0.record()
     if _wgrad_gemm_ok(n, cin, hin, win, cout, k, stride, d.precision) and x.is_contiguous() and dy.is_contiguous() and dw.is_contiguous():
         _wgrad_gemm(x, dy, dw, n, cin, in_coff, cout, dy_coff, hin, win, d.hout, d.wout, pad, dil, kcache)
