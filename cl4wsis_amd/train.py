@@ -42,6 +42,26 @@ class _NoScaler:
         pass
 
 
+def _clone_tree(v):
+    """Static twins of a nest of device tensors (dicts / tuples / lists): contiguous clones, planes twins dropped."""
+    if isinstance(v, dict):
+        return {k: _clone_tree(x) for k, x in v.items()}
+    if isinstance(v, (tuple, list)):
+        return type(v)(_clone_tree(x) for x in v)
+    return v.detach().clone().contiguous()
+
+
+def _copy_tree(dst, src):
+    if isinstance(dst, dict):
+        for k in dst:
+            _copy_tree(dst[k], src[k])
+    elif isinstance(dst, (tuple, list)):
+        for d, x in zip(dst, src):
+            _copy_tree(d, x)
+    else:
+        dst.copy_(src)
+
+
 class Trainer:
     def __init__(self, logger, device, opts):
         self.logger = logger
@@ -111,6 +131,14 @@ class Trainer:
         # body 362-364, head 361-362, after mod4 361-363, after mod3 349 = no pipelining: what pays is the overlap with the trainable
         # branch / backward, not with the new model's own convolutions.
         self._pipe_fork = os.environ.get("CL4_PIPE_FORK", "body")
+        # r04 — deep pipelining: ALL frozen work of batch t+1 (old model on one side stream; new model's semantic forward, PseudoLabeler, CAM,
+        # peaks and the semantic pseudo ground truth on a second one) runs beside batch t's trainable branch / label stage / backward / Adam, and
+        # hands its results over in per-parity static buffers. At 16 images per GPU the chip is full either way (the shallow form above is what
+        # pays there); at the 8 / 4 / 2 images per GPU of N = 2 / 4 / 8 the step is a chain of launches that fill a tenth of the chip, and
+        # three chains side by side shorten it to the longest one. CL4_DEEP_PIPE=0: shallow pipelining at every batch size.
+        self._deep_pipe = os.environ.get("CL4_DEEP_PIPE", "1") != "0" and self._pipeline
+        self._deep_max_b = int(os.environ.get("CL4_DEEP_PIPE_MAX_BATCH", "8"))
+        self._side2 = torch.cuda.Stream(device=self.device) if self._deep_pipe else None
         self._label_override = None
         self._label_acc = torch.zeros(5, dtype=torch.int32, device=self.device)   # sticky label-stage counters, see check_label_overflow
         # the launch advances the seed by 1 per step: the rank lives in bits 40+ so that no rank ever replays another rank's stream
@@ -459,8 +487,17 @@ class Trainer:
                 o, _ = self.model_old(images, interpolate=False)         # shapes of the two maps the step reads from the old model
             P = {"x": [images.clone(), images.clone()], "l": [l1h.clone(), l1h.clone()],
                  "old": [{k: torch.empty_like(o[k]) for k in ("center", "offset")} for _ in range(2)],
-                 "g": [], "out": [], "have_old": [False, False], "cur": 0}
+                 "g": [], "out": [], "have_old": [False, False], "cur": 0,
+                 "deep": self._deep_pipe and images.shape[0] <= self._deep_max_b}
             del o
+            if P["deep"]:                                # per-parity static copies of everything the frozen new model hands to the step
+                cur = torch.cuda.current_stream()        # (on the second side stream, so that its scratch buffers exist before the capture)
+                self._side2.wait_stream(cur)
+                with torch.no_grad(), torch.cuda.stream(self._side2):
+                    fz = self._frozen_new(images, l1h)
+                    P["fz"] = [_clone_tree(fz), _clone_tree(fz)]
+                    del fz
+                cur.wait_stream(self._side2)
             torch.cuda.synchronize()
             pool = torch.cuda.graph_pool_handle()
             P["pool"] = pool
@@ -478,8 +515,11 @@ class Trainer:
                 stale_trainable()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
-                    out = self._forward_backward(P["x"][q], P["l"][q], None, split_tail=self.buckets.distributed,
-                                                 old_outputs=P["old"][q], prefetch_old=(P["x"][1 - q], P["old"][1 - q]))
+                    if P["deep"]:
+                        out = self._deep_step(P, q)
+                    else:
+                        out = self._forward_backward(P["x"][q], P["l"][q], None, split_tail=self.buckets.distributed,
+                                                     old_outputs=P["old"][q], prefetch_old=(P["x"][1 - q], P["old"][1 - q]))
                     if not self.buckets.distributed:
                         opt.step(upload=False)
                 if not self.buckets.distributed:
@@ -499,8 +539,10 @@ class Trainer:
         if not P["have_old"][p]:                         # not announced by the previous call: the old model runs now, up front
             with torch.no_grad():
                 o, _ = self.model_old(P["x"][p], interpolate=False)
-            for k in ("center", "offset"):
-                P["old"][p][k].copy_(o[k])
+                for k in ("center", "offset"):
+                    P["old"][p][k].copy_(o[k])
+                if P["deep"]:                            # ... and so does the rest of the frozen stage
+                    _copy_tree(P["fz"][p], self._frozen_new(P["x"][p], P["l"][p]))
         # The graph always runs the old model on X[1-p]; its result counts only if the caller announced that batch and it has the
         # captured shape (a last, smaller batch of an epoch takes the eager path of step()). Nothing announced — the last step of an
         # epoch, a caller that stops looking ahead — leaves OLD[1-p] marked invalid, and the next call runs the old model itself.
@@ -527,10 +569,116 @@ class Trainer:
             self._distributed_tail(P["out"][p], P.get("pool"))
         return P["out"][p]
 
-    def _forward_backward(self, images, l1h, dropout_keep, split_tail=False, old_outputs=None, prefetch_old=None):
+    def _deep_step(self, P, q):
+        """Body of the deep-pipelined graph of parity q: the trainable stage of batch X[q] on its handed-over frozen results FZ[q] / OLD[q]
+        (main stream), beside the whole frozen stage of X[1 - q] into FZ[1 - q] / OLD[1 - q] (two side streams), joined at the end."""
+        main = torch.cuda.current_stream()
+        r = 1 - q
+        H, W = P["x"][q].shape[2:]
+        self._side_stream.wait_stream(main)
+        self._side2.wait_stream(main)
+        with torch.cuda.stream(self._side_stream):
+            o_next, _ = self.model_old(P["x"][r], interpolate=False)
+            for k in ("center", "offset"):
+                P["old"][r][k].copy_(o_next[k])
+            del o_next
+        with torch.cuda.stream(self._side2):
+            _copy_tree(P["fz"][r], self._frozen_new(P["x"][r], P["l"][r]))
+        self.optimizer.zero_grad()
+
+        def join_end():
+            main.wait_stream(self._side_stream)
+            main.wait_stream(self._side2)
+
+        return self._trainable_stage(P["fz"][q], P["old"][q], P["l"][q], None, (H, W), split_tail=self.buckets.distributed, join_end=join_end)
+
+    def _frozen_new(self, images, l1h, fork=None):
+        """The part of the step that only the FROZEN new model and the batch feed (train.py:259-263, 421-449): semantic forward on
+        [images ; flipped images], PseudoLabeler / PeakGenerator in eval mode -> CAM -> peaks, semantic pseudo ground truth. No trainable
+        weight is read, so a pipelined replay may run it for the NEXT batch (`_replay_pipelined`, deep mode). `fork` (shallow pipelining):
+        called where the next batch's old-model forward starts on the side stream."""
         opts = self.opts
         bs, _, H, W = images.shape
         oc = self.old_classes
+        x2 = torch.empty((2 * bs, 3, H, W), dtype=torch.float32, device=self.device)
+        x2[:bs].copy_(images)
+        ops.flip_w(images, out=x2[bs:])
+        self.model.body.f32_images = bs if os.environ.get('CL4_F32_HINT', '1') != '0' else None         # low-level fp32 features are read for the un-flipped half only (feats below)
+        if fork is not None and self._pipe_fork == "body":
+            # fork between the new model's body and its DeepLabV3 head (forward_seg = body -> head -> cls, segmentation_module.py:400-426)
+            feats_all = self.model.forward_seg(x2, as_feature_extractor=True)
+            fork()
+            outputs = {"seg": self.model.cls(self.model.head(feats_all["body"]))}
+            features = feats_all
+        else:
+            outputs, features = self.model.forward_seg(x2, interpolate=False)
+            if fork is not None:
+                fork()
+        self.model.body.f32_images = None
+        feats = {k: ops.batch_slice(v, bs) for k, v in features["features"].items()}   # first half = un-flipped images (contiguous views, planes twins kept)
+        # train.py:421-436 — CAM of the new classes -> peaks
+        self.pseudolabeler.eval()
+        self.peakgenerator.eval()
+        int_masks = self.pseudolabeler(ops.batch_slice(features["body"], bs))
+        label_new = l1h[:, oc - 1:].contiguous()
+        seg2b = outputs["seg"]
+        if self._label_override is not None:    # benchmark-only: see set_label_override (every network above still ran)
+            int_masks, seg2b = self._label_override["int_masks"], self._label_override["seg2b"]
+        cam = self.peakgenerator.cam(int_masks, label_new)
+        peaks = ops.peak_extract(cam, label_new, (H, W), kernel=15, K=25)
+        # train.py:438-449 — semantic pseudo ground truth
+        seg_gt, old_w, prob_win = ops.seg_pseudo_gt(seg2b, l1h, oc, (H, W), no_mask=opts.no_mask)
+        return {"feats": feats, "peaks": peaks, "seg_gt": seg_gt, "old_w": old_w, "prob_win": prob_win}
+
+    def _trainable_stage(self, fz, outputs_old, l1h, dropout_keep, size, split_tail=False, join_old=None, join_end=None):
+        """Everything behind the frozen networks (train.py:265-272, 451-541): trainable instance branch on the detached features, label
+        stage on its predictions, blended targets + losses, backward. `join_old` / `join_end`: stream joins (the old model's maps are
+        consumed from the loss on; a prefetch of the next batch is joined before the step, and its graph, ends)."""
+        opts = self.opts
+        H, W = size
+        oc = self.old_classes
+        feats = fz["feats"]
+        bs = l1h.shape[0]
+        if dropout_keep is None:
+            n5, _, h5, w5 = feats["res5"].shape
+            drop = self.model.decoder.instance_decoder.aspp.project
+            dropout_keep = ops.dropout_mask_dev((n5, drop[0].out_channels, h5, w5), drop[3].p, self._seed_dev,
+                                                1, self.device)        # the kernel hashes the seed: +1 per step is enough
+        pred, tape = self._branch.forward_train(feats, dropout_keep=dropout_keep)
+        torch._foreach_add_(self._bn_counters, 1)
+        label_new = l1h[:, oc - 1:].contiguous()
+        lab_center, lab_offset = pred["center"], pred["offset"]
+        if self._label_override is not None:
+            lab_center, lab_offset = self._label_override["center_lo"], self._label_override["offset_lo"]
+        seg_gt, old_w, prob_win, peaks = fz["seg_gt"], fz["old_w"], fz["prob_win"], fz["peaks"]
+        # train.py:451-500 — pseudo labels + refined labels
+        pseudo, refined = ops.label_generation(
+            seg_gt, prob_win, label_new, peaks, lab_center, lab_offset, self._g_dev, oc, sigma=self.sigma,
+            pseudo_thresh=opts.pseudo_thresh, refine_thresh=opts.refine_thresh, nms_kernel=opts.kernel, beta=opts.beta,
+            run_refine=opts.run_refine)
+        ops.label_counters_accumulate_(self._label_acc, bs, H, W)
+        if join_old is not None:
+            join_old()                               # the old model's centre / offset maps are consumed from here on
+        # train.py:503-522 — blended targets + four weighted losses (+ gradient w.r.t. the low-resolution maps)
+        losses, dcen, doff = ops.p2_loss(pred["center"], pred["offset"], outputs_old["center"], outputs_old["offset"],
+                                         old_w, pseudo, refined, (H, W), self.center_loss_weight, self.offset_loss_weight)
+        # train.py:537 — backward of the trainable sub-net; gradient buckets are all-reduced as they complete
+        out = {"losses": losses, "seg_gt": seg_gt, "peaks": peaks, "pseudo": pseudo, "refined": refined,
+               "center": pred["center"], "offset": pred["offset"], "old_w": old_w}
+        if split_tail:       # data-parallel graph capture: stop before the ASPP backward, see _replay
+            dy = self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map, stop_before_aspp=True)
+            out["_tail"] = (tape, dy)
+            if join_end is not None:
+                join_end()
+            return out
+        self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map,
+                              on_ready=self._ready if (self.buckets.distributed and not torch.cuda.is_current_stream_capturing()) else None)
+        if join_end is not None:
+            join_end()                               # join the next batch's frozen work before the step (and its graph) ends
+        return out
+
+    def _forward_backward(self, images, l1h, dropout_keep, split_tail=False, old_outputs=None, prefetch_old=None):
+        bs, _, H, W = images.shape
 
         # train.py:253-255 — frozen old model, full forward, low resolution outputs. It is independent of the new model's
         # forward below, so it runs on a side stream: the two kernel sequences interleave on the device and fill each
@@ -547,10 +695,7 @@ class Trainer:
         else:
             outputs_old, _ = self.model_old(images, interpolate=False)
         self.optimizer.zero_grad()
-        # train.py:259-263 — semantic forward on [images ; flipped images]
-        x2 = torch.empty((2 * bs, 3, H, W), dtype=torch.float32, device=self.device)
-        x2[:bs].copy_(images)
-        ops.flip_w(images, out=x2[bs:])
+
         def fork_old():                          # pipelined replay: the NEXT batch's old-model forward starts here, on the side stream
             x_next, old_next = prefetch_old
             self._side_stream.wait_stream(main)
@@ -559,65 +704,11 @@ class Trainer:
                 for k in ("center", "offset"):
                     old_next[k].copy_(o_next[k])
 
-        self.model.body.f32_images = bs if os.environ.get('CL4_F32_HINT', '1') != '0' else None         # low-level fp32 features are read for the un-flipped half only (feats below)
-        if prefetch_old is not None and self._pipe_fork == "body":
-            # fork between the new model's body and its DeepLabV3 head (forward_seg = body -> head -> cls, segmentation_module.py:400-426)
-            feats_all = self.model.forward_seg(x2, as_feature_extractor=True)
-            fork_old()
-            outputs = {"seg": self.model.cls(self.model.head(feats_all["body"]))}
-            features = feats_all
-        else:
-            outputs, features = self.model.forward_seg(x2, interpolate=False)
-            if prefetch_old is not None:
-                fork_old()
-        self.model.body.f32_images = None
-        feats = {k: ops.batch_slice(v, bs) for k, v in features["features"].items()}   # first half = un-flipped images (contiguous views, planes twins kept)
-        # train.py:265-272 — trainable instance decoder + heads on the detached features
-        if dropout_keep is None:
-            n5, _, h5, w5 = feats["res5"].shape
-            drop = self.model.decoder.instance_decoder.aspp.project
-            dropout_keep = ops.dropout_mask_dev((n5, drop[0].out_channels, h5, w5), drop[3].p, self._seed_dev,
-                                                1, self.device)        # the kernel hashes the seed: +1 per step is enough
-        pred, tape = self._branch.forward_train(feats, dropout_keep=dropout_keep)
-        torch._foreach_add_(self._bn_counters, 1)
-        # train.py:421-436 — CAM of the new classes -> peaks
-        self.pseudolabeler.eval()
-        self.peakgenerator.eval()
-        int_masks = self.pseudolabeler(ops.batch_slice(features["body"], bs))
-        label_new = l1h[:, oc - 1:].contiguous()
-        seg2b, lab_center, lab_offset = outputs["seg"], pred["center"], pred["offset"]
-        if self._label_override is not None:    # benchmark-only: see set_label_override (every network above still ran)
-            ov = self._label_override
-            int_masks, seg2b, lab_center, lab_offset = ov["int_masks"], ov["seg2b"], ov["center_lo"], ov["offset_lo"]
-        cam = self.peakgenerator.cam(int_masks, label_new)
-        peaks = ops.peak_extract(cam, label_new, (H, W), kernel=15, K=25)
-        # train.py:438-449 — semantic pseudo ground truth
-        seg_gt, old_w, prob_win = ops.seg_pseudo_gt(seg2b, l1h, oc, (H, W), no_mask=opts.no_mask)
-        # train.py:451-500 — pseudo labels + refined labels
-        pseudo, refined = ops.label_generation(
-            seg_gt, prob_win, label_new, peaks, lab_center, lab_offset, self._g_dev, oc, sigma=self.sigma,
-            pseudo_thresh=opts.pseudo_thresh, refine_thresh=opts.refine_thresh, nms_kernel=opts.kernel, beta=opts.beta,
-            run_refine=opts.run_refine)
-        ops.label_counters_accumulate_(self._label_acc, bs, H, W)
-        if self._side_stream is not None and old_outputs is None:
-            main.wait_stream(self._side_stream)      # the old model's centre / offset maps are consumed from here on
-        # train.py:503-522 — blended targets + four weighted losses (+ gradient w.r.t. the low-resolution maps)
-        losses, dcen, doff = ops.p2_loss(pred["center"], pred["offset"], outputs_old["center"], outputs_old["offset"],
-                                         old_w, pseudo, refined, (H, W), self.center_loss_weight, self.offset_loss_weight)
-        # train.py:537 — backward of the trainable sub-net; gradient buckets are all-reduced as they complete
-        out = {"losses": losses, "seg_gt": seg_gt, "peaks": peaks, "pseudo": pseudo, "refined": refined,
-               "center": pred["center"], "offset": pred["offset"], "old_w": old_w}
-        if split_tail:       # data-parallel graph capture: stop before the ASPP backward, see _replay
-            dy = self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map, stop_before_aspp=True)
-            out["_tail"] = (tape, dy)
-            if prefetch_old is not None:
-                main.wait_stream(self._side_stream)
-            return out
-        self._branch.backward(tape, {"center": dcen, "offset": doff}, grads=self._grad_map,
-                              on_ready=self._ready if (self.buckets.distributed and not torch.cuda.is_current_stream_capturing()) else None)
-        if prefetch_old is not None:
-            main.wait_stream(self._side_stream)      # join the next batch's old-model forward before the step (and its graph) ends
-        return out
+        fz = self._frozen_new(images, l1h, fork=fork_old if prefetch_old is not None else None)
+        join = (lambda: main.wait_stream(self._side_stream))
+        return self._trainable_stage(fz, outputs_old, l1h, dropout_keep, (H, W), split_tail=split_tail,
+                                     join_old=join if (self._side_stream is not None and old_outputs is None) else None,
+                                     join_end=join if prefetch_old is not None else None)
 
     def set_label_override(self, inputs):
         """Benchmark hook (SURVEY.md §8(d) *structured-labels* mode): with random-init networks the label stage only ever sees

@@ -319,8 +319,10 @@ def test_collective_path_over_rccl_single_rank(gpu, monkeypatch):
 
 
 def test_pipelined_replay_matches_plain_graph_replay(gpu, monkeypatch):
-    """Trainer.step(batch, next_batch=...) replays the frozen old model of the NEXT batch beside the current step's trainable branch
-    and backward (two parities of static buffers, one graph each, the fork inside the graph). Two alternating batches, eight steps (one of them without an announcement in mid-sequence): the losses of every step and the final weights equal those
+    """Trainer.step(batch, next_batch=...) replays frozen work of the NEXT batch beside the current step's trainable branch and backward
+    (two parities of static buffers, one graph each, the fork inside the graph) — shallow: the old model's forward; deep (r04, the default up
+    to 8 images per GPU): the old model on one side stream and the new model's whole frozen stage (semantic forward, CAM, peaks, semantic
+    pseudo ground truth) on a second one. Two alternating batches, eight steps (one of them without an announcement in mid-sequence): the losses of every step and the final weights equal those
     of the unpipelined graph path (same kernels; only the fp32 atomics of the split-K weight gradients may reorder)."""
     import copy
     from cl4wsis_amd.train import Trainer
@@ -340,35 +342,39 @@ def test_pipelined_replay_matches_plain_graph_replay(gpu, monkeypatch):
         debug = info
 
     results = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CL4_PIPELINE", mode)
+    for mode in ("plain", "shallow", "deep"):
+        monkeypatch.setenv("CL4_PIPELINE", "0" if mode == "plain" else "1")
+        monkeypatch.setenv("CL4_DEEP_PIPE", "1" if mode == "deep" else "0")
         monkeypatch.setenv("CL4_PIPELINE_MIN_BATCH", "1")       # the default keeps a batch of 1 per GPU on the one-graph path
         torch.manual_seed(0)
         tr = Trainer(_L(), gpu, copy.deepcopy(opts))
-        assert tr._pipeline == (mode == "1")
+        assert tr._pipeline == (mode != "plain") and tr._deep_pipe == (mode == "deep")
         losses = []
         for t in range(8):
-            # step 2 announces nothing (the end of an epoch) and step 3 brings a DIFFERENT batch than the one last seen: the old-model
-            # maps prefetched by step 2 must not be taken for it
+            # step 2 announces nothing (the end of an epoch) and step 3 brings a DIFFERENT batch than the one last seen: the frozen
+            # results prefetched by step 2 must not be taken for it
             b, nb = batches[t % 2], batches[(t + 1) % 2]
             out = tr.step(b, next_batch=None if t in (2, 7) else nb)
             losses.append(out["losses"].clone())
         torch.cuda.synchronize()
-        assert (tr._pipe is not None) == (mode == "1") and (tr._graph is not None) == (mode == "0")
+        assert (tr._pipe is not None) == (mode != "plain") and (tr._graph is not None) == (mode == "plain")
+        assert mode == "plain" or tr._pipe["deep"] == (mode == "deep")
         results[mode] = (torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()})
-    l0, w0 = results["0"]
-    l1, w1 = results["1"]
-    assert torch.isfinite(l1).all()
-    dev = ((l0 - l1).abs() / l0.abs().clamp_min(1e-6)).max(1).values      # per step
-    # the reordered fp32 atomics of the weight gradients grow through the discrete label stage step by step, differently from run to run
-    # (measured on two boxes: 0, 0, 1e-7, 4e-7, 2e-5, 8e-4, 2e-3, 4e-3 and 0, 1e-7, 2e-7, 2e-4, 5e-4, 3e-3, 8e-3, 1e-2); a wrong old-model
-    # map at step 3 (the step after the unannounced one) would show there as a deviation of order one
-    assert (dev[:3] < 1e-5).all() and dev[3] < 5e-3 and (dev[4:] < 5e-2).all(), (dev, l0, l1)
+    l0, w0 = results["plain"]
     lr = opts.lr * opts.lr_head
-    for k in w0:
-        if not w0[k].is_floating_point():
-            continue
-        if "running_" in k:                                # batch statistics of activations whose weights moved apart by up to +-lr per step
-            assert (w0[k] - w1[k]).abs().max() <= 5e-2 * w0[k].abs().max(), k
-        else:                                              # Adam: up to +-lr per step where a gradient is numerically zero
-            assert (w0[k] - w1[k]).abs().max() <= 3.2 * lr * 8 + 1e-6 * w0[k].abs().max(), k
+    for mode in ("shallow", "deep"):
+        l1, w1 = results[mode]
+        assert torch.isfinite(l1).all()
+        dev = ((l0 - l1).abs() / l0.abs().clamp_min(1e-6)).max(1).values      # per step
+        # the reordered fp32 atomics of the weight gradients grow through the discrete label stage step by step, differently from run to run
+        # (measured on two boxes: 0, 0, 1e-7, 4e-7, 2e-5, 8e-4, 2e-3, 4e-3 and 0, 1e-7, 2e-7, 2e-4, 5e-4, 3e-3, 8e-3, 1e-2); a wrong frozen
+        # result at step 3 (the step after the unannounced one) would show there as a deviation of order one
+        assert (dev[:3] < 1e-5).all() and dev[3] < 5e-3 and (dev[4:] < 5e-2).all(), (mode, dev, l0, l1)
+        for k in w0:
+            if not w0[k].is_floating_point():
+                continue
+            if "running_" in k:                                # batch statistics of activations whose weights moved apart by up to +-lr per step
+                assert (w0[k] - w1[k]).abs().max() <= 5e-2 * w0[k].abs().max(), (mode, k)
+            else:                                              # Adam: up to +-lr per step where a gradient is numerically zero
+                assert (w0[k] - w1[k]).abs().max() <= 3.2 * lr * 8 + 1e-6 * w0[k].abs().max(), (mode, k)
+
