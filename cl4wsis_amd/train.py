@@ -110,7 +110,8 @@ class Trainer:
         self.optimizer, self.scheduler = self.get_optimizer(opts)
         self.distribute(opts)
         self._iter = 0
-        self._side_stream = torch.cuda.Stream(device=self.device) if os.environ.get("CL4_OVERLAP", "1") != "0" else None
+        self._side_stream = (torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CL4_SIDE_PRIORITY", "0")))
+                             if os.environ.get("CL4_OVERLAP", "1") != "0" else None)
         self._use_graph = os.environ.get("CL4_GRAPH", "1") != "0"
         # N > 1: the ASPP tail as a chain of per-bucket graphs (_distributed_tail). Built and tested (world-size-1 RCCL rehearsal, two gloo ranks),
         # measured at world size 1: 34.57 / 19.53 / 11.95 / 8.27 ms per step at 16 / 8 / 4 / 2 images against 34.57 / 19.44 / 11.96 / 8.21 with the
@@ -138,7 +139,7 @@ class Trainer:
         # three chains side by side shorten it to the longest one. CL4_DEEP_PIPE=0: shallow pipelining at every batch size.
         self._deep_pipe = os.environ.get("CL4_DEEP_PIPE", "1") != "0" and self._pipeline
         self._deep_max_b = int(os.environ.get("CL4_DEEP_PIPE_MAX_BATCH", "8"))
-        self._side2 = torch.cuda.Stream(device=self.device) if self._deep_pipe else None
+        self._side2 = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CL4_SIDE2_PRIORITY", "0"))) if self._deep_pipe else None
         self._label_override = None
         self._label_acc = torch.zeros(5, dtype=torch.int32, device=self.device)   # sticky label-stage counters, see check_label_overflow
         # the launch advances the seed by 1 per step: the rank lives in bits 40+ so that no rank ever replays another rank's stream
