@@ -420,6 +420,9 @@ def worker(a):
         batch = (images, l1h)
         for i in range(warmup):
             trainer.step(batch, next_batch=batch)
+            if os.environ.get("CL4_BENCH_VERBOSE"):       # debugging aid: where a run stops
+                torch.cuda.synchronize()
+                _progress(f"rank {rank}: warm-up step {i} done")
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
