@@ -2040,7 +2040,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   const int BMv = small_m ? 64 : 128;
   const int gm = cl4::cdiv(a.cout, BMv), gn = cl4::cdiv(a.Nj, 128);
   // Split K (pixels) so that the grid fills the chip in whole rounds: `slots` workgroups are resident at once (2 per CU for
-  // the 64 KB kernels, 1 per CU for the 96 KB bf16x6 tile); among the split counts near 1024 / (gm*gn) pick the one whose last
+  // the 64 KB kernels, 1 per CU for the 96 KB bf16x6 tile); among the split counts near 512 / (gm*gn) (r01-r03: 1024) pick the one whose last
   // round is fullest (fewest splits on ties: every split adds one atomic pass over dW). Each slice is a multiple of BKP.
   // bf16x3 MFMA path: 32-bit buffer offsets, so both tensors must stay below 2 GiB (always true on the phase-2 path)
   const long lim = (1L << 31) - 4096;
@@ -2053,7 +2053,11 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   const int kpix = vec ? a.n * a.hw_pad : a.npix;
   const int tiles = cl4::cdiv(kpix, BKP);
   const int slots = (a.precision == 2 && KS > 1 && !small_m) ? 256 : 512;
-  int want = cl4::cdiv(1024, gm * gn);
+  // r04: one round of the 512 slots, not two (tools/probe_wgrad_split.py: 3x3 256 -> 256 at 33 x 33 x 16 132.7 -> 110.4 us, 1x1 1280 -> 256
+  // 83.9 -> 65.4 us, every other shape of the steps within 2 %; 256 is no better, 2048 is 10-30 % worse: each split is one more 64 KB
+  // atomic pass over the tile of dW)
+  static const int target_wgs = env_int("CL4_WGRAD_TARGET_WGS", 512);
+  int want = cl4::cdiv(target_wgs, gm * gn);
   if (want < 1) want = 1;
   if (want > tiles) want = tiles;
   int best_s = want;
