@@ -480,6 +480,9 @@ class Trainer:
     # of the next batch thus runs beside this step's trainable branch / label stage / backward / Adam — mostly memory-bound
     # kernels — instead of beside the new model's forward, which is the same kind of work. (Two separate graphs on two streams do
     # not overlap on this ROCm: their replays serialise — measured 49.2 vs 45.7 ms — so the fork has to live inside one graph.)
+    # Also used at N > 1 (graph up to the ASPP backward). Deep mode (r04, P["deep"]: up to `_deep_max_b` images per GPU): G[p] is the
+    # TRAINABLE stage of X[p] on the handed-over frozen results FZ[p] / OLD[p], beside the whole frozen stage of X[1-p] on two side
+    # streams (`_deep_step`); "have_old[p]" then stands for both OLD[p] and FZ[p].
     def _replay_pipelined(self, images, l1h, next_batch, batch=None):
         opt = self.optimizer
         if self._pipe is None:
