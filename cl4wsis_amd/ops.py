@@ -215,6 +215,7 @@ _SPLITS = [int(v) for v in os.environ.get("CL4_TUNE_SPLITS", "1,2,3,4,6,8,12,16,
 _CANDIDATES = [(1, 128, 1)] + [(2, t, s) for t in (128, 64) for s in _SPLITS]   # s < 0: main + split tail (-1: small-tile tail)
 
 
+SPLIT_MAX_TILES = int(os.environ.get("CL4_TUNE_SPLIT_MAX_TILES", "256"))   # whole-launch K splits only for launches of fewer 128-row tiles than this
 _FULL_SPLITS_MIN_N = int(os.environ.get("CL4_TUNE_FULL_SPLITS_MIN_N", "1000000"))   # experiment: launches of at least this many images may use whole-launch K splits
 
 
@@ -228,7 +229,7 @@ def _fills_the_chip(d):
     tiles = -(-d.cout // 128) * -(-(d.n * d.hout * d.wout) // 128)
     if d.n >= _FULL_SPLITS_MIN_N:
         return False
-    return d.precision != 0 and tiles >= 256
+    return d.precision != 0 and tiles >= SPLIT_MAX_TILES
 
 
 def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
@@ -270,13 +271,17 @@ def _autotune_conv(d, x, wp, scale, shift, pre, post, out, reps=6):
             run()
         e1.record()
         e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        ms = e0.elapsed_time(e1) / reps + (SPLIT_MARGIN_MS if splits > 1 else TAIL_MARGIN_MS if splits < 0 else 0.0)
         if ms < best_ms:
             best, best_ms = (impl, tile, splits), ms
     call("cl4_conv2d_fwd_set_plan", C.byref(d), *best)
     _tuned[key] = (best, best_ms)
 
 
+# A K-split plan is timed alone; inside the replayed step its second launch and its S-fold workgroups compete with the other chains of the
+# graph, so it has to win by this margin (ms) to be pinned (experiments at small per-GPU batches: tools/ab_split_margin.sh)
+SPLIT_MARGIN_MS = float(os.environ.get("CL4_TUNE_SPLIT_MARGIN_US", "0")) * 1e-3      # whole-launch K splits (splits > 1)
+TAIL_MARGIN_MS = float(os.environ.get("CL4_TUNE_TAIL_MARGIN_US", "0")) * 1e-3        # main launch + K-split tail launch (splits < 0)
 CONV_P = os.environ.get("CL4_CONV_P", "1") != "0"      # 0: never pick the persistent pipelined planes kernel (A/B measurements)
 SMALL_TILE_BELOW = int(os.environ.get("CL4_SMALL_TILE_BELOW", "384"))    # planes launches with fewer 128 x 128 tiles than this also try 64-pixel tiles (0: never)
 CONV_B = os.environ.get("CL4_CONV_B", "1") != "0"      # r03: the tuner may pick the big-tile LDS-DMA planes kernel (plan impl 4)
@@ -325,7 +330,7 @@ def _autotune_planes(d, args, reps=6):
         tiles = -(-d.cout // 128) * -(-npix // tile)
         if splits == -1 or abs(splits) > max(1, K // 64):
             continue
-        if splits > 1 and tiles >= 256 and d.n < _FULL_SPLITS_MIN_N:      # whole-launch splits only where a launch cannot fill the chip (_fills_the_chip)
+        if splits > 1 and tiles >= SPLIT_MAX_TILES and d.n < _FULL_SPLITS_MIN_N:      # whole-launch splits only where a launch cannot fill the chip (_fills_the_chip)
             continue
         call("cl4_conv2d_fwd_set_plan", C.byref(d), impl, tile, splits)
         need = lib.cl4_conv2d_fwd_workspace_bytes(C.byref(d))
@@ -342,7 +347,7 @@ def _autotune_planes(d, args, reps=6):
             run()
         e1.record()
         e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        ms = e0.elapsed_time(e1) / reps + (SPLIT_MARGIN_MS if splits > 1 else TAIL_MARGIN_MS if splits < 0 else 0.0)
         if ms < best_ms:
             best, best_ms = (impl, tile, splits), ms
     call("cl4_conv2d_fwd_set_plan", C.byref(d), *best)
