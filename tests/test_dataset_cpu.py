@@ -101,6 +101,9 @@ def test_coco_source_and_coco_voc_step0(tmp_path):
     train, val, test, labels_cum, n = get_dataset(o)
     td = tasks.get_task_dict("coco-voc", "voc", 0)
     assert n == len(td[0]) == 61 and len(train) == 5 and len(val) == 2 and len(test) == 2
+    import pickle
+    for ds in (train, val, test):                       # loader workers are spawned (worker_options): the dataset has to pickle
+        assert len(pickle.loads(pickle.dumps(ds))) == len(ds)
     random.seed(0)
     raw = train[0]
     H, W, boxes = truth["train"][0]
