@@ -308,8 +308,8 @@ def test_collective_path_over_rccl_single_rank(gpu, monkeypatch):
     try:
         ld, wd, tr = run()
         assert tr.buckets.distributed and tr.buckets.native_avg and tr._graph is not None
-        lp, wp_, trp = run(lookahead=True)               # the same with the next batch announced: pipelined graphs + eager ASPP tail
-        assert trp.buckets.distributed and trp._pipe is not None
+        lp, wp_, trp = run(lookahead=True)               # the same with the next batch announced: (deep-)pipelined graphs + eager ASPP tail
+        assert trp.buckets.distributed and trp._pipe is not None and trp._pipe["deep"]      # 2 images per GPU: deep pipelining
     finally:
         dist.destroy_process_group()
     for l_, w_ in ((ld, wd), (lp, wp_)):
