@@ -145,3 +145,106 @@ def test_two_rank_phase2_step_matches_sharded_single_process_emulation(gpu, monk
           f"Adam step of the emulation (max |w - w_emu| overall {float(diff.max()):.3e}, lr {lr_eff:.1e})")
     assert int(bigw.sum()) > 0.15 * bigw.numel()       # non-vacuity only (r03: 20.2 %, r04 with the fused res2 blocks: 19.5 %: the set moves with the last bits of the features)
     assert agree > 0.995 and float(diff.max()) <= 2.5 * STEPS * lr_eff
+
+
+# ---- the same with what an N = 8 run executes: 2 images per rank, HIP-graph replay with deep pipelining, eager ASPP tail ----------
+DEEP_STEPS = 4
+
+
+def _deep_inputs():
+    g = torch.Generator().manual_seed(23)
+    batches = []
+    for i in range(DEEP_STEPS):
+        x = torch.randn(4, 3, CROP, CROP, generator=g)
+        l1h = torch.zeros(4, 20)
+        for j, cs in enumerate(((15 + i % 3,), (17, 19), (16,), (18, 15 + i % 2))):
+            l1h[j, list(cs)] = 1
+        batches.append((x, l1h))
+    return batches
+
+
+def _make_trainer2(dev):
+    from cl4wsis_amd.train import Trainer
+    from oracle import weights
+    opts = p2_opts(CROP, extra=["--batch_size", "2"])
+    opts.max_iters, opts.start_decay = 1000, 1000
+    torch.manual_seed(0)
+    tr = Trainer(QuietLogger(), dev, opts)
+    for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
+        m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=61 + i))
+    tr._realias()
+    return tr
+
+
+def _rank_deep(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      CL4_DIST_BACKEND="gloo", CL4_AUTOTUNE="0")
+    torch.set_num_threads(8)
+    import torch.distributed as dist
+    from cl4wsis_amd.parallel import init_distributed
+    init_distributed()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    tr = _make_trainer2(dev)
+    assert tr.buckets.distributed and tr.buckets.world == world
+    batches = [(x[2 * rank:2 * rank + 2].to(dev), l[2 * rank:2 * rank + 2].to(dev)) for x, l in _deep_inputs()]
+    losses = []
+    for i, b in enumerate(batches):
+        out = tr.step(b, next_batch=batches[i + 1] if i + 1 < len(batches) else None)     # Dropout drawn on the device from the rank's seed
+        losses.append(out["losses"].cpu())
+    torch.cuda.synchronize()
+    assert tr._pipe is not None and tr._pipe["deep"], "steps 1.. must have been deep-pipelined graph replays"
+    ret[rank] = (torch.stack(losses), _weights(tr))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_deep_pipelined_graph_steps_match_sharded_emulation(gpu, monkeypatch):
+    """Two ranks x 2 images over gloo, next batch announced: step 0 eager, steps 1-3 replays of the deep-pipelined graphs (trainable stage of
+    batch t beside the whole frozen stage of batch t + 1 on two side streams) + the eager ASPP tail with the bucketed all-reduce + Adam —
+    against one trainer that runs the two shards eagerly one after the other with each rank's own Dropout seed, averages the flat gradient
+    buffers and steps. Identical weights on both ranks; losses of every step those of the emulation."""
+    monkeypatch.setenv("CL4_AUTOTUNE", "0")
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    ranks = mp.spawn(_rank_deep, args=(2, _free_port(), ret), nprocs=2, join=False)
+    tr = _make_trainer2(gpu)
+    assert not tr.buckets.distributed
+    base = int(tr._seed_dev.item())
+    emu_losses = []
+    for t, (x, l1h) in enumerate(_deep_inputs()):
+        tr._set_phase2_modes()
+        g, shard_losses = [], []
+        for r in range(2):
+            tr._seed_dev.fill_(base + (r << 40) + t)          # rank r's seed at its step t (train.py: the launch advances it by 1 per step)
+            out = tr._forward_backward(x[2 * r:2 * r + 2].to(gpu), l1h[2 * r:2 * r + 2].to(gpu), None)
+            g.append(tr.optimizer.grads_fb.flat.clone())
+            shard_losses.append(out["losses"].cpu())
+        tr.optimizer.grads_fb.flat.copy_((g[0] + g[1]) / 2)
+        tr.optimizer.step()
+        if tr.scheduler is not None:
+            tr.scheduler.step()
+        tr._iter += 1
+        emu_losses.append(torch.stack(shard_losses))
+    torch.cuda.synchronize()
+    w_emu = _weights(tr)
+    import time
+    deadline = time.time() + 600
+    while not ranks.join(timeout=5):
+        if time.time() > deadline:
+            for p in ranks.processes:
+                if p.is_alive():
+                    p.terminate()
+            pytest.fail("the two ranks did not finish within 600 s: a collective of the N > 1 path is unpaired")
+    (l0, w_r0), (l1, w_r1) = ret[0], ret[1]
+    assert torch.equal(w_r0, w_r1), "the two ranks diverged"
+    for t in range(DEEP_STEPS):
+        for r, lr in ((0, l0), (1, l1)):
+            # step 0: the same eager kernels; later steps: graph replays on weights that may differ by the Adam +-lr ambiguity of
+            # numerically-zero gradients (tests/test_golden_gpu.py::test_pipelined_replay_matches_plain_graph_replay)
+            assert torch.allclose(lr[t], emu_losses[t][r], rtol=1e-4 if t == 0 else 5e-3, atol=1e-6), (t, r, lr[t], emu_losses[t][r])
+    diff = (w_r0 - w_emu).abs()
+    lr_eff = tr.opts.lr * tr.opts.lr_head
+    print(f"DDP-DEEP max |w - w_emu| {float(diff.max()):.3e} = {float(diff.max()) / lr_eff:.2f} Adam steps over {DEEP_STEPS} iterations; "
+          f"{100 * float((diff < 0.05 * lr_eff).float().mean()):.2f} % of the weights within 5 % of one step")
+    assert float(diff.max()) <= 2.5 * DEEP_STEPS * lr_eff
