@@ -191,7 +191,9 @@ class ResNet(nn.Module):
                 elif frozen and blk.planes_capable(lim):
                     y, yp = blk.forward_planes(y, yp, want_fp32=(i == len(m) - 1), own_input=(i > 0))     # fp32 only where a stage output is handed out; from the second block on the input belongs to this loop
                 else:
-                    y, yp = blk(y if y is not None else ops.from_planes(yp)), None
+                    # with the `f32_images` hint a fused stage's fp32 copy holds the first images only: the planes twin is the whole map
+                    partial = yp is not None and self.f32_images is not None
+                    y, yp = blk(ops.from_planes(yp) if (y is None or partial) else y), None
             if yp is not None:
                 y._cl4_planes = yp                             # consumers that can read planes (DeeplabV3) pick it up
             outs.append(y)

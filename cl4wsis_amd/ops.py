@@ -387,7 +387,8 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     if K != cin * k * k:
         raise RuntimeError(f"conv2d: packed weight K={K} does not match cin*k*k={cin * k * k}")
     if (X6_ROUTE and (x6 or _x6_scope) and wp.precision == 2 and stride == 1 and in_coff == 0 and cin == in_ctot and cin % 32 == 0 and cout % 8 == 0
-            and cout >= 128 and scale is None and shift is None and pre is None and post is None and x.is_contiguous()
+            and cout >= 128 and scale is None and shift is None and pre is None and post is None and act1 == ACT_NONE and act2 == ACT_NONE
+            and x.is_contiguous()
             and ((k == 3 and K >= X6_ROUTE_MIN_K3) or (k == 1 and K >= X6_ROUTE_MIN_K1 and cout >= cin))):
         # r04: a plain bf16x6 convolution of the differentiated networks (phase 1 / step 0: body, DeepLabV3 head, PseudoLabeler, forward and
         # input gradient) whose K loop is long enough goes through a three-plane copy of its input and the LDS-DMA kernel (conv_b, FINDINGS.md
@@ -876,7 +877,8 @@ def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momen
     `group`, then BN + leaky-ReLU / identity. Returns (y, mean, var, count). `extra_sums` ([c*2] doubles, count) adds the
     statistics of shards held elsewhere — used by the tests to emulate a second rank on one GPU."""
     n, c, h, w = x.shape
-    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
+    # the count slot exists only when a caller brings extra shards (ADVICE r04: an uninitialised double must not go through the all-reduce)
+    sums = torch.empty(2 * c + (1 if extra_sums is not None else 0), dtype=torch.float64, device=x.device)
     ws = _workspace(x.device, bn_workspace_bytes(c))
     call("cl4_bn_sync_stats_local", ptr(x), n, c, h * w, c, 0, ptr(sums), ptr(ws), ws.numel(), stream())
     if extra_sums is not None:      # (a host scalar written into a device tensor is a synchronous copy: not inside a HIP-graph capture)

@@ -155,6 +155,11 @@ class FusedSGD(torch.optim.Optimizer):
             for p in g["params"]:
                 CACHE.touch(p)
 
+    def note_replayed_step(self):
+        """Bookkeeping after a graph replay that contained the update kernels (SGD keeps no step counter)."""
+        self._opt_called = True
+        self._step_count = getattr(self, "_step_count", 0) + 1
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         with torch.no_grad():

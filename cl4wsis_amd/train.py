@@ -347,6 +347,8 @@ class Trainer:
             with torch.cuda.graph(g, pool=S["pool"]):
                 losses = self._p1.run(S["images"], S["l1h"], self.pseudo_epoch if late else 0, angle, None)
                 opt.step(upload=False)
+            if hasattr(opt, "_step"):
+                opt._step -= 1                            # capture only recorded the kernels (as _replay does)
             stale_trainable()
             S["graphs"][key] = (g, losses)
             S["keep"].append(self._derived_snapshot())
@@ -356,6 +358,7 @@ class Trainer:
         opt.upload_lr()
         g.replay()
         self._graph_active = True
+        opt.note_replayed_step()                          # host step count == the device's step_dev (state_dict / resume)
         return losses
 
     # HIP-graph path: iteration 0 runs eagerly (autotuning), iteration 1 captures the whole step — both streams, ~600
@@ -608,17 +611,19 @@ class Trainer:
         x2[:bs].copy_(images)
         ops.flip_w(images, out=x2[bs:])
         self.model.body.f32_images = bs if os.environ.get('CL4_F32_HINT', '1') != '0' else None         # low-level fp32 features are read for the un-flipped half only (feats below)
-        if fork is not None and self._pipe_fork == "body":
-            # fork between the new model's body and its DeepLabV3 head (forward_seg = body -> head -> cls, segmentation_module.py:400-426)
-            feats_all = self.model.forward_seg(x2, as_feature_extractor=True)
-            fork()
-            outputs = {"seg": self.model.cls(self.model.head(feats_all["body"]))}
-            features = feats_all
-        else:
-            outputs, features = self.model.forward_seg(x2, interpolate=False)
-            if fork is not None:
+        try:
+            if fork is not None and self._pipe_fork == "body":
+                # fork between the new model's body and its DeepLabV3 head (forward_seg = body -> head -> cls, segmentation_module.py:400-426)
+                feats_all = self.model.forward_seg(x2, as_feature_extractor=True)
                 fork()
-        self.model.body.f32_images = None
+                outputs = {"seg": self.model.cls(self.model.head(feats_all["body"]))}
+                features = feats_all
+            else:
+                outputs, features = self.model.forward_seg(x2, interpolate=False)
+                if fork is not None:
+                    fork()
+        finally:
+            self.model.body.f32_images = None         # the hint must not outlive this forward (validate / flip-TTA read every image)
         feats = {k: ops.batch_slice(v, bs) for k, v in features["features"].items()}   # first half = un-flipped images (contiguous views, planes twins kept)
         # train.py:421-436 — CAM of the new classes -> peaks
         self.pseudolabeler.eval()

@@ -154,3 +154,35 @@ def test_phase1_graph_replay_matches_eager(gpu):
                                                    for k, v in sd.items() if k in dict(m.named_parameters())])).norm()).item()
         print("P1GRAPH angle", angle, "graphs", len(tr._p1_static["graphs"]), "update difference relative to the update", rel)
         assert rel < 2e-2, rel
+
+
+def test_phase1_adam_step_count_survives_graph_replays(gpu):
+    """`--phase 1 --optim adam` on one GPU is graph-replayed from the third call on; the host-side step count that
+    `state_dict()` writes (and `load_state_dict` feeds back into the device counter on resume) must advance with every replay exactly
+    like the device's `step_dev`, which the captured update kernels increment (train.py:537-541 with torch.optim.Adam's bias correction)."""
+    import numpy as np
+    from cl4wsis_amd.train import Trainer
+    from cl4wsis_amd.optim import FusedAdam
+    from oracle import weights
+    crop = 65
+    opts = p1_opts(crop)
+    opts.optim = "adam"
+    opts.max_iters, opts.start_decay = 1000, 1000
+    torch.manual_seed(0)
+    tr = Trainer(_Log(), gpu, opts)
+    assert isinstance(tr.optimizer, FusedAdam)
+    mods = (tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)
+    for i, m in enumerate(mods):
+        m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=41 + i))
+    tr._realias()
+    g = torch.Generator().manual_seed(5)
+    np.random.seed(3)
+    n = 9                                             # 2 eager + 7 replays over up to three FLAC-angle graphs (each captured once)
+    for i in range(n):
+        out = tr.step((torch.randn(2, 3, crop, crop, generator=g), torch.eye(20)[[15 + i % 5, 19 - i % 3]].clone()))
+    torch.cuda.synchronize()
+    assert tr._p1_static is not None and len(tr._p1_static["graphs"]) >= 1
+    assert all(np.isfinite(float(v)) for v in out["losses"].values())
+    assert int(tr.optimizer.step_dev.item()) == n
+    steps = {float(st["step"]) for st in tr.optimizer.state_dict()["state"].values()}
+    assert steps == {float(n)}, steps
