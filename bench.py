@@ -48,8 +48,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-side legs (cpu_baseline, stock_rocm)")
     ap.add_argument("--cpu-baseline-iters", type=int, default=3,
                     help="timed CPU iterations at batch 16 after the batch-2 warm-up (default 3 = BASELINE.md §4's protocol, ~80 s each on a "
-                         "16-thread box share; the stock-ops GPU comparator pays for it with ONE timed iteration after its MIOpen warm-up)")
+                         "16-thread box share; the stock-ops GPU comparator runs 3 timed iterations after its MIOpen warm-up)")
     ap.add_argument("--no-structured", action="store_true", help="skip the structured-labels sub-record")
+    ap.add_argument("--no-phase1", action="store_true", help="skip the `phase1` sub-record (BASELINE config 2, 10 timed steps; N = 1 only)")
     ap.add_argument("--config", choices=("p2", "p1"), default="p2",
                     help="p2 (default): BASELINE config 3, the metric; p1: BASELINE config 2 (VOC 15-5 step 1 phase 1, batch 16) through the same "
                          "Trainer.step, with its own roofline sub-record (no CPU / stock legs)")
@@ -69,8 +70,14 @@ def _free_port():
 
 def launch_workers(a, argv):
     """Parent of an N-rank run. It never imports torch.cuda state or touches a GPU: it only starts N fresh interpreters
-    (never re-execs itself) with the torch.distributed environment, forwards rank 0's stdout, and reaps the others."""
+    (never re-execs itself) with the torch.distributed environment, forwards rank 0's stdout, and reaps the others.
+    A deadline (CL4_BENCH_DEADLINE_S, default 540 s) bounds the whole run: ranks stuck in a mismatched collective are terminated, the
+    ranks that were still alive are named on stderr and the exit status is non-zero (124) — the driver sees a diagnosis, not its own
+    timeout. HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, what RCCL needs on this host driver) is what
+    cl4wsis_amd.parallel.init_distributed sets for every multi-rank process, run.py's included; it is passed here as well so that a
+    rank has it before its interpreter imports anything."""
     port = _free_port()
+    deadline = time.time() + float(os.environ.get("CL4_BENCH_DEADLINE_S", "540"))
     procs = []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
@@ -91,6 +98,17 @@ def launch_workers(a, argv):
                     print(f"bench.py: rank {r} exited with status {code}", file=sys.stderr)
                     for q in pending:                       # a dead rank leaves the others stuck in a collective
                         procs[q].terminate()
+            if pending and time.time() > deadline:
+                print(f"bench.py: deadline of {os.environ.get('CL4_BENCH_DEADLINE_S', '540')} s (CL4_BENCH_DEADLINE_S) passed with ranks "
+                      f"{sorted(pending)} of {a.gpus} still running (finished: {sorted(set(range(a.gpus)) - pending)}): terminating them",
+                      file=sys.stderr, flush=True)
+                for q in pending:
+                    procs[q].terminate()
+                t_kill = time.time() + 10
+                while time.time() < t_kill and any(procs[q].poll() is None for q in pending):
+                    time.sleep(0.2)
+                rc = rc or 124
+                break
             time.sleep(0.2)
     finally:
         for p in procs:
@@ -202,7 +220,7 @@ def cpu_baseline(opts, iters):
                       f"{iters} timed iterations after a batch-2 warm-up, torch threads = {cores}"}
 
 
-def stock_rocm(opts, device, iters=1, rank=0, world=1):
+def stock_rocm(opts, device, iters=3, rank=0, world=1):
     """BASELINE.md §4 second comparator: the same restatement with stock PyTorch-ROCm ops (MIOpen convolutions, ATen
     elementwise kernels) on this GPU, batch 16 — like the reference on a GPU it keeps the label stage on the host
     (OpenCV/numpy loops behind .cpu() copies, modules/utils.py:179-385) — under the reference's own autocast (train.py:252).
@@ -245,13 +263,15 @@ def stock_rocm(opts, device, iters=1, rank=0, world=1):
                 times.append(dt)
         del out, state
         torch.cuda.empty_cache()
-        res[name] = {"value": GLOBAL_BATCH / min(times), "ms_per_step": 1e3 * min(times), "seconds_per_iteration": [round(t, 2) for t in times]}
+        med = sorted(times)[len(times) // 2]
+        res[name] = {"value": GLOBAL_BATCH / med, "ms_per_step": 1e3 * med, "best_ms_per_step": 1e3 * min(times),
+                     "seconds_per_iteration": [round(t, 2) for t in times]}
     if world > 1:
         res["parallelism"] = f"dp{world}: per-rank step + torch.distributed all-reduce (SUM / N) of the 61 trainable gradient tensors before Adam"
     res["note"] = ("oracle p2_step on cuda: stock torch ops (MIOpen convolutions), the label stage as the reference runs it on a GPU "
                    "(per-contour torch ops on the device, masks / centroids via .cpu(), modules/utils.py:257-385), under the reference's "
-                   f"own amp.autocast(float16) (train.py:252); 1 warm-up + {iters} timed iterations, best of them (MIOpen's kernel search "
-                   "leaks into the first timed one); r02b measured fp32 at 9.3 s per iteration (CL4_BENCH_STOCK_FP32=1 adds that mode)")
+                   f"own amp.autocast(float16) (train.py:252); 1 warm-up (MIOpen's kernel search) + {iters} timed iterations, value = batch / their "
+                   "median; r02b measured fp32 at 9.3 s per iteration (CL4_BENCH_STOCK_FP32=1 adds that mode)")
     res["value"] = max(v["value"] for k, v in res.items() if isinstance(v, dict))
     return res
 
@@ -265,6 +285,8 @@ def rehearse(a):
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     seen = torch.ones(1)
+    if os.environ.get("CL4_BENCH_REHEARSE_HANG_RANK") == str(rank):       # test hook: a rank that never reaches the collective
+        time.sleep(3600)
     if world > 1:
         dist.all_reduce(seen)
         dist.barrier()
@@ -286,24 +308,16 @@ def p1_opts(batch):
 ALGO_GFLOP_PER_IMAGE_P1 = 684.0   # old fwd + new fwd / bwd + PseudoLabeler on 3b (FLAC) fwd / bwd + eval pass
 
 
-def worker_p1(a):
-    """--config p1: the phase-1 step (BASELINE config 2) at global batch 16, epoch >= pseudo_ep (PAMR, l_seg, l_cls, RandDrop active).
-    Same timing contract as the metric run; HIP-graph replayed on one GPU (three graphs, one per FLAC angle)."""
+def run_p1(a, device, rank, world, b, steps, warmup):
+    """The phase-1 step (BASELINE config 2) at global batch 16, epoch >= pseudo_ep (PAMR, l_seg, l_cls, RandDrop active): `steps` timed
+    `Trainer.step` calls under the metric run's timing contract; HIP-graph replayed on one GPU (three graphs, one per FLAC angle).
+    Returns the record (rank 0) or None."""
+    import numpy as np
     import torch
     import torch.distributed as dist
-    from cl4wsis_amd import ops
-    from cl4wsis_amd.parallel import init_distributed
+    from cl4wsis_amd import body_train, ops
     from cl4wsis_amd.synthetic import synthetic_batch
     from cl4wsis_amd.train import Trainer
-    rank, world, local = init_distributed()
-    if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
-    local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    b = int(os.environ.get("CL4_BENCH_PER_GPU_BATCH", GLOBAL_BATCH // world))
     opts = p1_opts(GLOBAL_BATCH)
     opts.batch_size = b
     opts.max_iters, opts.start_decay = 40 * 661, 5 * 661
@@ -317,16 +331,15 @@ def worker_p1(a):
     trainer._cur_epoch = opts.pseudo_ep                     # the full loss stack (train.py:370-416)
     images, l1h = synthetic_batch(b, 42 + rank, device, CROP)
     batch = (images, l1h)
-    import numpy as np
     np.random.seed(7)
-    for _ in range(max(a.warmup, 3) + 6):                   # eager + tuner, then every FLAC angle's graph gets captured before the timed region
+    for _ in range(max(warmup, 3) + 6):                     # eager + tuner, then every FLAC angle's graph gets captured before the timed region
         trainer.step(batch)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         out = trainer.step(batch)
     torch.cuda.synchronize()
     if world > 1:
@@ -345,32 +358,58 @@ def worker_p1(a):
     torch.cuda.synchronize()
     timer_p1 = ops.TIMER
     summ, ops.TIMER = ops.TIMER.summary(), None
-    if rank == 0 and os.environ.get("CL4_BENCH_LAYER_TABLE"):
+    if rank == 0 and os.environ.get("CL4_BENCH_LAYER_TABLE_P1"):
         rows = sorted(timer_p1.by_shape().items(), key=lambda kv: -kv[1][2])
         tot = sum(v[2] for _, v in rows)
-        with open(os.environ["CL4_BENCH_LAYER_TABLE"], "w") as f:
+        with open(os.environ["CL4_BENCH_LAYER_TABLE_P1"], "w") as f:
             f.write("kind (n,cin,hin,cout,k,stride,dil) launches/step ms/step TFLOP/s share\n")
             for (kind, shp), (n_, fl_, ms_) in rows:
                 f.write(f"{kind:16s} {str(shp):36s} {n_:5d} {ms_:8.3f} {fl_ / ms_ / 1e9:8.1f} {100 * ms_ / tot:5.1f}%\n")
+    res = None
     if rank == 0:
         peaks = {"conv_fwd_bf16x6": PEAK_BF16_MFMA_TFLOPS / 6.0, "conv_fwd_bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "conv_fwd_f32": PEAK_FP32_MFMA_TFLOPS,
-                 "conv_wgrad": PEAK_BF16_MFMA_TFLOPS / 3.0 if ops.WGRAD_PRECISION == 1 else PEAK_FP32_MFMA_TFLOPS}
+                 "conv_wgrad": PEAK_BF16_MFMA_TFLOPS / 3.0 if body_train.WGRAD_PRECISION == 1 else PEAK_FP32_MFMA_TFLOPS}
         kinds = {k: {"achieved": fl / (ms * 1e-3) / 1e12, "peak": peaks.get(k), "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peaks[k] if k in peaks else None,
                      "ms_per_step": ms, "launches_per_step": n} for k, (n, fl, ms) in summ.items()}
         dom = max(kinds, key=lambda k: kinds[k]["ms_per_step"])
-        res = {"metric": "images/sec at batch 16, VOC 15-5 step-1 phase-1 (BASELINE config 2), 1/2/4/8 MI355X", "value": GLOBAL_BATCH * a.steps / dt,
-               "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+        arith = {0: "exact fp32 MFMA", 1: "bf16x3 (three bf16 products per MAC, fp32 accumulation)", 2: "bf16x6 (fp32-level)"}[body_train.PRECISION]
+        res = {"metric": "images/sec at batch 16, VOC 15-5 step-1 phase-1 (BASELINE config 2), 1/2/4/8 MI355X", "value": GLOBAL_BATCH * steps / dt,
+               "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "VOC 15-5 step 1 phase 1 (BASELINE config 2), Trainer.step, global batch 16, 513x513, ResNet101 + DeepLabV3 + "
                                       "PseudoLabeler + PeakGenerator trained with SGD-Nesterov, epoch >= pseudo_ep (PAMR, l_seg, l_cls, RandDrop on), "
                                       "random-init weights", "global_batch": GLOBAL_BATCH, "per_gpu_batch": b, "crop": CROP, "parallelism": f"dp{world}",
-                          "arithmetic": "fp32 tensors; differentiated convolutions bf16x6 (fp32-level), weight gradients bf16x3, frozen old model bf16x3",
+                          "arithmetic": f"fp32 tensors; differentiated convolutions {arith}, weight gradients "
+                                        f"{'bf16x3' if body_train.WGRAD_PRECISION == 1 else 'fp32 MFMA'}, frozen old model bf16x3",
                           "hip_graphs": graphs},
                "roofline": dict(kinds[dom], bound="mfma", kernel=dom + ": every launch of one eager step after the timed region, HIP events on the launch stream",
                                 traffic=None),
                "kinds": kinds,
-               "algorithmic_tflops_whole_step": ALGO_GFLOP_PER_IMAGE_P1 * GLOBAL_BATCH * a.steps / dt / 1e3,
+               "algorithmic_tflops_whole_step": ALGO_GFLOP_PER_IMAGE_P1 * GLOBAL_BATCH * steps / dt / 1e3,
                "final_losses": {k: float(v) for k, v in out["losses"].items()}}
+    del trainer, out
+    from cl4wsis_amd.nn import CACHE
+    CACHE.clear()
+    torch.cuda.empty_cache()
+    return res
+
+
+def worker_p1(a):
+    """--config p1: BASELINE config 2 through the same Trainer.step (run_p1), as its own JSON line."""
+    import torch
+    import torch.distributed as dist
+    from cl4wsis_amd.parallel import init_distributed
+    rank, world, local = init_distributed()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    b = int(os.environ.get("CL4_BENCH_PER_GPU_BATCH", GLOBAL_BATCH // world))
+    res = run_p1(a, device, rank, world, b, a.steps, a.warmup)
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
@@ -609,12 +648,25 @@ def worker(a):
                              "launches_per_step": kn / 2}
     # Comparator legs, outside the timed region. stock_rocm is a COLLECTIVE leg at N > 1 (every rank takes part: stock PyTorch-ROCm
     # ops + gradient all-reduce = the DDP comparator BASELINE.md section 4 names); cpu_baseline runs on rank 0 at N = 1 only.
-    stock = None
+    stock, phase1 = None, None
+    del trainer, out
+    from cl4wsis_amd.nn import CACHE
+    CACHE.clear()
+    torch.cuda.empty_cache()
+    if world == 1 and not a.no_phase1 and b == GLOBAL_BATCH:
+        # BASELINE config 2 in the driver's record: the phase-1 step through the same Trainer.step, 10 timed graph
+        # replays after its own warm-up (tuner + one capture per FLAC angle), before the host-side legs
+        _progress("phase1 sub-record: warm-up + 10 timed steps")
+        phase1 = run_p1(a, device, rank, world, b, 10, 3)
+        if phase1 is not None:
+            for k in ("metric", "n_gpus", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "final_losses"):
+                phase1.pop(k, None)
+            _progress(f"phase1 sub-record: {phase1['ms_per_step']:.2f} ms/step")
     if not a.no_cpu_baseline:
-        del trainer, out
-        torch.cuda.empty_cache()
         stock = stock_rocm(opts, device, rank=rank, world=world)
     if rank == 0:
+        if phase1 is not None:
+            res["phase1"] = phase1
         if stock is not None:
             # BASELINE.md publishes no number for this metric; its §4 names stock PyTorch-ROCm as the comparator to beat (>= 4x),
             # measured here on the same GPUs, same global batch, same synthetic inputs.

@@ -18,6 +18,12 @@ def init_distributed(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     solo = os.environ.get("CL4_FORCE_COLLECTIVES") == "1"     # world-size-1 rehearsal of the N > 1 path (see BucketedAllReduce.solo)
+    if world > 1 or solo:
+        # The host driver of the MI355X pool only supports dmabuf IPC: without this RCCL's peer mappings (and CUDA-tensor sharing between
+        # processes) fail with `hipIpcGetMemHandle: invalid argument`. The HSA runtime reads it when the process makes its first HIP call,
+        # so it is set here, before anything below touches the GPU — run.py and bench.py both come through this function and therefore
+        # start RCCL identically; an explicit setting of the caller wins.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if (world > 1 or solo) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
