@@ -137,6 +137,7 @@ _decl("cl4_sign_axpy", _P, _P, _P, _I, _P)
 _decl("cl4_comm_unique_id", _P)
 _decl("cl4_comm_init", _I, _I, _P)
 _decl("cl4_allreduce_bucket", _P, C.c_size_t, _I, _P)
+_decl("cl4_allreduce_f64", _P, C.c_size_t, _P)
 _decl("cl4_comm_destroy")
 _decl("cl4_comm_world")
 _decl("cl4_comm_rank")

@@ -15,7 +15,7 @@ namespace {
 
 typedef struct { char internal[128]; } ncclUniqueId_t;
 typedef void* ncclComm_h;
-enum { NCCL_FLOAT32 = 7, NCCL_SUM = 0, NCCL_AVG = 4 };
+enum { NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_SUM = 0, NCCL_AVG = 4 };
 
 struct Rccl {
   void* lib = nullptr;
@@ -94,6 +94,12 @@ extern "C" int cl4_allreduce_bucket(void* buf, size_t count, int average, void* 
   CL4_REQUIRE(buf && count > 0, "allreduce_bucket: empty bucket");
   return check(g_rccl.AllReduce(buf, buf, count, NCCL_FLOAT32, average ? NCCL_AVG : NCCL_SUM, g_comm, cl4::as_stream(stream)),
                "ncclAllReduce");
+}
+
+extern "C" int cl4_allreduce_f64(void* buf, size_t count, void* stream) {
+  CL4_REQUIRE(g_comm, "allreduce_f64: cl4_comm_init has not been called");
+  CL4_REQUIRE(buf && count > 0, "allreduce_f64: empty vector");
+  return check(g_rccl.AllReduce(buf, buf, count, NCCL_FLOAT64, NCCL_SUM, g_comm, cl4::as_stream(stream)), "ncclAllReduce(f64)");
 }
 
 extern "C" int cl4_comm_destroy(void) {

@@ -39,6 +39,9 @@ struct ConvArgs {
   const void* xs;
   void* ys;
   const void* post_s;
+  // Experiments only (cl4_conv_debug_stagger, tools/probe_b.py): first-round workgroups on odd CUs start this many REFCLK ticks (10 ns)
+  // late, so that neighbouring CUs run their K loops and their epilogues in anti-phase. 0 in every product launch.
+  int dbg_stagger;
 };
 
 // conv_u.hip: the unified-wave bf16x3 kernel (every wave loads, splits and multiplies). One launch of `grid` workgroups of 256

@@ -25,7 +25,7 @@
 namespace {
 
 #ifndef CL4_B_DBG
-#define CL4_B_DBG 0   // experiments only: 1 = no LDS-DMA in the K loop, 4 = no MFMA
+#define CL4_B_DBG 0   // experiments only: 1 = no LDS-DMA in the K loop, 4 = no MFMA, 8 = no K loop at all (prologue + epilogue), 16 = no epilogue traffic
 #endif
 
 constexpr int BNB = 144;
@@ -47,7 +47,9 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, __amdgpu
 // NSTG = LDS stages (K-tiles in flight + 1): 3; 4 where they fit (the 128-row tile with two planes: 136 KB) — a tile is then requested
 // three K-tiles ahead, which is what the K-major GEMM of the weight gradient needs (both its operands miss L2 on every K-tile).
 template <int KS, int BMB, int NW, int PB, bool GEMM = false, int NSTG = 3>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvArgs a) {
+__global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void conv_b_bf16x3(ConvArgs a) {
+  // NSTG == 2 (r05 experiment, <128, 8> only): 70 KB of stages / 74 KB of parked tile -> TWO workgroups per CU, so that one's epilogue
+  // (HBM streaming) can run under the other's K loop (MFMA + L2 -> LDS)
   constexpr int KHW = KS * KS;
   constexpr int R = KG * PB;                               // chunk rows (k-group, plane) of an operand tile: 8 or 12
   constexpr int B_CH = R * 128;                            // [k-group * PB + plane][128 pixel columns]
@@ -65,8 +67,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
   constexpr int NHALF = BMB / 128;                         // 128-row halves of the tile, each finished by TH threads
   constexpr int TH = 64 * NW / NHALF;                      // 256, or 512 (<128, 8>)
   static_assert((BMB == 256 && NW == 8) || (BMB == 128 && (NW == 4 || NW == 8)), "tile");
-  static_assert(NSTG == 3 || NSTG == 4, "stages");
-  __shared__ u32x4 lds[NSTG * STGB];                       // the K-tile stages; reused as the parked [BMB][144] fp32 tile
+  static_assert(NSTG == 2 || NSTG == 3 || NSTG == 4, "stages");
+  constexpr int PARKC = BMB * BNB / 4;                     // chunks of the parked [BMB][144] fp32 tile
+  __shared__ u32x4 lds[NSTG * STGB > PARKC ? NSTG * STGB : PARKC];   // the K-tile stages; reused as the parked tile
   __shared__ float affine[NHALF][2 * BM];                  // scale / shift of the tile's 128-channel halves
 
   const int tid = threadIdx.x;
@@ -118,7 +121,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
     nv = __builtin_amdgcn_readfirstlane(nv);
     vlist = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(vlist >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)vlist);
   }
+#if CL4_B_DBG & 8
+  const int nk = 0;
+#else
   const int nk = (a.cin >> 5) * nv;
+#endif
+  if (a.dbg_stagger != 0) {                                // experiments only (shader cycles): > 0: odd CUs of the first round start late;
+    bool late = false;                                     // < 0: the second workgroup of every CU (first round) starts late
+    if (a.dbg_stagger > 0 && blockIdx.x < 256u) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      late = (hw >> 8) & 1u;
+    } else if (a.dbg_stagger < 0) late = blockIdx.x >= 256u && blockIdx.x < 512u;
+    if (late) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime(), d = (unsigned long long)(a.dbg_stagger > 0 ? a.dbg_stagger : -a.dbg_stagger);
+      while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
+    }
+  }
 
   // folded-ABN scale / shift of the tile's 256 channels -> LDS, before any LDS-DMA is in flight (hipcc counts ITS loads only)
   if (tid < 256 * NHALF) {
@@ -282,8 +301,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
     request_b(k, (unsigned)(k * STGB * 16));
   }
   request_a(NSTG - 1, (unsigned)((NSTG - 1) * STGB * 16));
-  if (wave < NE) wait_vmcnt<(NSTG - 2) * (NPW + 1) + NAP>();
-  else wait_vmcnt<(NSTG - 2) * NPW + NAP>();
+  if constexpr (NSTG == 2) {                               // two stages: tile 1 goes out whole (the loop requests tile t+2 in one piece too)
+    request_b(1, (unsigned)(STGB * 16));
+    if (wave < NE) wait_vmcnt<NPW + 1>();
+    else wait_vmcnt<NPW>();
+  } else {
+    if (wave < NE) wait_vmcnt<(NSTG - 2) * (NPW + 1) + NAP>();
+    else wait_vmcnt<(NSTG - 2) * NPW + NAP>();
+  }
   __builtin_amdgcn_s_barrier();
   bf16x8 a01[PB][NRB], a23[PB][NRB], bfr[5][PB];      // fragments of the first / second half of the wave's row blocks
   read_a(a01, lds, 0);
@@ -302,7 +327,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
     // pixel part of tile t+NSTG-1 is requested (its stage was left by every wave before the previous barrier; its weight part is on its way)
     read_a(a23, cur, NRB);
 #if !(CL4_B_DBG & 1)
-    prep_b(t + NSTG - 1, s_last * 16);
+    if constexpr (NSTG > 2) prep_b(t + NSTG - 1, s_last * 16);
 #endif
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -311,7 +336,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
         for (int i = 0; i < NRB; ++i) mma(acc[i][j], a01, i, bfr[j]);
       }
 #if !(CL4_B_DBG & 1)
-      if (j == 0) {
+      if constexpr (NSTG == 2) {
+        // two stages: nothing to request here (tile t+1 went out during the second half of iteration t-1)
+      } else if (j == 0) {
 #pragma unroll
         for (int q = 0; q < NBP / 2; ++q) piece_b(q);
       } else if (j == 1) {
@@ -326,6 +353,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
     __builtin_amdgcn_s_barrier();
 #if !(CL4_B_DBG & 1)
     prep_a(t + NSTG, s_cur * 16);                          // the weight part of tile t+NSTG goes into the stage every wave has just left
+    if constexpr (NSTG == 2) prep_b(t + 2, s_cur * 16);    // two stages: ... and its pixel part with it
 #endif
     // second half: the remaining row blocks, column block by column block; block j's B registers are refilled from tile t+1 as soon as
     // they are free, and the pieces of the request are spread between the blocks (an LDS-DMA issue costs 60+ cycles of this wave's stream)
@@ -339,6 +367,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
       }
 #if !(CL4_B_DBG & 1)
       if (j < NAP) piece_a(j);
+      if constexpr (NSTG == 2) {
+        if (j < NBP) piece_b(j);
+        if (j == 4) piece_e();
+      }
 #endif
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -360,6 +392,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_b_bf16x3(ConvAr
   SEpilogue<1, NGE, BNB> ep1;
   SEpilogue<2, 1, BNB> ex2;
   SEpilogue<1, 1, BNB> ex1;
+#if CL4_B_DBG & 16
+  {   // no epilogue traffic: one conditional store keeps the accumulators alive
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * NRB; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 1.2345e33f && a.y) a.y[tid] = sum;
+    return;
+  }
+#endif
   const int res_kind = a.post_s ? 2 : (a.post ? 1 : 0);
   if (res_kind == 2) {
     ep2.issue(a, m0h, g0, GST, px.valid, px.pn, px.phw, HWo);
@@ -412,9 +455,17 @@ bool conv_b_eligible(const ConvArgs& a, int ks, int rows) {
 }
 
 // waves: 8 (rows 256 or 128) or 4 (rows 128); planes: 2, or 3 (bf16x6; rows 128 / 8 waves only)
-int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, int planes, unsigned grid, hipStream_t st) {
+static int g_b_stagger = 0;
+}  // namespace cl4
+extern "C" void cl4_conv_debug_stagger(int refclk_ticks) { cl4::g_b_stagger = refclk_ticks; }
+namespace cl4 {
+
+int launch_conv_b(const ConvArgs& a_, int ks, int rows, int waves, int planes, unsigned grid, hipStream_t st) {
+  ConvArgs a = a_;
+  a.dbg_stagger = g_b_stagger;
   const dim3 g(grid), b(64 * waves);
-  static const bool stages4 = [] { const char* e = getenv("CL4_CONV_B_STAGES"); return e && atoi(e) == 4; }();   // experiments: four LDS stages on the 128-row / 8-wave tile
+  static const int stagesN = [] { const char* e = getenv("CL4_CONV_B_STAGES"); return e ? atoi(e) : 3; }();   // experiments: four / two LDS stages on the 128-row / 8-wave tile
+  const bool stages4 = stagesN == 4;
   ++g_b_launches;
   if (planes == 3) {
     if (ks == 1 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 3>), g, b, 0, st, a);
@@ -426,6 +477,7 @@ int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, int planes, un
   else if (ks == 3 && rows == 256 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<3, 256, 8, 2>), g, b, 0, st, a);
   else if (ks == 1 && rows == 128 && waves == 4) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 4, 2>), g, b, 0, st, a);
   else if (ks == 3 && rows == 128 && waves == 4) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 4, 2>), g, b, 0, st, a);
+  else if (ks == 1 && rows == 128 && waves == 8 && stagesN == 2) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 2, false, 2>), g, b, 0, st, a);
   else if (ks == 1 && rows == 128 && waves == 8 && stages4) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 2, false, 4>), g, b, 0, st, a);
   else if (ks == 3 && rows == 128 && waves == 8 && stages4) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 8, 2, false, 4>), g, b, 0, st, a);
   else if (ks == 1 && rows == 128 && waves == 8) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 2>), g, b, 0, st, a);

@@ -864,11 +864,55 @@ def _world(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+class StatExchange:
+    """The cross-rank exchange of InPlaceABNSync's batch statistics (segmentation_module.py:17-19: `group=WORLD`), one packed float64
+    vector per layer and direction ([sum x | sum x^2] forward, [sum dy | sum dy * xhat] backward — a layer's statistics depend on the
+    normalised output of the layer before it, so layers cannot share an exchange). r05: it goes through the library's own RCCL
+    communicator (`cl4_allreduce_f64`, enqueue-only on the compute stream, no torch.distributed call on the data path) whenever
+    GradBuckets has brought that communicator up; otherwise `dist.all_reduce` (gloo rehearsals, CL4_COMM=torch). `hook`, when set, is
+    handed the exchange as a closure instead of running it: a segmented graph capture (train._SegmentedGraph) cuts the graph there and
+    replays the closure between the segments. `count` = exchanges issued so far (Trainer.collectives_per_iteration prints the rate)."""
+
+    def __init__(self):
+        self.count = 0
+        self.hook = None
+
+    @staticmethod
+    def _active(group):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0
+        w = dist.get_world_size(group)
+        return w if (w > 1 or os.environ.get("CL4_FORCE_COLLECTIVES") == "1") else 0
+
+    def direct(self, t, group, world):
+        return (group is None and t.is_cuda and os.environ.get("CL4_COMM", "native") != "torch"
+                and _hip.load().cl4_comm_world() == world)
+
+    def run(self, t, group):
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+        if self.direct(t, group, world):
+            call("cl4_allreduce_f64", ptr(t), t.numel(), stream())
+        elif world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+    def allreduce(self, t, group):
+        if not self._active(group):
+            return t
+        self.count += 1
+        if self.hook is not None:
+            self.hook(lambda: self.run(t, group))
+        else:
+            self.run(t, group)
+        return t
+
+
+STAT_EXCHANGE = StatExchange()
+
+
 def _allreduce_sum(t, group):
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return t
+    return STAT_EXCHANGE.allreduce(t, group)
 
 
 def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=ACT_LEAKY, slope=0.01,

@@ -62,6 +62,57 @@ def _copy_tree(dst, src):
         dst.copy_(src)
 
 
+class _SegmentedGraph:
+    """A captured iteration cut at every point where the ranks exchange data: [graph, exchange, graph, exchange, ..., graph]. Collectives
+    are never captured (RCCL calls stay out of every capture, like the gradient buckets of phase 2; a gloo rehearsal could not be captured
+    at all): `cut(fn)` ends the current segment, remembers `fn` and begins the next segment in the same memory pool; `replay()` launches
+    the segments in order and runs each `fn` eagerly between them, on the replaying stream. Used by phase 1 at N > 1, where every
+    InPlaceABNSync layer exchanges its batch statistics once per direction (ops.STAT_EXCHANGE) — r04 ran that configuration eagerly."""
+
+    def __init__(self, pool):
+        self.pool = pool
+        self.items = []
+        self._g = None
+
+    def _begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._g.capture_begin(pool=self.pool)
+
+    def _end(self):
+        self._g.capture_end()
+        self.items.append(self._g)
+        self._g = None
+
+    def cut(self, fn):
+        self._end()
+        self.items.append(fn)
+        self._begin()
+
+    def capture(self, body):
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._begin()
+            try:
+                out = body(self)
+            finally:
+                self._end()
+        cur.wait_stream(side)
+        return out
+
+    @property
+    def n_graphs(self):
+        return sum(isinstance(it, torch.cuda.CUDAGraph) for it in self.items)
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+
 class Trainer:
     def __init__(self, logger, device, opts):
         self.logger = logger
@@ -120,6 +171,9 @@ class Trainer:
         self._tail_graph = os.environ.get("CL4_TAIL_GRAPH", "0") != "0"
         self._tail_segs, self._tail_keep = {}, []
         self._p1_static = None
+        # phase 1 at N > 1: graph segments cut at the cross-rank exchanges (_SegmentedGraph); CL4_P1_SEG_GRAPH=0 keeps that configuration eager
+        self._p1_seg_graph = os.environ.get("CL4_P1_SEG_GRAPH", "1") != "0"
+        self._p1_exchanges = None
         self._graph, self._static, self._graph_active = None, None, False
         # Software pipelining across iterations (single-GPU graph mode): the frozen old model's forward of batch t+1 is replayed on
         # its own stream while batch t's step runs (it depends on nothing the optimizer touches). CL4_PIPELINE=0 switches it off.
@@ -300,7 +354,7 @@ class Trainer:
         epoch = self._cur_epoch if cur_epoch is None else cur_epoch
         late = epoch >= self.pseudo_epoch
         use_graph = (self._use_graph and flac_angle is None and randrop_neg is None and self._iter >= 2 and ops.TIMER is None
-                     and not self.buckets.distributed
+                     and (not self.buckets.distributed or self._p1_seg_graph)
                      and (self._p1_static is None or tuple(images.shape) == tuple(self._p1_static["images"].shape)))
         if use_graph:
             angle = [90, 180, 270][np.random.randint(3)]          # train.py:316, drawn on the host like the reference does
@@ -343,10 +397,36 @@ class Trainer:
             opt.upload_lr()
             torch.cuda.synchronize()
             stale_trainable()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=S["pool"]):
-                losses = self._p1.run(S["images"], S["l1h"], self.pseudo_epoch if late else 0, angle, None)
-                opt.step(upload=False)
+            if not self.buckets.distributed:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=S["pool"]):
+                    losses = self._p1.run(S["images"], S["l1h"], self.pseudo_epoch if late else 0, angle, None)
+                    opt.step(upload=False)
+            else:
+                # N > 1 (r05): the same iteration as a chain of graph segments cut at every cross-rank exchange — the
+                # packed float64 statistics of each InPlaceABNSync layer and direction (ops.STAT_EXCHANGE -> _SegmentedGraph.cut), then the
+                # bucketed gradient average — with the update kernels in the last segment
+                g = _SegmentedGraph(S["pool"])
+
+                def body(seg):
+                    ops.STAT_EXCHANGE.hook = seg.cut
+                    try:
+                        out = self._p1.run(S["images"], S["l1h"], self.pseudo_epoch if late else 0, angle, None)
+                    finally:
+                        ops.STAT_EXCHANGE.hook = None
+
+                    def grad_average():
+                        for i in range(len(self.buckets.fb.sizes)):
+                            self.buckets.ready(i)
+                        self.buckets.finish()
+                    seg.cut(grad_average)
+                    opt.step(upload=False)
+                    return out
+
+                n0 = ops.STAT_EXCHANGE.count
+                losses = g.capture(body)
+                self._p1_exchanges = {"abn_statistics": ops.STAT_EXCHANGE.count - n0, "gradient_buckets": len(self.buckets.bounds),
+                                      "graph_segments": g.n_graphs}
             if hasattr(opt, "_step"):
                 opt._step -= 1                            # capture only recorded the kernels (as _replay does)
             stale_trainable()
@@ -739,6 +819,11 @@ class Trainer:
     def comm_stats(self):
         """Exposed gradient all-reduce time per step etc. (None unless `self.buckets.timing` was switched on; N > 1 only)."""
         return self.buckets.comm_stats() if self.buckets.distributed else None
+
+    def collectives_per_iteration(self):
+        """What one phase-1 iteration at N > 1 exchanges across ranks (None before its graph exists): packed ABN statistics (one float64
+        vector per layer and direction), gradient buckets, and the graph segments between them."""
+        return self._p1_exchanges
 
     def label_counters(self):
         """Running maxima of the label stage's device-side table counts since construction + the sticky overflow flag

@@ -592,6 +592,10 @@ int cl4_comm_init(int rank, int world, const void* unique_id128);
 int cl4_comm_world(void);
 int cl4_comm_rank(void);
 int cl4_allreduce_bucket(void* buf, size_t count, int average, void* stream);
+/* In-place float64 SUM all-reduce of `count` doubles on the same communicator: the cross-rank batch statistics of
+ * InPlaceABNSync(group=WORLD) (segmentation_module.py:17-19) — one call per layer and direction on the packed vector
+ * [sum x | sum x^2] (forward) / [sum dy | sum dy * xhat] (backward) instead of a torch.distributed call per layer. */
+int cl4_allreduce_f64(void* buf, size_t count, void* stream);
 int cl4_comm_destroy(void);
 
 #ifdef __cplusplus

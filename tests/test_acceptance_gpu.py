@@ -138,9 +138,19 @@ def test_phase2_gradients_well_conditioned(gpu, monkeypatch, frozen_precision):
     assert all(float(e[i]) < 0.05 for i in pool)
 
 
-def test_phase1_gradients_well_conditioned(gpu):
+@pytest.mark.parametrize("train_precision", [2, pytest.param(1, marks=pytest.mark.xfail(
+    strict=True, reason="measured r05: bf16x3 differentiated convolutions put the phase-1 gradients at 2.0e-1 (median) from float64 against the CPU-fp32 "
+                        "oracle's 4.5e-2 — 4.5x, the bar is 1.5x — so bf16x3 is NOT admissible as the phase-1 default (82.6 -> 73.3 ms would be the gain)"))])
+def test_phase1_gradients_well_conditioned(gpu, monkeypatch, train_precision):
+    """train_precision 2: bf16x6 (fp32-level products) in every differentiated convolution; 1: bf16x3 (three products, 16-17 significand
+    bits per operand) — VERDICT r04 item 3b: in this regime fp32 itself sits 4.5e-2 from float64, so the cheaper arithmetic is admissible
+    as the phase-1 default exactly if it stays within the same multiple of the CPU-fp32 oracle's own distance. It does not (see the
+    xfail reason: kept as a strict xfail so that the measurement stays in the suite)."""
+    from cl4wsis_amd import body_train
     from cl4wsis_amd.train import Trainer
     from oracle import step as ostep
+    monkeypatch.setattr(body_train, "PRECISION", train_precision)
+    monkeypatch.setattr(body_train, "WGRAD_PRECISION", 1)
     opts = p1_opts(CROP)
     opts.max_iters, opts.start_decay = 1000, 1000
     torch.manual_seed(0)
@@ -173,7 +183,9 @@ def test_phase1_gradients_well_conditioned(gpu):
             ours = tr._grad_map[id(p)].cpu().double()
             errs.append(((ours - gr64).norm() / gr64.norm()).item())
             cpu.append(((r32["grads"][(id(d32), k)].double() - gr64).norm() / gr64.norm()).item())
-    e, c = _report("phase 1", errs, cpu)
+    e, c = _report(f"phase 1 (train precision {train_precision})", errs, cpu)
+    print(f"WELLCOND phase 1 (train precision {train_precision}) bars: median ratio {float(e.median() / c.median()):.3f} (bar 1.5), "
+          f"worst e - 2c {float((e - 2 * c).max()):.2e} (bar 2e-4)")
     assert len(errs) > 300
     assert (e <= 2 * c + 2e-4).all() and e.median() <= 1.5 * c.median(), (e.median(), e.max(), c.median(), c.max())
 
