@@ -154,6 +154,7 @@ _decl("cl4_p2_loss", C.POINTER(P2LossIO), _P, C.c_size_t, _P)
 _decl("cl4_adam_step", _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P)
 _decl("cl4_adam_step_dev", _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _I, _P)
 _decl("cl4_fill_zero", _P, C.c_size_t, _P)
+_decl("cl4_stamp", _P, _P)
 _decl("cl4_peakgen_vjp", _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_peakgen_train_loss", _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_flac_loss", _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P)

@@ -44,5 +44,19 @@ hipError_t fill_bytes_async(void* p, int value, size_t bytes, hipStream_t st) {
 }
 }  // namespace cl4
 
+namespace {
+// one thread writes the 100 MHz wall clock (s_memrealtime): a time stamp INSIDE a stream / a captured graph
+__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+}  // namespace
+
+// Measurement aid (tools/chain_gantt.py): records the device's constant-rate clock (10 ns ticks) into `slot` when
+// the stream reaches this point. It is a kernel node like any other, so it can sit at the head and the tail of every chain of a
+// captured step and shows which chains really ran side by side — evidence a serialising profiler cannot give.
+extern "C" int cl4_stamp(void* slot, void* stream) {
+  CL4_REQUIRE(slot, "stamp: null pointer");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, cl4::as_stream(stream), (unsigned long long*)slot);
+  return cl4::launch_status();
+}
+
 extern "C" int cl4_abi_version(void) { return 1; }
 extern "C" const char* cl4_last_error(void) { return cl4::g_err; }

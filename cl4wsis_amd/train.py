@@ -602,6 +602,8 @@ class Trainer:
                 stale_trainable()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
+                    if getattr(self, "_stamps", None) is not None:
+                        self._stamps["prefix"] = f"g{q}."
                     if P["deep"]:
                         out = self._deep_step(P, q)
                     else:
@@ -609,6 +611,7 @@ class Trainer:
                                                      old_outputs=P["old"][q], prefetch_old=(P["x"][1 - q], P["old"][1 - q]))
                     if not self.buckets.distributed:
                         opt.step(upload=False)
+                    self._stamp("main.end")
                 if not self.buckets.distributed:
                     opt._step -= 1                        # capture only recorded the kernels
                 P["g"].append(g)
@@ -656,26 +659,61 @@ class Trainer:
             self._distributed_tail(P["out"][p], P.get("pool"))
         return P["out"][p]
 
+    def enable_chain_stamps(self, slots=64):
+        """Measurement aid (tools/chain_gantt.py): from the next capture on, the chains of the pipelined step graphs carry time-stamp
+        kernels (cl4_stamp, 10 ns device clock) at their heads, tails and stage boundaries. Call before the first graph step."""
+        self._stamps = {"buf": torch.zeros(slots, dtype=torch.int64, device=self.device), "names": [], "prefix": ""}
+
+    def _stamp(self, name):
+        S = getattr(self, "_stamps", None)
+        if S is None:
+            return
+        full = S["prefix"] + name
+        if full not in S["names"]:
+            if len(S["names"]) >= S["buf"].numel():
+                return
+            S["names"].append(full)
+        i = S["names"].index(full)
+        ops.call("cl4_stamp", S["buf"][i:i + 1].data_ptr(), ops.stream())
+
+    def chain_stamps(self):
+        """{name: device clock in microseconds} of the most recent replays (host synchronisation)."""
+        S = getattr(self, "_stamps", None)
+        if S is None:
+            return {}
+        torch.cuda.synchronize()
+        v = S["buf"].cpu().tolist()
+        return {n: v[i] * 0.01 for i, n in enumerate(S["names"])}
+
     def _deep_step(self, P, q):
         """Body of the deep-pipelined graph of parity q: the trainable stage of batch X[q] on its handed-over frozen results FZ[q] / OLD[q]
         (main stream), beside the whole frozen stage of X[1 - q] into FZ[1 - q] / OLD[1 - q] (two side streams), joined at the end."""
         main = torch.cuda.current_stream()
         r = 1 - q
         H, W = P["x"][q].shape[2:]
+        if getattr(self, "_stamps", None) is not None:
+            self._stamps["prefix"] = f"g{q}."
+        self._stamp("main.head")
         self._side_stream.wait_stream(main)
         self._side2.wait_stream(main)
         with torch.cuda.stream(self._side_stream):
+            self._stamp("old_model.head")
             o_next, _ = self.model_old(P["x"][r], interpolate=False)
             for k in ("center", "offset"):
                 P["old"][r][k].copy_(o_next[k])
             del o_next
+            self._stamp("old_model.tail")
         with torch.cuda.stream(self._side2):
+            self._stamp("frozen_new.head")
             _copy_tree(P["fz"][r], self._frozen_new(P["x"][r], P["l"][r]))
+            self._stamp("frozen_new.tail")
         self.optimizer.zero_grad()
 
         def join_end():
+            self._stamp("main.trainable_tail")
             main.wait_stream(self._side_stream)
             main.wait_stream(self._side2)
+            self._stamp("main.joined")
 
         return self._trainable_stage(P["fz"][q], P["old"][q], P["l"][q], None, (H, W), split_tail=self.buckets.distributed, join_end=join_end)
 
@@ -734,6 +772,7 @@ class Trainer:
             dropout_keep = ops.dropout_mask_dev((n5, drop[0].out_channels, h5, w5), drop[3].p, self._seed_dev,
                                                 1, self.device)        # the kernel hashes the seed: +1 per step is enough
         pred, tape = self._branch.forward_train(feats, dropout_keep=dropout_keep)
+        self._stamp("main.branch_forward_done")
         torch._foreach_add_(self._bn_counters, 1)
         label_new = l1h[:, oc - 1:].contiguous()
         lab_center, lab_offset = pred["center"], pred["offset"]
@@ -746,6 +785,7 @@ class Trainer:
             pseudo_thresh=opts.pseudo_thresh, refine_thresh=opts.refine_thresh, nms_kernel=opts.kernel, beta=opts.beta,
             run_refine=opts.run_refine)
         ops.label_counters_accumulate_(self._label_acc, bs, H, W)
+        self._stamp("main.labels_done")
         if join_old is not None:
             join_old()                               # the old model's centre / offset maps are consumed from here on
         # train.py:503-522 — blended targets + four weighted losses (+ gradient w.r.t. the low-resolution maps)
@@ -787,14 +827,25 @@ class Trainer:
 
         def fork_old():                          # pipelined replay: the NEXT batch's old-model forward starts here, on the side stream
             x_next, old_next = prefetch_old
+            self._stamp("main.fork")
             self._side_stream.wait_stream(main)
             with torch.cuda.stream(self._side_stream):
+                self._stamp("old_model.head")
                 o_next, _ = self.model_old(x_next, interpolate=False)
                 for k in ("center", "offset"):
                     old_next[k].copy_(o_next[k])
+                self._stamp("old_model.tail")
 
+        if prefetch_old is not None:
+            self._stamp("main.head")
         fz = self._frozen_new(images, l1h, fork=fork_old if prefetch_old is not None else None)
-        join = (lambda: main.wait_stream(self._side_stream))
+        if prefetch_old is not None:
+            self._stamp("main.frozen_new_done")
+
+        def join():
+            self._stamp("main.trainable_tail")
+            main.wait_stream(self._side_stream)
+            self._stamp("main.joined")
         return self._trainable_stage(fz, outputs_old, l1h, dropout_keep, (H, W), split_tail=split_tail,
                                      join_old=join if (self._side_stream is not None and old_outputs is None) else None,
                                      join_end=join if prefetch_old is not None else None)

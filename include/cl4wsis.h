@@ -347,6 +347,9 @@ int cl4_adam_step_dev(float* p, const float* g, float* m, float* v, long n, cons
 int cl4_sgd_step(float* p, const float* g, float* buf, long n, float lr, const float* lr_dev, float momentum,
                  float weight_decay, int nesterov, void* stream);
 int cl4_fill_zero(void* p, size_t bytes, void* stream);
+/* Measurement aid: a one-thread kernel that writes the device's 100 MHz wall clock (10 ns ticks, uint64) into *slot when `stream`
+ * reaches it; capturable like any kernel (per-chain time stamps inside the captured step, tools/chain_gantt.py). */
+int cl4_stamp(void* slot, void* stream);
 
 /* ------------------------------------------------------------------------
  * Weakly-supervised loss stack of phase 1 / step 0. Class maps are [b,c,h,w] fp32 at the

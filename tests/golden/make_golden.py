@@ -128,6 +128,52 @@ def model_fixture(R, out_dir=None, fname="model_p2_c65.npz", task="15-5", classe
     print(fname, {k: getattr(v, "shape", None) for k, v in out.items() if k != "grad_names"})
 
 
+WELLCOND_CROP = 193
+
+
+def model_wellcond_fixture(R, out_dir=None, fname="model_p2_c193_grads.npz"):
+    """r05: the reference's train-mode instance branch at crop 193, batch 4 — >= 676 samples per batch-normalised
+    channel at the coarsest level, the configuration tests/test_acceptance_gpu.py calls well-conditioned — under a recorded Dropout mask:
+    gradient norms of every trainable tensor for seeded upstream gradients, and a strided sample of the two predictions. Small on
+    purpose: inputs are regenerated from the seeds, only what the reference computed is stored."""
+    out_dir = _dir(out_dir)
+    classes, model_seed, x_seed = [16, 5], MODEL_SEED + 50, 55
+    opts = ref_opts(R, WELLCOND_CROP)
+    sm = R["segmentation_module"]
+    torch.manual_seed(0)
+    new = sm.make_model(opts, classes=classes)
+    new.load_state_dict(weights.fill_(new.state_dict(), seed=model_seed))
+    g = torch.Generator().manual_seed(x_seed)
+    x = torch.randn(4, 3, WELLCOND_CROP, WELLCOND_CROP, generator=g)
+    new.train()
+    new.body.eval(); new.head.eval(); new.cls.eval()          # train.py:234-240
+    with torch.no_grad():
+        _, f2 = new.forward_seg(x, interpolate=False)
+    feats = {k: v.detach().clone() for k, v in f2["features"].items()}
+    drop = new.decoder.instance_decoder.aspp.project[3]
+    rec = {}
+    h = drop.register_forward_hook(lambda m, i, o: rec.update(inp=i[0].detach(), out=o.detach()))
+    torch.manual_seed(321)
+    _, ins = new.decoder(feats)
+    pred = new.instance_head(ins)
+    h.remove()
+    keep = (rec["out"] != 0) | (rec["inp"] == 0)
+    out = {"dropout_keep": np.packbits(keep.numpy().astype(np.uint8)), "dropout_shape": np.array(keep.shape),
+           "train_center_s4": pred["center"].detach()[:, :, ::4, ::4].numpy().copy(), "train_offset_s4": pred["offset"].detach()[:, :, ::4, ::4].numpy().copy(),
+           "classes": np.array(classes), "model_seed": np.array(model_seed), "x_seed": np.array(x_seed), "crop": np.array(WELLCOND_CROP)}
+    gc = torch.randn(pred["center"].shape, generator=g)
+    go = torch.randn(pred["offset"].shape, generator=g)
+    ((pred["center"] * gc).sum() + (pred["offset"] * go).sum()).backward()
+    names, norms = [], []
+    for k, p in new.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            norms.append(p.grad.double().norm().item())
+    out["grad_names"], out["grad_norms"] = np.array(names), np.array(norms)
+    np.savez_compressed(os.path.join(out_dir, fname), **out)
+    print(fname, {k: getattr(v, "shape", None) for k, v in out.items() if k != "grad_names"})
+
+
 def three_head_fixtures(R, out_dir=None):
     for fname, (task, step, classes, ms, xs, labels) in THREE_HEAD_CASES.items():
         model_fixture(R, out_dir=out_dir, fname=fname, task=task, classes=classes, model_seed=ms, x_seed=xs, labels=labels, full=False)
@@ -472,7 +518,7 @@ if __name__ == "__main__":
     import argparse
     cli = argparse.ArgumentParser()
     cli.add_argument("--out", default=None, help="write the fixtures here instead of tests/golden/")
-    cli.add_argument("--only", default=None, help="comma-separated subset: state,model,three_head,p1,wrn,insmap,dataset,label,edge,wss")
+    cli.add_argument("--only", default=None, help="comma-separated subset: state,model,three_head,wellcond,p1,wrn,insmap,dataset,label,edge,wss")
     a = cli.parse_args()
     if a.out:
         os.makedirs(a.out, exist_ok=True)
@@ -486,6 +532,8 @@ if __name__ == "__main__":
         model_fixture(R)
     if want("three_head"):
         three_head_fixtures(R)
+    if want("wellcond"):
+        model_wellcond_fixture(R)
     if want("p1"):
         model_p1_fixture(R)
     if want("wrn"):

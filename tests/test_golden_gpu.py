@@ -80,10 +80,11 @@ def test_networks_match_reference_golden(gpu, fixture):
     # gradient that a train-mode BatchNorm has just made zero-mean over the batch) x (globally pooled features that are nearly the same for
     # every image) — FINDINGS.md finding 29: the kernels are exact for their inputs to 3e-6, the 1e-6-level element noise upstream is amplified
     # by the cancellation (measured here: 7e-2 on the four-head fixture, 8e-3 / 3e-3 on the others).
-    # (the other tensors: 2e-2 in r01-r03; 3e-2 since the fused res2 blocks of r04 moved one batch-norm weight of the three-head fixture
-    # from 1.7e-2 to 2.1e-2 — features that differ in their last bits, see the comment on batch-statistics BN above)
-    rtol = np.where(np.array([str(n).endswith("aspp_pooling.1.weight") for n in gold["grad_names"]]), 0.15, 3e-2)
-    assert (dev <= rtol).all(), [(str(gold["grad_names"][i]), float(dev[i])) for i in np.flatnonzero(dev > rtol)]
+    # r05: at 2 x 5 x 5 samples per batch-normalised channel single tensors move by per cent with the last bits of the
+    # features (1.7e-2 -> 2.1e-2 on one BN weight when the res2 kernels changed), so this configuration carries the MEDIAN bar and a sanity
+    # ceiling only; the per-tensor 2e-2 bar against the reference's own gradients lives on the well-conditioned fixture (crop 193, batch 4):
+    # test_gradient_norms_match_reference_well_conditioned below.
+    assert (dev <= 0.15).all(), [(str(gold["grad_names"][i]), float(dev[i])) for i in np.flatnonzero(dev > 0.15)]
     med = float(np.median(np.abs(norms / gold["grad_norms"] - 1)))
     print("GRADNORM median", med, "max", float(np.abs(norms / gold["grad_norms"] - 1).max()))
     assert med < 2e-3, med
@@ -92,6 +93,38 @@ def test_networks_match_reference_golden(gpu, fixture):
     assert rel_err(im.cpu(), torch.from_numpy(gold["int_masks"])) < NET_TOL
     cam = pg.cam(im, l1h[:, oc1:].contiguous())
     assert rel_err(cam.cpu(), torch.from_numpy(gold["cam_lo"][:, oc1:])) < NET_TOL
+
+
+def test_gradient_norms_match_reference_well_conditioned(gpu):
+    """The per-tensor gradient bar against the REFERENCE'S OWN gradients (tests/golden/model_p2_c193_grads.npz, made by
+    tests/golden/make_golden.py --only wellcond from /root/reference): train-mode instance branch at crop 193, batch 4 (>= 676 samples per
+    batch-normalised channel), recorded Dropout mask, seeded upstream gradients: every one of the 61 gradient norms within 2e-2 (the r01-r03
+    bar), median within 2e-3, predictions within the network tolerance — in the default arithmetic (bf16x3 frozen
+    networks feeding a bf16x6 trainable branch)."""
+    gold = np.load(os.path.join(GOLD, "model_p2_c193_grads.npz"))
+    crop = int(gold["crop"])
+    opts, (new, _, _, _) = _build(gpu, crop=crop, classes=tuple(int(c) for c in gold["classes"]), seed=int(gold["model_seed"]))
+    g = torch.Generator().manual_seed(int(gold["x_seed"]))
+    x = torch.randn(4, 3, crop, crop, generator=g).to(gpu)
+    new.train(); new.body.eval(); new.head.eval(); new.cls.eval()
+    _, f2 = new.forward_seg(x, interpolate=False)
+    shape = tuple(gold["dropout_shape"])
+    keep = torch.from_numpy(np.unpackbits(gold["dropout_keep"])[:int(np.prod(shape))].reshape(shape)).to(gpu)
+    br = new.instance_branch()
+    pred, tape = br.forward_train(dict(f2["features"]), dropout_keep=keep)
+    assert rel_err(pred["center"][:, :, ::4, ::4].cpu(), torch.from_numpy(gold["train_center_s4"])) < NET_TOL
+    assert rel_err(pred["offset"][:, :, ::4, ::4].cpu(), torch.from_numpy(gold["train_offset_s4"])) < NET_TOL
+    gc = torch.randn(pred["center"].shape, generator=g).to(gpu)
+    go = torch.randn(pred["offset"].shape, generator=g).to(gpu)
+    grads = br.backward(tape, {"center": gc, "offset": go})
+    params = dict(new.named_parameters())
+    norms = np.array([grads[id(params[str(n)])].double().norm().item() for n in gold["grad_names"]])
+    dev = np.abs(norms / gold["grad_norms"] - 1)
+    for i in np.argsort(-dev)[:4]:
+        print(f"GRADNORM193 worst {str(gold['grad_names'][i]):60s} ours {norms[i]:.6e} reference {gold['grad_norms'][i]:.6e} dev {dev[i]:.2e}")
+    print("GRADNORM193 median", float(np.median(dev)), "max", float(dev.max()))
+    assert len(dev) == 61 and (dev <= 2e-2).all(), [(str(gold["grad_names"][i]), float(dev[i])) for i in np.flatnonzero(dev > 2e-2)]
+    assert float(np.median(dev)) < 2e-3
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "label_*.npz"))))
@@ -325,6 +358,7 @@ def test_pipelined_replay_matches_plain_graph_replay(gpu, monkeypatch):
     pseudo ground truth) on a second one. Two alternating batches, eight steps (one of them without an announcement in mid-sequence): the losses of every step and the final weights equal those
     of the unpipelined graph path (same kernels; only the fp32 atomics of the split-K weight gradients may reorder)."""
     import copy
+    from cl4wsis_amd.nn import CACHE
     from cl4wsis_amd.train import Trainer
     from util import p2_opts
     opts = p2_opts(65)
@@ -349,32 +383,46 @@ def test_pipelined_replay_matches_plain_graph_replay(gpu, monkeypatch):
         torch.manual_seed(0)
         tr = Trainer(_L(), gpu, copy.deepcopy(opts))
         assert tr._pipeline == (mode != "plain") and tr._deep_pipe == (mode == "deep")
-        losses = []
+        # r05: every step starts from the SAME trainable state — weights, Adam moments and step count, decoder
+        # BatchNorm statistics are put back after each step — so a step's losses and gradients depend on nothing but its batch and the frozen
+        # results handed to it, which is what this test guards. (r04 chained eight steps and had to bound the chaotic growth of the
+        # reordered fp32 atomics through the discrete label stage: 5e-2 from step 4 on.)
+        opt = tr.optimizer
+        snap = ([t.clone() for t in (opt.params_fb.flat, opt.m_fb.flat, opt.v_fb.flat, opt.step_dev)],
+                {k: v.detach().clone() for k, v in tr.model.state_dict().items() if "running_" in k or "num_batches" in k})
+
+        def restore():
+            for dst, src in zip((opt.params_fb.flat, opt.m_fb.flat, opt.v_fb.flat, opt.step_dev), snap[0]):
+                dst.copy_(src)
+            sd = tr.model.state_dict()
+            for k, v in snap[1].items():
+                sd[k].copy_(v)
+            for grp in opt.param_groups:
+                for prm in grp["params"]:
+                    CACHE.touch(prm)
+
+        losses, gnorm = [], []
         for t in range(8):
             # step 2 announces nothing (the end of an epoch) and step 3 brings a DIFFERENT batch than the one last seen: the frozen
             # results prefetched by step 2 must not be taken for it
             b, nb = batches[t % 2], batches[(t + 1) % 2]
             out = tr.step(b, next_batch=None if t in (2, 7) else nb)
             losses.append(out["losses"].clone())
+            gnorm.append(opt.grads_fb.flat.clone())
+            restore()
         torch.cuda.synchronize()
         assert (tr._pipe is not None) == (mode != "plain") and (tr._graph is not None) == (mode == "plain")
         assert mode == "plain" or tr._pipe["deep"] == (mode == "deep")
-        results[mode] = (torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()})
-    l0, w0 = results["plain"]
-    lr = opts.lr * opts.lr_head
+        results[mode] = (torch.stack(losses).cpu(), torch.stack(gnorm).cpu())
+    l0, g0 = results["plain"]
     for mode in ("shallow", "deep"):
-        l1, w1 = results[mode]
+        l1, g1 = results[mode]
         assert torch.isfinite(l1).all()
         dev = ((l0 - l1).abs() / l0.abs().clamp_min(1e-6)).max(1).values      # per step
-        # the reordered fp32 atomics of the weight gradients grow through the discrete label stage step by step, differently from run to run
-        # (measured on two boxes: 0, 0, 1e-7, 4e-7, 2e-5, 8e-4, 2e-3, 4e-3 and 0, 1e-7, 2e-7, 2e-4, 5e-4, 3e-3, 8e-3, 1e-2); a wrong frozen
+        gdev = (g0 - g1).norm(dim=1) / g0.norm(dim=1)                          # per step: the whole flat gradient buffer
+        print(f"PIPEREPLAY {mode}: per-step loss deviation {[f'{float(d):.1e}' for d in dev]}, gradient deviation {[f'{float(d):.1e}' for d in gdev]}")
+        # same kernels on the same operands: only the fp32 atomics of the split-K weight gradients may reorder within ONE step; a wrong frozen
         # result at step 3 (the step after the unannounced one) would show there as a deviation of order one
-        assert (dev[:3] < 1e-5).all() and dev[3] < 5e-3 and (dev[4:] < 5e-2).all(), (mode, dev, l0, l1)
-        for k in w0:
-            if not w0[k].is_floating_point():
-                continue
-            if "running_" in k:                                # batch statistics of activations whose weights moved apart by up to +-lr per step
-                assert (w0[k] - w1[k]).abs().max() <= 5e-2 * w0[k].abs().max(), (mode, k)
-            else:                                              # Adam: up to +-lr per step where a gradient is numerically zero
-                assert (w0[k] - w1[k]).abs().max() <= 3.2 * lr * 8 + 1e-6 * w0[k].abs().max(), (mode, k)
+        assert (dev < 1e-4).all() and (gdev < 1e-3).all(), (mode, dev, gdev)
+
 

@@ -76,6 +76,33 @@ def test_model_restatement_matches_reference(fixture):
     assert rel_err(cam, torch.from_numpy(gold["cam_lo"])) < 1e-5
 
 
+def test_model_restatement_matches_reference_well_conditioned():
+    """The crop-193 / batch-4 gradient fixture of the reference (make_golden.py --only wellcond): the oracle reproduces the sampled
+    predictions to 1e-5 and every gradient norm to 2e-3 — the fixture the GPU's per-tensor 2e-2 bar is asserted on."""
+    from oracle import model as M
+    gold = np.load(os.path.join(GOLD, "model_p2_c193_grads.npz"))
+    crop = int(gold["crop"])
+    opts, (new, _, _, _) = _state_dicts(tuple(int(c) for c in gold["classes"]), int(gold["model_seed"]))
+    g = torch.Generator().manual_seed(int(gold["x_seed"]))
+    x = torch.randn(4, 3, crop, crop, generator=g)
+    with torch.no_grad():
+        _, aux = M.forward_seg(x, new, pooling=opts.pooling)
+    shape = tuple(gold["dropout_shape"])
+    keep = torch.from_numpy(np.unpackbits(gold["dropout_keep"])[:int(np.prod(shape))].reshape(shape)).float()
+    names = [str(n) for n in gold["grad_names"]]
+    for k in names:
+        new[k].requires_grad_(True)
+    feats = {k: v.detach() for k, v in aux["features"].items()}
+    pred = M.instance_head(M.instance_decoder(feats, new, training=True, dropout_mask=keep), new, training=True)
+    assert rel_err(pred["center"].detach()[:, :, ::4, ::4], torch.from_numpy(gold["train_center_s4"])) < 1e-5
+    assert rel_err(pred["offset"].detach()[:, :, ::4, ::4], torch.from_numpy(gold["train_offset_s4"])) < 1e-5
+    gc = torch.randn(pred["center"].shape, generator=g)
+    go = torch.randn(pred["offset"].shape, generator=g)
+    ((pred["center"] * gc).sum() + (pred["offset"] * go).sum()).backward()
+    norms = np.array([new[k].grad.double().norm().item() for k in names])
+    np.testing.assert_allclose(norms, gold["grad_norms"], rtol=2e-3)
+
+
 def _wrn_opts(crop=65):
     from cl4wsis_amd import argparser
     args = ["--dataset", "coco-voc", "--task", "voc", "--step", "1", "--weakly", "--phase", "2", "--alpha", "0.9", "--loss_de", "1",
