@@ -368,11 +368,13 @@ def run_p1(a, device, rank, world, b, steps, warmup):
     res = None
     if rank == 0:
         peaks = {"conv_fwd_bf16x6": PEAK_BF16_MFMA_TFLOPS / 6.0, "conv_fwd_bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "conv_fwd_f32": PEAK_FP32_MFMA_TFLOPS,
+                 "conv_fwd_f16x3": PEAK_BF16_MFMA_TFLOPS / 3.0,      # fp16 MFMA = the bf16 rate (tools/f16x3_probe.hip), three products per MAC
                  "conv_wgrad": PEAK_BF16_MFMA_TFLOPS / 3.0 if body_train.WGRAD_PRECISION == 1 else PEAK_FP32_MFMA_TFLOPS}
         kinds = {k: {"achieved": fl / (ms * 1e-3) / 1e12, "peak": peaks.get(k), "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peaks[k] if k in peaks else None,
                      "ms_per_step": ms, "launches_per_step": n} for k, (n, fl, ms) in summ.items()}
         dom = max(kinds, key=lambda k: kinds[k]["ms_per_step"])
-        arith = {0: "exact fp32 MFMA", 1: "bf16x3 (three bf16 products per MAC, fp32 accumulation)", 2: "bf16x6 (fp32-level)"}[body_train.PRECISION]
+        arith = {0: "exact fp32 MFMA", 1: "bf16x3 (three bf16 products per MAC, fp32 accumulation)", 2: "bf16x6 (fp32-level)",
+                 3: "fp16x3 (three fp16 products per MAC on split-fp16 operands with power-of-two scales: fp32-level, like bf16x6; bf16x6 where the shape is not routed)"}[body_train.PRECISION]
         res = {"metric": "images/sec at batch 16, VOC 15-5 step-1 phase-1 (BASELINE config 2), 1/2/4/8 MI355X", "value": GLOBAL_BATCH * steps / dt,
                "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -639,7 +641,7 @@ def worker(a):
         if trainer.buckets.distributed:
             res["allreduce"] = trainer.comm_stats()
         wgrad_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if ops.WGRAD_PRECISION == 1 else PEAK_FP32_MFMA_TFLOPS
-        for kind, pk in (("conv_fwd_bf16x6", PEAK_BF16_MFMA_TFLOPS / 6.0), ("conv_fwd_f32", PEAK_FP32_MFMA_TFLOPS),
+        for kind, pk in (("conv_fwd_bf16x6", PEAK_BF16_MFMA_TFLOPS / 6.0), ("conv_fwd_f16x3", PEAK_BF16_MFMA_TFLOPS / 3.0), ("conv_fwd_f32", PEAK_FP32_MFMA_TFLOPS),
                          ("conv_wgrad", wgrad_peak)):
             if kind in summ:
                 kn, kf, kms = summ[kind]

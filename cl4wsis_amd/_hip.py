@@ -138,6 +138,9 @@ _decl("cl4_comm_unique_id", _P)
 _decl("cl4_comm_init", _I, _I, _P)
 _decl("cl4_allreduce_bucket", _P, C.c_size_t, _I, _P)
 _decl("cl4_allreduce_f64", _P, C.c_size_t, _P)
+_decl("cl4_pack_conv_weight_f16x3", _P, _P, _I, _I, _I, _I, _P)
+_decl("cl4_to_planes_f16", _P, _P, _I, _I, _I, _I, _I, _I, _P, _P)
+_decl("cl4_conv2d_fwd_planes_f16", _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_comm_destroy")
 _decl("cl4_comm_world")
 _decl("cl4_comm_rank")
@@ -226,6 +229,8 @@ def load():
         getattr(lib, nm).argtypes = []
     lib.cl4_stem_weight_bytes.restype = C.c_size_t
     lib.cl4_stem_weight_bytes.argtypes = []
+    lib.cl4_to_planes_f16_slot_floats.restype = C.c_size_t
+    lib.cl4_to_planes_f16_slot_floats.argtypes = []
     lib.cl4_kpack_bytes.restype = C.c_size_t
     lib.cl4_kpack_bytes.argtypes = [C.c_int, C.c_int]
     lib.cl4_dwconv5_stats_parts.restype = C.c_int

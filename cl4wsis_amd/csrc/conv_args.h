@@ -39,6 +39,10 @@ struct ConvArgs {
   const void* xs;
   void* ys;
   const void* post_s;
+  // fp16x3 launches (r05, precision code 5): the planes operand holds fp16 hi / lo of x * s and the packed weights fp16 hi / lo of
+  // w * 2^12; *xs_scale = s (a power of two written by cl4_to_planes_f16), and the accumulators are multiplied by 1 / (2^12 * s)
+  // before the epilogue. Null for every bf16 launch.
+  const float* xs_scale;
   // Experiments only (cl4_conv_debug_stagger, tools/probe_b.py): first-round workgroups on odd CUs start this many REFCLK ticks (10 ns)
   // late, so that neighbouring CUs run their K loops and their epilogues in anti-phase. 0 in every product launch.
   int dbg_stagger;
@@ -65,6 +69,7 @@ int launch_conv_p(const ConvArgs& a, unsigned ntile, hipStream_t st);
 // tiles to fill the chip); 144 pixels per tile. Unsplit; `grid` = cdiv(cout, rows) * cdiv(npix, 144) with a.gx = cdiv(cout, rows).
 bool conv_b_eligible(const ConvArgs& a, int ks, int rows);
 // planes = 2, or 3 (bf16x6 operands; rows 128 / 8 waves only).
-int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, int planes, unsigned grid, hipStream_t st);
+// f16: fp16x3 operands (two fp16 planes, a.xs_scale set) instead of bf16x3; 8 waves, two planes only.
+int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, int planes, unsigned grid, hipStream_t st, bool f16 = false);
 
 }  // namespace cl4

@@ -1310,8 +1310,9 @@ struct PlanKey {
 std::map<PlanKey, FwdPlan>& plan_table() { static std::map<PlanKey, FwdPlan> t; return t; }
 std::mutex& plan_mutex() { static std::mutex m; return m; }
 
-// precision codes of the planes-input launches: 3 = two planes (bf16x3), 4 = three planes (bf16x6, 144-pixel tiles only)
-static inline bool planes_code(int precision) { return precision == 3 || precision == 4; }
+// precision codes of the planes-input launches: 3 = two planes (bf16x3), 4 = three planes (bf16x6, 144-pixel tiles only),
+// 5 = two fp16 planes (fp16x3, r05: the LDS-DMA kernel only — plan impl 4 / 6, unsplit, fp32 output)
+static inline bool planes_code(int precision) { return precision >= 3 && precision <= 5; }
 
 FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision = 0) {
   FwdPlan p{1, 128, 1, 0, 0};
@@ -1319,7 +1320,7 @@ FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision
     p.impl = 3; p.tile = 128; p.splits = 1; p.kchunk = cl4::cdiv(K, BK2) * BK2;
     return p;
   }
-  if ((impl >= 4 && impl <= 6 && precision == 3) || (impl == 6 && precision == 4)) {                            // LDS-DMA planes kernel (conv_b.hip): unsplit 256 x 144 (4) or 128 x 144 tiles (5: four waves, 6: eight)
+  if ((impl >= 4 && impl <= 6 && precision == 3) || (impl == 6 && precision == 4) || ((impl == 4 || impl == 6) && precision == 5)) {                            // LDS-DMA planes kernel (conv_b.hip): unsplit 256 x 144 (4) or 128 x 144 tiles (5: four waves, 6: eight)
     p.impl = impl; p.tile = 128; p.bn = 144; p.splits = 1; p.kchunk = cl4::cdiv(K, BK2) * BK2;
     return p;
   }
@@ -1477,7 +1478,17 @@ int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace
     cl4::set_error("conv2d_fwd_planes: 7x7 kernels are not built for planes input");
     return CL4_EINVAL;
   } else {
-    const FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 8 + pcode});
+    FwdPlan pl = plan_fwd(PlanKey{a.cout, a.npix, a.K, KS, a.stride, a.dil, a.hin * 8 + pcode});
+    if (pcode == 5) {
+      // fp16x3: the LDS-DMA kernel, unsplit. Without a pinned plan: 256-row tiles when they fill the chip, else eight waves on 128 rows
+      if (pl.impl != 4 && pl.impl != 6) pl = make_plan((a.cout % 256 == 0 && (a.cout / 256) * cl4::cdiv(a.npix, 144) >= 200) ? 4 : 6, 144, 1, a.cout, a.K, 5);
+      const int rows = pl.impl == 4 ? 256 : 128;
+      if (!cl4::conv_b_eligible(a, KS, rows)) { cl4::set_error("conv2d_fwd_planes_f16: shape not eligible for the LDS-DMA kernel (cin %% 32, cout %% 8, cout >= %d)", rows); return CL4_EINVAL; }
+      a.gx = cl4::cdiv(a.cout, rows);
+      a.ntile_l = a.gx * cl4::cdiv(a.npix, 144);
+      a.tile_base = 0; a.ws = nullptr; a.ws_p0 = 0; a.ws_npix = a.npix; a.kchunk = pl.kchunk;
+      return cl4::launch_conv_b(a, KS, rows, 8, 2, (unsigned)a.ntile_l, st, true);
+    }
     if (pl.impl < 2 || pl.impl > 6 || pl.tile != 128) { cl4::set_error("conv2d_fwd_planes: no 128x128 plan for this shape"); return CL4_EINVAL; }
     if (pl.impl == 3) {
       if (pcode == 3 && cl4::conv_p_eligible(a, KS)) {
@@ -2160,8 +2171,9 @@ extern "C" int cl4_conv2d_fwd_set_plan(const cl4_conv_desc* d, int impl, int til
   const PlanKey key{d->cout, d->n * d->hout * d->wout, K, d->kh, d->stride, d->dil, d->hin * 8 + d->precision};
   std::lock_guard<std::mutex> g(plan_mutex());
   if (impl == 0) { plan_table().erase(key); return CL4_OK; }
-  CL4_REQUIRE(impl == 1 || impl == 2 || (impl >= 3 && impl <= 6 && d->precision == 3) || (impl == 6 && d->precision == 4),
-              "set_plan: impl must be 0, 1 or 2 (3 ... 6: planes-input launches only; three planes: 6 only)");
+  CL4_REQUIRE(((impl == 1 || impl == 2) && d->precision != 5) || (impl >= 3 && impl <= 6 && d->precision == 3) || (impl == 6 && d->precision == 4) ||
+                  ((impl == 4 || impl == 6) && d->precision == 5),
+              "set_plan: impl must be 0, 1 or 2 (3 ... 6: planes-input launches only; three planes: 6 only; fp16x3: 4 or 6)");
   CL4_REQUIRE(tile == 64 || tile == 128 || (tile == 144 && planes_code(d->precision)), "set_plan: tile must be 64 or 128 (144: planes-input launches only)");
   plan_table()[key] = make_plan(impl, tile, splits, d->cout, K, d->precision);
   return CL4_OK;
@@ -2175,8 +2187,10 @@ extern "C" int cl4_conv2d_fwd_clear_plans(void) {
 
 static int conv2d_fwd_common(const cl4_conv_desc* d, const float* x, const void* xs, const float* wp, const float* scale,
                              const float* shift, const float* pre, const float* post, const void* post_s, float* y, void* ys,
-                             void* workspace, size_t workspace_bytes, void* stream) {
+                             void* workspace, size_t workspace_bytes, void* stream, const float* xs_scale = nullptr) {
   ConvArgs a;
+  a.xs_scale = xs_scale;
+  a.dbg_stagger = 0;
   a.x = x; a.wp = wp; a.scale = scale; a.shift = shift; a.pre = pre; a.post = post; a.y = y;
   a.n = d->n; a.cin = d->cin; a.hin = d->hin; a.win = d->win; a.cout = d->cout;
   a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.hout = d->hout; a.wout = d->wout;
@@ -2218,7 +2232,7 @@ extern "C" int cl4_conv2d_fwd_planes(const cl4_conv_desc* d, const void* xs, con
   int rc = check_desc(d);
   if (rc) return rc;
   CL4_REQUIRE(xs && wp && (y || ys), "conv2d_fwd_planes: null tensor");
-  CL4_REQUIRE(d->precision == 3 || d->precision == 4, "conv2d_fwd_planes: the descriptor's precision must be 3 (bf16x3 on a two-plane input) or 4 (bf16x6 on a three-plane input)");
+  CL4_REQUIRE(d->precision == 3 || d->precision == 4, "conv2d_fwd_planes: the descriptor's precision must be 3 (bf16x3 on a two-plane input) or 4 (bf16x6 on a three-plane input); fp16x3: cl4_conv2d_fwd_planes_f16");
   CL4_REQUIRE(d->precision == 3 || (!ys && !post_s), "conv2d_fwd_planes: a three-plane (bf16x6) launch writes fp32 only and takes no planes residual");
   CL4_REQUIRE(d->kh == 1 || d->kh == 3, "conv2d_fwd_planes: 1x1 and 3x3 kernels only");
   CL4_REQUIRE(d->cin % 32 == 0 && d->in_ctot % 8 == 0 && d->in_coff % 8 == 0, "conv2d_fwd_planes: cin %% 32 == 0 and 8-aligned input channel slices");
@@ -2228,6 +2242,22 @@ extern "C" int cl4_conv2d_fwd_planes(const cl4_conv_desc* d, const void* xs, con
   CL4_REQUIRE(!(post && post_s), "conv2d_fwd_planes: one residual operand (post or post_s)");
   CL4_REQUIRE((long)d->n * d->in_ctot * d->hin * d->win * (d->precision == 4 ? 6 : 4) < 0x7FFFFFFFL, "conv2d_fwd_planes: input >= 2 GiB is not addressable by the 32-bit buffer offsets");
   return conv2d_fwd_common(d, nullptr, xs, wp, scale, shift, pre, post, post_s, y, ys, workspace, workspace_bytes, stream);
+}
+
+// fp16x3 (r05): the same convolution group on an fp16 two-plane input (cl4_to_planes_f16: fp16 hi / lo of x * *xs_scale) and
+// cl4_pack_conv_weight_f16x3 weights (fp16 hi / lo of w * 2^12): three MFMA products per MAC at bf16x6's accuracy. fp32 output.
+extern "C" int cl4_conv2d_fwd_planes_f16(const cl4_conv_desc* d, const void* xs, const float* xs_scale, const float* wp, const float* scale,
+                                         const float* shift, const float* pre, const float* post, float* y, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CL4_REQUIRE(xs && xs_scale && wp && y, "conv2d_fwd_planes_f16: null tensor");
+  CL4_REQUIRE(d->precision == 5, "conv2d_fwd_planes_f16: the descriptor's precision must be 5 (fp16x3 on a two-plane fp16 input)");
+  CL4_REQUIRE(d->kh == 1 || d->kh == 3, "conv2d_fwd_planes_f16: 1x1 and 3x3 kernels only");
+  CL4_REQUIRE(d->cin % 32 == 0 && d->in_ctot % 8 == 0 && d->in_coff % 8 == 0, "conv2d_fwd_planes_f16: cin %% 32 == 0 and 8-aligned input channel slices");
+  CL4_REQUIRE(d->cout % 8 == 0 && d->cout >= 128, "conv2d_fwd_planes_f16: cout %% 8 == 0 and cout >= 128");
+  CL4_REQUIRE((long)d->n * d->in_ctot * d->hin * d->win * 4 < 0x7FFFFFFFL, "conv2d_fwd_planes_f16: input >= 2 GiB is not addressable by the 32-bit buffer offsets");
+  return conv2d_fwd_common(d, nullptr, xs, wp, scale, shift, pre, post, nullptr, y, nullptr, workspace, workspace_bytes, stream, xs_scale);
 }
 
 // Experiments only (not part of the drop-in boundary): device buffer of 8 x uint64 per workgroup that the bf16 forward kernels

@@ -509,6 +509,87 @@ __global__ void to_planes3_kernel(const float* __restrict__ x, u32x4* __restrict
   }
 }
 
+// ---- fp16x3 operands (r05, planes_epilogue.h): fp32 NCHW (channel slice) -> two fp16 planes of x * s, same chunk layout as the bf16 planes.
+// s is a power of two: `static_scale` (activations of O(1) networks: 2^4), or — dynamic, for gradients whose magnitude is anything —
+// 2^(14 - e) with max |x| < 2^e. The maximum is a two-stage reduction without atomics or a cell that would have to be cleared (the launch
+// must replay inside a HIP graph unchanged): absmax_kernel leaves one partial maximum per workgroup in slot[4 ..], every workgroup of the
+// conversion kernel folds them itself. The kernel writes s to slot[0]: what the consuming convolution divides by.
+constexpr int ABSMAX_PARTS = 512;
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, float* __restrict__ partial, int n, int ctot, int coff, int c, long hw) {
+  __shared__ float red[4];
+  const long per = (long)c * hw, total = (long)n * per;
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long im = i / per, r = i - im * per;
+    m = fmaxf(m, fabsf(x[(im * ctot + coff) * hw + r]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void to_planes_f16_kernel(const float* __restrict__ x, u32x4* __restrict__ xs, int n, int ctot, int coff, int c, int hw,
+                                                            float static_scale, float* __restrict__ slot, int nparts) {
+  __shared__ float red[4];
+  float s = static_scale;
+  if (nparts > 0) {                                       // dynamic: fold the partial maxima (the same value in every workgroup)
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, slot[4 + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    s = 1.f;
+    if (am > 0.f && am < 3.0e38f) {
+      int e;
+      frexpf(am, &e);                                     // am = f * 2^e, f in [0.5, 1)
+      s = ldexpf(1.f, min(max(14 - e, -100), 100));
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) slot[0] = s;
+  const int c8 = c >> 3;
+  const long total = (long)n * c8 * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % hw);
+    const long r = i / hw;
+    const int g = (int)(r % c8), im = (int)(r / c8);
+    const float* src = x + ((long)im * ctot + coff + g * 8) * hw + px;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(long)j * hw];
+    u32x4 hi, lo;
+    split8_f16(v, s, hi, lo);
+    u32x4* dst = xs + (((long)im * c8 + g) * 2) * hw + px;
+    dst[0] = hi;
+    dst[hw] = lo;
+  }
+}
+
+// fp16x3 flavour of the two-plane pack (r05): fp16 hi / lo of w * 2^12 (saturating at +-65504: |w| < 16), same layout
+__global__ void pack_weight_f16x3_kernel(const float* __restrict__ w, u32x4* __restrict__ wq, int cout, int K, int khw) {
+  const int KGtot = (K + 7) / 8;
+  const long total = (long)KGtot * cout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = i % cout;
+    const int kg = i / cout;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kg * 8 + j;                      // tap-major K order (cin % 32 == 0 is required): k = (cb*khw + tap)*32 + cil
+      const int t32 = k >> 5, cil = k & 31;
+      const int cb = t32 / khw, tap = t32 - cb * khw;
+      v[j] = k < K ? w[(long)m * K + (cb * 32 + cil) * khw + tap] : 0.f;
+    }
+    u32x4 hi, lo;
+    split8_f16(v, F16_WSCALE, hi, lo);
+    wq[((long)kg * 2 + 0) * cout + m] = hi;
+    wq[((long)kg * 2 + 1) * cout + m] = lo;
+  }
+}
+
 }  // namespace
 
 static long g_s_launches = 0;
@@ -527,6 +608,32 @@ extern "C" int cl4_to_planes3(const float* x, void* xs, int n, int ctot, int cof
   CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0 && coff >= 0 && coff + c <= ctot, "to_planes3: bad channel slice (c %% 8 == 0 required)");
   const long total = (long)n * (c >> 3) * hw;
   hipLaunchKernelGGL(to_planes3_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, (u32x4*)xs, n, ctot, coff, c, hw);
+  return cl4::launch_status();
+}
+
+extern "C" size_t cl4_to_planes_f16_slot_floats(void) { return 4 + ABSMAX_PARTS; }
+
+extern "C" int cl4_to_planes_f16(const float* x, void* xs, int n, int ctot, int coff, int c, int hw, int dynamic, float* slot, void* stream) {
+  CL4_REQUIRE(x && xs && slot, "to_planes_f16: null pointer");
+  CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0 && coff >= 0 && coff + c <= ctot, "to_planes_f16: bad channel slice (c %% 8 == 0 required)");
+  hipStream_t st = cl4::as_stream(stream);
+  int nparts = 0;
+  if (dynamic) {
+    const long elems = (long)n * c * hw;
+    nparts = (int)std::min<long>(ABSMAX_PARTS, std::max<long>(1, cl4::cdiv((int)std::min<long>(elems, 1L << 30), 2048)));
+    hipLaunchKernelGGL(absmax_kernel, dim3(nparts), dim3(256), 0, st, x, slot + 4, n, ctot, coff, c, (long)hw);
+  }
+  const long total = (long)n * (c >> 3) * hw;
+  hipLaunchKernelGGL(to_planes_f16_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, x, (u32x4*)xs, n, ctot, coff, c, hw, F16_XSCALE, slot, nparts);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_pack_conv_weight_f16x3(const float* w, void* wq, int cout, int cin, int kh, int kw, void* stream) {
+  CL4_REQUIRE(w && wq && cout > 0 && cin > 0 && kh > 0 && kw > 0, "pack_conv_weight_f16x3: bad arguments");
+  CL4_REQUIRE(cin % 32 == 0 && cout % 8 == 0, "pack_conv_weight_f16x3: cin %% 32 == 0 and cout %% 8 == 0 (the planes kernels' shapes)");
+  const int K = cin * kh * kw;
+  const long total = (long)(K / 8) * cout;
+  hipLaunchKernelGGL(pack_weight_f16x3_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), w, (u32x4*)wq, cout, K, kh * kw);
   return cl4::launch_status();
 }
 

@@ -52,6 +52,27 @@ __device__ __forceinline__ void join8(const u32x4& hi, const u32x4& lo, float (&
   }
 }
 
+// ---- fp16x3 (r05): x = h + l with h = fp16(x * s), l = fp16(x * s - h): 22 significant bits for three MFMA products (hh + hl + lh), the
+// accuracy of bf16x6's six (tools/f16x3_probe.hip: 5.3e-7 against 7.8e-7 relative L2 on a K = 2304 dot product; bf16x3 4.6e-6) — provided
+// the operands sit inside fp16's range, hence the power-of-two scales: 2^12 on weights (|w| < 16), 2^4 on activations of O(1) networks,
+// and 2^(14 - exponent of max |x|) on gradients (cl4_to_planes_f16, dynamic). fp16 subnormals are honoured by the MFMA (same probe).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float F16_WSCALE = 4096.f, F16_XSCALE = 16.f, F16_MAX = 65504.f;
+__device__ __forceinline__ unsigned pack_f16(float lo, float hi) {    // {fp16(lo), fp16(hi)} in one dword (round to nearest even, saturating)
+  f32x2v t = {fminf(fmaxf(lo, -F16_MAX), F16_MAX), fminf(fmaxf(hi, -F16_MAX), F16_MAX)};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2));
+}
+__device__ __forceinline__ void split8_f16(const float (&v)[8], float s, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i] * s, b = v[2 * i + 1] * s;
+    hi[i] = pack_f16(a, b);
+    const f16x2 h = __builtin_bit_cast(f16x2, hi[i]);
+    lo[i] = pack_f16(sub_f32(a, (float)h[0]), sub_f32(b, (float)h[1]));
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

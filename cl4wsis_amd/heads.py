@@ -39,7 +39,7 @@ def _dx_1x1(dz, conv):
     the transposed GEMM; bf16x3 / bf16x6: the transposed weight in split planes (cached until the optimiser touches it)."""
     if TRAIN_PRECISION and ops.bf16x3_ok(conv.in_channels):
         wd = CACHE.get(conv, ("dgrad", TRAIN_PRECISION), (conv.weight,), lambda: ops.dgrad_weight(conv.weight.detach(), TRAIN_PRECISION))
-        return ops.conv2d(dz, wd, 1)
+        return ops.conv2d(dz, wd, 1, xdyn=True)
     return ops.conv2d(dz, conv.weight.detach().reshape(conv.out_channels, conv.in_channels), 1)
 
 
@@ -373,12 +373,16 @@ class InstanceBranch:
         # bf16x6 on the planes kernel (r03): the four ASPP branches read ONE three-plane copy of the (frozen, detached) res5 features —
         # 144-pixel tiles, no conversion in the K loop — instead of re-splitting the fp32 map per tile and tap in the r01 role-split kernel
         x3 = None
-        if (X6_PLANES and TRAIN_PRECISION == 2 and x.is_contiguous() and x.shape[1] % 32 == 0
+        if (X6_PLANES and TRAIN_PRECISION == 3 and x.is_contiguous() and all(ops.f16x3_ok(x.shape[1], aspp.convs[i][0].out_channels) for i in range(4))):
+            x3 = ops.to_planes_f16(x)          # r05, fp16x3: ONE fp16 two-plane copy, three products per MAC at bf16x6's accuracy
+        elif (X6_PLANES and TRAIN_PRECISION >= 2 and x.is_contiguous() and x.shape[1] % 32 == 0
                 and all(ops.bf16x3_ok(aspp.convs[i][0].out_channels) for i in range(4))):
             x3 = ops.to_planes(x, planes=3)
         for i in range(4):
             conv, bn = aspp.convs[i][0], aspp.convs[i][1]
-            if x3 is not None:
+            if x3 is not None and x3.slot is not None:
+                z = ops.conv2d_planes_f16(x3, packed_weight(conv, 3), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0])
+            elif x3 is not None:
                 z = ops.conv2d_planes(x3, packed_weight(conv, 2), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0],
                                       want_fp32=True)[0]
             else:

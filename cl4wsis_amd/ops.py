@@ -106,6 +106,14 @@ def bf16x3_ok(cout):
     return cout % 4 == 0 and cout >= 64
 
 
+F16X3_MIN_COUT = int(os.environ.get("CL4_F16X3_MIN_COUT", "128"))
+
+
+def f16x3_ok(cin, cout):
+    """Shapes the fp16x3 route takes (conv_b: 32-channel K-tiles, 8-channel output groups, at least one 128-row tile)."""
+    return cin % 32 == 0 and cout % 8 == 0 and cout >= F16X3_MIN_COUT
+
+
 def pack_conv_weight(w, precision=None):
     """[cout, cin, kh, kw] -> the operand layout cl4_conv2d_fwd streams (fp32 [K][cout], or the bf16x3 split planes)."""
     _f32(w, "pack_conv_weight")
@@ -113,6 +121,13 @@ def pack_conv_weight(w, precision=None):
     K = cin * kh * kw
     if precision is None:
         precision = CONV_PRECISION
+    if precision == 3:
+        # fp16x3 (r05): fp16 hi / lo of w * 2^12 for the LDS-DMA planes kernel; shapes it does not take keep bf16x6 (the same accuracy)
+        if f16x3_ok(cin, cout):
+            wq = torch.empty((K // 8) * 2 * cout * 16, dtype=torch.uint8, device=w.device)
+            call("cl4_pack_conv_weight_f16x3", ptr(w.contiguous()), ptr(wq), cout, cin, kh, kw, stream())
+            return PackedWeight(wq, K, cout, 3)
+        precision = 2
     if precision in (1, 2) and bf16x3_ok(cout):
         planes = 2 if precision == 1 else 3
         wq = torch.empty(((K + 7) // 8) * planes * cout * 16, dtype=torch.uint8, device=w.device)
@@ -371,8 +386,9 @@ def _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, a
 
 def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, post=None,
            act1=ACT_NONE, slope1=0.01, act2=ACT_NONE, slope2=0.01,
-           out=None, out_coff=0, in_coff=0, cin=None, x6=False):
-    """Fused conv (+affine +act +residual +act). `wp` comes from pack_conv_weight. `x6`: see X6_ROUTE.
+           out=None, out_coff=0, in_coff=0, cin=None, x6=False, xdyn=False):
+    """Fused conv (+affine +act +residual +act). `wp` comes from pack_conv_weight. `x6`: see X6_ROUTE. `xdyn`: `x` is a gradient (any
+    magnitude): an fp16x3 launch then scales it by a power of two taken from its maximum (to_planes_f16(dynamic=True)).
 
     `out`/`out_coff` write into a channel slice of a wider tensor (replaces torch.cat);
     `in_coff`/`cin` read a channel slice of `x`.
@@ -386,6 +402,12 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     K, cout = wp.K, wp.cout
     if K != cin * k * k:
         raise RuntimeError(f"conv2d: packed weight K={K} does not match cin*k*k={cin * k * k}")
+    if wp.precision == 3:
+        # r05, fp16x3: the differentiated convolutions as three fp16 MFMA products per MAC (the accuracy of bf16x6's six) through an fp16
+        # two-plane copy of the input and the LDS-DMA kernel (conv_b.hip, F16)
+        xs = to_planes_f16(x, dynamic=xdyn, in_coff=in_coff, c=cin)
+        return conv2d_planes_f16(xs, wp, k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift, pre=pre, post=post, act1=act1, slope1=slope1,
+                                 act2=act2, slope2=slope2, out=out, out_coff=out_coff)
     if (X6_ROUTE and (x6 or _x6_scope) and wp.precision == 2 and stride == 1 and in_coff == 0 and cin == in_ctot and cin % 32 == 0 and cout % 8 == 0
             and cout >= 128 and scale is None and shift is None and pre is None and post is None and act1 == ACT_NONE and act2 == ACT_NONE
             and x.is_contiguous()
@@ -430,12 +452,13 @@ class Planes:
     """An activation tensor [n, c, h, w] kept as pre-split bf16 planes — [n][c/8][hi, lo][h*w][8 x bf16], 4 bytes per element
     (include/cl4wsis.h, "Planes" activations): what conv2d_planes reads and can write. `planes` = 3: [hi, mid, lo], 6 bytes per
     element — the operand of the bf16x6 launches (read only)."""
-    __slots__ = ("data", "n", "c", "h", "w", "planes")
+    __slots__ = ("data", "n", "c", "h", "w", "planes", "slot")
 
-    def __init__(self, n, c, h, w, device, data=None, planes=2):
+    def __init__(self, n, c, h, w, device, data=None, planes=2, slot=None):
         if c % 8:
             raise RuntimeError(f"Planes: channel count {c} is not a multiple of 8")
         self.n, self.c, self.h, self.w, self.planes = n, c, h, w, planes
+        self.slot = slot       # fp16x3 operand (to_planes_f16): device floats, [0] = the power-of-two scale of the stored values; None: bf16 planes
         self.data = torch.empty(n * c * h * w * planes // 2, dtype=torch.int32, device=device) if data is None else data
 
     @property
@@ -460,6 +483,79 @@ def to_planes(x, in_coff=0, c=None, out=None, planes=2):
     ps = Planes(n, c, h, w, x.device, planes=planes) if out is None else out
     call("cl4_to_planes3" if ps.planes == 3 else "cl4_to_planes", ptr(x), ptr(ps.data), n, ctot, in_coff, c, h * w, stream())
     return ps
+
+
+def to_planes_f16(x, dynamic=False, in_coff=0, c=None):
+    """fp32 NCHW (channel slice) -> the fp16x3 operand of conv2d_planes_f16: two fp16 planes of x * s, s a power of two (2^4, or —
+    `dynamic`, for gradients — chosen from max |x| by a reduction launch in front). The scale lives in device memory (`.slot[0]`)."""
+    _f32(x, "to_planes_f16")
+    n, ctot, h, w = x.shape
+    c = ctot - in_coff if c is None else c
+    slot = torch.empty(_hip.load().cl4_to_planes_f16_slot_floats(), dtype=torch.float32, device=x.device)
+    ps = Planes(n, c, h, w, x.device, planes=2, slot=slot)
+    call("cl4_to_planes_f16", ptr(x), ptr(ps.data), n, ctot, in_coff, c, h * w, int(bool(dynamic)), ptr(slot), stream())
+    return ps
+
+
+def conv2d_planes_f16(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, post=None,
+                      act1=ACT_NONE, slope1=0.01, act2=ACT_NONE, slope2=0.01, out=None, out_coff=0):
+    """conv2d on an fp16x3 operand (to_planes_f16) with pack_conv_weight(w, 3) weights: three fp16 MFMA products per MAC, fp32
+    accumulation, the accuracy of bf16x6 (csrc/conv_b.hip, F16). fp32 NCHW output (optionally a channel slice of `out`)."""
+    if not isinstance(xs, Planes) or xs.slot is None:
+        raise RuntimeError("conv2d_planes_f16: the input must come from ops.to_planes_f16")
+    if not isinstance(wp, PackedWeight) or wp.precision != 3:
+        raise RuntimeError("conv2d_planes_f16: fp16x3 packed weights (pack_conv_weight(w, 3)) expected")
+    n, cin, hin, win = xs.shape
+    K, cout = wp.K, wp.cout
+    if K != cin * k * k:
+        raise RuntimeError(f"conv2d_planes_f16: packed weight K={K} does not match cin*k*k={cin * k * k}")
+    hout = conv_out_size(hin, k, stride, pad, dil)
+    wout = conv_out_size(win, k, stride, pad, dil)
+    dev = xs.data.device
+    if out is None:
+        out = torch.empty((n, cout, hout, wout), dtype=torch.float32, device=dev)
+        out_coff = 0
+    elif tuple(out.shape[2:]) != (hout, wout) or out.shape[0] != n:
+        raise RuntimeError(f"conv2d_planes_f16: out shape {tuple(out.shape)} incompatible with {(n, cout, hout, wout)}")
+    for t, nm in ((pre, "pre"), (post, "post")):
+        if t is not None and tuple(t.shape) != (n, cout, hout, wout):
+            raise RuntimeError(f"conv2d_planes_f16: {nm} shape {tuple(t.shape)} != {(n, cout, hout, wout)}")
+    d = ConvDescFor(n, cin, hin, win, cin, 0, cout, k, stride, pad, dil, out.shape[1], out_coff, act1, slope1, act2, slope2, 5)
+    if TIMER is not None:
+        e0, e1 = TIMER.span("conv_fwd_f16x3", 2.0 * n * hout * wout * cout * K, (n, cin, hin, cout, k, stride, dil),
+                            4 * n * cout * hout * wout * ((pre is not None) + (post is not None)))
+        e0.record()
+    args = (ptr(xs.data), ptr(xs.slot), ptr(wp.data), ptr(scale), ptr(shift), ptr(pre), ptr(post), ptr(out))
+    if AUTOTUNE and not _planes_tuned(d):
+        _autotune_f16(d, args)
+    call("cl4_conv2d_fwd_planes_f16", C.byref(d), *args, None, 0, stream())
+    if TIMER is not None:
+        e1.record()
+    return out
+
+
+def _autotune_f16(d, args, reps=6):
+    """fp16x3 launches run on the LDS-DMA kernel only: 256-row tiles (impl 4) against eight waves on 128-row tiles (impl 6)."""
+    key = _planes_key(d)
+    if key in _tuned:
+        return
+    cands = [(6, 144, 1)] + ([(4, 144, 1)] if d.cout % 256 == 0 else [])
+    best, best_ms = cands[0], float("inf")
+    for cand in cands if len(cands) > 1 else ():
+        call("cl4_conv2d_fwd_set_plan", C.byref(d), *cand)
+        run = lambda: call("cl4_conv2d_fwd_planes_f16", C.byref(d), *args, None, 0, stream())
+        run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        if ms < best_ms:
+            best, best_ms = cand, ms
+    call("cl4_conv2d_fwd_set_plan", C.byref(d), *best)
+    _tuned[key] = (best, best_ms if best_ms < float("inf") else 0.0)
 
 
 def from_planes(ps, out=None, out_coff=0):
@@ -1482,10 +1578,10 @@ def conv2d_dgrad(dy, wd, in_size, k, stride=1, pad=0, dil=1, x6=False):
     """Input gradient of conv2d(x, w, stride, pad, dil): `wd` = dgrad_weight(w); in_size = (hin, win) of x."""
     hin, win = in_size
     if k == 1 and pad == 0:
-        dx = conv2d(dy, wd, 1, x6=x6)
+        dx = conv2d(dy, wd, 1, x6=x6, xdyn=True)
         return dx if stride == 1 else zero_insert(dx, stride, (hin, win))
     up = dy if stride == 1 else zero_insert(dy, stride, (hin + 2 * pad - dil * (k - 1), win + 2 * pad - dil * (k - 1)))
-    return conv2d(up, wd, k, stride=1, pad=dil * (k - 1) - pad, dil=dil, x6=x6)
+    return conv2d(up, wd, k, stride=1, pad=dil * (k - 1) - pad, dil=dil, x6=x6, xdyn=True)
 
 
 def rot90(x, k, out=None):

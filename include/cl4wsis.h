@@ -579,6 +579,21 @@ int cl4_from_planes(const void* xs, float* y, int n, int c, int hw, int out_ctot
 int cl4_conv2d_fwd_planes(const cl4_conv_desc* d, const void* xs, const float* wp, const float* scale, const float* shift,
                           const float* pre, const float* post, const void* post_s, float* y, void* ys, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* fp16x3 (r05): the differentiated convolutions (train.py:272 forward, train.py:537 input gradients) as THREE MFMA products per MAC on
+ * split-fp16 operands — x = h + l, both fp16, 22 significant bits: the accuracy of bf16x6's six products (tools/f16x3_probe.hip) —
+ * with power-of-two operand scales that keep both halves inside fp16's range:
+ *   cl4_pack_conv_weight_f16x3: w [cout][cin][kh][kw] -> [K/8][hi, lo][cout][8 x fp16] of w * 2^12 (cin % 32 == 0, cout % 8 == 0, |w| < 16);
+ *   cl4_to_planes_f16: fp32 NCHW channel slice -> [n][c/8][hi, lo][h*w][8 x fp16] of x * s; s = 2^4 (dynamic == 0: activations), or
+ *     2^(14 - e) with max |x| < 2^e (dynamic != 0: gradients; one reduction launch in front, no atomics). slot: caller-owned device
+ *     memory of cl4_to_planes_f16_slot_floats() floats — [0] receives s, the rest is the reduction's scratch;
+ *   cl4_conv2d_fwd_planes_f16: conv (+ the fused affine / activation / fp32 residual group) on such an input, descriptor precision 5,
+ *     fp32 NCHW output; xs_scale = &slot[0]. 1x1 / 3x3, any stride / dilation, cout >= 128. */
+int cl4_pack_conv_weight_f16x3(const float* w, void* wq, int cout, int cin, int kh, int kw, void* stream);
+size_t cl4_to_planes_f16_slot_floats(void);
+int cl4_to_planes_f16(const float* x, void* xs, int n, int ctot, int coff, int c, int hw, int dynamic, float* slot, void* stream);
+int cl4_conv2d_fwd_planes_f16(const cl4_conv_desc* d, const void* xs, const float* xs_scale, const float* wp, const float* scale,
+                              const float* shift, const float* pre, const float* post, float* y, void* workspace,
+                              size_t workspace_bytes, void* stream);
 int cl4_abs_eps(const float* w, float* out, int n, float eps, void* stream);
 int cl4_sign_axpy(float* y, const float* x, const float* w, int n, void* stream);
 

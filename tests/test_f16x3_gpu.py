@@ -1,0 +1,124 @@
+"""fp16x3 (r05): the differentiated convolutions as THREE fp16 MFMA products per MAC on split-fp16 operands (x = h + l, 22 significant
+bits, power-of-two operand scales) instead of bf16x6's six bf16 products — cl4_pack_conv_weight_f16x3, cl4_to_planes_f16,
+cl4_conv2d_fwd_planes_f16 (csrc/conv_b.hip, F16). Every case is compared with a float64 convolution and with the bf16x6 kernel on the
+same operands: the bar is fp32-level agreement (5e-7 relative L2, the bar of the bf16x6 tests) and no worse than 2x bf16x6."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # n, cin, h, w, cout, k, stride, pad, dil
+    (2, 256, 33, 33, 256, 3, 1, 1, 1),
+    (3, 1024, 17, 19, 256, 1, 1, 0, 1),
+    (2, 256, 33, 33, 1024, 1, 1, 0, 1),
+    (1, 2048, 33, 33, 256, 3, 1, 12, 12),
+    (2, 128, 65, 65, 128, 3, 2, 1, 1),
+    (2, 160, 21, 21, 136, 1, 1, 0, 1),           # partial M tile (cout 136), cin % 32 == 0 only
+]
+
+
+def _rel(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("plan", [(6, 144, 1), (4, 144, 1)])
+def test_f16x3_conv_matches_float64_like_bf16x6(gpu, shape, plan):
+    from cl4wsis_amd import _hip, ops
+    n, cin, h, w, cout, k, stride, pad, dil = shape
+    if plan[0] == 4 and cout < 256:
+        pytest.skip("256-row tiles need cout >= 256")
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w, generator=g) * torch.logspace(-2, 2, cin)[None, :, None, None]
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    ref = F.conv2d(x.double(), wt.double(), stride=stride, padding=pad, dilation=dil)
+    wp = ops.pack_conv_weight(wt.to(gpu), 3)
+    assert wp.precision == 3
+    xs = ops.to_planes_f16(x.to(gpu))
+    assert float(xs.slot[0]) == 16.0
+    ho, wo = ref.shape[2:]
+    out = torch.full((n, cout + 16, ho, wo), 7.0, device=gpu)
+    d = ops.ConvDescFor(n, cin, h, w, cin, 0, cout, k, stride, pad, dil, cout + 16, 8, 0, 0.0, 0, 0.0, 5)
+    _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), *plan)
+    before = _hip.load().cl4_conv_debug_b_launches()
+    try:
+        ops.conv2d_planes_f16(xs, wp, k, stride=stride, pad=pad, dil=dil, out=out, out_coff=8)
+        torch.cuda.synchronize()
+    finally:
+        _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 0, 64, 1)
+    assert _hip.load().cl4_conv_debug_b_launches() > before
+    assert (out[:, :8] == 7).all() and (out[:, 8 + cout:] == 7).all()
+    err = _rel(out[:, 8:8 + cout].cpu().double(), ref)
+    y6 = ops.conv2d(x.to(gpu), ops.pack_conv_weight(wt.to(gpu), 2), k, stride=stride, pad=pad, dil=dil).cpu().double()
+    err6 = _rel(y6, ref)
+    y3 = ops.conv2d(x.to(gpu), ops.pack_conv_weight(wt.to(gpu), 1), k, stride=stride, pad=pad, dil=dil).cpu().double()
+    print(f"F16X3 {shape} plan {plan}: fp16x3 {err:.2e}  bf16x6 {err6:.2e}  bf16x3 {_rel(y3, ref):.2e}")
+    assert err < 5e-7 and err <= 2 * err6 + 1e-8, (err, err6)
+
+
+@pytest.mark.parametrize("magnitude", [1e-7, 1e-3, 1.0, 3e3])
+def test_f16x3_dynamic_scale_makes_the_error_scale_free(gpu, magnitude):
+    """Gradients have any magnitude: with the scale taken from max |x| the relative error does not depend on it (the conv route of
+    ops.conv2d(..., xdyn=True), what conv2d_dgrad uses); the static 2^4 of the forward activations would lose the small ones."""
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 256, 33, 33, generator=g) * magnitude
+    wt = torch.randn(256, 256, 3, 3, generator=g) / 48.0
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    wp = ops.pack_conv_weight(wt.to(gpu), 3)
+    y = ops.conv2d(x.to(gpu), wp, 3, pad=1, xdyn=True).cpu().double()
+    xs = ops.to_planes_f16(x.to(gpu), dynamic=True)
+    s = float(xs.slot[0])
+    amax = float(x.abs().max())
+    assert s == 2.0 ** round(torch.log2(torch.tensor(s)).item()) and 2.0 ** 13 <= amax * s < 2.0 ** 14, (s, amax)
+    err = _rel(y, ref)
+    print(f"F16X3 dynamic scale, |x| ~ {magnitude:g}: scale 2^{int(torch.log2(torch.tensor(s)).item())}, error {err:.2e}")
+    assert err < 5e-7, err
+
+
+def test_f16x3_zero_input_and_fused_epilogue(gpu):
+    from cl4wsis_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 128, 19, 23, generator=g)
+    wt = torch.randn(256, 128, 1, 1, generator=g) / 11.0
+    sc, sh = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    post = torch.randn(2, 256, 19, 23, generator=g)
+    wp = ops.pack_conv_weight(wt.to(gpu), 3)
+    y = ops.conv2d(x.to(gpu), wp, 1, scale=sc.to(gpu), shift=sh.to(gpu), post=post.to(gpu), act1=ops.ACT_LEAKY, slope1=0.01, act2=ops.ACT_RELU).cpu().double()
+    ref = F.relu(F.leaky_relu(F.conv2d(x.double(), wt.double()) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None], 0.01) + post.double())
+    assert _rel(y, ref) < 5e-7
+    z = ops.conv2d(torch.zeros(2, 128, 19, 23, device=gpu), wp, 1, xdyn=True)       # max |x| = 0: scale 1, output exactly 0
+    assert (z == 0).all()
+
+
+@pytest.mark.parametrize("case", [(2, 256, 33, 256, 3, 1, 1, 1), (2, 512, 17, 128, 1, 1, 0, 1), (2, 128, 33, 256, 3, 2, 1, 1), (2, 256, 33, 256, 3, 1, 2, 2)])
+def test_f16x3_input_gradient(gpu, case):
+    """conv2d_dgrad with fp16x3 dgrad weights (transposed-flipped, cl4_pack_conv_weight_f16x3) against float64 autograd, gradient
+    magnitudes of 1e-5: the scale comes from the data."""
+    from cl4wsis_amd import ops
+    n, cin, h, cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, cin, h, h, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    y = F.conv2d(x, wt.double(), stride=stride, padding=pad, dilation=dil)
+    dy = torch.randn(y.shape, generator=g) * 1e-5
+    (y * dy.double()).sum().backward()
+    wd = ops.dgrad_weight(wt.to(gpu), 3)
+    assert wd.precision == 3
+    dx = ops.conv2d_dgrad(dy.to(gpu), wd, (h, h), k, stride=stride, pad=pad, dil=dil).cpu().double()
+    wd6 = ops.dgrad_weight(wt.to(gpu), 2)
+    dx6 = ops.conv2d_dgrad(dy.to(gpu), wd6, (h, h), k, stride=stride, pad=pad, dil=dil).cpu().double()
+    err, err6 = _rel(dx, x.grad), _rel(dx6, x.grad)
+    print(f"F16X3 dgrad {case}: fp16x3 {err:.2e} bf16x6 {err6:.2e}")
+    assert err < 5e-7 and err <= 2 * err6 + 1e-8, (err, err6)
+
+
+def test_f16x3_falls_back_to_bf16x6_for_shapes_the_route_does_not_take(gpu):
+    from cl4wsis_amd import ops
+    for cout, cin in ((64, 256), (256, 144), (16, 256)):
+        wp = ops.pack_conv_weight(torch.randn(cout, cin, 1, 1, device=gpu), 3)
+        assert wp.precision in (2, 0), (cout, cin, wp.precision)
+    assert ops.pack_conv_weight(torch.randn(128, 160, 1, 1, device=gpu), 3).precision == 3
