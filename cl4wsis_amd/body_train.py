@@ -37,12 +37,12 @@ def _dgrad_weight(conv):
     return CACHE.get(conv, ("dgrad", PRECISION), (conv.weight,), lambda: ops.dgrad_weight(conv.weight.detach(), PRECISION))
 
 
-def conv_abn_train(x, conv, bn, group=None):
+def conv_abn_train(x, conv, bn, group=None, xs_cache=None):
     """conv -> ABN (batch statistics) -> activation. Returns (y, record)."""
     k = conv.kernel_size[0]
     r = _Rec()
     r.x = x
-    r.z = ops.conv2d(x, packed_weight(conv, PRECISION), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], x6=True)
+    r.z = ops.conv2d(x, packed_weight(conv, PRECISION), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], x6=True, xs_cache=xs_cache)
     act, slope = bn.act_code()
     r.y, r.mean, r.var, r.count = ops.abn_train_forward(r.z, gamma_of(bn), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                         bn.momentum, bn.eps, act, slope, group)
@@ -69,13 +69,14 @@ def conv_abn_backward(r, conv, bn, dy, grad_of, need_dx=True, group=None):
 def block_forward(blk, x, group=None):
     """ResidualBlock.forward in training mode — modules/residual.py:84-97."""
     c = blk.convs
-    a1, r1 = conv_abn_train(x, c.conv1, c.bn1, group)
+    shared = {} if hasattr(blk, "proj_conv") else None      # fp16x3: conv1 and the projection read one converted copy of x (same stride only)
+    a1, r1 = conv_abn_train(x, c.conv1, c.bn1, group, xs_cache=shared)
     a2, r2 = conv_abn_train(a1, c.conv2, c.bn2, group)
     b3, r3 = conv_abn_train(a2, c.conv3, c.bn3, group)
     rp = None
     sc = x
     if hasattr(blk, "proj_conv"):
-        sc, rp = conv_abn_train(x, blk.proj_conv, blk.proj_bn, group)
+        sc, rp = conv_abn_train(x, blk.proj_conv, blk.proj_bn, group, xs_cache=shared)
     act, slope = c.bn1.act_code()
     out = ops.add_act(b3, sc, act, slope)
     return out, (r1, r2, r3, rp, out)
@@ -114,6 +115,7 @@ def body_forward(body, x, group=None, seed=None):
     return outs, tape
 
 
+@ops.gradient_scope
 def body_backward(body, tape, douts, grad_of, group=None):
     """douts: {index of a module output (0..4): gradient or None}. Accumulates the parameter gradients; the input image
     needs no gradient (the stem's input gradient is skipped)."""
@@ -264,6 +266,7 @@ def wrn_body_forward(body, x, group=None, keeps=None, seed=0):
     return prevs + [out7], tape
 
 
+@ops.gradient_scope
 def wrn_body_backward(body, tape, douts, grad_of, group=None):
     """douts: {index into [out3, out4, out5, out6, out7]: gradient or None}. The input image needs no gradient."""
     dy = None

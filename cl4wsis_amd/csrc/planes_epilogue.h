@@ -67,9 +67,11 @@ __device__ __forceinline__ void split8_f16(const float (&v)[8], float s, u32x4& 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float a = v[2 * i] * s, b = v[2 * i + 1] * s;
-    hi[i] = pack_f16(a, b);
-    const f16x2 h = __builtin_bit_cast(f16x2, hi[i]);
-    lo[i] = pack_f16(sub_f32(a, (float)h[0]), sub_f32(b, (float)h[1]));
+    const unsigned hp = pack_f16(a, b);
+    const f16x2 h = __builtin_bit_cast(f16x2, hp);
+    const float ha = (float)h[0], hb = (float)h[1];
+    hi[i] = hp;
+    lo[i] = pack_f16(a - ha, b - hb);
   }
 }
 

@@ -470,6 +470,7 @@ class InstanceBranch:
         ops.dwconv5_wgrad_(G(dw.weight), x, dz0)
         return ops.dwconv5(dz0, dw.weight.detach(), flip=True) if need_dx else None
 
+    @ops.gradient_scope
     def backward(self, tape, dpred, grads=None, on_ready=None, feature_grads=None, stop_before_aspp=False):
         """Back-propagates d(loss)/d(pred[key]) through the recorded forward. Returns {id(param): grad}.
         `feature_grads` (a dict) additionally receives d(loss)/d(feature) for the backbone features the decoder read —
@@ -493,6 +494,7 @@ class InstanceBranch:
         self._flush_ready()
         return grads
 
+    @ops.gradient_scope
     def backward_aspp(self, tape, dy, grads, on_ready=None):
         """The ASPP part of `backward` on its own (see `stop_before_aspp`)."""
         self._on_ready = on_ready
@@ -504,12 +506,14 @@ class InstanceBranch:
     def aspp_parameters(self):
         return list(self.dec.aspp.parameters())
 
+    @ops.gradient_scope
     def head_backward(self, tape, dpred, grads=None):
         """Backward of head_forward_train alone: returns d(loss)/d(decoder features); parameter gradients go to `grads`."""
         grads = {} if grads is None else grads
         self._on_ready, self._queue = None, []
         return self._head_backward(tape, dpred, grads), grads
 
+    @ops.gradient_scope
     def decoder_backward(self, tape, dy, grads=None, feature_grads=None):
         """Backward of decoder_forward_train alone."""
         grads = {} if grads is None else grads

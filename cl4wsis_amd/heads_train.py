@@ -44,8 +44,10 @@ def deeplab_forward(head, x, group=None):
     n, _, h, w = x.shape
     hid = head.hidden
     cat = torch.empty((n, 4 * hid, h, w), dtype=torch.float32, device=x.device)
+    shared = {}                                                       # fp16x3: the four branches read ONE converted copy of x
     for i, conv in enumerate(head.map_convs):
-        ops.conv2d(x, packed_weight(conv, BT.PRECISION), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0], out=cat, out_coff=i * hid, x6=True)
+        ops.conv2d(x, packed_weight(conv, BT.PRECISION), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0], out=cat, out_coff=i * hid, x6=True,
+                   xs_cache=shared)
     a, r_map = _abn_fwd(cat, head.map_bn, group)
     out = ops.conv2d(a, packed_weight(head.red_conv, BT.PRECISION), 1, x6=True)
     g = ops.global_mean(x)                                            # [n, cin, 1, 1]
@@ -57,6 +59,7 @@ def deeplab_forward(head, x, group=None):
     return y, (x, a, r_map, g, pa, r_pool, r_red)
 
 
+@ops.gradient_scope
 def deeplab_backward(head, tape, dy, grad_of, group=None):
     x, a, r_map, g, pa, r_pool, r_red = tape
     n, cin, h, w = x.shape
@@ -91,6 +94,7 @@ def cls_forward(cls, x):
     return cls._forward(x), x
 
 
+@ops.gradient_scope
 def cls_backward(cls, x, dy, grad_of, need_dx=True):
     dx, off = None, 0
     for m in cls:
@@ -115,6 +119,7 @@ def pseudolabeler_forward(pl, x, group=None):
     return conv_bias(a2, pl.cls), (r1, r2, a2)
 
 
+@ops.gradient_scope
 def pseudolabeler_backward(pl, tape, dy, grad_of, need_dx=True, group=None):
     r1, r2, a2 = tape
     ops.conv2d_wgrad(a2, dy, grad_of(pl.cls.weight), 1, precision=BT.WGRAD_PRECISION)

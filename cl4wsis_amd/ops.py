@@ -384,11 +384,32 @@ def _conv_desc(x, cin, in_coff, cout, k, stride, pad, dil, out_ctot, out_coff, a
     return d
 
 
+_grad_depth = 0
+
+
+def gradient_scope(fn):
+    """Decorator of the hand-written BACKWARD passes: every convolution launched inside takes a gradient as its input — any magnitude —
+    so an fp16x3 launch scales it dynamically (conv2d's `xdyn`) without each call site having to say so."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        global _grad_depth
+        _grad_depth += 1
+        try:
+            return fn(*a, **k)
+        finally:
+            _grad_depth -= 1
+    return wrapped
+
+
 def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, post=None,
            act1=ACT_NONE, slope1=0.01, act2=ACT_NONE, slope2=0.01,
-           out=None, out_coff=0, in_coff=0, cin=None, x6=False, xdyn=False):
+           out=None, out_coff=0, in_coff=0, cin=None, x6=False, xdyn=False, xs_cache=None):
     """Fused conv (+affine +act +residual +act). `wp` comes from pack_conv_weight. `x6`: see X6_ROUTE. `xdyn`: `x` is a gradient (any
-    magnitude): an fp16x3 launch then scales it by a power of two taken from its maximum (to_planes_f16(dynamic=True)).
+    magnitude): an fp16x3 launch then scales it by a power of two taken from its maximum (to_planes_f16(dynamic=True)). `xs_cache`: a
+    dict the caller shares between convolutions that read the SAME input tensor (the ASPP branches, a block's conv1 and projection):
+    the fp16x3 operand is converted once.
 
     `out`/`out_coff` write into a channel slice of a wider tensor (replaces torch.cat);
     `in_coff`/`cin` read a channel slice of `x`.
@@ -405,9 +426,29 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     if wp.precision == 3:
         # r05, fp16x3: the differentiated convolutions as three fp16 MFMA products per MAC (the accuracy of bf16x6's six) through an fp16
         # two-plane copy of the input and the LDS-DMA kernel (conv_b.hip, F16)
-        xs = to_planes_f16(x, dynamic=xdyn, in_coff=in_coff, c=cin)
-        return conv2d_planes_f16(xs, wp, k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift, pre=pre, post=post, act1=act1, slope1=slope1,
-                                 act2=act2, slope2=slope2, out=out, out_coff=out_coff)
+        global TIMER
+        timer, e1 = TIMER, None
+        if timer is not None:          # one span over the conversion AND the convolution: what the route costs against a direct bf16x6 launch
+            hout_, wout_ = conv_out_size(hin, k, stride, pad, dil), conv_out_size(win, k, stride, pad, dil)
+            e0, e1 = timer.span("conv_fwd_f16x3", 2.0 * n * hout_ * wout_ * cout * K, (n, cin, hin, cout, k, stride, dil),
+                                4 * n * cout * hout_ * wout_ * ((pre is not None) + (post is not None)))
+            e0.record()
+            TIMER = None
+        try:
+            dyn = xdyn or _grad_depth > 0
+            ckey = (x.data_ptr(), tuple(x.shape), in_coff, cin, dyn)
+            xs = xs_cache.get(ckey) if xs_cache is not None else None
+            if xs is None:
+                xs = to_planes_f16(x, dynamic=dyn, in_coff=in_coff, c=cin)
+                if xs_cache is not None:
+                    xs_cache[ckey] = xs
+            y = conv2d_planes_f16(xs, wp, k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift, pre=pre, post=post, act1=act1, slope1=slope1,
+                                  act2=act2, slope2=slope2, out=out, out_coff=out_coff)
+        finally:
+            TIMER = timer
+        if e1 is not None:
+            e1.record()
+        return y
     if (X6_ROUTE and (x6 or _x6_scope) and wp.precision == 2 and stride == 1 and in_coff == 0 and cin == in_ctot and cin % 32 == 0 and cout % 8 == 0
             and cout >= 128 and scale is None and shift is None and pre is None and post is None and act1 == ACT_NONE and act2 == ACT_NONE
             and x.is_contiguous()

@@ -696,17 +696,28 @@ class Trainer:
         self._stamp("main.head")
         self._side_stream.wait_stream(main)
         self._side2.wait_stream(main)
-        with torch.cuda.stream(self._side_stream):
-            self._stamp("old_model.head")
-            o_next, _ = self.model_old(P["x"][r], interpolate=False)
-            for k in ("center", "offset"):
-                P["old"][r][k].copy_(o_next[k])
-            del o_next
-            self._stamp("old_model.tail")
-        with torch.cuda.stream(self._side2):
-            self._stamp("frozen_new.head")
-            _copy_tree(P["fz"][r], self._frozen_new(P["x"][r], P["l"][r]))
-            self._stamp("frozen_new.tail")
+
+        def old_chain():
+            with torch.cuda.stream(self._side_stream):
+                self._stamp("old_model.head")
+                o_next, _ = self.model_old(P["x"][r], interpolate=False)
+                for k in ("center", "offset"):
+                    P["old"][r][k].copy_(o_next[k])
+                del o_next
+                self._stamp("old_model.tail")
+
+        def frozen_chain():
+            with torch.cuda.stream(self._side2):
+                self._stamp("frozen_new.head")
+                _copy_tree(P["fz"][r], self._frozen_new(P["x"][r], P["l"][r]))
+                self._stamp("frozen_new.tail")
+
+        # r05: the in-graph time stamps (tools/chain_gantt.py) show that the chain captured SECOND starts ~0.5 ms after the first — the
+        # replay enqueues the graph's ~570 nodes in capture order — so the longest chain (the new model's frozen stage: it ends last) is
+        # captured first; CL4_DEEP_ORDER=old restores the r04 order
+        order = (old_chain, frozen_chain) if os.environ.get("CL4_DEEP_ORDER", "frozen") == "old" else (frozen_chain, old_chain)
+        for chain in order:
+            chain()
         self.optimizer.zero_grad()
 
         def join_end():

@@ -265,8 +265,9 @@ def test_map_after_training_is_an_unremarkable_draw_from_the_reference_distribut
     names = ("center_old", "offset_old", "center_new", "offset_new")
     work = batches(K, 12)
 
-    def hip_trajectory(frozen_precision):
-        """K iterations of the HIP path from the common start; returns (per-iteration losses, trained state dicts)."""
+    def hip_trajectory(frozen_precision, noise_gen=None):
+        """K iterations of the HIP path from the common start; returns (per-iteration losses, trained state dicts). `noise_gen`: the
+        same relative input perturbation the B runs of the oracle get (drawn in the same order from an equally seeded generator)."""
         with monkeypatch.context() as mp:
             mp.setattr(ops, "CONV_PRECISION", frozen_precision)
             torch.manual_seed(0)
@@ -274,7 +275,11 @@ def test_map_after_training_is_an_unremarkable_draw_from_the_reference_distribut
             for m, sd in zip((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator), start):
                 m.load_state_dict(sd)
             tr._realias()
-            losses = [tr.step((images, l1h), dropout_keep=keep.to(torch.uint8).to(gpu))["losses"].cpu().tolist() for images, l1h, keep in work]
+            losses = []
+            for images, l1h, keep in work:
+                if noise_gen is not None:
+                    images = (images.cpu() * (1.0 + NOISE * torch.randn(images.shape, generator=noise_gen))).to(gpu)
+                losses.append(tr.step((images, l1h), dropout_keep=keep.to(torch.uint8).to(gpu))["losses"].cpu().tolist())
             torch.cuda.synchronize()
             sds = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
                    for m in (tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)]
@@ -299,6 +304,12 @@ def test_map_after_training_is_an_unremarkable_draw_from_the_reference_distribut
     loss_a, A = oracle_trajectory(None)
     gn = torch.Generator().manual_seed(13)
     runs_b = [oracle_trajectory(gn) for _ in range(NB)]
+    # r05: the HIP path along the SAME twenty perturbations (an equally seeded generator, the same draw order), at
+    # both arithmetic settings — a BIAS estimate (mean of 20 against mean of 20, paired run by run) instead of one draw against a distribution
+    gh = torch.Generator().manual_seed(13)
+    runs_h = [hip_trajectory(1, gh) for _ in range(NB)]
+    gh6 = torch.Generator().manual_seed(13)
+    runs_h6 = [hip_trajectory(2, gh6) for _ in range(NB)]
     tot = lambda t: torch.tensor(t, dtype=torch.float64).sum(1)
     ta = tot(loss_a)
     dev = lambda t: ((tot(t) - ta).abs() / ta)
@@ -397,8 +408,25 @@ def test_map_after_training_is_an_unremarkable_draw_from_the_reference_distribut
           f"({d_h:.2f}); of the {len(ens)} reference runs themselves {sum(v <= 0.2 for v in d_r)} are — after {K} iterations from this start the "
           f"reference arithmetic does not reproduce its own mAP to 0.2 points under a 3e-5 input perturbation, so the bar is decidable here "
           f"only as 'indistinguishable from the reference runs' (the percentile above)")
+    # ---- bias: mean(HIP runs) - mean(reference runs) over the same 20 perturbations, with its standard error (paired differences) --------
+    map_hb, map_h6b = [hip_map(sd) for _, sd in runs_h], [hip_map(sd) for _, sd in runs_h6]
+    verdicts = {}
+    for tag, mh in (("default (bf16x3 frozen networks)", map_hb), ("bf16x6 frozen networks", map_h6b)):
+        diff = np.array(mh) - np.array(map_b)
+        bias, se = float(diff.mean()), float(diff.std(ddof=1) / np.sqrt(len(diff)))
+        se_unpaired = float(np.sqrt(np.var(mh, ddof=1) / len(mh) + np.var(map_b, ddof=1) / len(map_b)))
+        verdicts[tag] = (bias, se)
+        print(f"MAPPROXY BIAS HIP {tag}: mean of {len(mh)} perturbed runs {np.mean(mh):.2f} (sd {np.std(mh, ddof=1):.2f}) against the reference's "
+              f"{np.mean(map_b):.2f} (sd {np.std(map_b, ddof=1):.2f}) on the same perturbations: bias {bias:+.2f} +- {se:.2f} points (paired standard error; "
+              f"unpaired {se_unpaired:.2f}); |bias| <= 0.2: {'yes' if abs(bias) <= 0.2 else 'NO'}; 0.2 resolvable at this sample size (2 se <= 0.2): "
+              f"{'yes' if 2 * se <= 0.2 else 'NO'}; bias consistent with zero (|bias| <= 2.5 se): {'yes' if abs(bias) <= 2.5 * se else 'NO'}")
     assert n_inst >= 40 and 20.0 < map_start < 100.0      # non-vacuous: the start state scores high but not 100 against its own degraded predictions
+    for tag, (bias, se) in verdicts.items():
+        # the decidable form of the 0.2-point bar: no systematic offset beyond what 20 paired runs can resolve, and an absolute backstop of
+        # 2 points on the offset itself (keep an absolute ceiling next to the distribution-relative one)
+        assert abs(bias) <= max(0.2, 2.5 * se), (tag, bias, se)
+        assert abs(bias) <= 2.0, (tag, bias, se)
     assert abs(map_a - map_a_oracle) <= 1.0, (map_a, map_a_oracle)          # the evaluation path itself
     assert q75(d_r) <= 6.0, d_r                                         # sanity ceiling on the reference distribution (measured: 2-3 points)
-    assert d_h <= cap, (map_h, centre, d_r)
-    assert d_h6 <= cap, (map_h6, centre, d_r)
+    assert d_h <= min(cap, 8.0), (map_h, centre, d_r)                  # distribution-relative cap AND an absolute one
+    assert d_h6 <= min(cap, 8.0), (map_h6, centre, d_r)
