@@ -607,8 +607,11 @@ def worker(a):
                                    "513x513, ResNet101+DeepLabV3+Panoptic-DeepLab, run_refine on, random-init weights, "
                                    "label stage fed by the networks' own outputs (e2e-random mode)",
                        "global_batch": GLOBAL_BATCH, "per_gpu_batch": b, "crop": CROP, "parallelism": f"dp{world}",
-                       "arithmetic": "fp32 tensors; convolutions as split-bf16 MFMA products with fp32 accumulation (bf16x3 frozen networks, "
-                                     "bf16x6 = fp32-level for the differentiated convs, bf16x3 weight gradients)"},
+                       "arithmetic": "fp32 tensors; convolutions as split 16-bit MFMA products with fp32 accumulation: bf16x3 frozen networks; differentiated "
+                                     "convs " + {0: "exact fp32 MFMA", 1: "bf16x3", 2: "bf16x6 (six bf16 products, fp32-level)",
+                                                 3: "fp16x3 (three fp16 products on split-fp16 operands with power-of-two scales, fp32-level; bf16x6 where "
+                                                    "the shape is not routed)"}[__import__("cl4wsis_amd.heads", fromlist=["x"]).TRAIN_PRECISION]
+                                     + "; bf16x3 weight gradients"},
             "label_counters": counters_random,
             "roofline": {"bound": "mfma", "kernel": "bf16x3 forward convolution (cl4_conv2d_fwd precision 1 + cl4_conv2d_fwd_planes + cl4_stem_fused: kernels "
                                                     "conv_igemm_bf16x3 / conv_u_bf16x3 / conv_s_bf16x3 / conv_b_bf16x3 / stem_fused): all its launches of 2 "

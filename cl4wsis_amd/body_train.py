@@ -14,11 +14,12 @@ import os
 from . import ops
 from .nn import CACHE, gamma_grad, gamma_of, packed_weight
 
-# Arithmetic of the convolutions of the step-0 / phase-1 training paths (forward, input and weight gradients): 2 (default) = bf16x6, three bf16 planes per operand and six products — fp32-level
-# accuracy (the gradient parity bar of the tests) at about twice the speed of the fp32 MFMA kernels; 0 = exact fp32 MFMA;
-# 1 = bf16x3 (~4e-6 relative per layer — still far tighter than the fp16 autocast the reference trains under on GPUs,
-# train.py:252 — fastest, outside the strict gradient bar).
-PRECISION = int(os.environ.get("CL4_TRAIN_PRECISION", "2"))
+# Arithmetic of the convolutions of the step-0 / phase-1 training paths (forward and input gradients): 3 (default, r05) = fp16x3 — split-fp16
+# operands with power-of-two scales, THREE MFMA products per MAC at fp32-level accuracy (FINDINGS.md finding 47) wherever the LDS-DMA kernel
+# takes the shape, bf16x6 elsewhere; 2 = bf16x6 everywhere (three bf16 planes per operand, six products: the r01-r04 default); 0 = exact fp32
+# MFMA; 1 = bf16x3 (~4e-6 relative per layer, fastest — measured in r05 to put the phase-1 gradients 4.5x further from float64 than the CPU
+# fp32 oracle, bar 1.5x: tests/test_acceptance_gpu.py).
+PRECISION = int(os.environ.get("CL4_TRAIN_PRECISION", "3"))
 # Weight gradients: a dW rounding error stays in that tensor (it does not propagate through BN / ReLU masks like a forward or
 # input-gradient error does), so the 4e-6 of bf16x3 is harmless there and twice as fast as either fp32-level kernel — the same
 # choice phase 2 makes (ops.WGRAD_PRECISION). 0 keeps exact fp32 products with PRECISION == 0.

@@ -27,7 +27,9 @@ EPS = 1e-5
 # the default is "bf16x6" (2): three bf16 planes per operand, six products, fp32-level accuracy on the fast MFMA pipe
 # (about twice the speed of the fp32 MFMA kernels). 0 = exact fp32 MFMA, 1 = bf16x3 (fastest, ~4e-6 per layer). The frozen,
 # no-grad networks (old model, flip-TTA semantic forward, PseudoLabeler) run at ops.CONV_PRECISION (bf16x3 by default).
-TRAIN_PRECISION = int(__import__("os").environ.get("CL4_TRAIN_PRECISION", "2"))
+# r05: 3 (the default) = fp16x3 — three fp16 products per MAC on split-fp16 operands with power-of-two scales, the accuracy of bf16x6 at
+# half its MFMA work (FINDINGS.md finding 47) — wherever the LDS-DMA kernel takes the shape, bf16x6 elsewhere.
+TRAIN_PRECISION = int(__import__("os").environ.get("CL4_TRAIN_PRECISION", "3"))
 # The trainable ASPP reads a three-plane (hi, mid, lo) copy of the frozen res5 features through the LDS-DMA planes kernel (conv_b.hip,
 # plan impl 6): 0.82 -> 0.61 ms per dilated branch (r03); 0 = the role-split bf16x6 kernel on the fp32 features.
 X6_PLANES = __import__("os").environ.get("CL4_X6_PLANES", "1") == "1"
@@ -373,15 +375,18 @@ class InstanceBranch:
         # bf16x6 on the planes kernel (r03): the four ASPP branches read ONE three-plane copy of the (frozen, detached) res5 features —
         # 144-pixel tiles, no conversion in the K loop — instead of re-splitting the fp32 map per tile and tap in the r01 role-split kernel
         x3 = None
-        if (X6_PLANES and TRAIN_PRECISION == 3 and x.is_contiguous() and all(ops.f16x3_ok(x.shape[1], aspp.convs[i][0].out_channels) for i in range(4))):
+        if (X6_PLANES and TRAIN_PRECISION == 3 and x.is_contiguous()
+                and all(ops.f16x3_ok(x.shape[1], aspp.convs[i][0].out_channels, aspp.convs[i][0].kernel_size[0]) or i == 0 for i in range(4))
+                and ops.f16x3_ok(x.shape[1], aspp.convs[0][0].out_channels, 3)):
             x3 = ops.to_planes_f16(x)          # r05, fp16x3: ONE fp16 two-plane copy, three products per MAC at bf16x6's accuracy
         elif (X6_PLANES and TRAIN_PRECISION >= 2 and x.is_contiguous() and x.shape[1] % 32 == 0
                 and all(ops.bf16x3_ok(aspp.convs[i][0].out_channels) for i in range(4))):
             x3 = ops.to_planes(x, planes=3)
         for i in range(4):
             conv, bn = aspp.convs[i][0], aspp.convs[i][1]
-            if x3 is not None and x3.slot is not None:
-                z = ops.conv2d_planes_f16(x3, packed_weight(conv, 3), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0])
+            if x3 is not None and x3.slot is not None:      # (the 1x1 branch rides on the shared copy although it shrinks the channel count)
+                wq = CACHE.get(conv, "wp3f", (conv.weight,), lambda: ops.pack_conv_weight(conv.weight.detach(), 3, force_f16=True))
+                z = ops.conv2d_planes_f16(x3, wq, conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0])
             elif x3 is not None:
                 z = ops.conv2d_planes(x3, packed_weight(conv, 2), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0],
                                       want_fp32=True)[0]

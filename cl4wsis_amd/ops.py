@@ -109,12 +109,17 @@ def bf16x3_ok(cout):
 F16X3_MIN_COUT = int(os.environ.get("CL4_F16X3_MIN_COUT", "128"))
 
 
-def f16x3_ok(cin, cout):
-    """Shapes the fp16x3 route takes (conv_b: 32-channel K-tiles, 8-channel output groups, at least one 128-row tile)."""
-    return cin % 32 == 0 and cout % 8 == 0 and cout >= F16X3_MIN_COUT
+def f16x3_ok(cin, cout, k=3):
+    """Shapes the fp16x3 route takes: what conv_b needs (32-channel K-tiles, 8-channel output groups, at least one 128-row tile), and only
+    where the conversion pass of the input pays — every 3x3 layer, 1x1 layers that do not shrink the channel count (a 1024 -> 256 1x1
+    convolution reads 4x the elements it writes: converting them costs more than the bf16x6 launch it replaces, profiles/r05_f16x3_ab.txt)."""
+    return cin % 32 == 0 and cout % 8 == 0 and cout >= F16X3_MIN_COUT and (k > 1 or cout >= cin or F16X3_ALL_1X1)
 
 
-def pack_conv_weight(w, precision=None):
+F16X3_ALL_1X1 = os.environ.get("CL4_F16X3_ALL_1X1", "0") != "0"
+
+
+def pack_conv_weight(w, precision=None, force_f16=False):
     """[cout, cin, kh, kw] -> the operand layout cl4_conv2d_fwd streams (fp32 [K][cout], or the bf16x3 split planes)."""
     _f32(w, "pack_conv_weight")
     cout, cin, kh, kw = w.shape
@@ -123,7 +128,7 @@ def pack_conv_weight(w, precision=None):
         precision = CONV_PRECISION
     if precision == 3:
         # fp16x3 (r05): fp16 hi / lo of w * 2^12 for the LDS-DMA planes kernel; shapes it does not take keep bf16x6 (the same accuracy)
-        if f16x3_ok(cin, cout):
+        if f16x3_ok(cin, cout, kh) or (force_f16 and f16x3_ok(cin, cout, 3)):
             wq = torch.empty((K // 8) * 2 * cout * 16, dtype=torch.uint8, device=w.device)
             call("cl4_pack_conv_weight_f16x3", ptr(w.contiguous()), ptr(wq), cout, cin, kh, kw, stream())
             return PackedWeight(wq, K, cout, 3)
