@@ -48,7 +48,7 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, __amdgpu
 // three K-tiles ahead, which is what the K-major GEMM of the weight gradient needs (both its operands miss L2 on every K-tile).
 // F16 (r05): the two planes hold fp16 hi / lo (planes_epilogue.h, fp16x3) — the same K loop with v_mfma_f32_16x16x32_f16, and the
 // accumulators scaled by 1 / (2^12 * *a.xs_scale) on their way into the parked tile. fp32 output (no planes residual / output yet).
-template <int KS, int BMB, int NW, int PB, bool GEMM = false, int NSTG = 3, bool F16 = false>
+template <int KS, int BMB, int NW, int PB, bool GEMM = false, int NSTG = 3>
 __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void conv_b_bf16x3(ConvArgs a) {
   // NSTG == 2 (r05 experiment, <128, 8> only): 70 KB of stages / 74 KB of parked tile -> TWO workgroups per CU, so that one's epilogue
   // (HBM streaming) can run under the other's K loop (MFMA + L2 -> LDS)
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void co
   constexpr int E_CH = R * 16;                             // [k-group * PB + plane][16 extra pixel columns]
   constexpr int NE = R / 4;                                // extra pieces per K-tile (4 chunk rows x 16 columns each): waves 0 .. NE-1
   static_assert(PB == 2 || (PB == 3 && BMB == 128 && NW == 8), "planes");
-  static_assert(!F16 || (PB == 2 && !GEMM), "fp16x3: two planes");
+  constexpr bool F16 = plfmt::F16 && PB == 2 && !GEMM;     // the two-plane format of this build (planes_fmt.h); the k-planes GEMM and three planes are bf16
   constexpr int WR = 2 * BMB / NW;                         // rows per wave: 64 or 32
   constexpr int NRB = WR / 32;                             // MFMA row blocks per half of a K-tile's work: 2 or 1
   constexpr int RB64 = BMB / 64;                           // 64-row groups of the tile (= weight pieces per chunk row)
@@ -283,11 +283,7 @@ __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void co
     c[0] += (float)af[PB - 1][i][0] * (float)bf[0][0] + (float)af[0][i][1] * (float)bf[PB - 1][1];
 #else
     if constexpr (F16) {
-      const f16x8 ah = __builtin_bit_cast(f16x8, af[0][i]), al = __builtin_bit_cast(f16x8, af[1][i]);
-      const f16x8 bh = __builtin_bit_cast(f16x8, bf[0]), bl = __builtin_bit_cast(f16x8, bf[1]);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+      c = plfmt::mfma16_x3(af[0][i], af[1][i], bf[0], bf[1], c);
     } else if constexpr (PB == 2) {
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[0], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[1], c, 0, 0, 0);
@@ -423,8 +419,8 @@ __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void co
   float* park = reinterpret_cast<float*>(&lds[0]);
   {
     const int l4 = lane >> 4;
-    if constexpr (F16) {                                   // undo the operand scales: exact (powers of two)
-      const float accm = 1.f / (F16_WSCALE * a.xs_scale[0]);
+    if constexpr (F16) {                                   // undo the operand scales: exact (powers of two); xs_scale: a dynamically scaled operand
+      const float accm = a.xs_scale ? 1.f / (plfmt::WSCALE * a.xs_scale[0]) : plfmt::ACC;
 #pragma unroll
       for (int i = 0; i < 2 * NRB; ++i)
 #pragma unroll
@@ -480,15 +476,9 @@ int launch_conv_b(const ConvArgs& a_, int ks, int rows, int waves, int planes, u
   ConvArgs a = a_;
   a.dbg_stagger = g_b_stagger;
   const dim3 g(grid), b(64 * waves);
-  if (f16) {
-    if (!a.xs_scale || a.ys || a.post_s || planes != 2 || waves != 8) { set_error("conv_b: an fp16x3 launch needs the operand scale, two planes, eight waves and an fp32 output"); return CL4_EINVAL; }
-    ++g_b_launches;
-    if (ks == 1 && rows == 256) hipLaunchKernelGGL((conv_b_bf16x3<1, 256, 8, 2, false, 3, true>), g, b, 0, st, a);
-    else if (ks == 3 && rows == 256) hipLaunchKernelGGL((conv_b_bf16x3<3, 256, 8, 2, false, 3, true>), g, b, 0, st, a);
-    else if (ks == 1 && rows == 128) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 2, false, 3, true>), g, b, 0, st, a);
-    else if (ks == 3 && rows == 128) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 8, 2, false, 3, true>), g, b, 0, st, a);
-    else { set_error("conv_b: fp16x3 kernel size %d / %d rows not built", ks, rows); return CL4_EINVAL; }
-    return launch_status();
+  if (f16 && (!plfmt::F16 || !a.xs_scale || planes != 2)) {
+    set_error("conv_b: a dynamically scaled fp16x3 launch needs an fp16 build (CL4_F16_PLANES), the operand scale and two planes");
+    return CL4_EINVAL;
   }
   static const int stagesN = [] { const char* e = getenv("CL4_CONV_B_STAGES"); return e ? atoi(e) : 3; }();   // experiments: four / two LDS stages on the 128-row / 8-wave tile
   const bool stages4 = stagesN == 4;

@@ -61,10 +61,7 @@ __device__ __forceinline__ f32x4a mfma3(const bf16x8& ah, const bf16x8& al, cons
   c[0] += (float)al[0] * (float)bh[0] + (float)ah[1] * (float)bl[1];
   return c;
 #endif
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
-  return c;
+  return plfmt::mfma16_x3(ah, al, bh, bl, c);      // the two-plane arithmetic of this build (planes_fmt.h)
 }
 
 // RS = row split of phases 1 and 2: the NW waves form NW / RS column groups x RS row groups; a wave multiplies CM / RS of the CM rows of W1 /
@@ -146,7 +143,11 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   const int y0 = ty * TH, x0 = tx * TW;
   const int H = a.h, W = a.w, HW = H * W;
 
-  for (int i = tid; i < NAFF; i += NT) aff[i] = a.aff[i];
+  // (fp16x3 build: the operand scales 2^-16 ride in the folded-ABN SCALES — exact, powers of two — so the epilogues stay as they are)
+  for (int i = tid; i < NAFF; i += NT) {
+    const bool is_scale = i < CM || (i >= 2 * CM && i < 3 * CM) || (i >= 4 * CM && i < 4 * CM + C4) || (i >= 4 * CM + 2 * C4 && i < 4 * CM + 3 * C4);
+    aff[i] = a.aff[i] * (is_scale ? plfmt::ACC : 1.f);
+  }
 
   const unsigned act_bytes = (unsigned)((long)a.n * C4 * HW * 4);      // < 2^31: checked on the host
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xs, 0, (unsigned)((long)a.n * CIN * HW * 4), 0x00020000);

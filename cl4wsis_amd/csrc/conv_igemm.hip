@@ -21,6 +21,7 @@
 #include <type_traits>
 #include "common.h"
 #include "conv_args.h"
+#include "planes_fmt.h"
 
 namespace {
 
@@ -1439,10 +1440,7 @@ __global__ void conv_splitk_epilogue_s(ConvArgs a, int splits) {
     const u32x4* ps = reinterpret_cast<const u32x4*>(a.post_s) + (((long)n * (a.cout >> 3) + (co0 >> 3)) * 2) * HWo + hw;
     const u32x4 hi = ps[0], lo = ps[HWo];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      t[2 * q] = __builtin_bit_cast(float, hi[q] << 16) + __builtin_bit_cast(float, lo[q] << 16);
-      t[2 * q + 1] = __builtin_bit_cast(float, hi[q] & 0xFFFF0000u) + __builtin_bit_cast(float, lo[q] & 0xFFFF0000u);
-    }
+    for (int q = 0; q < 4; ++q) plfmt::join2(hi[q], lo[q], t[2 * q], t[2 * q + 1]);
   }
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -1457,12 +1455,11 @@ __global__ void conv_splitk_epilogue_s(ConvArgs a, int splits) {
   if (a.ys) {
     u32x4 hi, lo;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {                          // the same split as conv_s.hip::split8 (round to nearest even twice)
-      const float x0 = v[2 * q], x1 = v[2 * q + 1];
-      const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
-      const __bf16 l0 = (__bf16)(x0 - (float)h0), l1 = (__bf16)(x1 - (float)h1);
-      hi[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-      lo[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    for (int q = 0; q < 4; ++q) {                          // the same split as conv_s.hip::split8 (planes_fmt.h)
+      unsigned h_, l_;
+      plfmt::split2(v[2 * q], v[2 * q + 1], h_, l_);
+      hi[q] = h_;
+      lo[q] = l_;
     }
     u32x4* ys = reinterpret_cast<u32x4*>(a.ys) + (((long)n * (a.out_ctot >> 3) + ((a.out_coff + co0) >> 3)) * 2) * HWo + hw;
     ys[0] = hi;

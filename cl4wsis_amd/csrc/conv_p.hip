@@ -22,6 +22,7 @@
 // residual or none, no `pre`, no K split.
 #include <type_traits>
 #include "conv_args.h"
+#include "planes_fmt.h"
 
 namespace {
 
@@ -155,9 +156,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_p_bf16x3(ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         f32x4v& c = acc[2 * s2 + i][j];
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh16[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl16[j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh16[j], c, 0, 0, 0);
+        c = plfmt::mfma16_x3(ah[i], al[i], bh16[j], bl16[j], c);
       }
   };
 
@@ -211,24 +210,26 @@ __global__ __launch_bounds__(THREADS, 2) void conv_p_bf16x3(ConvArgs a) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float u = prev[c][j][r] * sc[r] + sh[r];
+        const float u = (prev[c][j][r] * plfmt::ACC) * sc[r] + sh[r];      // (x 1 in a bf16 build; the fp16x3 operand scales otherwise)
         v[r] = u > 0.f ? u : u * a.neg1;
       }
       if constexpr (RES) {
         const unsigned h0 = (unsigned)rres[c & 1][j][0], h1 = (unsigned)(rres[c & 1][j][0] >> 32);
         const unsigned l0 = (unsigned)rres[c & 1][j][1], l1 = (unsigned)(rres[c & 1][j][1] >> 32);
-        v[0] += __builtin_bit_cast(float, h0 << 16) + __builtin_bit_cast(float, l0 << 16);
-        v[1] += __builtin_bit_cast(float, h0 & 0xFFFF0000u) + __builtin_bit_cast(float, l0 & 0xFFFF0000u);
-        v[2] += __builtin_bit_cast(float, h1 << 16) + __builtin_bit_cast(float, l1 << 16);
-        v[3] += __builtin_bit_cast(float, h1 & 0xFFFF0000u) + __builtin_bit_cast(float, l1 & 0xFFFF0000u);
+        float t0, t1, t2, t3;
+        plfmt::join2(h0, l0, t0, t1);
+        plfmt::join2(h1, l1, t2, t3);
+        v[0] += t0; v[1] += t1; v[2] += t2; v[3] += t3;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.neg2;
       u32x2 hi, lo;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        hi[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
-        lo[i] = pack_bf16(sub_f32(v[2 * i], __builtin_bit_cast(float, hi[i] << 16)), sub_f32(v[2 * i + 1], __builtin_bit_cast(float, hi[i] & 0xFFFF0000u)));
+        unsigned h, l;
+        plfmt::split2(v[2 * i], v[2 * i + 1], h, l);
+        hi[i] = h;
+        lo[i] = l;
       }
       const bool ok = pv.pix[j] != OOB;
       const unsigned o0 = ok ? half_off(pv.pix[j], c8out, a.out_coff >> 3, g, 0) : OOB;

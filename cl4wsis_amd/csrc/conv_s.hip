@@ -275,9 +275,7 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : (BNT == 64 ? 3 : 2)) void conv_s
 #if CL4_S_DBG & 4
           acc[i][j][0] += (float)al[i][0] * (float)bh[j][0] + (float)ah[i][1] * (float)bl[j][1];
 #else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = plfmt::mfma32_x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
 #endif
         }
     } else {
@@ -311,9 +309,7 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : (BNT == 64 ? 3 : 2)) void conv_s
             c[0] += (float)afr[P - 1][i][0] * (float)bfr[0][j][0] + (float)afr[0][i][1] * (float)bfr[P - 1][j][1];
 #else
             if constexpr (P == 2) {
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[1][i], bfr[0][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0][i], bfr[1][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0][i], bfr[0][j], c, 0, 0, 0);
+              c = plfmt::mfma16_x3(afr[0][i], afr[1][i], bfr[0][j], bfr[1][j], c);
             } else {
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[2][i], bfr[0][j], c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[0][i], bfr[2][j], c, 0, 0, 0);
@@ -378,6 +374,8 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : (BNT == 64 ? 3 : 2)) void conv_s
     if constexpr (WIDE) ex1.issue(a, m0, erow, 0, ex.valid, ex.pn, ex.phw, HWo);
   }
   float* stage = reinterpret_cast<float*>(&lds[0]);
+  // two-plane launches of an fp16x3 build: the operand scales leave the accumulators here (exact: powers of two; planes_fmt.h)
+  const float accm = (P == 2 && plfmt::F16) ? (a.xs_scale ? 1.f / (plfmt::WSCALE * a.xs_scale[0]) : plfmt::ACC) : 1.f;
   if constexpr (MF == 32) {
     const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -386,7 +384,7 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : (BNT == 64 ? 3 : 2)) void conv_s
       for (int j = 0; j < NBJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          stage[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BNT + cb0 + j * 32 + lr] = acc[i][j][r];
+          stage[(wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BNT + cb0 + j * 32 + lr] = acc[i][j][r] * accm;
   } else {
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
@@ -396,7 +394,7 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : (BNT == 64 ? 3 : 2)) void conv_s
         if (j < nbj) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            stage[(wm * WTM + i * 16 + l4 * 4 + r) * BNT + cb0 + j * 16 + l15] = acc[i][j][r];
+            stage[(wm * WTM + i * 16 + l4 * 4 + r) * BNT + cb0 + j * 16 + l15] = acc[i][j][r] * accm;
         }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -611,6 +609,7 @@ extern "C" int cl4_to_planes3(const float* x, void* xs, int n, int ctot, int cof
   return cl4::launch_status();
 }
 
+extern "C" int cl4_planes_format(void) { return plfmt::F16 ? 1 : 0; }      // 1: fp16x3 two-plane format / arithmetic (planes_fmt.h), 0: bf16x3
 extern "C" size_t cl4_to_planes_f16_slot_floats(void) { return 4 + ABSMAX_PARTS; }
 
 extern "C" int cl4_to_planes_f16(const float* x, void* xs, int n, int ctot, int coff, int c, int hw, int dynamic, float* slot, void* stream) {
@@ -630,7 +629,7 @@ extern "C" int cl4_to_planes_f16(const float* x, void* xs, int n, int ctot, int 
 
 extern "C" int cl4_pack_conv_weight_f16x3(const float* w, void* wq, int cout, int cin, int kh, int kw, void* stream) {
   CL4_REQUIRE(w && wq && cout > 0 && cin > 0 && kh > 0 && kw > 0, "pack_conv_weight_f16x3: bad arguments");
-  CL4_REQUIRE(cin % 32 == 0 && cout % 8 == 0, "pack_conv_weight_f16x3: cin %% 32 == 0 and cout %% 8 == 0 (the planes kernels' shapes)");
+  CL4_REQUIRE(cin % 32 == 0, "pack_conv_weight_f16x3: cin %% 32 == 0 (the planes kernels' tap-major K order)");
   const int K = cin * kh * kw;
   const long total = (long)(K / 8) * cout;
   hipLaunchKernelGGL(pack_weight_f16x3_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), w, (u32x4*)wq, cout, K, kh * kw);

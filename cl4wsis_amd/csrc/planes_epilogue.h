@@ -2,6 +2,7 @@
 // epilogue of one thread over the accumulator tile parked in LDS.
 #pragma once
 #include "conv_args.h"
+#include "planes_fmt.h"
 
 namespace {
 
@@ -36,20 +37,19 @@ __device__ __forceinline__ float sub_f32(float a, float b) {          // one v_s
   asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-// split 8 fp32 values into the hi / lo chunks of the planes format
+// split 8 fp32 values into the hi / lo chunks of the planes format (planes_fmt.h: fp16 hi / lo of 16 x, or — CL4_F16_PLANES=0 — bf16 hi / lo of x)
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    hi[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
-    lo[i] = pack_bf16(sub_f32(v[2 * i], __builtin_bit_cast(float, hi[i] << 16)), sub_f32(v[2 * i + 1], __builtin_bit_cast(float, hi[i] & 0xFFFF0000u)));
+    unsigned h, l;
+    plfmt::split2(v[2 * i], v[2 * i + 1], h, l);
+    hi[i] = h;
+    lo[i] = l;
   }
 }
 __device__ __forceinline__ void join8(const u32x4& hi, const u32x4& lo, float (&v)[8]) {     // hi + lo, exact in fp32
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    v[2 * i] = __builtin_bit_cast(float, hi[i] << 16) + __builtin_bit_cast(float, lo[i] << 16);
-    v[2 * i + 1] = __builtin_bit_cast(float, hi[i] & 0xFFFF0000u) + __builtin_bit_cast(float, lo[i] & 0xFFFF0000u);
-  }
+  for (int i = 0; i < 4; ++i) plfmt::join2(hi[i], lo[i], v[2 * i], v[2 * i + 1]);
 }
 
 // ---- fp16x3 (r05): x = h + l with h = fp16(x * s), l = fp16(x * s - h): 22 significant bits for three MFMA products (hh + hl + lh), the

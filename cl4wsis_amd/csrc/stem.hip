@@ -15,6 +15,7 @@
 // 16 conv pixels (9 x 33 conv pixels = the pooled tile's receptive field), conv + ABN values to LDS, 3x3/2 max over them, store as
 // fp32 NCHW and / or planes. The next tile's patch is requested before the MFMA phase and lands under it.
 #include "common.h"
+#include "planes_fmt.h"
 
 namespace {
 
@@ -235,8 +236,10 @@ __global__ __launch_bounds__(THREADS, 1) void stem_fused_kernel(StemArgs a) {
           u32x4 hi, lo;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            hi[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
-            lo[i] = pack_bf16(v[2 * i] - __builtin_bit_cast(float, hi[i] << 16), v[2 * i + 1] - __builtin_bit_cast(float, hi[i] & 0xFFFF0000u));
+            unsigned h_, l_;
+            plfmt::split2(v[2 * i], v[2 * i + 1], h_, l_);      // the planes format of this build (planes_fmt.h); the stem's own products stay bf16x3
+            hi[i] = h_;
+            lo[i] = l_;
           }
           u32x4* ys = a.ys + (((long)img * 8 + g8) * 2) * hw + p;
           ys[0] = hi;

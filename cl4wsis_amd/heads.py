@@ -375,18 +375,21 @@ class InstanceBranch:
         # bf16x6 on the planes kernel (r03): the four ASPP branches read ONE three-plane copy of the (frozen, detached) res5 features —
         # 144-pixel tiles, no conversion in the K loop — instead of re-splitting the fp32 map per tile and tap in the r01 role-split kernel
         x3 = None
-        if (X6_PLANES and TRAIN_PRECISION == 3 and x.is_contiguous()
-                and all(ops.f16x3_ok(x.shape[1], aspp.convs[i][0].out_channels, aspp.convs[i][0].kernel_size[0]) or i == 0 for i in range(4))
-                and ops.f16x3_ok(x.shape[1], aspp.convs[0][0].out_channels, 3)):
-            x3 = ops.to_planes_f16(x)          # r05, fp16x3: ONE fp16 two-plane copy, three products per MAC at bf16x6's accuracy
+        if (X6_PLANES and TRAIN_PRECISION == 3 and ops.planes_f16() and x.is_contiguous() and ops.f16x3_ok(x.shape[1], aspp.convs[0][0].out_channels, 3)
+                and all(ops.f16x3_ok(x.shape[1], aspp.convs[i][0].out_channels, 3) for i in range(4))):
+            # r05, fp16x3: the four branches multiply the planes twin the frozen body left beside res5 (the build's two-plane format IS the
+            # fp16x3 operand: fp16 hi / lo of 16 x) — three products per MAC at bf16x6's accuracy, and no conversion pass at all
+            x3 = planes_of(x)
+            if x3 is None or x3.planes != 2:
+                x3 = ops.to_planes(x)
         elif (X6_PLANES and TRAIN_PRECISION >= 2 and x.is_contiguous() and x.shape[1] % 32 == 0
                 and all(ops.bf16x3_ok(aspp.convs[i][0].out_channels) for i in range(4))):
             x3 = ops.to_planes(x, planes=3)
         for i in range(4):
             conv, bn = aspp.convs[i][0], aspp.convs[i][1]
-            if x3 is not None and x3.slot is not None:      # (the 1x1 branch rides on the shared copy although it shrinks the channel count)
+            if x3 is not None and x3.planes == 2:           # (the 1x1 branch rides on the shared copy although it shrinks the channel count)
                 wq = CACHE.get(conv, "wp3f", (conv.weight,), lambda: ops.pack_conv_weight(conv.weight.detach(), 3, force_f16=True))
-                z = ops.conv2d_planes_f16(x3, wq, conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0])
+                z = ops.conv2d_planes(x3, wq, conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0], want_fp32=True)[0]
             elif x3 is not None:
                 z = ops.conv2d_planes(x3, packed_weight(conv, 2), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0],
                                       want_fp32=True)[0]

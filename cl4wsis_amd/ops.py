@@ -91,11 +91,17 @@ class x6_route_scope:
 
 
 class PackedWeight:
-    """Device-side operand of cl4_conv2d_fwd: `data` in the layout of `precision` for a [cout, cin, k, k] weight."""
-    __slots__ = ("data", "K", "cout", "precision")
+    """Device-side operand of cl4_conv2d_fwd: `data` in the layout of `precision` for a [cout, cin, k, k] weight. `planes`: the operand of
+    the kernels that read a two-plane activation (conv_s / conv_b / conv_p / the fused bottleneck) when that differs from `data` — an
+    fp16x3 build of the library (cl4_planes_format() == 1, the default since r05) multiplies fp16 hi / lo planes of 4096 w there, while the
+    fp32-input bf16x3 kernels (conv_u, conv_igemm) keep the bf16 split in `data`."""
+    __slots__ = ("data", "K", "cout", "precision", "planes")
 
-    def __init__(self, data, K, cout, precision):
-        self.data, self.K, self.cout, self.precision = data, K, cout, precision
+    def __init__(self, data, K, cout, precision, planes=None):
+        self.data, self.K, self.cout, self.precision, self.planes = data, K, cout, precision, planes
+
+    def for_planes(self):
+        return self.planes if self.planes is not None else self.data
 
     @property
     def shape(self):
@@ -104,6 +110,17 @@ class PackedWeight:
 
 def bf16x3_ok(cout):
     return cout % 4 == 0 and cout >= 64
+
+
+_PLANES_F16 = None
+
+
+def planes_f16():
+    """True when the loaded library's two-plane format / arithmetic is fp16x3 (cl4_planes_format(), csrc/planes_fmt.h)."""
+    global _PLANES_F16
+    if _PLANES_F16 is None:
+        _PLANES_F16 = bool(_hip.load().cl4_planes_format())
+    return _PLANES_F16
 
 
 F16X3_MIN_COUT = int(os.environ.get("CL4_F16X3_MIN_COUT", "128"))
@@ -126,6 +143,8 @@ def pack_conv_weight(w, precision=None, force_f16=False):
     K = cin * kh * kw
     if precision is None:
         precision = CONV_PRECISION
+    if precision == 3 and not planes_f16():
+        precision = 2
     if precision == 3:
         # fp16x3 (r05): fp16 hi / lo of w * 2^12 for the LDS-DMA planes kernel; shapes it does not take keep bf16x6 (the same accuracy)
         if f16x3_ok(cin, cout, kh) or (force_f16 and f16x3_ok(cin, cout, 3)):
@@ -138,7 +157,11 @@ def pack_conv_weight(w, precision=None, force_f16=False):
         wq = torch.empty(((K + 7) // 8) * planes * cout * 16, dtype=torch.uint8, device=w.device)
         call("cl4_pack_conv_weight_bf16x3" if precision == 1 else "cl4_pack_conv_weight_bf16x6", ptr(w.contiguous()), ptr(wq),
              cout, cin, kh, kw, stream())
-        return PackedWeight(wq, K, cout, precision)
+        wq16 = None
+        if precision == 1 and planes_f16() and cin % 32 == 0:       # the planes kernels of an fp16x3 build read their own pack of the same weight
+            wq16 = torch.empty((K // 8) * 2 * cout * 16, dtype=torch.uint8, device=w.device)
+            call("cl4_pack_conv_weight_f16x3", ptr(w.contiguous()), ptr(wq16), cout, cin, kh, kw, stream())
+        return PackedWeight(wq, K, cout, precision, planes=wq16)
     wp = torch.empty((K, cout), dtype=torch.float32, device=w.device)
     call("cl4_pack_conv_weight", ptr(w.contiguous()), ptr(wp), cout, cin, kh, kw, stream())
     return PackedWeight(wp, K, cout, 0)
@@ -428,6 +451,8 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
     K, cout = wp.K, wp.cout
     if K != cin * k * k:
         raise RuntimeError(f"conv2d: packed weight K={K} does not match cin*k*k={cin * k * k}")
+    if wp.precision == 3 and not planes_f16():
+        raise RuntimeError("conv2d: fp16x3 packed weights need an fp16x3 build of the library (cl4_planes_format() == 1)")
     if wp.precision == 3:
         # r05, fp16x3: the differentiated convolutions as three fp16 MFMA products per MAC (the accuracy of bf16x6's six) through an fp16
         # two-plane copy of the input and the LDS-DMA kernel (conv_b.hip, F16)
@@ -444,11 +469,19 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
             ckey = (x.data_ptr(), tuple(x.shape), in_coff, cin, dyn)
             xs = xs_cache.get(ckey) if xs_cache is not None else None
             if xs is None:
-                xs = to_planes_f16(x, dynamic=dyn, in_coff=in_coff, c=cin)
+                # a forward activation: the planes format of the build itself (fp16 hi / lo of 16 x) — the frozen producer's twin when it
+                # left one; a gradient: its own power-of-two scale, in device memory
+                xs = (getattr(x, "_cl4_planes", None) if (not dyn and in_coff == 0 and cin == in_ctot) else None)
+                if xs is None or xs.planes != 2 or xs.slot is not None:
+                    xs = to_planes_f16(x, dynamic=True, in_coff=in_coff, c=cin) if dyn else to_planes(x, in_coff=in_coff, c=cin)
                 if xs_cache is not None:
                     xs_cache[ckey] = xs
-            y = conv2d_planes_f16(xs, wp, k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift, pre=pre, post=post, act1=act1, slope1=slope1,
-                                  act2=act2, slope2=slope2, out=out, out_coff=out_coff)
+            if xs.slot is not None:
+                y = conv2d_planes_f16(xs, wp, k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift, pre=pre, post=post, act1=act1, slope1=slope1,
+                                      act2=act2, slope2=slope2, out=out, out_coff=out_coff)
+            else:
+                y = conv2d_planes(xs, wp, k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift, pre=pre, post=post, act1=act1, slope1=slope1,
+                                  act2=act2, slope2=slope2, out=out, out_coff=out_coff, want_fp32=True)[0]
         finally:
             TIMER = timer
         if e1 is not None:
@@ -626,9 +659,11 @@ def conv2d_planes(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre
     if cin is None:
         cin = in_ctot - in_coff
     x6 = xs.planes == 3
-    if not isinstance(wp, PackedWeight) or wp.precision != (2 if x6 else 1):
-        raise RuntimeError("conv2d_planes: bf16x3 packed weights (pack_conv_weight(w, 1)) expected for a two-plane input, bf16x6 "
+    if not isinstance(wp, PackedWeight) or (wp.precision != 2 if x6 else wp.precision not in (1, 3)) or (not x6 and planes_f16() and wp.precision == 1 and wp.planes is None):
+        raise RuntimeError("conv2d_planes: x3 packed weights (pack_conv_weight(w, 1), or (w, 3) in an fp16x3 build) expected for a two-plane input, bf16x6 "
                            "(pack_conv_weight(w, 2)) for a three-plane one")
+    if not x6 and wp.precision == 3 and not planes_f16():
+        raise RuntimeError("conv2d_planes: fp16x3 packed weights need an fp16x3 build of the library")
     if x6 and (isinstance(post, Planes) or out_planes is not None or want_planes):
         raise RuntimeError("conv2d_planes: a three-plane (bf16x6) launch writes fp32 only and takes no planes residual")
     K, cout = wp.K, wp.cout
@@ -656,7 +691,7 @@ def conv2d_planes(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre
         e0, e1 = TIMER.span("conv_fwd_bf16x6" if x6 else "conv_fwd_bf16x3", 2.0 * n * hout * wout * cout * K, (n, cin, hin, cout, k, stride, dil),
                             4 * n * cout * hout * wout * ((pre is not None) + (post is not None)))
         e0.record()
-    args = (ptr(xs.data), ptr(wp.data), ptr(scale), ptr(shift), ptr(pre), ptr(post_f), ptr(post_s.data) if post_s is not None else None,
+    args = (ptr(xs.data), ptr(wp.data if x6 else wp.for_planes()), ptr(scale), ptr(shift), ptr(pre), ptr(post_f), ptr(post_s.data) if post_s is not None else None,
             ptr(out), ptr(out_planes.data) if out_planes is not None else None)
     if AUTOTUNE and not _planes_tuned(d):
         targs, scratch = args, None
@@ -795,7 +830,7 @@ def bottleneck_fused(xs, w1, w2, w3, aff, slope1, slope2, slope_out, want_fp32=F
     cm = cin if wp is not None else cin // 4
     c4 = 4 * cm
     for pw, K, co in ((w1, cin, cm), (w2, 9 * cm, cm), (w3, cm, c4)) + (((wp, cin, c4),) if wp is not None else ()):
-        if not isinstance(pw, PackedWeight) or pw.precision != 1 or pw.K != K or pw.cout != co:
+        if not isinstance(pw, PackedWeight) or pw.precision != 1 or pw.K != K or pw.cout != co or (planes_f16() and pw.planes is None):
             raise RuntimeError("bottleneck_fused: bf16x3 packed weights of a [c_in -> cm -> cm (3x3) -> 4 cm] bottleneck (+ c_in -> 4 cm shortcut) expected")
     if aff.numel() != 4 * cm + 2 * c4 + (2 * c4 if wp is not None else 0):
         raise RuntimeError("bottleneck_fused: aff must hold 4 cm + 8 cm (+ 8 cm with a projection shortcut) floats")
@@ -810,10 +845,10 @@ def bottleneck_fused(xs, w1, w2, w3, aff, slope1, slope2, slope_out, want_fp32=F
         e0.record()
     f32n = -1 if f32_images is None else int(f32_images)
     if wp is None:
-        call("cl4_bottleneck_fused", ptr(xs.data), ptr(ys.data), ptr(y), f32n, ptr(w1.data), ptr(w2.data), ptr(w3.data), ptr(aff), n, cm, h, w,
+        call("cl4_bottleneck_fused", ptr(xs.data), ptr(ys.data), ptr(y), f32n, ptr(w1.for_planes()), ptr(w2.for_planes()), ptr(w3.for_planes()), ptr(aff), n, cm, h, w,
              C.c_float(slope1), C.c_float(slope2), C.c_float(slope_out), stream())
     else:
-        call("cl4_bottleneck_fused_proj", ptr(xs.data), ptr(ys.data), ptr(y), f32n, ptr(w1.data), ptr(w2.data), ptr(w3.data), ptr(wp.data),
+        call("cl4_bottleneck_fused_proj", ptr(xs.data), ptr(ys.data), ptr(y), f32n, ptr(w1.for_planes()), ptr(w2.for_planes()), ptr(w3.for_planes()), ptr(wp.for_planes()),
              ptr(aff), n, cm, h, w, C.c_float(slope1), C.c_float(slope2), C.c_float(slope_out), stream())
     if TIMER is not None:
         e1.record()

@@ -589,6 +589,10 @@ int cl4_conv2d_fwd_planes(const cl4_conv_desc* d, const void* xs, const float* w
  *   cl4_conv2d_fwd_planes_f16: conv (+ the fused affine / activation / fp32 residual group) on such an input, descriptor precision 5,
  *     fp32 NCHW output; xs_scale = &slot[0]. 1x1 / 3x3, any stride / dilation, cout >= 128. */
 int cl4_pack_conv_weight_f16x3(const float* w, void* wq, int cout, int cin, int kh, int kw, void* stream);
+/* Which two-plane format / arithmetic this build of the library uses for EVERY planes tensor (cl4_to_planes, the ys / post_s operands, the
+ * fused bottleneck and stem outputs): 1 = fp16x3 (fp16 hi / lo of 16 x; weights from cl4_pack_conv_weight_f16x3 — the default build),
+ * 0 = bf16x3 (bf16 hi / lo of x; weights from cl4_pack_conv_weight_bf16x3; hipcc -DCL4_F16_PLANES=0: the r02-r04 format). */
+int cl4_planes_format(void);
 size_t cl4_to_planes_f16_slot_floats(void);
 int cl4_to_planes_f16(const float* x, void* xs, int n, int ctot, int coff, int c, int hw, int dynamic, float* slot, void* stream);
 int cl4_conv2d_fwd_planes_f16(const cl4_conv_desc* d, const void* xs, const float* xs_scale, const float* wp, const float* scale,
