@@ -47,6 +47,14 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
     lo[i] = l;
   }
 }
+// the bf16 hi / lo split whatever the build's planes format is: the k-planes operands of the weight-gradient GEMM (wgrad_gemm.hip) are bf16
+__device__ __forceinline__ void split8_bf16(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
+    lo[i] = pack_bf16(sub_f32(v[2 * i], __builtin_bit_cast(float, hi[i] << 16)), sub_f32(v[2 * i + 1], __builtin_bit_cast(float, hi[i] & 0xFFFF0000u)));
+  }
+}
 __device__ __forceinline__ void join8(const u32x4& hi, const u32x4& lo, float (&v)[8]) {     // hi + lo, exact in fp32
 #pragma unroll
   for (int i = 0; i < 4; ++i) plfmt::join2(hi[i], lo[i], v[2 * i], v[2 * i + 1]);

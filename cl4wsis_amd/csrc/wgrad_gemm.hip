@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void kpack_kernel(const float* __restrict__ sr
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = tile[cl][qc * 8 + j];
     u32x4 hi, lo;
-    split8(v, hi, lo);
+    split8_bf16(v, hi, lo);      // k-planes are bf16 in every build (the GEMM flavour of conv_b multiplies bf16)
     const long chunk = ((long)(q0 / 8 + qc) * 2) * R + (long)tap * c + c0 + cl;
     dst[chunk] = hi;
     dst[chunk + R] = lo;

@@ -31,9 +31,9 @@ def test_stem_fused_matches_float64_and_the_two_launch_path(gpu, shape):
     assert tuple(y.shape) == tuple(ref.shape)
     err = ((y.cpu() - ref).abs().max() / ref.abs().max()).item()
     assert err < 2e-5, err
-    hi = y.to(torch.bfloat16).float()
-    lo = (y - hi).to(torch.bfloat16).float()
-    assert torch.equal(ops.from_planes(ys), hi + lo)
+    from util import planes_split_ref
+    hi, lo = planes_split_ref(y.cpu())                          # the build's two-plane split of the fp32 output, bit for bit
+    assert torch.equal(ops.from_planes(ys).cpu(), hi + lo)
     # the path it replaces: bf16x3 conv + ABN epilogue, then the max-pool kernel
     y2 = ops.maxpool3x3s2(ops.conv2d(xd, ops.pack_conv_weight(wd, 1), 7, stride=2, pad=3, scale=sd, shift=hd, act1=ops.ACT_LEAKY, slope1=0.01))
     assert ((y - y2).abs().max() / ref.abs().max()).item() < 2e-5

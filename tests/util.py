@@ -144,3 +144,29 @@ def label_inputs_for(gold):
         return synth.label_stage_edge_inputs(str(gold["edge_name"]))
     seed, b, H, W = (int(v) for v in gold["case"])
     return synth.label_stage_inputs(seed, b=b, H=H, W=W)
+
+
+def planes_split_ref(x):
+    """The two-plane split of the loaded library's build, restated in torch (csrc/planes_fmt.h): (hi, lo) as fp32 tensors with
+    x ~ hi + lo. fp16x3 build (the default): hi = fp16(16 x) / 16, lo = fp16(16 x - fp16(16 x)) / 16 — saturating at |16 x| = 65504;
+    bf16x3 build (CL4_F16_PLANES=0): hi = bf16(x), lo = bf16(x - hi)."""
+    import torch
+    from cl4wsis_amd import ops
+    if ops.planes_f16():
+        a = x.float() * 16.0
+        hi = a.clamp(-65504.0, 65504.0).to(torch.float16).float()
+        lo = (a - hi).clamp(-65504.0, 65504.0).to(torch.float16).float()
+        return hi / 16.0, lo / 16.0
+    hi = x.to(torch.bfloat16).float()
+    lo = (x - hi).to(torch.bfloat16).float()
+    return hi, lo
+
+
+def planes_raw_ref(x):
+    """(hi, lo) of planes_split_ref as the 16-bit patterns the library stores (int16 views of fp16 / bf16)."""
+    import torch
+    from cl4wsis_amd import ops
+    hi, lo = planes_split_ref(x)
+    if ops.planes_f16():
+        return (hi * 16.0).to(torch.float16).view(torch.int16), (lo * 16.0).to(torch.float16).view(torch.int16)
+    return hi.to(torch.bfloat16).view(torch.int16), lo.to(torch.bfloat16).view(torch.int16)
