@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void co
     const int h = tid >> 8, t = tid & 255;
     const int ch = min(m0 + h * BM + (t & 127), a.cout - 1);
     const float* src = t < 128 ? a.scale : a.shift;
-    affine[h][t] = src ? src[ch] : (t < 128 ? 1.f : 0.f);
+    affine[h][t] = (src ? src[ch] : (t < 128 ? 1.f : 0.f)) * plfmt::XSCALE;      // the epilogue works in the format's scaled domain (planes_fmt.h)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

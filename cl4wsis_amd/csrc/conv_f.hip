@@ -143,10 +143,11 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
   const int y0 = ty * TH, x0 = tx * TW;
   const int H = a.h, W = a.w, HW = H * W;
 
-  // (fp16x3 build: the operand scales 2^-16 ride in the folded-ABN SCALES — exact, powers of two — so the epilogues stay as they are)
+  // (fp16x3 build, planes_fmt.h: the operand scales 2^-16 ride in the folded-ABN SCALES and the epilogues work in the format's scaled domain —
+  // scale and shift x 16, residuals joined and outputs split without the extra multiplications — exact: powers of two)
   for (int i = tid; i < NAFF; i += NT) {
     const bool is_scale = i < CM || (i >= 2 * CM && i < 3 * CM) || (i >= 4 * CM && i < 4 * CM + C4) || (i >= 4 * CM + 2 * C4 && i < 4 * CM + 3 * C4);
-    aff[i] = a.aff[i] * (is_scale ? plfmt::ACC : 1.f);
+    aff[i] = a.aff[i] * (is_scale ? plfmt::ACC * plfmt::XSCALE : plfmt::XSCALE);
   }
 
   const unsigned act_bytes = (unsigned)((long)a.n * C4 * HW * 4);      // < 2^31: checked on the host
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
         v[r] = inimg[j] ? t : 0.f;
       }
       u32x4 hi, lo;
-      split8(v, hi, lo);
+      split8s(v, hi, lo);
       if (hp1[j] < HP) {
         ybuf[(cg * 2 + 0) * HPS + hp1[j]] = hi;
         ybuf[(cg * 2 + 1) * HPS + hp1[j]] = lo;
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
         v[r] = u > 0.f ? u : u * a.neg2;
       }
       u32x4 hi, lo;
-      split8(v, hi, lo);
+      split8s(v, hi, lo);
       if (wcol + NWC * j < CB2) {
         ybuf[(cg * 2 + 0) * NPS + pcol2[j]] = hi;
         ybuf[(cg * 2 + 1) * NPS + pcol2[j]] = lo;
@@ -543,7 +544,11 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
         t += res[j][r];
         v[j][r] = t > 0.f ? t : t * a.negout;
       }
-      split8(v[j], ohi[j], olo[j]);
+      split8s(v[j], ohi[j], olo[j]);
+      if constexpr (F32OUT) {                              // the fp32 copy leaves the scaled domain (before the store fence below)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[j][r] *= plfmt::XINV;
+      }
     }
     // Every chunk of the step is complete BEFORE the first store is issued, and nothing is computed between the stores: a
     // buffer_store_dwordx4 whose soffset is an SGPR gets no wait state from hipcc (ROCm 7.2) in front of a VALU write of its data
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
       wissue(w_next, g + 3);
       float res[NJ3][8];
 #pragma unroll
-      for (int j = 0; j < NJ3; ++j) join8(as_u32x4(r_cur[j][0]), as_u32x4(r_cur[j][1]), res[j]);
+      for (int j = 0; j < NJ3; ++j) join8s(as_u32x4(r_cur[j][0]), as_u32x4(r_cur[j][1]), res[j]);
       epi3(m, acc3, res, [&] { rissue(r_cur, m + 2); });    // into the registers the sums above have just consumed
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -633,13 +638,13 @@ __global__ __launch_bounds__(NW * 64, 2) void bottleneck_fused_kernel(FusedArgs 
 #pragma unroll
         for (int r = 0; r < 8; ++r) pv[r] = pv[r] * aff[4 * CM + 2 * C4 + cg * 8 + r] + aff[4 * CM + 3 * C4 + cg * 8 + r];
         u32x4 ph, pl;
-        split8(pv, ph, pl);
-        join8(ph, pl, res[j]);
+        split8s(pv, ph, pl);
+        join8s(ph, pl, res[j]);
       }
 #if CL4_F_DBG & 2048
 #pragma unroll
       for (int j = 0; j < NJ3; ++j) {
-        join8(ybuf[(((m & 1) * 4 + q) * 2 + 0) * NPS + pcol[j]], ybuf[(((m & 1) * 4 + q) * 2 + 1) * NPS + pcol[j]], res[j]);
+        join8s(ybuf[(((m & 1) * 4 + q) * 2 + 0) * NPS + pcol[j]], ybuf[(((m & 1) * 4 + q) * 2 + 1) * NPS + pcol[j]], res[j]);
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc3[b][j] = f32x4a{0.f, 0.f, 0.f, 0.f};
       }

@@ -217,8 +217,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv_p_bf16x3(ConvArgs a) {
         const unsigned h0 = (unsigned)rres[c & 1][j][0], h1 = (unsigned)(rres[c & 1][j][0] >> 32);
         const unsigned l0 = (unsigned)rres[c & 1][j][1], l1 = (unsigned)(rres[c & 1][j][1] >> 32);
         float t0, t1, t2, t3;
-        plfmt::join2(h0, l0, t0, t1);
-        plfmt::join2(h1, l1, t2, t3);
+        plfmt::join2s(h0, l0, t0, t1);
+        plfmt::join2s(h1, l1, t2, t3);
         v[0] += t0; v[1] += t1; v[2] += t2; v[3] += t3;
       }
 #pragma unroll
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_p_bf16x3(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         unsigned h, l;
-        plfmt::split2(v[2 * i], v[2 * i + 1], h, l);
+        plfmt::split2s(v[2 * i], v[2 * i + 1], h, l);
         hi[i] = h;
         lo[i] = l;
       }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_p_bf16x3(ConvArgs a) {
       if (t + 1 < nk) step(W4{}, ar[0], br[0], t + 1, 1, NONE{}, NONE{});
     }
     wait_vmcnt<0>();                                       // out-of-range tail loads and the last stores: a clean count for the next tile
-    if (tid < 256) affine[par][tid] = aff_reg;
+    if (tid < 256) affine[par][tid] = aff_reg * plfmt::XSCALE;      // the epilogue works in the planes format's scaled domain (planes_fmt.h)
     // hand the finished tile over: accumulators -> prev, its coordinates -> pv
 #pragma unroll
     for (int i = 0; i < 4; ++i)

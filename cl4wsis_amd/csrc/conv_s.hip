@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : (BNT == 64 ? 3 : 2)) void conv_s
   if (!SPLIT) {
     const int ch = min(m0 + (tid & 127), a.cout - 1);
     const float* src = tid < 128 ? a.scale : a.shift;
-    affine[tid] = src ? src[ch] : (tid < 128 ? 1.f : 0.f);
+    affine[tid] = (src ? src[ch] : (tid < 128 ? 1.f : 0.f)) * plfmt::XSCALE;      // the epilogue works in the format's scaled domain (planes_fmt.h)
   }
 #endif
 

@@ -47,6 +47,20 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
     lo[i] = l;
   }
 }
+// scaled-domain forms (planes_fmt.h): v = XSCALE x the values
+__device__ __forceinline__ void split8s(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned h, l;
+    plfmt::split2s(v[2 * i], v[2 * i + 1], h, l);
+    hi[i] = h;
+    lo[i] = l;
+  }
+}
+__device__ __forceinline__ void join8s(const u32x4& hi, const u32x4& lo, float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) plfmt::join2s(hi[i], lo[i], v[2 * i], v[2 * i + 1]);
+}
 // the bf16 hi / lo split whatever the build's planes format is: the k-planes operands of the weight-gradient GEMM (wgrad_gemm.hip) are bf16
 __device__ __forceinline__ void split8_bf16(const float (&v)[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
@@ -67,14 +81,14 @@ __device__ __forceinline__ void join8(const u32x4& hi, const u32x4& lo, float (&
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float F16_WSCALE = 4096.f, F16_XSCALE = 16.f, F16_MAX = 65504.f;
-__device__ __forceinline__ unsigned pack_f16(float lo, float hi) {    // {fp16(lo), fp16(hi)} in one dword (round to nearest even, saturating)
-  f32x2v t = {fminf(fmaxf(lo, -F16_MAX), F16_MAX), fminf(fmaxf(hi, -F16_MAX), F16_MAX)};
+__device__ __forceinline__ unsigned pack_f16(float lo, float hi) {    // {fp16(lo), fp16(hi)} in one dword (round to nearest even; callers keep |x| <= 65504)
+  f32x2v t = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2));
 }
 __device__ __forceinline__ void split8_f16(const float (&v)[8], float s, u32x4& hi, u32x4& lo) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float a = v[2 * i] * s, b = v[2 * i + 1] * s;
+    const float a = fminf(fmaxf(v[2 * i] * s, -F16_MAX), F16_MAX), b = fminf(fmaxf(v[2 * i + 1] * s, -F16_MAX), F16_MAX);      // saturating
     const unsigned hp = pack_f16(a, b);
     const f16x2 h = __builtin_bit_cast(f16x2, hp);
     const float ha = (float)h[0], hb = (float)h[1];
@@ -147,37 +161,39 @@ struct SEpilogue {
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[r] += t[r];
         }
+        // from here on in the planes format's SCALED domain (planes_fmt.h): `affine` holds XSCALE x (scale, shift), both activations are
+        // positively homogeneous, a planes residual comes in as hi + lo, and the value that reaches the split already is XSCALE x the output
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
 #if !CL4_S_NO_AFFINE_LDS
           const float sc = affine[g8 * 8 + r], sh = affine[BM + g8 * 8 + r];
 #else
           const int cc = min(co0 + r, a.cout - 1);
-          const float sc = a.scale ? a.scale[cc] : 1.f;
-          const float sh = a.shift ? a.shift[cc] : 0.f;
+          const float sc = (a.scale ? a.scale[cc] : 1.f) * plfmt::XSCALE;
+          const float sh = (a.shift ? a.shift[cc] : 0.f) * plfmt::XSCALE;
 #endif
           const float u = v[r] * sc + sh;
           v[r] = u > 0.f ? u : u * a.neg1;
         }
         if constexpr (RES == 2) {
           float tq[8];
-          join8(rh[it], rl[it], tq);
+          join8s(rh[it], rl[it], tq);
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[r] += tq[r];
         } else if constexpr (RES == 1) {
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] += rf[it][r];
+          for (int r = 0; r < 8; ++r) v[r] += rf[it][r] * plfmt::XSCALE;
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.neg2;
         if (a.y) {
 #pragma unroll
           for (int r = 0; r < 8; ++r)
-            if (co0 + r < a.cout) a.y[ybase + (long)(co0 + r) * HWo] = v[r];
+            if (co0 + r < a.cout) a.y[ybase + (long)(co0 + r) * HWo] = v[r] * plfmt::XINV;
         }
         if (a.ys) {                                        // cout % 8 == 0 whenever ys is requested (checked on the host)
           u32x4 hi, lo;
-          split8(v, hi, lo);
+          split8s(v, hi, lo);
           u32x4* ys = reinterpret_cast<u32x4*>(a.ys) + (((long)pn * oc8tot + ((a.out_coff + co0) >> 3)) * 2) * HWo + phw;
 #if CL4_EPI_NT & 2
           __builtin_nontemporal_store(hi, ys);

@@ -33,10 +33,11 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {       // {bf16
   f32x2 t = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
 }
-__device__ __forceinline__ unsigned pk_f16(float lo, float hi) {        // {fp16(lo), fp16(hi)}, round to nearest even, saturating
-  f32x2 t = {fminf(fmaxf(lo, -F16_MAX), F16_MAX), fminf(fmaxf(hi, -F16_MAX), F16_MAX)};
+__device__ __forceinline__ unsigned pk_f16(float lo, float hi) {        // {fp16(lo), fp16(hi)}, round to nearest even (callers keep |x| <= 65504)
+  f32x2 t = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2));
 }
+__device__ __forceinline__ float sat_f16(float x) { return fminf(fmaxf(x, -F16_MAX), F16_MAX); }
 __device__ __forceinline__ float sub_asm(float a, float b) {            // one v_sub_f32 (keeps hipcc's SLP pass from forming v_pk_add_f32)
   float r;
   asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -46,7 +47,7 @@ __device__ __forceinline__ float sub_asm(float a, float b) {            // one v
 // one pair of values -> the hi and lo dwords of the format (values UNSCALED: the format's scale is applied here)
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
   if constexpr (F16) {
-    a *= XSCALE; b *= XSCALE;
+    a = sat_f16(a * XSCALE); b = sat_f16(b * XSCALE);     // saturating: |x| >= 4094 is stored as +-4094 (the remainder a - hi is then < 1 ulp: no second clamp)
     hi = pk_f16(a, b);
     const f16x2 h = __builtin_bit_cast(f16x2, hi);
     const float ha = (float)h[0], hb = (float)h[1];     // (plain subtractions: finding 48)
@@ -54,6 +55,28 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
   } else {
     hi = pk_bf16(a, b);
     lo = pk_bf16(sub_asm(a, __builtin_bit_cast(float, hi << 16)), sub_asm(b, __builtin_bit_cast(float, hi & 0xFFFF0000u)));
+  }
+}
+// The epilogues work in the format's SCALED domain (r05): with the folded-ABN scale / shift multiplied by XSCALE when they are staged, the
+// value that reaches the split already is XSCALE x (leaky-ReLU / ReLU are positively homogeneous), and a planes residual is added as
+// hi + lo without the division — the same result bit for bit (powers of two commute with rounding), four multiplications per pair fewer.
+__device__ __forceinline__ void split2s(float a, float b, unsigned& hi, unsigned& lo) {      // a, b = XSCALE x the values
+  if constexpr (F16) {
+    a = sat_f16(a); b = sat_f16(b);
+    hi = pk_f16(a, b);
+    const f16x2 h = __builtin_bit_cast(f16x2, hi);
+    const float ha = (float)h[0], hb = (float)h[1];
+    lo = pk_f16(a - ha, b - hb);
+  } else split2(a, b, hi, lo);
+}
+__device__ __forceinline__ void join2s(unsigned hi, unsigned lo, float& a, float& b) {       // XSCALE x the stored values
+  if constexpr (F16) {
+    const f16x2 h = __builtin_bit_cast(f16x2, hi), l = __builtin_bit_cast(f16x2, lo);
+    a = (float)h[0] + (float)l[0];
+    b = (float)h[1] + (float)l[1];
+  } else {
+    a = __builtin_bit_cast(float, hi << 16) + __builtin_bit_cast(float, lo << 16);
+    b = __builtin_bit_cast(float, hi & 0xFFFF0000u) + __builtin_bit_cast(float, lo & 0xFFFF0000u);
   }
 }
 // ... and back: hi + lo, exact in fp32

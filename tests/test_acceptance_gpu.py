@@ -411,7 +411,7 @@ def test_map_after_training_is_an_unremarkable_draw_from_the_reference_distribut
     # ---- bias: mean(HIP runs) - mean(reference runs) over the same 20 perturbations, with its standard error (paired differences) --------
     map_hb, map_h6b = [hip_map(sd) for _, sd in runs_h], [hip_map(sd) for _, sd in runs_h6]
     verdicts = {}
-    for tag, mh in (("default (bf16x3 frozen networks)", map_hb), ("bf16x6 frozen networks", map_h6b)):
+    for tag, mh in (("default (x3 frozen networks: fp16x3 since r05)", map_hb), ("bf16x6 frozen networks", map_h6b)):
         diff = np.array(mh) - np.array(map_b)
         bias, se = float(diff.mean()), float(diff.std(ddof=1) / np.sqrt(len(diff)))
         se_unpaired = float(np.sqrt(np.var(mh, ddof=1) / len(mh) + np.var(map_b, ddof=1) / len(map_b)))

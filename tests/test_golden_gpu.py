@@ -126,9 +126,11 @@ def test_gradient_norms_match_reference_well_conditioned(gpu, monkeypatch, froze
     for i in np.argsort(-dev)[:4]:
         print(f"GRADNORM193 worst {str(gold['grad_names'][i]):60s} ours {norms[i]:.6e} reference {gold['grad_norms'][i]:.6e} dev {dev[i]:.2e}")
     print(f"GRADNORM193 frozen precision {frozen_precision}: median", float(np.median(dev)), "max", float(dev.max()))
-    pool = np.array([str(n).endswith("aspp_pooling.1.weight") for n in gold["grad_names"]])      # cancellation-dominated (finding 29): own bar
-    assert len(dev) == 61 and (dev[~pool] <= 2e-2).all(), [(str(gold["grad_names"][i]), float(dev[i])) for i in np.flatnonzero((dev > 2e-2) & ~pool)]
-    assert (dev[pool] <= 5e-2).all() and float(np.median(dev)) < 2e-3
+    # 2e-2 on EVERY tensor (measured r05, fp16x3 planes: max 6.6e-3 at the default, 4.0e-3 with bf16x6 frozen networks). A bf16x3 build of the
+    # library (CL4_F16_PLANES=0: the r02-r04 arithmetic) puts two tensors at 3.2e-2 — the frozen features' 1e-4 — and is held to 4e-2.
+    bar = 2e-2 if (ops.planes_f16() or frozen_precision != 1) else 4e-2
+    assert len(dev) == 61 and (dev <= bar).all(), [(str(gold["grad_names"][i]), float(dev[i])) for i in np.flatnonzero(dev > bar)]
+    assert float(np.median(dev)) < 2e-3
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "label_*.npz"))))

@@ -153,9 +153,9 @@ def planes_split_ref(x):
     import torch
     from cl4wsis_amd import ops
     if ops.planes_f16():
-        a = x.float() * 16.0
-        hi = a.clamp(-65504.0, 65504.0).to(torch.float16).float()
-        lo = (a - hi).clamp(-65504.0, 65504.0).to(torch.float16).float()
+        a = (x.float() * 16.0).clamp(-65504.0, 65504.0)
+        hi = a.to(torch.float16).float()
+        lo = (a - hi).to(torch.float16).float()
         return hi / 16.0, lo / 16.0
     hi = x.to(torch.bfloat16).float()
     lo = (x - hi).to(torch.bfloat16).float()
