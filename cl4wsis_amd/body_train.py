@@ -38,15 +38,24 @@ def _dgrad_weight(conv):
     return CACHE.get(conv, ("dgrad", PRECISION), (conv.weight,), lambda: ops.dgrad_weight(conv.weight.detach(), PRECISION))
 
 
-def conv_abn_train(x, conv, bn, group=None, xs_cache=None):
-    """conv -> ABN (batch statistics) -> activation. Returns (y, record)."""
+def _twin_pays(c):
+    """Does an activation of c channels get a planes twin from its producer? fp16x3 arithmetic, a planes-kernel shape downstream."""
+    return PRECISION == 3 and ops.PRODUCER_PLANES and ops.planes_f16() and c % 32 == 0 and c >= 128
+
+
+def conv_abn_train(x, conv, bn, group=None, xs_cache=None, emit_planes=False):
+    """conv -> ABN (batch statistics) -> activation. Returns (y, record). `emit_planes`: the ABN apply also writes the planes twin of y
+    (the next convolution is an fp16x3 launch: no conversion pass)."""
     k = conv.kernel_size[0]
     r = _Rec()
     r.x = x
-    r.z = ops.conv2d(x, packed_weight(conv, PRECISION), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], x6=True, xs_cache=xs_cache)
+    has_twin = getattr(x, "_cl4_planes", None) is not None
+    r.z = ops.conv2d(x, packed_weight(conv, PRECISION, force_f16=PRECISION == 3 and has_twin), k, stride=conv.stride[0], pad=conv.padding[0],
+                     dil=conv.dilation[0], x6=True, xs_cache=xs_cache)
     act, slope = bn.act_code()
     r.y, r.mean, r.var, r.count = ops.abn_train_forward(r.z, gamma_of(bn), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                                        bn.momentum, bn.eps, act, slope, group)
+                                                        bn.momentum, bn.eps, act, slope, group,
+                                                        want_planes=emit_planes and _twin_pays(conv.out_channels))
     CACHE.touch(bn.running_mean)
     CACHE.touch(bn.running_var)
     return r.y, r
@@ -71,15 +80,15 @@ def block_forward(blk, x, group=None):
     """ResidualBlock.forward in training mode — modules/residual.py:84-97."""
     c = blk.convs
     shared = {} if hasattr(blk, "proj_conv") else None      # fp16x3: conv1 and the projection read one converted copy of x (same stride only)
-    a1, r1 = conv_abn_train(x, c.conv1, c.bn1, group, xs_cache=shared)
-    a2, r2 = conv_abn_train(a1, c.conv2, c.bn2, group)
+    a1, r1 = conv_abn_train(x, c.conv1, c.bn1, group, xs_cache=shared, emit_planes=True)      # -> conv2 (3x3)
+    a2, r2 = conv_abn_train(a1, c.conv2, c.bn2, group, emit_planes=True)                      # -> conv3 (1x1, expanding)
     b3, r3 = conv_abn_train(a2, c.conv3, c.bn3, group)
     rp = None
     sc = x
     if hasattr(blk, "proj_conv"):
         sc, rp = conv_abn_train(x, blk.proj_conv, blk.proj_bn, group, xs_cache=shared)
     act, slope = c.bn1.act_code()
-    out = ops.add_act(b3, sc, act, slope)
+    out = ops.add_act(b3, sc, act, slope, want_planes=_twin_pays(b3.shape[1]))      # -> the next block's conv1 / projection, the heads
     return out, (r1, r2, r3, rp, out)
 
 

@@ -6,6 +6,7 @@
 //   * add_act / act_bwd  : residual add + in-place leaky-ReLU of modules/residual.py:91-93 and its derivative;
 //   * transpose_flip     : w[co][ci][ky][kx] -> wt[ci][co][k-1-ky][k-1-kx], the weight of the input-gradient conv.
 #include "common.h"
+#include "planes_fmt.h"
 
 namespace {
 
@@ -69,6 +70,36 @@ __global__ void add_act_kernel(const float* __restrict__ a, const float* __restr
                                float slope) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = cl4::apply_act(a[i] + b[i], act, slope);
+}
+
+// add_act for contiguous [n][c][hw] tensors with c % 8 == 0 that also writes the two-plane twin of y (r05, see bn_apply_planes_kernel)
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+__global__ void add_act_planes_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, u32x4b* __restrict__ ys,
+                                      int n, int c, int hw, int act, float slope) {
+  const int c8 = c >> 3;
+  const long total = (long)n * c8 * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % hw);
+    const long r = i / hw;
+    const int g = (int)(r % c8), im = (int)(r / c8);
+    const long base = ((long)im * c + g * 8) * hw + px;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = cl4::apply_act(a[base + (long)j * hw] + b[base + (long)j * hw], act, slope);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[base + (long)j * hw] = v[j];
+    u32x4b hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned h_, l_;
+      plfmt::split2(v[2 * q], v[2 * q + 1], h_, l_);
+      hi[q] = h_;
+      lo[q] = l_;
+    }
+    u32x4b* dst = ys + (((long)im * c8 + g) * 2) * hw + px;
+    dst[0] = hi;
+    dst[hw] = lo;
+  }
 }
 
 // dx = dy * act'(pre-activation); for ReLU / leaky-ReLU the sign of the output y equals the sign of the pre-activation.
@@ -162,6 +193,13 @@ extern "C" int cl4_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, 
 extern "C" int cl4_add_act(const float* a, const float* b, float* y, long n, int act, float slope, void* stream) {
   CL4_REQUIRE(a && b && y && n > 0, "add_act: bad arguments");
   hipLaunchKernelGGL(add_act_kernel, dim3(cl4::stream_grid(n, 256)), dim3(256), 0, cl4::as_stream(stream), a, b, y, n, act, slope);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_add_act_planes(const float* a, const float* b, float* y, void* ys, int n, int c, int hw, int act, float slope, void* stream) {
+  CL4_REQUIRE(a && b && y && ys && n > 0 && c > 0 && hw > 0 && c % 8 == 0, "add_act_planes: bad arguments (c %% 8 == 0)");
+  const long total = (long)n * (c >> 3) * hw;
+  hipLaunchKernelGGL(add_act_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), a, b, y, (u32x4b*)ys, n, c, hw, act, slope);
   return cl4::launch_status();
 }
 

@@ -4,6 +4,7 @@
 // the activation once with the pixel index on the lane; per-channel sums are kept in fp64 so the
 // single-pass variance is as accurate as PyTorch's two-pass one.
 #include "common.h"
+#include "planes_fmt.h"
 
 namespace {
 
@@ -141,6 +142,45 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, float* __restrict__
     v = cl4::apply_act(v, act, slope);
     if (kp) v = kp[p] ? v * keep_scale : 0.f;
     yp[p] = v;
+  }
+}
+
+// bn_apply_kernel for a contiguous [n][c][hw] tensor with c % 8 == 0 that ALSO writes the two-plane twin of y (planes_fmt.h) — the operand
+// the next convolution multiplies (r05: the fp16x3 route of the differentiated networks reads it instead of converting y in a pass of its
+// own). One thread per (image, 8-channel group, pixel): 8 strided dword loads and stores (coalesced along pixels), two 16-byte chunk stores.
+// The per-element expression is bn_apply_kernel's, so y is bit-identical to the plain launch.
+typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+__global__ void bn_apply_planes_kernel(const float* __restrict__ x, float* __restrict__ y, u32x4n* __restrict__ ys, const float* __restrict__ mean,
+                                       const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float eps, int act, float slope, int n, int c, int hw) {
+  const int c8 = c >> 3;
+  const long total = (long)n * c8 * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % hw);
+    const long r = i / hw;
+    const int g = (int)(r % c8), im = (int)(r / c8);
+    const long base = ((long)im * c + g * 8) * hw + px;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = g * 8 + j;
+      const float rstd = 1.f / sqrtf(var[ch] + eps);
+      const float mu = mean[ch], gm = gamma ? gamma[ch] : 1.f, bb = beta ? beta[ch] : 0.f;
+      v[j] = cl4::apply_act((x[base + (long)j * hw] - mu) * rstd * gm + bb, act, slope);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[base + (long)j * hw] = v[j];
+    u32x4n hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned h_, l_;
+      plfmt::split2(v[2 * q], v[2 * q + 1], h_, l_);
+      hi[q] = h_;
+      lo[q] = l_;
+    }
+    u32x4n* dst = ys + (((long)im * c8 + g) * 2) * hw + px;
+    dst[0] = hi;
+    dst[hw] = lo;
   }
 }
 
@@ -390,6 +430,16 @@ extern "C" int cl4_bn_apply(const float* x, float* y, int n, int c, int hw, int 
   long total = (long)n * c * hw;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, cl4::as_stream(stream), x, y, mean,
                      var, gamma, beta, eps, act, slope, s, y_ctot, y_coff, keep, keep_scale);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_bn_apply_planes(const float* x, float* y, void* ys, int n, int c, int hw, const float* mean, const float* var,
+                                   const float* gamma, const float* beta, float eps, int act, float slope, void* stream) {
+  CL4_REQUIRE(x && y && ys && mean && var, "bn_apply_planes: null pointer");
+  CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0, "bn_apply_planes: c %% 8 == 0 required");
+  const long total = (long)n * (c >> 3) * hw;
+  hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, (u32x4n*)ys, mean, var,
+                     gamma, beta, eps, act, slope, n, c, hw);
   return cl4::launch_status();
 }
 

@@ -8,10 +8,10 @@ from .body_train import _Rec, _dgrad_weight, conv_abn_backward, conv_abn_train
 from .nn import CACHE, gamma_grad, gamma_of, packed_weight
 
 
-def _abn_fwd(z, bn, group):
+def _abn_fwd(z, bn, group, emit_planes=False):
     act, slope = bn.act_code()
     y, mean, var, count = ops.abn_train_forward(z, gamma_of(bn), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                                bn.momentum, bn.eps, act, slope, group)
+                                                bn.momentum, bn.eps, act, slope, group, want_planes=emit_planes and BT._twin_pays(z.shape[1]))
     CACHE.touch(bn.running_mean)
     CACHE.touch(bn.running_var)
     return y, (z, mean, var, count)
@@ -48,8 +48,8 @@ def deeplab_forward(head, x, group=None):
     for i, conv in enumerate(head.map_convs):
         ops.conv2d(x, packed_weight(conv, BT.PRECISION), conv.kernel_size[0], pad=conv.padding[0], dil=conv.dilation[0], out=cat, out_coff=i * hid, x6=True,
                    xs_cache=shared)
-    a, r_map = _abn_fwd(cat, head.map_bn, group)
-    out = ops.conv2d(a, packed_weight(head.red_conv, BT.PRECISION), 1, x6=True)
+    a, r_map = _abn_fwd(cat, head.map_bn, group, emit_planes=True)
+    out = ops.conv2d(a, packed_weight(head.red_conv, BT.PRECISION, force_f16=BT.PRECISION == 3 and getattr(a, "_cl4_planes", None) is not None), 1, x6=True)
     g = ops.global_mean(x)                                            # [n, cin, 1, 1]
     pz = ops.conv2d(g, packed_weight(head.global_pooling_conv, BT.PRECISION), 1)
     pa, r_pool = _abn_fwd(pz, head.global_pooling_bn, group)
@@ -113,7 +113,7 @@ def cls_backward(cls, x, dy, grad_of, need_dx=True):
 # PseudoLabeler (wss/modules.py:322-343)
 # ---------------------------------------------------------------------------------------------------------------------
 def pseudolabeler_forward(pl, x, group=None):
-    a1, r1 = conv_abn_train(x, pl.conv1, pl.norm1, group)
+    a1, r1 = conv_abn_train(x, pl.conv1, pl.norm1, group, emit_planes=True)
     a2, r2 = conv_abn_train(a1, pl.conv2, pl.norm2, group)
     from .nn import conv_bias
     return conv_bias(a2, pl.cls), (r1, r2, a2)

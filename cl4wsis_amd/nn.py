@@ -123,11 +123,13 @@ class _Cache:
 CACHE = _Cache()
 
 
-def packed_weight(conv, precision=None):
-    """The conv's weight in the operand layout of `precision` (default: ops.CONV_PRECISION), cached until it changes."""
+def packed_weight(conv, precision=None, force_f16=False):
+    """The conv's weight in the operand layout of `precision` (default: ops.CONV_PRECISION), cached until it changes. `force_f16`
+    (precision 3): the fp16x3 pack also for a 1x1 layer that shrinks the channel count — its input arrives with a planes twin made by the
+    producer (ops.bn_apply / add_act want_planes), so there is no conversion pass to lose against."""
     w = conv.weight
     prec = ops.CONV_PRECISION if precision is None else precision
-    return CACHE.get(conv, "wp%d" % prec, (w,), lambda: ops.pack_conv_weight(w.detach(), prec))
+    return CACHE.get(conv, "wp%d%s" % (prec, "f" if force_f16 else ""), (w,), lambda: ops.pack_conv_weight(w.detach(), prec, force_f16=force_f16))
 
 
 def folded_bn(bn, lo=0, hi=None):

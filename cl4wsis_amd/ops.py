@@ -1009,11 +1009,24 @@ def bn_train_fwd(x, gamma, beta, running_mean=None, running_var=None, momentum=0
     return out, mean, var
 
 
+PRODUCER_PLANES = os.environ.get("CL4_PRODUCER_PLANES", "1") != "0"     # r05: train-mode ABN apply / residual add write the planes twin the next fp16x3 convolution reads
+
+
 def bn_apply(x, mean, var, gamma, beta, eps=1e-5, act=ACT_RELU, slope=0.01, keep=None, keep_scale=1.0,
-             c=None, x_coff=0, out=None, out_coff=0):
+             c=None, x_coff=0, out=None, out_coff=0, want_planes=False):
+    """`want_planes` (whole contiguous tensors, c % 8 == 0, fp16x3 build): also write the two-plane twin of the output and attach it as
+    `y._cl4_planes` — what ops.conv2d's fp16x3 route multiplies instead of converting y in a pass of its own."""
     n, x_ctot, h, w = x.shape
     if c is None:
         c = x_ctot - x_coff
+    if (want_planes and PRODUCER_PLANES and planes_f16() and out is None and keep is None and x_coff == 0 and c == x_ctot and c % 8 == 0
+            and x.is_contiguous()):
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        ps = Planes(n, c, h, w, x.device)
+        call("cl4_bn_apply_planes", ptr(x), ptr(out), ptr(ps.data), n, c, h * w, ptr(mean), ptr(var), ptr(gamma), ptr(beta), C.c_float(eps), act,
+             C.c_float(slope), stream())
+        out._cl4_planes = ps
+        return out
     if out is None:
         out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
         out_coff = 0
@@ -1093,7 +1106,7 @@ def _allreduce_sum(t, group):
 
 
 def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=ACT_LEAKY, slope=0.01,
-                      group=None, extra_sums=None):
+                      group=None, extra_sums=None, want_planes=False):
     """InPlaceABNSync in training mode (segmentation_module.py:17-29): batch statistics over every rank of
     `group`, then BN + leaky-ReLU / identity. Returns (y, mean, var, count). `extra_sums` ([c*2] doubles, count) adds the
     statistics of shards held elsewhere — used by the tests to emulate a second rank on one GPU."""
@@ -1112,7 +1125,7 @@ def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momen
     var = torch.empty(c, dtype=torch.float32, device=x.device)
     call("cl4_bn_sync_stats_final", ptr(sums), C.c_double(count), ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
          C.c_float(momentum), c, stream())
-    y = bn_apply(x, mean, var, gamma, beta, eps=eps, act=act, slope=slope)
+    y = bn_apply(x, mean, var, gamma, beta, eps=eps, act=act, slope=slope, want_planes=want_planes)
     return y, mean, var, count
 
 
@@ -1614,10 +1627,16 @@ def maxpool3x3s2_bwd(x, dy):
     return dx
 
 
-def add_act(a, b, act=ACT_LEAKY, slope=0.01):
+def add_act(a, b, act=ACT_LEAKY, slope=0.01, want_planes=False):
     if a.shape != b.shape:
         raise RuntimeError("add_act: shape mismatch")
     y = torch.empty_like(a)
+    if (want_planes and PRODUCER_PLANES and planes_f16() and a.dim() == 4 and a.shape[1] % 8 == 0 and a.is_contiguous() and b.is_contiguous()):
+        n, c, h, w = a.shape
+        ps = Planes(n, c, h, w, a.device)
+        call("cl4_add_act_planes", ptr(a), ptr(b), ptr(y), ptr(ps.data), n, c, h * w, act, C.c_float(slope), stream())
+        y._cl4_planes = ps
+        return y
     call("cl4_add_act", ptr(a), ptr(b), ptr(y), a.numel(), act, C.c_float(slope), stream())
     return y
 

@@ -598,6 +598,13 @@ int cl4_to_planes_f16(const float* x, void* xs, int n, int ctot, int coff, int c
 int cl4_conv2d_fwd_planes_f16(const cl4_conv_desc* d, const void* xs, const float* xs_scale, const float* wp, const float* scale,
                               const float* shift, const float* pre, const float* post, float* y, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* Producer-side planes (r05): cl4_bn_apply / cl4_add_act on contiguous [n][c][hw] tensors (c % 8 == 0) that also write the two-plane twin of
+ * their output (the build's planes format), so that the convolution behind them multiplies it without a conversion pass of its own:
+ * train-mode InPlaceABN apply (segmentation_module.py:17-29) and the residual add + activation of modules/residual.py:91-97. y is bit-identical
+ * to the plain entry points. */
+int cl4_bn_apply_planes(const float* x, float* y, void* ys, int n, int c, int hw, const float* mean, const float* var, const float* gamma,
+                        const float* beta, float eps, int act, float slope, void* stream);
+int cl4_add_act_planes(const float* a, const float* b, float* y, void* ys, int n, int c, int hw, int act, float slope, void* stream);
 int cl4_abs_eps(const float* w, float* out, int n, float eps, void* stream);
 int cl4_sign_axpy(float* y, const float* x, const float* w, int n, void* stream);
 

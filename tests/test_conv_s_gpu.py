@@ -34,7 +34,7 @@ def test_planes_round_trip_is_the_bf16_split(gpu):
     x = torch.randn(3, 40, 9, 7, generator=g) * (torch.logspace(-4, 2, 40) if f16 else torch.logspace(-6, 6, 40))[None, :, None, None]
     x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1.0, -3.5])
     if f16:
-        x[1, 8, 0, :3] = torch.tensor([5000.0, -1e9, 3e-9])          # beyond the range: saturates at +-65504 / 16 + its lo half; below it: flushed
+        x[1, 8, 0, :3] = torch.tensor([5000.0, -1e9, 1e-9])          # beyond the range: saturates at +-65504 / 16 + its lo half; below it: flushed
     ps = ops.to_planes(x.to(gpu), in_coff=8, c=24)
     hi, lo = _split_ref(x[:, 8:32])
     back = ops.from_planes(ps).cpu()
