@@ -9,7 +9,7 @@ mkdir -p gpurun_out/$TAG
 timeout -k 10 1000 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err || { tail -5 gpurun_out/$TAG/bench.err; exit 1; }
 tail -c 1200 gpurun_out/$TAG/bench.json
 export TMPDIR=/tmp
-cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/prof -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $R/gpurun_out/$TAG/prof_bench.json 2> $R/gpurun_out/$TAG/prof.err
+cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/prof -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-phase1 > $R/gpurun_out/$TAG/prof_bench.json 2> $R/gpurun_out/$TAG/prof.err
 cd $R
 # steps of the profiled process: 0-2 warm-up, 3-12 timed graph replays, 13-14 eager roofline leg, 15-16 + 17-26 structured-labels leg
 python tools/roofline_leg_stats.py gpurun_out/$TAG/prof 13 2 > gpurun_out/$TAG/roofline_leg.txt

@@ -5,6 +5,6 @@ cd $R
 O=gpurun_out/${1:-r02g}_small
 mkdir -p $O
 for b in 8 4 2; do
-  CL4_BENCH_PER_GPU_BATCH=$b timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-structured > $O/b$b.json 2> $O/b$b.err || { tail -5 $O/b$b.err; exit 1; }
+  CL4_BENCH_PER_GPU_BATCH=$b timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-structured --no-phase1 > $O/b$b.json 2> $O/b$b.err || { tail -5 $O/b$b.err; exit 1; }
   python -c "import json; d=json.load(open('$O/b$b.json')); print('per-GPU batch $b: ms_per_step', round(d['ms_per_step'],3), 'images/s', round(d['value'],1))"
 done

@@ -6,7 +6,7 @@ cd $R
 O=gpurun_out/${1:-r02g}_solo
 mkdir -p $O
 for b in 16 8 4 2; do
-  CL4_FORCE_COLLECTIVES=1 CL4_BENCH_PER_GPU_BATCH=$b MASTER_PORT=$((29600 + b)) timeout -k 10 200 python bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --no-structured \
+  CL4_FORCE_COLLECTIVES=1 CL4_BENCH_PER_GPU_BATCH=$b MASTER_PORT=$((29600 + b)) timeout -k 10 200 python bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --no-structured --no-phase1 \
     > $O/b$b.json 2> $O/b$b.err || { tail -5 $O/b$b.err; exit 1; }
   python -c "import json; d=json.loads(open('$O/b$b.json').read().strip().splitlines()[-1]); print('collective path, per-GPU batch $b: ms_per_step', round(d['ms_per_step'],3), d.get('allreduce'))"
 done
