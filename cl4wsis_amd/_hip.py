@@ -139,7 +139,7 @@ _decl("cl4_comm_init", _I, _I, _P)
 _decl("cl4_allreduce_bucket", _P, C.c_size_t, _I, _P)
 _decl("cl4_allreduce_f64", _P, C.c_size_t, _P)
 _decl("cl4_planes_format")
-_decl("cl4_bn_apply_planes", _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P)
+_decl("cl4_bn_apply_planes", _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _I, _F, _P)
 _decl("cl4_add_act_planes", _P, _P, _P, _P, _I, _I, _I, _I, _F, _P)
 _decl("cl4_pack_conv_weight_f16x3", _P, _P, _I, _I, _I, _I, _P)
 _decl("cl4_to_planes_f16", _P, _P, _I, _I, _I, _I, _I, _I, _P, _P)

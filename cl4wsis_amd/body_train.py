@@ -38,12 +38,15 @@ def _dgrad_weight(conv):
     return CACHE.get(conv, ("dgrad", PRECISION), (conv.weight,), lambda: ops.dgrad_weight(conv.weight.detach(), PRECISION))
 
 
+FUSE_BLOCK_TAIL = os.environ.get("CL4_FUSE_BLOCK_TAIL", "1") != "0"      # r05: bn3 + add + activation in one pass; shortcut gradient in the dgrad epilogue
+
+
 def _twin_pays(c):
     """Does an activation of c channels get a planes twin from its producer? fp16x3 arithmetic, a planes-kernel shape downstream."""
     return PRECISION == 3 and ops.PRODUCER_PLANES and ops.planes_f16() and c % 32 == 0 and c >= 128
 
 
-def conv_abn_train(x, conv, bn, group=None, xs_cache=None, emit_planes=False):
+def conv_abn_train(x, conv, bn, group=None, xs_cache=None, emit_planes=False, post=None, act2=ops.ACT_NONE, slope2=0.01):
     """conv -> ABN (batch statistics) -> activation. Returns (y, record). `emit_planes`: the ABN apply also writes the planes twin of y
     (the next convolution is an fp16x3 launch: no conversion pass)."""
     k = conv.kernel_size[0]
@@ -55,13 +58,13 @@ def conv_abn_train(x, conv, bn, group=None, xs_cache=None, emit_planes=False):
     act, slope = bn.act_code()
     r.y, r.mean, r.var, r.count = ops.abn_train_forward(r.z, gamma_of(bn), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                         bn.momentum, bn.eps, act, slope, group,
-                                                        want_planes=emit_planes and _twin_pays(conv.out_channels))
+                                                        want_planes=emit_planes and _twin_pays(conv.out_channels), post=post, act2=act2, slope2=slope2)
     CACHE.touch(bn.running_mean)
     CACHE.touch(bn.running_var)
     return r.y, r
 
 
-def conv_abn_backward(r, conv, bn, dy, grad_of, need_dx=True, group=None):
+def conv_abn_backward(r, conv, bn, dy, grad_of, need_dx=True, group=None, post=None):
     act, slope = bn.act_code()
     gw, fin = gamma_grad(bn, grad_of)
     dz = ops.abn_train_backward(r.z, dy, r.mean, r.var, gamma_of(bn), bn.bias.detach(), gw, grad_of(bn.bias),
@@ -73,7 +76,7 @@ def conv_abn_backward(r, conv, bn, dy, grad_of, need_dx=True, group=None):
     if not need_dx:
         return None
     return ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(r.x.shape[2:]), k, stride=conv.stride[0], pad=conv.padding[0],
-                            dil=conv.dilation[0], x6=True)
+                            dil=conv.dilation[0], x6=True, post=post)
 
 
 def block_forward(blk, x, group=None):
@@ -82,13 +85,19 @@ def block_forward(blk, x, group=None):
     shared = {} if hasattr(blk, "proj_conv") else None      # fp16x3: conv1 and the projection read one converted copy of x (same stride only)
     a1, r1 = conv_abn_train(x, c.conv1, c.bn1, group, xs_cache=shared, emit_planes=True)      # -> conv2 (3x3)
     a2, r2 = conv_abn_train(a1, c.conv2, c.bn2, group, emit_planes=True)                      # -> conv3 (1x1, expanding)
-    b3, r3 = conv_abn_train(a2, c.conv3, c.bn3, group)
     rp = None
     sc = x
     if hasattr(blk, "proj_conv"):
         sc, rp = conv_abn_train(x, blk.proj_conv, blk.proj_bn, group, xs_cache=shared)
     act, slope = c.bn1.act_code()
-    out = ops.add_act(b3, sc, act, slope, want_planes=_twin_pays(b3.shape[1]))      # -> the next block's conv1 / projection, the heads
+    cout = c.conv3.out_channels
+    if FUSE_BLOCK_TAIL and cout % 8 == 0 and sc.is_contiguous():
+        # r05: bn3 (identity activation) + shortcut add + the block's activation in ONE pass — the bn3 output is never written — which also
+        # leaves the planes twin for the next block's conv1 / projection and the heads
+        out, r3 = conv_abn_train(a2, c.conv3, c.bn3, group, emit_planes=True, post=sc, act2=act, slope2=slope)
+    else:
+        b3, r3 = conv_abn_train(a2, c.conv3, c.bn3, group)
+        out = ops.add_act(b3, sc, act, slope, want_planes=_twin_pays(cout))
     return out, (r1, r2, r3, rp, out)
 
 
@@ -99,6 +108,11 @@ def block_backward(blk, rec, dout, grad_of, group=None):
     dsum = ops.act_bwd(out, dout, act, slope)
     d = conv_abn_backward(r3, c.conv3, c.bn3, dsum, grad_of, group=group)
     d = conv_abn_backward(r2, c.conv2, c.bn2, d, grad_of, group=group)
+    if FUSE_BLOCK_TAIL:      # r05: the shortcut's gradient rides in the epilogue of the last input-gradient convolution (no axpy pass)
+        if rp is None:
+            return conv_abn_backward(r1, c.conv1, c.bn1, d, grad_of, group=group, post=dsum)
+        dx = conv_abn_backward(r1, c.conv1, c.bn1, d, grad_of, group=group)
+        return conv_abn_backward(rp, blk.proj_conv, blk.proj_bn, dsum, grad_of, group=group, post=dx)
     dx = conv_abn_backward(r1, c.conv1, c.bn1, d, grad_of, group=group)
     if rp is not None:
         return ops.axpy_(dx, conv_abn_backward(rp, blk.proj_conv, blk.proj_bn, dsum, grad_of, group=group))

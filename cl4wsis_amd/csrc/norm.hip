@@ -150,9 +150,11 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, float* __restrict__
 // own). One thread per (image, 8-channel group, pixel): 8 strided dword loads and stores (coalesced along pixels), two 16-byte chunk stores.
 // The per-element expression is bn_apply_kernel's, so y is bit-identical to the plain launch.
 typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
+// `post` / act2 (r05): y = act2(act(bn(x)) + post) — the residual add + activation of modules/residual.py:91-97 in the same pass (the bn3
+// output of a bottleneck is then never written). `ys` may be null (no twin wanted).
 __global__ void bn_apply_planes_kernel(const float* __restrict__ x, float* __restrict__ y, u32x4n* __restrict__ ys, const float* __restrict__ mean,
                                        const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       float eps, int act, float slope, int n, int c, int hw) {
+                                       float eps, int act, float slope, int n, int c, int hw, const float* __restrict__ post, int act2, float slope2) {
   const int c8 = c >> 3;
   const long total = (long)n * c8 * hw;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -168,8 +170,13 @@ __global__ void bn_apply_planes_kernel(const float* __restrict__ x, float* __res
       const float mu = mean[ch], gm = gamma ? gamma[ch] : 1.f, bb = beta ? beta[ch] : 0.f;
       v[j] = cl4::apply_act((x[base + (long)j * hw] - mu) * rstd * gm + bb, act, slope);
     }
+    if (post) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = cl4::apply_act(v[j] + post[base + (long)j * hw], act2, slope2);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[base + (long)j * hw] = v[j];
+    if (!ys) continue;
     u32x4n hi, lo;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -434,12 +441,13 @@ extern "C" int cl4_bn_apply(const float* x, float* y, int n, int c, int hw, int 
 }
 
 extern "C" int cl4_bn_apply_planes(const float* x, float* y, void* ys, int n, int c, int hw, const float* mean, const float* var,
-                                   const float* gamma, const float* beta, float eps, int act, float slope, void* stream) {
-  CL4_REQUIRE(x && y && ys && mean && var, "bn_apply_planes: null pointer");
+                                   const float* gamma, const float* beta, float eps, int act, float slope, const float* post, int act2,
+                                   float slope2, void* stream) {
+  CL4_REQUIRE(x && y && mean && var, "bn_apply_planes: null pointer");
   CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0, "bn_apply_planes: c %% 8 == 0 required");
   const long total = (long)n * (c >> 3) * hw;
   hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, (u32x4n*)ys, mean, var,
-                     gamma, beta, eps, act, slope, n, c, hw);
+                     gamma, beta, eps, act, slope, n, c, hw, post, act2, slope2);
   return cl4::launch_status();
 }
 

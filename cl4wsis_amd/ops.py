@@ -1013,20 +1013,26 @@ PRODUCER_PLANES = os.environ.get("CL4_PRODUCER_PLANES", "1") != "0"     # r05: t
 
 
 def bn_apply(x, mean, var, gamma, beta, eps=1e-5, act=ACT_RELU, slope=0.01, keep=None, keep_scale=1.0,
-             c=None, x_coff=0, out=None, out_coff=0, want_planes=False):
+             c=None, x_coff=0, out=None, out_coff=0, want_planes=False, post=None, act2=ACT_NONE, slope2=0.01):
     """`want_planes` (whole contiguous tensors, c % 8 == 0, fp16x3 build): also write the two-plane twin of the output and attach it as
-    `y._cl4_planes` — what ops.conv2d's fp16x3 route multiplies instead of converting y in a pass of its own."""
+    `y._cl4_planes` — what ops.conv2d's fp16x3 route multiplies instead of converting y in a pass of its own. `post` / `act2`:
+    y = act2(act(bn(x)) + post) in the same pass (whole contiguous tensors, c % 8 == 0)."""
     n, x_ctot, h, w = x.shape
     if c is None:
         c = x_ctot - x_coff
-    if (want_planes and PRODUCER_PLANES and planes_f16() and out is None and keep is None and x_coff == 0 and c == x_ctot and c % 8 == 0
-            and x.is_contiguous()):
-        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
-        ps = Planes(n, c, h, w, x.device)
-        call("cl4_bn_apply_planes", ptr(x), ptr(out), ptr(ps.data), n, c, h * w, ptr(mean), ptr(var), ptr(gamma), ptr(beta), C.c_float(eps), act,
-             C.c_float(slope), stream())
-        out._cl4_planes = ps
-        return out
+    twin = want_planes and PRODUCER_PLANES and planes_f16()
+    if post is not None or twin:
+        whole = out is None and keep is None and x_coff == 0 and c == x_ctot and c % 8 == 0 and x.is_contiguous()
+        if post is not None and not (whole and post.is_contiguous() and tuple(post.shape) == tuple(x.shape)):
+            raise RuntimeError("bn_apply: the fused residual needs whole contiguous tensors with c % 8 == 0")
+        if whole:
+            out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+            ps = Planes(n, c, h, w, x.device) if twin else None
+            call("cl4_bn_apply_planes", ptr(x), ptr(out), ptr(ps.data) if ps is not None else None, n, c, h * w, ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+                 C.c_float(eps), act, C.c_float(slope), ptr(post), act2, C.c_float(slope2), stream())
+            if ps is not None:
+                out._cl4_planes = ps
+            return out
     if out is None:
         out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
         out_coff = 0
@@ -1106,7 +1112,7 @@ def _allreduce_sum(t, group):
 
 
 def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=ACT_LEAKY, slope=0.01,
-                      group=None, extra_sums=None, want_planes=False):
+                      group=None, extra_sums=None, want_planes=False, post=None, act2=ACT_NONE, slope2=0.01):
     """InPlaceABNSync in training mode (segmentation_module.py:17-29): batch statistics over every rank of
     `group`, then BN + leaky-ReLU / identity. Returns (y, mean, var, count). `extra_sums` ([c*2] doubles, count) adds the
     statistics of shards held elsewhere — used by the tests to emulate a second rank on one GPU."""
@@ -1125,7 +1131,7 @@ def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momen
     var = torch.empty(c, dtype=torch.float32, device=x.device)
     call("cl4_bn_sync_stats_final", ptr(sums), C.c_double(count), ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
          C.c_float(momentum), c, stream())
-    y = bn_apply(x, mean, var, gamma, beta, eps=eps, act=act, slope=slope, want_planes=want_planes)
+    y = bn_apply(x, mean, var, gamma, beta, eps=eps, act=act, slope=slope, want_planes=want_planes, post=post, act2=act2, slope2=slope2)
     return y, mean, var, count
 
 
@@ -1674,14 +1680,18 @@ def dgrad_weight(w, precision=0):
     return pack_conv_weight(wt, precision if bf16x3_ok(cin) else 0)
 
 
-def conv2d_dgrad(dy, wd, in_size, k, stride=1, pad=0, dil=1, x6=False):
-    """Input gradient of conv2d(x, w, stride, pad, dil): `wd` = dgrad_weight(w); in_size = (hin, win) of x."""
+def conv2d_dgrad(dy, wd, in_size, k, stride=1, pad=0, dil=1, x6=False, post=None):
+    """Input gradient of conv2d(x, w, stride, pad, dil): `wd` = dgrad_weight(w); in_size = (hin, win) of x. `post` ([n, cin, hin, win]):
+    returns the gradient PLUS post — the shortcut's gradient of a residual block rides in the convolution's epilogue (r05) instead of a
+    separate axpy pass."""
     hin, win = in_size
     if k == 1 and pad == 0:
-        dx = conv2d(dy, wd, 1, x6=x6, xdyn=True)
-        return dx if stride == 1 else zero_insert(dx, stride, (hin, win))
+        if stride == 1:
+            return conv2d(dy, wd, 1, x6=x6 and post is None, xdyn=True, post=post)
+        dx = zero_insert(conv2d(dy, wd, 1, x6=x6, xdyn=True), stride, (hin, win))
+        return dx if post is None else axpy_(dx, post)
     up = dy if stride == 1 else zero_insert(dy, stride, (hin + 2 * pad - dil * (k - 1), win + 2 * pad - dil * (k - 1)))
-    return conv2d(up, wd, k, stride=1, pad=dil * (k - 1) - pad, dil=dil, x6=x6, xdyn=True)
+    return conv2d(up, wd, k, stride=1, pad=dil * (k - 1) - pad, dil=dil, x6=x6 and post is None, xdyn=True, post=post)
 
 
 def rot90(x, k, out=None):

@@ -603,7 +603,8 @@ int cl4_conv2d_fwd_planes_f16(const cl4_conv_desc* d, const void* xs, const floa
  * train-mode InPlaceABN apply (segmentation_module.py:17-29) and the residual add + activation of modules/residual.py:91-97. y is bit-identical
  * to the plain entry points. */
 int cl4_bn_apply_planes(const float* x, float* y, void* ys, int n, int c, int hw, const float* mean, const float* var, const float* gamma,
-                        const float* beta, float eps, int act, float slope, void* stream);
+                        const float* beta, float eps, int act, float slope, const float* post, int act2, float slope2, void* stream);
+                        /* ys may be null; post != null: y = act2(act(bn(x)) + post) (the residual add of a bottleneck in the same pass) */
 int cl4_add_act_planes(const float* a, const float* b, float* y, void* ys, int n, int c, int hw, int act, float slope, void* stream);
 int cl4_abs_eps(const float* w, float* out, int n, float eps, void* stream);
 int cl4_sign_axpy(float* y, const float* x, const float* w, int n, void* stream);
