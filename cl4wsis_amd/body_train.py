@@ -12,7 +12,7 @@ import torch
 import os
 
 from . import ops
-from .nn import CACHE, gamma_grad, gamma_of, packed_weight
+from .nn import CACHE, PackBatch, gamma_grad, gamma_of, packed_weight
 
 # Arithmetic of the convolutions of the step-0 / phase-1 training paths (forward and input gradients): 3 (default, r05) = fp16x3 — split-fp16
 # operands with power-of-two scales, THREE MFMA products per MAC at fp32-level accuracy (FINDINGS.md finding 47) wherever the LDS-DMA kernel
@@ -34,8 +34,20 @@ class _Rec:
     __slots__ = ("x", "z", "mean", "var", "count", "y")
 
 
-def _dgrad_weight(conv):
-    return CACHE.get(conv, ("dgrad", PRECISION), (conv.weight,), lambda: ops.dgrad_weight(conv.weight.detach(), PRECISION))
+def _dgrad_weight(conv, force_f16=False):
+    key = ("dgrad", PRECISION, bool(force_f16))
+    wd = CACHE.get(conv, key, (conv.weight,), lambda: ops.dgrad_weight(conv.weight.detach(), PRECISION, force_f16=force_f16))
+    if PackBatch.ACTIVE is not None and PRECISION == 3:
+        PackBatch.ACTIVE.register(conv, key, True, wd)
+    return wd
+
+
+def _grad_twin_pays(conv):
+    """Does the ABN backward behind `conv` hand its gradient on as fp16 planes (r05, ops.abn_train_backward(want_planes=True))? When the
+    input-gradient convolution of `conv` can read them: fp16x3 arithmetic, stride 1 (a strided layer's gradient is zero-inserted first), a
+    shape the LDS-DMA kernel takes — channel-shrinking 1x1 gradients included, since no conversion pass is left to outweigh the gain."""
+    return (PRECISION == 3 and ops.GRAD_PLANES and ops.planes_f16() and conv.stride[0] == 1
+            and ops.f16x3_ok(conv.out_channels, conv.in_channels, 3))
 
 
 FUSE_BLOCK_TAIL = os.environ.get("CL4_FUSE_BLOCK_TAIL", "1") != "0"      # r05: bn3 + add + activation in one pass; shortcut gradient in the dgrad epilogue
@@ -67,16 +79,17 @@ def conv_abn_train(x, conv, bn, group=None, xs_cache=None, emit_planes=False, po
 def conv_abn_backward(r, conv, bn, dy, grad_of, need_dx=True, group=None, post=None):
     act, slope = bn.act_code()
     gw, fin = gamma_grad(bn, grad_of)
+    twin = need_dx and _grad_twin_pays(conv)
     dz = ops.abn_train_backward(r.z, dy, r.mean, r.var, gamma_of(bn), bn.bias.detach(), gw, grad_of(bn.bias),
-                                r.count, bn.eps, act, slope, group)
+                                r.count, bn.eps, act, slope, group, want_planes=twin)
     if fin is not None:
         fin()
     k = conv.kernel_size[0]
     ops.conv2d_wgrad(r.x, dz, grad_of(conv.weight), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], precision=WGRAD_PRECISION)
     if not need_dx:
         return None
-    return ops.conv2d_dgrad(dz, _dgrad_weight(conv), tuple(r.x.shape[2:]), k, stride=conv.stride[0], pad=conv.padding[0],
-                            dil=conv.dilation[0], x6=True, post=post)
+    return ops.conv2d_dgrad(dz, _dgrad_weight(conv, force_f16=twin and getattr(dz, "_cl4_planes", None) is not None), tuple(r.x.shape[2:]), k,
+                            stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], x6=True, post=post)
 
 
 def block_forward(blk, x, group=None):

@@ -588,6 +588,47 @@ __global__ void pack_weight_f16x3_kernel(const float* __restrict__ w, u32x4* __r
   }
 }
 
+// r05: every fp16x3 weight pack of a training step in ONE launch. The differentiated networks re-derive the packed operand of each trainable
+// convolution once per iteration — forward weight and the transposed / flipped input-gradient weight: ~320 launches of 14-20 us each in phase 1
+// (5 ms of a 75 ms step, profiles/r05n_*), each too small to fill the chip. `jobs` (device memory, built once per set of layers): one entry per
+// pack; a work item = one (8-deep K group, output row) pair of 16-byte chunks, items numbered across jobs (`first` = a job's first item), the
+// job of an item found by binary search. transposed != 0: the pack of wt[ci][co][kh][kw] = w[co][ci][k-1-kh][k-1-kw] (cl4_transpose_flip_weight
+// + cl4_pack_conv_weight_f16x3 in one pass: rows = cin, K runs over cout). Output bit-identical to the single-layer launches.
+struct PackJob {
+  const float* w;
+  u32x4* wq;
+  long first;
+  int cout, cin, khw, transposed;
+};
+
+__global__ __launch_bounds__(256) void pack_weights_f16x3_batched_kernel(const PackJob* __restrict__ jobs, int njobs, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int lo_ = 0, hi_ = njobs - 1;
+    while (lo_ < hi_) {                                  // last job with first <= i
+      const int mid = (lo_ + hi_ + 1) >> 1;
+      if (jobs[mid].first <= i) lo_ = mid; else hi_ = mid - 1;
+    }
+    const PackJob jb = jobs[lo_];
+    const long r = i - jb.first;
+    const int rows = jb.transposed ? jb.cin : jb.cout, red = jb.transposed ? jb.cout : jb.cin;      // output rows, reduction channels
+    const int K = red * jb.khw;
+    const int m = (int)(r % rows), kg = (int)(r / rows);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kg * 8 + j;                          // tap-major K order: k = (cb*khw + tap)*32 + cil
+      const int t32 = k >> 5, cil = k & 31;
+      const int cb = t32 / jb.khw, tap = t32 - cb * jb.khw;
+      const int c = cb * 32 + cil;
+      v[j] = jb.transposed ? jb.w[((long)c * jb.cin + m) * jb.khw + (jb.khw - 1 - tap)] : jb.w[((long)m * red + c) * jb.khw + tap];
+    }
+    u32x4 hi, lo;
+    split8_f16(v, F16_WSCALE, hi, lo);
+    jb.wq[((long)kg * 2 + 0) * rows + m] = hi;
+    jb.wq[((long)kg * 2 + 1) * rows + m] = lo;
+  }
+}
+
 }  // namespace
 
 static long g_s_launches = 0;
@@ -633,6 +674,14 @@ extern "C" int cl4_pack_conv_weight_f16x3(const float* w, void* wq, int cout, in
   const int K = cin * kh * kw;
   const long total = (long)(K / 8) * cout;
   hipLaunchKernelGGL(pack_weight_f16x3_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), w, (u32x4*)wq, cout, K, kh * kw);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_pack_conv_weights_f16x3_batched(const cl4_pack_job* jobs, int njobs, long total_items, void* stream) {
+  CL4_REQUIRE(jobs && njobs > 0 && total_items > 0, "pack_conv_weights_f16x3_batched: bad arguments");
+  static_assert(sizeof(PackJob) == sizeof(cl4_pack_job) && sizeof(PackJob) == 40, "cl4_pack_job layout (include/cl4wsis.h)");
+  hipLaunchKernelGGL(pack_weights_f16x3_batched_kernel, dim3(cl4::stream_grid(total_items, 256)), dim3(256), 0, cl4::as_stream(stream), (const PackJob*)jobs, njobs,
+                     total_items);
   return cl4::launch_status();
 }
 

@@ -241,13 +241,14 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
                                       const float* __restrict__ mean, const float* __restrict__ var,
                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
                                       float slope, BnShape s, int dy_ctot, int dy_coff, const uint8_t* __restrict__ keep,
-                                      float keep_scale) {
+                                      float keep_scale, float* __restrict__ maxima = nullptr) {
   const int c = blockIdx.x, sp = blockIdx.y;
   const int per_c = s.n * s.hw;
   const int step = SPLIT * blockDim.x;
   const float mu = mean[c], rstd = 1.f / sqrtf(var[c] + eps);
   const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
   double a = 0.0, b = 0.0;
+  float md = 0.f, mx = 0.f;          // max |dz|, max |xhat| of this workgroup's share (r05: the bound behind cl4_bn_sync_bwd_apply_planes)
   int i = sp * blockDim.x + threadIdx.x;
   int n = i / s.hw, p = i - n * s.hw;
   const float* xc = x + (long)(s.coff + c) * s.hw;
@@ -261,6 +262,8 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
     d = act_grad(d, xh * g + bb, act, slope);
     a += (double)d;
     b += (double)d * (double)xh;
+    md = fmaxf(md, fabsf(d));
+    mx = fmaxf(mx, fabsf(xh));
     p += step;
     while (p >= s.hw) { p -= s.hw; ++n; }
   }
@@ -268,6 +271,17 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
   if (threadIdx.x == 0) {
     partial[((long)c * SPLIT + sp) * 2 + 0] = a;
     partial[((long)c * SPLIT + sp) * 2 + 1] = b;
+  }
+  if (maxima) {                      // (uniform branch; block_reduce2's shared arrays are not reused)
+    __shared__ float sm[8];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { md = fmaxf(md, __shfl_xor(md, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = md; sm[4 + (threadIdx.x >> 6)] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      maxima[((long)c * SPLIT + sp) * 2 + 0] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+      maxima[((long)c * SPLIT + sp) * 2 + 1] = fmaxf(fmaxf(sm[4], sm[5]), fmaxf(sm[6], sm[7]));
+    }
   }
 }
 
@@ -340,6 +354,100 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     if (kp) d = kp[p] ? d * keep_scale : 0.f;
     d = act_grad(d, xh * g + bb, act, slope);
     dxp[p] = g * rstd * (d - sa - xh * sb);
+  }
+}
+
+// r05: the input gradient with its fp16 planes twin — what the fp16x3 input-gradient convolution of the layer in front reads instead of a
+// max |dx| pass + a conversion pass over the fp32 tensor (12 bytes per element of traffic less, 4 more here). The twin needs its power-of-two
+// scale BEFORE dx exists, so the scale comes from a bound: |dx| <= |gamma| rstd (max |dz| + |mean dz| + max |xhat| |mean dz xhat|) per channel,
+// with the two maxima from the reduction pass that already reads x and dy. s = 2^(15 - e), B = f 2^e: B s in [2^14, 2^15) < 65504, so nothing
+// saturates; the bound is within ~2x of max |dx| (the mean terms are small beside max |dz|), i.e. the same headroom as the data-derived
+// 2^(14 - e) of cl4_to_planes_f16. Two steps, neither serial: one WAVE per channel folds that channel's SPLIT maxima, converts its two sums
+// to float (bn_bwd_sums_to_float_kernel's job) and leaves the channel's bound in bound[c]; every workgroup of the apply kernel then folds the
+// c bounds itself (8 KB at most, from L2), like to_planes_f16_kernel folds its partial maxima.
+// coef[c][8] = {mean, rstd, gamma, beta, mean dz, mean dz xhat, -, -}: the apply kernel's per-channel constants as two 16-byte loads.
+__global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const double* __restrict__ sums, const float* __restrict__ maxima, const float* __restrict__ mean,
+                                                          const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float invn, int c, float* __restrict__ coef, float* __restrict__ bound) {
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ch >= c) return;
+  float md = 0.f, mx = 0.f;
+  if (lane < SPLIT) {
+    md = maxima[((long)ch * SPLIT + lane) * 2 + 0];
+    mx = maxima[((long)ch * SPLIT + lane) * 2 + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { md = fmaxf(md, __shfl_xor(md, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+  if (lane == 0) {
+    const float a = (float)sums[2 * ch], b = (float)sums[2 * ch + 1];
+    const float rstd = 1.f / sqrtf(var[ch] + eps), g = gamma ? gamma[ch] : 1.f;
+    float* q = coef + (long)ch * 8;
+    q[0] = mean[ch]; q[1] = rstd; q[2] = g; q[3] = beta ? beta[ch] : 0.f;
+    q[4] = a * invn; q[5] = b * invn; q[6] = 0.f; q[7] = 0.f;
+    bound[ch] = fabsf(g) * rstd * (md + fabsf(a) * invn + mx * fabsf(b) * invn);
+  }
+}
+
+__device__ __forceinline__ float scale_from_bounds(const float* __restrict__ bound, int c) {      // the same value in every workgroup
+  __shared__ float red[4];
+  float bmax = 0.f;
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) bmax = fmaxf(bmax, bound[ch]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bmax;
+  __syncthreads();
+  const float b = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 1.0001f;        // (rounding of the bound's own arithmetic)
+  float sc = 1.f;
+  if (b > 0.f && b < 3.0e38f) {
+    int e;
+    frexpf(b, &e);
+    sc = ldexpf(1.f, min(max(15 - e, -100), 100));
+  }
+  return sc;
+}
+
+// One thread per (image, 8-channel group, pixel), like bn_apply_planes_kernel; per element the expression of bn_bwd_apply_kernel (dx is
+// bit-identical to the plain launch).
+__global__ void bn_bwd_apply_planes_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, u32x4n* __restrict__ dxs,
+                                           const float* __restrict__ coef, int act, float slope, int n, int c, int hw, int dy_ctot, int dy_coff,
+                                           const float* __restrict__ bound, float* __restrict__ slot) {
+  typedef float f32x4n __attribute__((ext_vector_type(4)));
+  const float sc = scale_from_bounds(bound, c);
+  if (blockIdx.x == 0 && threadIdx.x == 0) slot[0] = sc;
+  const int c8 = c >> 3;
+  const long total = (long)n * c8 * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int px = (int)(i % hw);
+    const long r = i / hw;
+    const int g8 = (int)(r % c8), im = (int)(r / c8);
+    const long base = ((long)im * c + g8 * 8) * hw + px;
+    const long dbase = ((long)im * dy_ctot + dy_coff + g8 * 8) * hw + px;
+    float xv[8], dv[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xv[j] = x[base + (long)j * hw]; dv[j] = dy[dbase + (long)j * hw]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4n* q = (const f32x4n*)(coef + (long)(g8 * 8 + j) * 8);
+      const f32x4n k0 = q[0], k1 = q[1];                       // {mean, rstd, gamma, beta}, {mean dz, mean dz xhat, -, -}
+      const float xh = (xv[j] - k0[0]) * k0[1];
+      const float d = act_grad(dv[j], xh * k0[2] + k0[3], act, slope);
+      v[j] = k0[2] * k0[1] * (d - k1[0] - xh * k1[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dx[base + (long)j * hw] = v[j];
+    u32x4n hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float a = plfmt::sat_f16(v[2 * q] * sc), b = plfmt::sat_f16(v[2 * q + 1] * sc);
+      const unsigned hp = plfmt::pk_f16(a, b);
+      const plfmt::f16x2 h = __builtin_bit_cast(plfmt::f16x2, hp);
+      const float ha = (float)h[0], hb = (float)h[1];       // (plain subtractions: finding 48)
+      hi[q] = hp;
+      lo[q] = plfmt::pk_f16(a - ha, b - hb);
+    }
+    u32x4n* dst = dxs + (((long)im * c8 + g8) * 2) * hw + px;
+    dst[0] = hi;
+    dst[hw] = lo;
   }
 }
 
@@ -579,6 +687,53 @@ extern "C" int cl4_bn_sync_bwd_apply(const float* x, const float* dy, float* dx,
   long total = (long)n * c * hw;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, st, x, dy, dx, mean, var, gamma,
                      beta, fsum, fsum + c, eps, act, slope, (float)(1.0 / count), s, dy_ctot, dy_coff, keep, keep_scale);
+  return cl4::launch_status();
+}
+
+// r05: cl4_bn_sync_bwd_local that also leaves max |dz| / max |xhat| per (channel, reduction workgroup) in `maxima` (2 * c * 32 floats:
+// cl4_bn_bwd_maxima_floats), and cl4_bn_sync_bwd_apply that also writes dx's fp16 planes twin `dxs` (cl4_planes_bytes(n, c, hw, 2)) scaled by
+// the power of two it leaves in slot[0] (see bn_bwd_bound_kernel). x and dx whole tensors, c % 8 == 0; no Dropout mask.
+extern "C" size_t cl4_bn_bwd_maxima_floats(int c) { return (size_t)c * SPLIT * 2; }
+
+extern "C" int cl4_bn_sync_bwd_local_max(const float* x, const float* dy, int n, int c, int hw, int dy_ctot, int dy_coff, const float* mean,
+                                         const float* var, const float* gamma, const float* beta, float eps, int act, float slope, double* sums,
+                                         float* dgamma, float* dbeta, float* maxima, void* workspace, size_t workspace_bytes, void* stream) {
+  BnShape s{n, c, hw, c, 0};
+  int rc = check_shape(s);
+  if (rc) return rc;
+  CL4_REQUIRE(x && dy && mean && var && sums && workspace && maxima, "bn_sync_bwd_local_max: null pointer");
+  CL4_REQUIRE(dy_coff >= 0 && dy_coff + c <= dy_ctot, "bn_sync_bwd_local_max: dy slice out of range");
+  size_t need = cl4_bn_workspace_bytes(c) + (size_t)2 * c * sizeof(float);
+  if (workspace_bytes < need) { cl4::set_error("bn_sync_bwd_local_max: workspace too small"); return CL4_ENOSPC; }
+  double* partial = (double*)workspace;
+  float* fsum = (float*)((char*)workspace + cl4_bn_workspace_bytes(c));
+  hipStream_t st = cl4::as_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
+                     slope, s, dy_ctot, dy_coff, (const uint8_t*)nullptr, 1.f, maxima);
+  hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, c);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, fsum, fsum + c, dgamma,
+                     dbeta, c);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_bn_sync_bwd_apply_planes(const float* x, const float* dy, float* dx, void* dxs, float* slot, int n, int c, int hw, int dy_ctot,
+                                            int dy_coff, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
+                                            int act, float slope, const double* sums, double count, const float* maxima, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+  BnShape s{n, c, hw, c, 0};
+  int rc = check_shape(s);
+  if (rc) return rc;
+  CL4_REQUIRE(x && dy && dx && dxs && slot && mean && var && sums && maxima && workspace && count > 0.0, "bn_sync_bwd_apply_planes: bad arguments");
+  CL4_REQUIRE(c % 8 == 0, "bn_sync_bwd_apply_planes: c %% 8 == 0 (the planes format's channel groups)");
+  CL4_REQUIRE(dy_coff >= 0 && dy_coff + c <= dy_ctot, "bn_sync_bwd_apply_planes: dy slice out of range");
+  if (workspace_bytes < (size_t)9 * c * sizeof(float)) { cl4::set_error("bn_sync_bwd_apply_planes: workspace too small"); return CL4_ENOSPC; }
+  float* coef = (float*)workspace;            // (hipMalloc'ed by the caller: 16-byte aligned)
+  hipStream_t st = cl4::as_stream(stream);
+  const float invn = (float)(1.0 / count);
+  hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3(cl4::cdiv(c, 4)), dim3(256), 0, st, sums, maxima, mean, var, gamma, beta, eps, invn, c, coef, coef + 8 * (long)c);
+  const long total = (long)n * (c >> 3) * hw;
+  hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, x, dy, dx, (u32x4n*)dxs, (const float*)coef, act, slope,
+                     n, c, hw, dy_ctot, dy_coff, (const float*)(coef + 8 * (long)c), slot);
   return cl4::launch_status();
 }
 

@@ -123,13 +123,79 @@ class _Cache:
 CACHE = _Cache()
 
 
+class PackBatch:
+    """All fp16x3 weight packs of a training iteration in one launch (r05, cl4_pack_conv_weights_f16x3_batched). While a batch is the
+    ACTIVE one (`with batch:`), every fp16x3 pack that packed_weight / body_train._dgrad_weight build lazily for a TRAINABLE convolution is
+    registered with it — the PackedWeight it returned becomes that layer's persistent buffer. `refresh()` (the start of every later
+    iteration) re-derives ALL registered packs in place with one launch and marks the cache entries current, so the lazy path finds
+    nothing to do. The job table lives in device memory and is rebuilt only when a layer is added, never while a HIP graph is being
+    captured (a captured iteration contains just the launch). In-place is safe because every reader of a pack runs on the stream that
+    issues the refresh, behind it; a cache entry that somebody rebuilt lazily in between (validation after stale_trainable()) is
+    simply replaced by the persistent buffer again at the next refresh."""
+
+    ACTIVE = None
+    ENABLED = os.environ.get("CL4_PACK_BATCH", "1") != "0"
+
+    def __init__(self):
+        self.entries = {}        # (id(conv), key) -> (conv, key, transposed, PackedWeight)
+        self._table = None       # (device tensor of cl4_pack_job, njobs, total items), valid for len(entries) == njobs
+        self.launches = 0
+
+    def __enter__(self):
+        self._prev, PackBatch.ACTIVE = PackBatch.ACTIVE, (self if PackBatch.ENABLED else None)
+        return self
+
+    def __exit__(self, *exc):
+        PackBatch.ACTIVE = self._prev
+        return False
+
+    def register(self, conv, key, transposed, wp):
+        if (isinstance(wp, ops.PackedWeight) and wp.precision == 3 and conv.weight.requires_grad and conv.weight.is_cuda
+                and conv.weight.is_contiguous() and (id(conv), key) not in self.entries):
+            self.entries[(id(conv), key)] = (conv, key, bool(transposed), wp)
+
+    def _build_table(self):
+        import ctypes as C
+        from ._hip import PackJob
+        jobs = (PackJob * len(self.entries))()
+        first = 0
+        for j, (conv, key, transposed, wp) in zip(jobs, self.entries.values()):
+            cout, cin, kh, kw = conv.weight.shape
+            j.w, j.wq, j.first = conv.weight.data_ptr(), wp.data.data_ptr(), first
+            j.cout, j.cin, j.khw, j.transposed = cout, cin, kh * kw, int(transposed)
+            first += (kh * kw * (cout if transposed else cin) // 8) * (cin if transposed else cout)
+        raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).clone()
+        dev = next(iter(self.entries.values()))[0].weight.device
+        self._table = (raw.to(dev), len(self.entries), first, [e[0].weight.data_ptr() for e in self.entries.values()])
+
+    def refresh(self):
+        """Re-derive every registered pack from the current weights (one launch) and mark the cache entries current."""
+        if not self.entries:
+            return False
+        ptrs = [e[0].weight.data_ptr() for e in self.entries.values()]
+        if self._table is None or self._table[1] != len(self.entries) or self._table[3] != ptrs:
+            if torch.cuda.is_current_stream_capturing():
+                return False                                 # (no host-to-device copy inside a capture: the lazy path packs layer by layer)
+            self._build_table()
+        table, njobs, total, _ = self._table
+        ops.call("cl4_pack_conv_weights_f16x3_batched", ops.ptr(table), njobs, total, ops.stream())
+        self.launches += 1
+        for conv, key, _, wp in self.entries.values():
+            conv.__dict__.setdefault("_cl4_cache", {})[key] = (CACHE._sig((conv.weight,)), wp)
+        return True
+
+
 def packed_weight(conv, precision=None, force_f16=False):
     """The conv's weight in the operand layout of `precision` (default: ops.CONV_PRECISION), cached until it changes. `force_f16`
     (precision 3): the fp16x3 pack also for a 1x1 layer that shrinks the channel count — its input arrives with a planes twin made by the
     producer (ops.bn_apply / add_act want_planes), so there is no conversion pass to lose against."""
     w = conv.weight
     prec = ops.CONV_PRECISION if precision is None else precision
-    return CACHE.get(conv, "wp%d%s" % (prec, "f" if force_f16 else ""), (w,), lambda: ops.pack_conv_weight(w.detach(), prec, force_f16=force_f16))
+    key = "wp%d%s" % (prec, "f" if force_f16 else "")
+    wp = CACHE.get(conv, key, (w,), lambda: ops.pack_conv_weight(w.detach(), prec, force_f16=force_f16))
+    if PackBatch.ACTIVE is not None and prec == 3:
+        PackBatch.ACTIVE.register(conv, key, False, wp)
+    return wp
 
 
 def folded_bn(bn, lo=0, hi=None):

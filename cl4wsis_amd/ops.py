@@ -471,8 +471,9 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
             if xs is None:
                 # a forward activation: the planes format of the build itself (fp16 hi / lo of 16 x) — the frozen producer's twin when it
                 # left one; a gradient: its own power-of-two scale, in device memory
-                xs = (getattr(x, "_cl4_planes", None) if (not dyn and in_coff == 0 and cin == in_ctot) else None)
-                if xs is None or xs.planes != 2 or xs.slot is not None:
+                # (a gradient's twin carries its scale — `slot` — and comes from abn_train_backward(want_planes=True))
+                xs = getattr(x, "_cl4_planes", None) if (in_coff == 0 and cin == in_ctot) else None
+                if xs is None or xs.planes != 2 or (xs.slot is not None) != dyn:
                     xs = to_planes_f16(x, dynamic=True, in_coff=in_coff, c=cin) if dyn else to_planes(x, in_coff=in_coff, c=cin)
                 if xs_cache is not None:
                     xs_cache[ckey] = xs
@@ -763,9 +764,57 @@ def _wgrad_gemm(x, dy, dw, n, cin, in_coff, cout, dy_coff, hin, win, hout, wout,
     call("cl4_wgrad_scatter", ptr(y), ptr(dw), cin, cout, 9, stream())
 
 
+class WgradSide:
+    """Weight gradients on a second stream (r05): nothing in a backward pass reads a layer's dw before the update, so inside
+    `with ops.WGRAD_SIDE.on(stream):` every conv2d_wgrad launch goes to `stream` behind an event of the launching stream, and the input
+    gradients / ABN backward kernels of the following layers run beside it; `join()` (also the end of the `with` block) makes the
+    launching stream wait for all of them. The operands of every forked launch are kept alive until the join (they were allocated on
+    the launching stream: the allocator must not hand their memory out while the side stream still reads it). Works the same eagerly
+    and under HIP-graph capture (fork and join are inside the capture)."""
+
+    def __init__(self):
+        self.stream = None
+        self.keep = []
+        self.launches = 0
+
+    def on(self, stream):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            if stream is None or self.stream is not None:
+                yield self
+                return
+            self.stream = stream
+            try:
+                yield self
+            finally:
+                try:
+                    self.join()
+                finally:
+                    self.stream = None
+        return scope()
+
+    def join(self):
+        if self.stream is not None and self.keep:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep.clear()
+
+
+WGRAD_SIDE = WgradSide()
+WGRAD_SIDE_ON = os.environ.get("CL4_WGRAD_SIDE", "0") != "0"       # (measured: no gain at 16 images per GPU, FINDINGS.md)
+
+
 def conv2d_wgrad(x, dy, dw, k, stride=1, pad=0, dil=1, in_coff=0, cin=None, dy_coff=0, cout=None, precision=None, kcache=None):
     """dw[cout,cin,k,k] += conv weight gradient. dw is accumulated into (zero it first). `kcache` (optional dict, valid while x's
     contents do not change): lets several layers on one input share x's repacked copy on the GEMM path (_wgrad_gemm)."""
+    side = WGRAD_SIDE.stream
+    if side is not None and TIMER is None and x.is_cuda and torch.cuda.current_stream() != side:      # (per-layer timings: one stream)
+        side.wait_stream(torch.cuda.current_stream())
+        WGRAD_SIDE.keep.append((x, dy, dw))
+        WGRAD_SIDE.launches += 1
+        with torch.cuda.stream(side):
+            return conv2d_wgrad(x, dy, dw, k, stride, pad, dil, in_coff, cin, dy_coff, cout, precision, kcache)
     n, in_ctot, hin, win = x.shape
     if cin is None:
         cin = in_ctot - in_coff
@@ -1010,6 +1059,7 @@ def bn_train_fwd(x, gamma, beta, running_mean=None, running_var=None, momentum=0
 
 
 PRODUCER_PLANES = os.environ.get("CL4_PRODUCER_PLANES", "1") != "0"     # r05: train-mode ABN apply / residual add write the planes twin the next fp16x3 convolution reads
+GRAD_PLANES = os.environ.get("CL4_GRAD_PLANES", "1") != "0"             # r05: ABN backward writes the fp16 planes twin of the gradient it hands on
 
 
 def bn_apply(x, mean, var, gamma, beta, eps=1e-5, act=ACT_RELU, slope=0.01, keep=None, keep_scale=1.0,
@@ -1136,22 +1186,38 @@ def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momen
 
 
 def abn_train_backward(x, dy, mean, var, gamma, beta, dgamma, dbeta, count, eps=1e-5, act=ACT_LEAKY, slope=0.01, group=None,
-                       extra_sums=None, return_sums=False):
-    """Backward of abn_train_forward: dx; this rank's share of the affine gradients is accumulated into dgamma / dbeta."""
+                       extra_sums=None, return_sums=False, want_planes=False):
+    """Backward of abn_train_forward: dx; this rank's share of the affine gradients is accumulated into dgamma / dbeta. `want_planes`
+    (r05): dx also leaves as the fp16x3 operand of the input-gradient convolution in front (`dx._cl4_planes`, its power-of-two scale from
+    a bound the reduction pass provides — cl4_bn_sync_bwd_apply_planes): no max |dx| pass, no conversion pass."""
     n, c, h, w = x.shape
     sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
     ws = _workspace(x.device, bn_workspace_bytes(c))
-    call("cl4_bn_sync_bwd_local", ptr(x), ptr(dy), n, c, h * w, c, 0, dy.shape[1], 0, ptr(mean), ptr(var), ptr(gamma), ptr(beta),
-         C.c_float(eps), act, C.c_float(slope), None, C.c_float(1.0), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(),
-         stream())
+    want_planes = bool(want_planes) and c % 8 == 0 and planes_f16() and x.is_contiguous()
+    if want_planes:
+        maxima = torch.empty(_hip.load().cl4_bn_bwd_maxima_floats(c), dtype=torch.float32, device=x.device)
+        call("cl4_bn_sync_bwd_local_max", ptr(x), ptr(dy), n, c, h * w, dy.shape[1], 0, ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+             C.c_float(eps), act, C.c_float(slope), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(maxima), ptr(ws), ws.numel(), stream())
+    else:
+        call("cl4_bn_sync_bwd_local", ptr(x), ptr(dy), n, c, h * w, c, 0, dy.shape[1], 0, ptr(mean), ptr(var), ptr(gamma), ptr(beta),
+             C.c_float(eps), act, C.c_float(slope), None, C.c_float(1.0), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(),
+             stream())
     local = sums.clone() if return_sums else None
     if extra_sums is not None:
         sums += extra_sums
     _allreduce_sum(sums, group)
     dx = torch.empty_like(x)
-    call("cl4_bn_sync_bwd_apply", ptr(x), ptr(dy), ptr(dx), n, c, h * w, c, 0, dy.shape[1], 0, ptr(mean), ptr(var), ptr(gamma),
-         ptr(beta), C.c_float(eps), act, C.c_float(slope), None, C.c_float(1.0), ptr(sums), C.c_double(count), ptr(ws),
-         ws.numel(), stream())
+    if want_planes:
+        # (the bound uses this rank's maxima and the global sums: each rank scales its own dx)
+        slot = torch.empty(_hip.load().cl4_to_planes_f16_slot_floats(), dtype=torch.float32, device=x.device)
+        ps = Planes(n, c, h, w, x.device, planes=2, slot=slot)
+        call("cl4_bn_sync_bwd_apply_planes", ptr(x), ptr(dy), ptr(dx), ptr(ps.data), ptr(slot), n, c, h * w, dy.shape[1], 0, ptr(mean), ptr(var),
+             ptr(gamma), ptr(beta), C.c_float(eps), act, C.c_float(slope), ptr(sums), C.c_double(count), ptr(maxima), ptr(ws), ws.numel(), stream())
+        dx._cl4_planes = ps
+    else:
+        call("cl4_bn_sync_bwd_apply", ptr(x), ptr(dy), ptr(dx), n, c, h * w, c, 0, dy.shape[1], 0, ptr(mean), ptr(var), ptr(gamma),
+             ptr(beta), C.c_float(eps), act, C.c_float(slope), None, C.c_float(1.0), ptr(sums), C.c_double(count), ptr(ws),
+             ws.numel(), stream())
     return (dx, local) if return_sums else dx
 
 
@@ -1672,12 +1738,13 @@ def dropout2d(x, keep, p):
     return y
 
 
-def dgrad_weight(w, precision=0):
-    """[cout,cin,k,k] -> packed operand of the input-gradient convolution (a stride-1 conv over dy with cin' = cout)."""
+def dgrad_weight(w, precision=0, force_f16=False):
+    """[cout,cin,k,k] -> packed operand of the input-gradient convolution (a stride-1 conv over dy with cin' = cout). `force_f16`: see
+    pack_conv_weight (the gradient arrives with its fp16 planes twin, so a channel-shrinking 1x1 is routed to fp16x3 as well)."""
     cout, cin, k, _ = w.shape
     wt = torch.empty((cin, cout, k, k), dtype=torch.float32, device=w.device)
     call("cl4_transpose_flip_weight", ptr(w), ptr(wt), cout, cin, k, stream())
-    return pack_conv_weight(wt, precision if bf16x3_ok(cin) else 0)
+    return pack_conv_weight(wt, precision if bf16x3_ok(cin) else 0, force_f16=force_f16)
 
 
 def conv2d_dgrad(dy, wd, in_size, k, stride=1, pad=0, dil=1, x6=False, post=None):

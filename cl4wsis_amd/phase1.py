@@ -8,13 +8,17 @@ Everything runs on the HIP kernels of libcl4wsis_hip.so: train-mode forward with
 (body_train / heads_train), the loss kernels of wss.hip / p1loss.hip (value + gradient), the hand-written backward, the
 bucketed RCCL gradient average and the fused SGD. The frozen old model uses the eval path (bf16x3 convs).
 """
+import os
+
 import numpy as np
 import torch
 
 from . import body_train, heads_train, ops
+from .nn import PackBatch
 
 DENORM_MEAN = (0.485, 0.456, 0.4069)      # utils/utils.py:23 (sic)
 DENORM_STD = (0.229, 0.224, 0.225)
+P1_OVERLAP = os.environ.get("CL4_P1_OVERLAP", "0") != "0"      # r05 experiment: the frozen old model on the second stream (measured: no gain, FINDINGS.md)
 
 
 class Phase1Step:
@@ -24,8 +28,22 @@ class Phase1Step:
         self._dn_scale = torch.tensor(DENORM_STD, dtype=torch.float32, device=dev)
         self._dn_shift = torch.tensor(DENORM_MEAN, dtype=torch.float32, device=dev)
         self._draws = 0
+        self.packs = PackBatch()
 
     def run(self, images, l1h, cur_epoch, flac_angle=None, randrop_neg=None, debug=None):
+        tr = self.tr
+        # r05: two things of this iteration do not depend on the kernels around them and run on the trainer's second stream — the frozen old
+        # model's forward (needed by the losses only) beside the new model's forward, and every weight gradient beside the input gradients
+        # and ABN backward passes of the layers behind it (ops.WGRAD_SIDE). Not when the iteration is being captured as graph segments
+        # (N > 1: a segment must not end with work forked off it).
+        side = tr._side_stream if (P1_OVERLAP and getattr(tr, "_side_stream", None) is not None and ops.STAT_EXCHANGE.hook is None
+                                     and ops.TIMER is None) else None
+        main = torch.cuda.current_stream() if side is not None else None
+        with self.packs, ops.WGRAD_SIDE.on(side if ops.WGRAD_SIDE_ON else None):
+            self.packs.refresh()          # r05: every fp16x3 weight pack of the iteration (forward + input-gradient operands) in one launch
+            return self._run(images, l1h, cur_epoch, flac_angle, randrop_neg, debug, side, main)
+
+    def _run(self, images, l1h, cur_epoch, flac_angle, randrop_neg, debug, side, main):
         tr, opts = self.tr, self.tr.opts
         bs = images.shape[0]
         old, tot = tr.old_classes, tr.tot_classes
@@ -33,7 +51,12 @@ class Phase1Step:
         model, pl, pg = tr.model, tr.pseudolabeler, tr.peakgenerator
 
         # train.py:253-255 — frozen old model (eval), low-resolution outputs
-        out_old, feats_old = tr.model_old(images, interpolate=False)
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                out_old, feats_old = tr.model_old(images, interpolate=False)
+        else:
+            out_old, feats_old = tr.model_old(images, interpolate=False)
         old_seg, res5_old = out_old["seg"], feats_old["body"]
 
         tr.optimizer.zero_grad()
@@ -60,6 +83,8 @@ class Phase1Step:
         raw = A[:bs]
         lab_new = l1h[:, old - 1:].contiguous()
 
+        if side is not None:
+            main.wait_stream(side)                   # the old model's outputs enter the losses from here on
         losses = {}
         losses["flac"], dA = ops.flac_loss(A, bs, old, flac_angle)
         draw = dA[:bs]

@@ -6,14 +6,21 @@ import torch
 
 from . import body_train as BT
 from . import body_train, heads_train, ops
+from .nn import PackBatch
 
 
 class Step0:
     def __init__(self, trainer):
         self.tr = trainer
         self._zero_w = None
+        self.packs = PackBatch()
 
     def run(self, images, seg_maps, center_maps, offset_maps, weights, dropout_keep=None):
+        with self.packs:
+            self.packs.refresh()          # r05: every fp16x3 weight pack of the iteration in one launch (nn.PackBatch)
+            return self._run(images, seg_maps, center_maps, offset_maps, weights, dropout_keep)
+
+    def _run(self, images, seg_maps, center_maps, offset_maps, weights, dropout_keep):
         tr = self.tr
         bs, _, H, W = images.shape
         G = lambda p: tr._grad_map[id(p)]
@@ -44,9 +51,12 @@ class Step0:
             branch.backward(itape, {"center": dcen, "offset": doff}, grads=tr._grad_map, feature_grads=fg)
         finally:
             ops.WGRAD_PRECISION = saved
-        dhy = heads_train.cls_backward(model.cls, cx, dseg, G)
-        dres5 = heads_train.deeplab_backward(model.head, htape, dhy, G)
-        ops.axpy_(dres5, fg["res5"])
-        douts = {4: dres5, 3: fg.get("res4"), 2: fg.get("res3"), 1: fg.get("res2")}
-        body_train.body_backward(model.body, btape, douts, G)
+        # r05: the weight gradients of the heads and the body on the trainer's second stream, beside the input-gradient chain (ops.WgradSide)
+        side = tr._side_stream if (ops.WGRAD_SIDE_ON and getattr(tr, "_side_stream", None) is not None and ops.STAT_EXCHANGE.hook is None) else None
+        with ops.WGRAD_SIDE.on(side):
+            dhy = heads_train.cls_backward(model.cls, cx, dseg, G)
+            dres5 = heads_train.deeplab_backward(model.head, htape, dhy, G)
+            ops.axpy_(dres5, fg["res5"])
+            douts = {4: dres5, 3: fg.get("res4"), 2: fg.get("res3"), 1: fg.get("res2")}
+            body_train.body_backward(model.body, btape, douts, G)
         return {"seg_loss": seg_loss, "center_loss": l4[2:3], "offset_loss": l4[3:4]}

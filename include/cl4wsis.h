@@ -223,6 +223,19 @@ int cl4_bn_sync_bwd_apply(const float* x, const float* dy, float* dx, int n, int
                           int dy_coff, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
                           int act, float slope, const uint8_t* keep, float keep_scale, const double* sums, double count,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* r05: the backward pair that also hands the input gradient to the NEXT convolution in its operand format (the fp16x3 input-gradient
+ * convolution of the layer in front — modules/residual.py:84-97 differentiated — reads fp16 planes scaled by a power of two): _local_max also
+ * leaves max |dz| and max |xhat| per (channel, reduction workgroup) in `maxima` (cl4_bn_bwd_maxima_floats(c) floats), _apply_planes derives the
+ * scale from the bound |dx| <= |gamma| rstd (max |dz| + |mean dz| + max |xhat| |mean dz xhat|), writes it to slot[0], and writes dx (fp32,
+ * bit-identical to cl4_bn_sync_bwd_apply) plus its planes twin `dxs` (cl4_planes_bytes(n, c, hw, 2) bytes). x / dx whole tensors, c % 8 == 0. */
+size_t cl4_bn_bwd_maxima_floats(int c);
+int cl4_bn_sync_bwd_local_max(const float* x, const float* dy, int n, int c, int hw, int dy_ctot, int dy_coff, const float* mean,
+                              const float* var, const float* gamma, const float* beta, float eps, int act, float slope, double* sums,
+                              float* dgamma, float* dbeta, float* maxima, void* workspace, size_t workspace_bytes, void* stream);
+int cl4_bn_sync_bwd_apply_planes(const float* x, const float* dy, float* dx, void* dxs, float* slot, int n, int c, int hw, int dy_ctot,
+                                 int dy_coff, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act,
+                                 float slope, const double* sums, double count, const float* maxima, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 /* db[c] += sum_{n,hw} dy — bias gradient of the classifier convs. */
 int cl4_bias_grad(const float* dy, float* db, int n, int c, int hw, int ctot, int coff, void* stream);
 /* Counter-based keep mask for nn.Dropout(p) — modules/panoptic_deeplab.py:123. */
@@ -589,6 +602,19 @@ int cl4_conv2d_fwd_planes(const cl4_conv_desc* d, const void* xs, const float* w
  *   cl4_conv2d_fwd_planes_f16: conv (+ the fused affine / activation / fp32 residual group) on such an input, descriptor precision 5,
  *     fp32 NCHW output; xs_scale = &slot[0]. 1x1 / 3x3, any stride / dilation, cout >= 128. */
 int cl4_pack_conv_weight_f16x3(const float* w, void* wq, int cout, int cin, int kh, int kw, void* stream);
+/* r05: all fp16x3 weight packs of a training iteration in one launch (the trainable convolutions of train.py:272 / :537 re-derive their
+ * packed forward weight and their transposed / flipped input-gradient weight after every optimizer step: ~320 small launches in phase 1).
+ * jobs: device array of njobs entries; `first` = running sum of the items of the jobs in front, items of a job = (K / 8) * rows with
+ * K = kh * kw * (transposed ? cout : cin), rows = transposed ? cin : cout; total_items = their sum. transposed != 0 packs
+ * wt[ci][co][kh][kw] = w[co][ci][k-1-kh][k-1-kw] (cl4_transpose_flip_weight followed by cl4_pack_conv_weight_f16x3). Same constraints and
+ * bit-identical output as cl4_pack_conv_weight_f16x3 per job. */
+typedef struct cl4_pack_job {
+  const float* w;   /* [cout][cin][kh][kw] */
+  void* wq;         /* the pack: (K / 8) * 2 * rows * 16 bytes */
+  long first;
+  int cout, cin, khw, transposed;
+} cl4_pack_job;
+int cl4_pack_conv_weights_f16x3_batched(const cl4_pack_job* jobs, int njobs, long total_items, void* stream);
 /* Which two-plane format / arithmetic this build of the library uses for EVERY planes tensor (cl4_to_planes, the ys / post_s operands, the
  * fused bottleneck and stem outputs): 1 = fp16x3 (fp16 hi / lo of 16 x; weights from cl4_pack_conv_weight_f16x3 — the default build),
  * 0 = bf16x3 (bf16 hi / lo of x; weights from cl4_pack_conv_weight_bf16x3; hipcc -DCL4_F16_PLANES=0: the r02-r04 format). */

@@ -158,3 +158,78 @@ def test_inplace_abn_scales_with_abs_gamma_plus_eps(gpu):
         assert _rel(grads[id(bn.weight)], gr.grad) < 1e-4, cls.__name__
         assert _rel(grads[id(bn.bias)], br.grad) < 1e-4
         assert _rel(grads[id(conv.weight)], wr.grad) < 1e-4
+
+
+def _decode_f16_planes(ps):
+    """hi + lo of an fp16 two-plane tensor [n][c/8][hi, lo][h*w][8], still multiplied by its scale (float64 [n, c, h, w])."""
+    n, c, h, w = ps.shape
+    raw = ps.data.view(torch.float16).reshape(n, c // 8, 2, h * w, 8).double()
+    return (raw[:, :, 0] + raw[:, :, 1]).permute(0, 1, 3, 2).reshape(n, c, h, w)
+
+
+@pytest.mark.parametrize("magnitude", [1e-6, 1.0, 4e3])
+@pytest.mark.parametrize("slope", [0.01, None])
+def test_abn_backward_hands_the_gradient_on_as_fp16_planes(gpu, slope, magnitude):
+    """r05 (cl4_bn_sync_bwd_local_max / _apply_planes): dx is bit-identical to the plain launch; its fp16 planes twin carries a
+    power-of-two scale taken from a BOUND on |dx| (known before dx is), so nothing saturates, the bound is tight enough to keep the
+    headroom of the data-derived scale (max |dx| s >= 2^12), and hi + lo reproduce dx to 2^-21 of the tensor's maximum."""
+    from cl4wsis_amd import ops
+    if not ops.planes_f16():
+        pytest.skip("fp16 planes build only")
+    g = torch.Generator().manual_seed(11)
+    c = 72
+    x = torch.randn(3, c, 19, 23, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    dy = torch.randn(x.shape, generator=g) * magnitude * torch.logspace(-1, 1, c)[None, :, None, None]
+    act = ops.ACT_LEAKY if slope is not None else ops.ACT_NONE
+    rm, rv = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
+    xd, gd, bd, dyd = x.to(gpu), gamma.to(gpu), beta.to(gpu), dy.to(gpu)
+    _, mean, var, count = ops.abn_train_forward(xd, gd, bd, rm, rv, act=act, slope=slope or 0.0)
+    out = []
+    for twin in (False, True):
+        dgamma, dbeta = torch.zeros(c, device=gpu), torch.zeros(c, device=gpu)
+        dx = ops.abn_train_backward(xd, dyd, mean, var, gd, bd, dgamma, dbeta, count, act=act, slope=slope or 0.0, want_planes=twin)
+        out.append((dx, dgamma, dbeta))
+    (dx0, dg0, db0), (dx1, dg1, db1) = out
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert getattr(dx0, "_cl4_planes", None) is None
+    ps = dx1._cl4_planes
+    s = float(ps.slot[0])
+    amax = float(dx1.abs().max())
+    assert s > 0 and s == 2.0 ** round(torch.log2(torch.tensor(s)).item()), s
+    assert 2.0 ** 12 <= amax * s < 65504.0, (amax, s, amax * s)
+    dec = _decode_f16_planes(ps).cpu() / s
+    err = (dec - dx1.double().cpu()).abs().max().item()
+    print(f"ABN gradient twin, |dy| ~ {magnitude:g}: scale 2^{round(torch.log2(torch.tensor(s)).item())}, max |dx| s = {amax * s:.0f}, max error / max |dx| = {err / amax:.2e}")
+    assert err <= 2.0 ** -21 * amax, (err, amax)
+
+
+def test_input_gradient_convolution_reads_the_abn_twin(gpu):
+    """The fp16x3 input-gradient convolution fed by the twin equals the one fed by a converted copy of the same fp32 gradient up to the
+    two roundings' difference (both fp32-level), and channel-shrinking 1x1 gradients are routed to fp16x3 when the twin exists."""
+    from cl4wsis_amd import ops
+    if not ops.planes_f16():
+        pytest.skip("fp16 planes build only")
+    g = torch.Generator().manual_seed(12)
+    cin, cout = 256, 1024                                    # conv3 of a res4 bottleneck: its input gradient maps 1024 -> 256 channels
+    x = torch.randn(2, cout, 33, 33, generator=g)
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    dy = torch.randn(x.shape, generator=g) * 1e-4
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / 16.0
+    rm, rv = torch.zeros(cout, device=gpu), torch.ones(cout, device=gpu)
+    xd, gd, bd = x.to(gpu), gamma.to(gpu), beta.to(gpu)
+    _, mean, var, count = ops.abn_train_forward(xd, gd, bd, rm, rv, act=ops.ACT_NONE)
+    dz = ops.abn_train_backward(xd, dy.to(gpu), mean, var, gd, bd, torch.zeros(cout, device=gpu), torch.zeros(cout, device=gpu), count,
+                                act=ops.ACT_NONE, want_planes=True)
+    wd = ops.dgrad_weight(wt.to(gpu), 3, force_f16=True)
+    assert wd.precision == 3 and ops.dgrad_weight(wt.to(gpu), 3).precision == 2
+    before = ops._hip.load().cl4_conv_debug_b_launches()
+    with_twin = ops.conv2d_dgrad(dz, wd, (33, 33), 1)
+    assert ops._hip.load().cl4_conv_debug_b_launches() == before + 1
+    plain = dz.clone()                                       # no twin: converted from the fp32 tensor with the data-derived scale
+    converted = ops.conv2d_dgrad(plain, wd, (33, 33), 1)
+    ref = F.conv_transpose2d(dz.double().cpu(), wt.double())
+    e1 = ((with_twin.double().cpu() - ref).norm() / ref.norm()).item()
+    e2 = ((converted.double().cpu() - ref).norm() / ref.norm()).item()
+    print(f"input gradient 1024 -> 256 from the ABN twin {e1:.2e}, from a converted copy {e2:.2e}")
+    assert e1 < 1e-6 and e2 < 1e-6

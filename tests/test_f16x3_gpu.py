@@ -125,3 +125,35 @@ def test_f16x3_falls_back_to_bf16x6_for_shapes_the_route_does_not_take(gpu):
         assert wp.precision in (2, 0), (cout, cin, wp.precision)
     assert ops.pack_conv_weight(torch.randn(256, 160, 1, 1, device=gpu), 3).precision == 3
     assert ops.pack_conv_weight(torch.randn(128, 1024, 3, 3, device=gpu), 3).precision == 3       # every 3x3 layer is routed
+
+
+def test_batched_weight_packs_equal_the_single_layer_launches(gpu):
+    """cl4_pack_conv_weights_f16x3_batched (r05: all packs of a training iteration in one launch) against cl4_pack_conv_weight_f16x3 and
+    cl4_transpose_flip_weight + cl4_pack_conv_weight_f16x3, bit for bit, through nn.PackBatch (registration, in-place refresh, cache marks)."""
+    import torch.nn as tnn
+    from cl4wsis_amd import body_train, nn as cnn, ops
+    if not ops.planes_f16() or body_train.PRECISION != 3:
+        pytest.skip("fp16x3 training arithmetic only")
+    g = torch.Generator().manual_seed(21)
+    shapes = [(256, 128, 1), (64 + 64, 256, 3), (1024, 256, 1), (256, 1024, 1), (160, 128, 3)]     # cout, cin, k
+    convs = []
+    for cout, cin, k in shapes:
+        c = tnn.Conv2d(cin, cout, k, bias=False)
+        c.weight.data = torch.randn(cout, cin, k, k, generator=g) * 0.05
+        convs.append(c.to(gpu))
+    batch = cnn.PackBatch()
+    with batch:
+        first = [(cnn.packed_weight(c, 3, force_f16=True), body_train._dgrad_weight(c, force_f16=True)) for c in convs]
+    assert len(batch.entries) == 2 * len(convs) and all(a.precision == 3 and b.precision == 3 for a, b in first)
+    with torch.no_grad():
+        for c in convs:
+            c.weight.mul_(1.5).add_(0.01)                    # an "optimizer step": bumps the version, the cache entries go stale
+    with batch:
+        assert batch.refresh() and batch.launches == 1
+        again = [(cnn.packed_weight(c, 3, force_f16=True), body_train._dgrad_weight(c, force_f16=True)) for c in convs]
+    for (a0, b0), (a1, b1), c in zip(first, again, convs):
+        assert a1 is a0 and b1 is b0                         # refreshed in place, the lazy path found the entries current
+        ref_f = ops.pack_conv_weight(c.weight.detach(), 3, force_f16=True)
+        ref_d = ops.dgrad_weight(c.weight.detach(), 3, force_f16=True)
+        assert torch.equal(a1.data, ref_f.data), tuple(c.weight.shape)
+        assert torch.equal(b1.data, ref_d.data), tuple(c.weight.shape)

@@ -4,7 +4,7 @@ tag = sys.argv[1]
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = lambda *p: os.path.join(R, "gpurun_out", *p)
 d = json.load(open(g(tag, "bench.json")))
-print("bench default:", round(d["value"], 1), "images/s", round(d["ms_per_step"], 2), "ms  vs_baseline", round(d["vs_baseline"], 1))
+print("bench default:", round(d["value"], 1), "images/s", round(d["ms_per_step"], 2), "ms  vs_stock_rocm", round(d.get("vs_stock_rocm") or 0, 1))
 r = d["roofline"]
 for k in ("achieved", "frac", "kernel_ms_per_step", "avg_launch_ms", "launches_per_step", "traffic", "algorithmic_bytes_per_launch",
           "algorithmic_bytes_per_launch_incl_epilogue_operands", "traffic_over_algorithmic", "mfma_busy", "hbm_gbs"):
