@@ -33,6 +33,10 @@ class PackJob(C.Structure):
                 ("cout", C.c_int32), ("cin", C.c_int32), ("khw", C.c_int32), ("transposed", C.c_int32)]
 
 
+class AbsJob(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("first", C.c_long), ("n", C.c_int32), ("eps", C.c_float)]
+
+
 class LabelIO(C.Structure):
     _fields_ = [
         ("b", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
@@ -175,10 +179,12 @@ _decl("cl4_p1_seg_loss", _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P,
 _D = C.c_double
 _decl("cl4_bn_sync_stats_local", _P, _I, _I, _I, _I, _I, _P, _P, C.c_size_t, _P)
 _decl("cl4_bn_sync_stats_final", _P, _D, _P, _P, _P, _P, _F, _I, _P)
-_decl("cl4_bn_sync_bwd_local", _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _F, _P, _P, _P, _P, C.c_size_t, _P)
+_decl("cl4_bn_sync_bwd_local", _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _F, _P, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_bn_sync_bwd_apply", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _F, _P, _D, _P, C.c_size_t, _P)
 _decl("cl4_pack_conv_weights_f16x3_batched", _P, _I, _L, _P)
-_decl("cl4_bn_sync_bwd_local_max", _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, C.c_size_t, _P)
+_decl("cl4_abs_eps_batched", _P, _I, _L, _P)
+_decl("cl4_bn_sync_bwd_local_max", _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P, C.c_size_t, _P)
+_decl("cl4_bn_train_bwd_act", _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_bn_sync_bwd_apply_planes", _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _D, _P, _P, C.c_size_t, _P)
 _decl("cl4_zero_insert", _P, _P, _L, _I, _I, _I, _I, _I, _P)
 _decl("cl4_maxpool3x3s2_bwd", _P, _P, _P, _L, _I, _I, _I, _I, _P)
@@ -227,6 +233,8 @@ def load():
     lib.cl4_bn_workspace_bytes.argtypes = [C.c_int]
     lib.cl4_bn_bwd_maxima_floats.restype = C.c_size_t
     lib.cl4_bn_bwd_maxima_floats.argtypes = [C.c_int]
+    lib.cl4_bn_train_bwd_act_workspace_bytes.restype = C.c_size_t
+    lib.cl4_bn_train_bwd_act_workspace_bytes.argtypes = [C.c_int]
     lib.cl4_conv2d_fwd_workspace_bytes.restype = C.c_size_t
     lib.cl4_conv2d_fwd_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
     for nm, at in (("cl4_peak_workspace_bytes", [C.c_int] * 5), ("cl4_label_workspace_bytes", [C.c_int] * 3),

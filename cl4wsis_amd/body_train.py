@@ -78,12 +78,10 @@ def conv_abn_train(x, conv, bn, group=None, xs_cache=None, emit_planes=False, po
 
 def conv_abn_backward(r, conv, bn, dy, grad_of, need_dx=True, group=None, post=None):
     act, slope = bn.act_code()
-    gw, fin = gamma_grad(bn, grad_of)
+    gw, gsign = gamma_grad(bn, grad_of)
     twin = need_dx and _grad_twin_pays(conv)
     dz = ops.abn_train_backward(r.z, dy, r.mean, r.var, gamma_of(bn), bn.bias.detach(), gw, grad_of(bn.bias),
-                                r.count, bn.eps, act, slope, group, want_planes=twin)
-    if fin is not None:
-        fin()
+                                r.count, bn.eps, act, slope, group, want_planes=twin, gamma_sign=gsign)
     k = conv.kernel_size[0]
     ops.conv2d_wgrad(r.x, dz, grad_of(conv.weight), k, stride=conv.stride[0], pad=conv.padding[0], dil=conv.dilation[0], precision=WGRAD_PRECISION)
     if not need_dx:
@@ -198,11 +196,9 @@ def _abn_train(x, bn, group=None):
 
 def _abn_backward(r, bn, dy, grad_of, group=None):
     act, slope = bn.act_code()
-    gw, fin = gamma_grad(bn, grad_of)
+    gw, gsign = gamma_grad(bn, grad_of)
     dx = ops.abn_train_backward(r.z, dy, r.mean, r.var, gamma_of(bn), bn.bias.detach(), gw, grad_of(bn.bias), r.count, bn.eps,
-                                act, slope, group)
-    if fin is not None:
-        fin()
+                                act, slope, group, gamma_sign=gsign)
     return dx
 
 

@@ -285,8 +285,12 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
   }
 }
 
+// `sign_src` (r05; InPlaceABN: the kernels' gamma is |weight| + eps, mapillary/inplace_abn believed behaviour, see cl4_sign_axpy): dgamma
+// receives d(weight) = (weight > 0 ? 1 : -1) * d(gamma) directly — no scratch gradient, no zero fill, no cl4_sign_axpy launch per layer.
+__device__ __forceinline__ float gamma_sign(const float* __restrict__ sign_src, int c) { return (sign_src && !(sign_src[c] > 0.f)) ? -1.f : 1.f; }
+
 __global__ void bn_bwd_final_kernel(const double* __restrict__ partial, float* __restrict__ sum_dz, float* __restrict__ sum_dz_xh,
-                                    float* dgamma, float* dbeta, int c) {
+                                    float* dgamma, float* dbeta, int c, const float* __restrict__ sign_src = nullptr) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c) return;
   double a = 0.0, b = 0.0;
@@ -296,7 +300,7 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ partial, float* _
   }
   sum_dz[i] = (float)a;
   sum_dz_xh[i] = (float)b;
-  if (dgamma) dgamma[i] += (float)b;
+  if (dgamma) dgamma[i] += gamma_sign(sign_src, i) * (float)b;
   if (dbeta) dbeta[i] += (float)a;
 }
 
@@ -307,13 +311,13 @@ __global__ void bn_bwd_apply_fused_kernel(const float* __restrict__ x, const flo
                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                           const double* __restrict__ partial, float* dgamma, float* dbeta, float eps, int act,
                                           float slope, float invn, BnShape s, int dy_ctot, int dy_coff,
-                                          const uint8_t* __restrict__ keep, float keep_scale) {
+                                          const uint8_t* __restrict__ keep, float keep_scale, const float* __restrict__ sign_src = nullptr) {
   const int plane = blockIdx.x;
   const int n = plane / s.c, c = plane - n * s.c;
   double a, b;
   channel_sums(partial, c, a, b);
   if (n == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    if (dgamma) dgamma[c] += (float)b;
+    if (dgamma) dgamma[c] += gamma_sign(sign_src, c) * (float)b;
     if (dbeta) dbeta[c] += (float)a;
   }
   const float rstd = 1.f / sqrtf(var[c] + eps);
@@ -366,11 +370,23 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 // to float (bn_bwd_sums_to_float_kernel's job) and leaves the channel's bound in bound[c]; every workgroup of the apply kernel then folds the
 // c bounds itself (8 KB at most, from L2), like to_planes_f16_kernel folds its partial maxima.
 // coef[c][8] = {mean, rstd, gamma, beta, mean dz, mean dz xhat, -, -}: the apply kernel's per-channel constants as two 16-byte loads.
+// One-rank form (`partial` instead of `sums`): the channel's two sums come straight from the reduction workgroups' partials (channel_sums, the
+// fixed order the fused apply kernels use) and the wave also adds them into dgamma / dbeta — no fold, no final launch.
 __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const double* __restrict__ sums, const float* __restrict__ maxima, const float* __restrict__ mean,
                                                           const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float eps, float invn, int c, float* __restrict__ coef, float* __restrict__ bound) {
+                                                          float eps, float invn, int c, float* __restrict__ coef, float* __restrict__ bound,
+                                                          const double* __restrict__ partial = nullptr, float* dgamma = nullptr, float* dbeta = nullptr,
+                                                          const float* __restrict__ sign_src = nullptr) {
   const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (ch >= c) return;
+  double sa_ = 0.0, sb_ = 0.0;
+  if (partial) {
+    channel_sums(partial, ch, sa_, sb_);
+    if (lane == 0) {
+      if (dgamma) dgamma[ch] += gamma_sign(sign_src, ch) * (float)sb_;
+      if (dbeta) dbeta[ch] += (float)sa_;
+    }
+  }
   float md = 0.f, mx = 0.f;
   if (lane < SPLIT) {
     md = maxima[((long)ch * SPLIT + lane) * 2 + 0];
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(256) void bn_bwd_prep_kernel(const double* __restri
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { md = fmaxf(md, __shfl_xor(md, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
   if (lane == 0) {
-    const float a = (float)sums[2 * ch], b = (float)sums[2 * ch + 1];
+    const float a = partial ? (float)sa_ : (float)sums[2 * ch], b = partial ? (float)sb_ : (float)sums[2 * ch + 1];
     const float rstd = 1.f / sqrtf(var[ch] + eps), g = gamma ? gamma[ch] : 1.f;
     float* q = coef + (long)ch * 8;
     q[0] = mean[ch]; q[1] = rstd; q[2] = g; q[3] = beta ? beta[ch] : 0.f;
@@ -651,7 +667,8 @@ extern "C" int cl4_bn_sync_stats_final(const double* sums, double count, float* 
 extern "C" int cl4_bn_sync_bwd_local(const float* x, const float* dy, int n, int c, int hw, int x_ctot, int x_coff, int dy_ctot,
                                      int dy_coff, const float* mean, const float* var, const float* gamma, const float* beta,
                                      float eps, int act, float slope, const uint8_t* keep, float keep_scale, double* sums,
-                                     float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+                                     float* dgamma, float* dbeta, const float* gamma_sign_src, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
   BnShape s{n, c, hw, x_ctot, x_coff};
   int rc = check_shape(s);
   if (rc) return rc;
@@ -667,7 +684,7 @@ extern "C" int cl4_bn_sync_bwd_local(const float* x, const float* dy, int n, int
   hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, c);
   // the affine gradients are this rank's share (the gradient all-reduce averages them with everything else)
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, fsum, fsum + c, dgamma,
-                     dbeta, c);
+                     dbeta, c, gamma_sign_src);
   return cl4::launch_status();
 }
 
@@ -697,7 +714,8 @@ extern "C" size_t cl4_bn_bwd_maxima_floats(int c) { return (size_t)c * SPLIT * 2
 
 extern "C" int cl4_bn_sync_bwd_local_max(const float* x, const float* dy, int n, int c, int hw, int dy_ctot, int dy_coff, const float* mean,
                                          const float* var, const float* gamma, const float* beta, float eps, int act, float slope, double* sums,
-                                         float* dgamma, float* dbeta, float* maxima, void* workspace, size_t workspace_bytes, void* stream) {
+                                         float* dgamma, float* dbeta, const float* gamma_sign_src, float* maxima, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
   BnShape s{n, c, hw, c, 0};
   int rc = check_shape(s);
   if (rc) return rc;
@@ -712,7 +730,48 @@ extern "C" int cl4_bn_sync_bwd_local_max(const float* x, const float* dy, int n,
                      slope, s, dy_ctot, dy_coff, (const uint8_t*)nullptr, 1.f, maxima);
   hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, c);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, fsum, fsum + c, dgamma,
-                     dbeta, c);
+                     dbeta, c, gamma_sign_src);
+  return cl4::launch_status();
+}
+
+// The whole backward of a ONE-RANK train-mode ABN (no exchange between the reduction and the elementwise pass) in two launches, three with
+// the planes twin: reduction (+ maxima) -> [per-channel constants, bound, dgamma / dbeta] -> dx (+ twin). The two-phase pair above is
+// 5 launches (7 with the InPlaceABN sign rule as separate passes) of which 3-5 are a few microseconds of work each: 109 layers per phase-1
+// iteration. workspace: cl4_bn_train_bwd_act_workspace_bytes(c).
+extern "C" size_t cl4_bn_train_bwd_act_workspace_bytes(int c) {
+  return cl4_bn_workspace_bytes(c) + (size_t)c * SPLIT * 2 * sizeof(float) + (size_t)9 * c * sizeof(float);
+}
+
+extern "C" int cl4_bn_train_bwd_act(const float* x, const float* dy, float* dx, void* dxs, float* slot, int n, int c, int hw, int dy_ctot,
+                                    int dy_coff, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act,
+                                    float slope, float* dgamma, float* dbeta, const float* gamma_sign_src, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  BnShape s{n, c, hw, c, 0};
+  int rc = check_shape(s);
+  if (rc) return rc;
+  CL4_REQUIRE(x && dy && dx && mean && var && workspace, "bn_train_bwd_act: null pointer");
+  CL4_REQUIRE((dxs == nullptr) == (slot == nullptr), "bn_train_bwd_act: dxs and slot come together");
+  CL4_REQUIRE(!dxs || c % 8 == 0, "bn_train_bwd_act: c %% 8 == 0 for the planes twin");
+  CL4_REQUIRE(dy_coff >= 0 && dy_coff + c <= dy_ctot, "bn_train_bwd_act: dy slice out of range");
+  if (workspace_bytes < cl4_bn_train_bwd_act_workspace_bytes(c)) { cl4::set_error("bn_train_bwd_act: workspace too small"); return CL4_ENOSPC; }
+  double* partial = (double*)workspace;
+  float* maxima = (float*)((char*)workspace + cl4_bn_workspace_bytes(c));
+  float* coef = maxima + (size_t)c * SPLIT * 2;
+  hipStream_t st = cl4::as_stream(stream);
+  const float invn = (float)(1.0 / (double)((long)n * hw));       // (as cl4_bn_sync_bwd_apply computes it from the global count)
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act, slope, s, dy_ctot,
+                     dy_coff, (const uint8_t*)nullptr, 1.f, dxs ? maxima : (float*)nullptr);
+  if (!dxs) {
+    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, st, x, dy, dx, mean,
+                       var, gamma, beta, (const double*)partial, dgamma, dbeta, eps, act, slope, invn, s, dy_ctot, dy_coff, (const uint8_t*)nullptr, 1.f,
+                       gamma_sign_src);
+    return cl4::launch_status();
+  }
+  hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3(cl4::cdiv(c, 4)), dim3(256), 0, st, (const double*)nullptr, (const float*)maxima, mean, var, gamma, beta, eps,
+                     invn, c, coef, coef + 8 * (long)c, (const double*)partial, dgamma, dbeta, gamma_sign_src);
+  const long total = (long)n * (c >> 3) * hw;
+  hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, x, dy, dx, (u32x4n*)dxs, (const float*)coef, act, slope,
+                     n, c, hw, dy_ctot, dy_coff, (const float*)(coef + 8 * (long)c), slot);
   return cl4::launch_status();
 }
 
@@ -784,6 +843,34 @@ __global__ void sign_axpy_kernel(float* __restrict__ y, const float* __restrict_
 extern "C" int cl4_abs_eps(const float* w, float* out, int n, float eps, void* stream) {
   CL4_REQUIRE(w && out && n > 0, "abs_eps: bad arguments");
   hipLaunchKernelGGL(abs_eps_kernel, dim3(cl4::cdiv(n, 256)), dim3(256), 0, cl4::as_stream(stream), w, out, n, eps);
+  return cl4::launch_status();
+}
+// r05: cl4_abs_eps of every InPlaceABN layer of a network in one launch (109 launches of ~5 us per phase-1 iteration otherwise); the job
+// table is laid out like cl4_pack_job's (include/cl4wsis.h: cl4_abs_job), one item per channel.
+struct AbsJob {
+  const float* w;
+  float* out;
+  long first;
+  int n;
+  float eps;
+};
+__global__ __launch_bounds__(256) void abs_eps_batched_kernel(const AbsJob* __restrict__ jobs, int njobs, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].first <= i) lo = mid; else hi = mid - 1;
+    }
+    const AbsJob jb = jobs[lo];
+    const long r = i - jb.first;
+    jb.out[r] = fabsf(jb.w[r]) + jb.eps;
+  }
+}
+extern "C" int cl4_abs_eps_batched(const cl4_abs_job* jobs, int njobs, long total_items, void* stream) {
+  CL4_REQUIRE(jobs && njobs > 0 && total_items > 0, "abs_eps_batched: bad arguments");
+  static_assert(sizeof(AbsJob) == sizeof(cl4_abs_job) && sizeof(AbsJob) == 32, "cl4_abs_job layout (include/cl4wsis.h)");
+  hipLaunchKernelGGL(abs_eps_batched_kernel, dim3(cl4::stream_grid(total_items, 256)), dim3(256), 0, cl4::as_stream(stream), (const AbsJob*)jobs, njobs,
+                     total_items);
   return cl4::launch_status();
 }
 extern "C" int cl4_sign_axpy(float* y, const float* x, const float* w, int n, void* stream) {

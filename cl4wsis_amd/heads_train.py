@@ -20,11 +20,9 @@ def _abn_fwd(z, bn, group, emit_planes=False):
 def _abn_bwd(rec, bn, dy, grad_of, group):
     z, mean, var, count = rec
     act, slope = bn.act_code()
-    gw, fin = gamma_grad(bn, grad_of)
+    gw, gsign = gamma_grad(bn, grad_of)
     dz = ops.abn_train_backward(z, dy, mean, var, gamma_of(bn), bn.bias.detach(), gw, grad_of(bn.bias), count,
-                                bn.eps, act, slope, group)
-    if fin is not None:
-        fin()
+                                bn.eps, act, slope, group, gamma_sign=gsign)
     return dz
 
 

@@ -60,18 +60,19 @@ class InPlaceABNSync(InPlaceABN):
 def gamma_of(bn):
     """The scale the normalisation kernels must use: |weight| + eps for InPlaceABN(Sync), weight otherwise."""
     if getattr(bn, "abs_gamma", False):
-        return CACHE.get(bn, "absg", (bn.weight,), lambda: ops.abs_eps(bn.weight.detach(), bn.eps))
+        val = CACHE.get(bn, "absg", (bn.weight,), lambda: ops.abs_eps(bn.weight.detach(), bn.eps))
+        if PackBatch.ACTIVE is not None:
+            PackBatch.ACTIVE.register_scale(bn, val)
+        return val
     return bn.weight.detach()
 
 
 def gamma_grad(bn, grad_of):
-    """(buffer the backward kernel accumulates d(scale) into, finaliser or None). For InPlaceABN the kernel's result is the
-    gradient of the effective scale; the finaliser folds it into the weight's gradient with the sign rule."""
+    """(buffer the backward kernel accumulates the weight's gradient into, `gamma_sign` operand of ops.abn_train_backward or None). For
+    InPlaceABN the kernels differentiate the effective scale |weight| + eps; handed the raw weight they apply the sign rule themselves
+    (r05: no scratch gradient, zero fill and cl4_sign_axpy launch per layer)."""
     gw = grad_of(bn.weight)
-    if not getattr(bn, "abs_gamma", False):
-        return gw, None
-    tmp = torch.zeros_like(gw)
-    return tmp, (lambda: ops.sign_axpy_(gw, tmp, bn.weight.detach()))
+    return gw, (bn.weight.detach() if getattr(bn, "abs_gamma", False) else None)
 
 
 class _Cache:
@@ -124,7 +125,8 @@ CACHE = _Cache()
 
 
 class PackBatch:
-    """All fp16x3 weight packs of a training iteration in one launch (r05, cl4_pack_conv_weights_f16x3_batched). While a batch is the
+    """All fp16x3 weight packs (and InPlaceABN scales) of a training iteration in one launch each (r05, cl4_pack_conv_weights_f16x3_batched,
+    cl4_abs_eps_batched). While a batch is the
     ACTIVE one (`with batch:`), every fp16x3 pack that packed_weight / body_train._dgrad_weight build lazily for a TRAINABLE convolution is
     registered with it — the PackedWeight it returned becomes that layer's persistent buffer. `refresh()` (the start of every later
     iteration) re-derives ALL registered packs in place with one launch and marks the cache entries current, so the lazy path finds
@@ -138,7 +140,8 @@ class PackBatch:
 
     def __init__(self):
         self.entries = {}        # (id(conv), key) -> (conv, key, transposed, PackedWeight)
-        self._table = None       # (device tensor of cl4_pack_job, njobs, total items), valid for len(entries) == njobs
+        self.scales = {}         # id(bn) -> (bn, |weight| + eps tensor): the InPlaceABN scales ride along (cl4_abs_eps_batched)
+        self._table = None       # device job tables and what they were built for
         self.launches = 0
 
     def __enter__(self):
@@ -154,34 +157,55 @@ class PackBatch:
                 and conv.weight.is_contiguous() and (id(conv), key) not in self.entries):
             self.entries[(id(conv), key)] = (conv, key, bool(transposed), wp)
 
+    def register_scale(self, bn, val):
+        if bn.weight.requires_grad and bn.weight.is_cuda and id(bn) not in self.scales:
+            self.scales[id(bn)] = (bn, val)
+
+    def _signature(self):
+        return ([e[0].weight.data_ptr() for e in self.entries.values()], [e[0].weight.data_ptr() for e in self.scales.values()])
+
     def _build_table(self):
-        import ctypes as C
-        from ._hip import PackJob
-        jobs = (PackJob * len(self.entries))()
-        first = 0
+        from ._hip import AbsJob, PackJob
+
+        def upload(jobs, dev):
+            return torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).clone().to(dev)
+
+        jobs = (PackJob * max(len(self.entries), 1))()
+        first, dev = 0, None
         for j, (conv, key, transposed, wp) in zip(jobs, self.entries.values()):
             cout, cin, kh, kw = conv.weight.shape
             j.w, j.wq, j.first = conv.weight.data_ptr(), wp.data.data_ptr(), first
             j.cout, j.cin, j.khw, j.transposed = cout, cin, kh * kw, int(transposed)
             first += (kh * kw * (cout if transposed else cin) // 8) * (cin if transposed else cout)
-        raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).clone()
-        dev = next(iter(self.entries.values()))[0].weight.device
-        self._table = (raw.to(dev), len(self.entries), first, [e[0].weight.data_ptr() for e in self.entries.values()])
+            dev = conv.weight.device
+        ajobs = (AbsJob * max(len(self.scales), 1))()
+        afirst = 0
+        for j, (bn, val) in zip(ajobs, self.scales.values()):
+            j.w, j.out, j.first, j.n, j.eps = bn.weight.data_ptr(), val.data_ptr(), afirst, bn.weight.numel(), bn.eps
+            afirst += bn.weight.numel()
+            dev = bn.weight.device
+        self._table = {"packs": (upload(jobs, dev), len(self.entries), first), "scales": (upload(ajobs, dev), len(self.scales), afirst),
+                       "sig": self._signature()}
 
     def refresh(self):
-        """Re-derive every registered pack from the current weights (one launch) and mark the cache entries current."""
-        if not self.entries:
+        """Re-derive every registered pack / scale from the current weights (one launch each) and mark the cache entries current."""
+        if not self.entries and not self.scales:
             return False
-        ptrs = [e[0].weight.data_ptr() for e in self.entries.values()]
-        if self._table is None or self._table[1] != len(self.entries) or self._table[3] != ptrs:
+        if self._table is None or self._table["sig"] != self._signature():
             if torch.cuda.is_current_stream_capturing():
-                return False                                 # (no host-to-device copy inside a capture: the lazy path packs layer by layer)
+                return False                                 # (no host-to-device copy inside a capture: the lazy path derives layer by layer)
             self._build_table()
-        table, njobs, total, _ = self._table
-        ops.call("cl4_pack_conv_weights_f16x3_batched", ops.ptr(table), njobs, total, ops.stream())
-        self.launches += 1
+        table, njobs, total = self._table["packs"]
+        if njobs:
+            ops.call("cl4_pack_conv_weights_f16x3_batched", ops.ptr(table), njobs, total, ops.stream())
+            self.launches += 1
+        table, njobs, total = self._table["scales"]
+        if njobs:
+            ops.call("cl4_abs_eps_batched", ops.ptr(table), njobs, total, ops.stream())
         for conv, key, _, wp in self.entries.values():
             conv.__dict__.setdefault("_cl4_cache", {})[key] = (CACHE._sig((conv.weight,)), wp)
+        for bn, val in self.scales.values():
+            bn.__dict__.setdefault("_cl4_cache", {})["absg"] = (CACHE._sig((bn.weight,)), val)
         return True
 
 

@@ -1060,6 +1060,7 @@ def bn_train_fwd(x, gamma, beta, running_mean=None, running_var=None, momentum=0
 
 PRODUCER_PLANES = os.environ.get("CL4_PRODUCER_PLANES", "1") != "0"     # r05: train-mode ABN apply / residual add write the planes twin the next fp16x3 convolution reads
 GRAD_PLANES = os.environ.get("CL4_GRAD_PLANES", "1") != "0"             # r05: ABN backward writes the fp16 planes twin of the gradient it hands on
+ABN_ONE_RANK = os.environ.get("CL4_ABN_ONE_RANK", "1") != "0"           # r05: train-mode ABN without an exchange step when there is one rank (fewer launches)
 
 
 def bn_apply(x, mean, var, gamma, beta, eps=1e-5, act=ACT_RELU, slope=0.01, keep=None, keep_scale=1.0,
@@ -1167,6 +1168,12 @@ def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momen
     `group`, then BN + leaky-ReLU / identity. Returns (y, mean, var, count). `extra_sums` ([c*2] doubles, count) adds the
     statistics of shards held elsewhere — used by the tests to emulate a second rank on one GPU."""
     n, c, h, w = x.shape
+    if ABN_ONE_RANK and extra_sums is None and not STAT_EXCHANGE._active(group):
+        # r05: nobody to exchange sums with — statistics straight from the reduction's partials (cl4_bn_train_stats: the same arithmetic
+        # as fold + all-reduce + final, one launch less per layer)
+        mean, var = bn_train_stats(x, running_mean=running_mean, running_var=running_var, momentum=momentum)
+        y = bn_apply(x, mean, var, gamma, beta, eps=eps, act=act, slope=slope, want_planes=want_planes, post=post, act2=act2, slope2=slope2)
+        return y, mean, var, float(n * h * w)
     # the count slot exists only when a caller brings extra shards (ADVICE r04: an uninitialised double must not go through the all-reduce)
     sums = torch.empty(2 * c + (1 if extra_sums is not None else 0), dtype=torch.float64, device=x.device)
     ws = _workspace(x.device, bn_workspace_bytes(c))
@@ -1186,32 +1193,44 @@ def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momen
 
 
 def abn_train_backward(x, dy, mean, var, gamma, beta, dgamma, dbeta, count, eps=1e-5, act=ACT_LEAKY, slope=0.01, group=None,
-                       extra_sums=None, return_sums=False, want_planes=False):
+                       extra_sums=None, return_sums=False, want_planes=False, gamma_sign=None):
     """Backward of abn_train_forward: dx; this rank's share of the affine gradients is accumulated into dgamma / dbeta. `want_planes`
     (r05): dx also leaves as the fp16x3 operand of the input-gradient convolution in front (`dx._cl4_planes`, its power-of-two scale from
-    a bound the reduction pass provides — cl4_bn_sync_bwd_apply_planes): no max |dx| pass, no conversion pass."""
+    a bound the reduction pass provides — cl4_bn_sync_bwd_apply_planes): no max |dx| pass, no conversion pass. `gamma_sign` (InPlaceABN:
+    `gamma` is |weight| + eps): the raw weight — dgamma then receives d(weight) = sign(weight) d(gamma). With nobody to exchange sums with
+    (one rank, no extra shards) the whole backward is cl4_bn_train_bwd_act: two launches, three with the twin."""
     n, c, h, w = x.shape
+    want_planes = bool(want_planes) and c % 8 == 0 and planes_f16() and x.is_contiguous()
+    dx = torch.empty_like(x)
+    ps = None
+    if want_planes:
+        slot = torch.empty(_hip.load().cl4_to_planes_f16_slot_floats(), dtype=torch.float32, device=x.device)
+        ps = Planes(n, c, h, w, x.device, planes=2, slot=slot)
+    if ABN_ONE_RANK and extra_sums is None and not return_sums and not STAT_EXCHANGE._active(group) and count == float(n * h * w):
+        ws = _workspace(x.device, _hip.load().cl4_bn_train_bwd_act_workspace_bytes(c))
+        call("cl4_bn_train_bwd_act", ptr(x), ptr(dy), ptr(dx), ptr(ps.data) if ps is not None else None, ptr(ps.slot) if ps is not None else None,
+             n, c, h * w, dy.shape[1], 0, ptr(mean), ptr(var), ptr(gamma), ptr(beta), C.c_float(eps), act, C.c_float(slope), ptr(dgamma), ptr(dbeta),
+             ptr(gamma_sign), ptr(ws), ws.numel(), stream())
+        if ps is not None:
+            dx._cl4_planes = ps
+        return dx
     sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
     ws = _workspace(x.device, bn_workspace_bytes(c))
-    want_planes = bool(want_planes) and c % 8 == 0 and planes_f16() and x.is_contiguous()
     if want_planes:
         maxima = torch.empty(_hip.load().cl4_bn_bwd_maxima_floats(c), dtype=torch.float32, device=x.device)
         call("cl4_bn_sync_bwd_local_max", ptr(x), ptr(dy), n, c, h * w, dy.shape[1], 0, ptr(mean), ptr(var), ptr(gamma), ptr(beta),
-             C.c_float(eps), act, C.c_float(slope), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(maxima), ptr(ws), ws.numel(), stream())
+             C.c_float(eps), act, C.c_float(slope), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(gamma_sign), ptr(maxima), ptr(ws), ws.numel(), stream())
     else:
         call("cl4_bn_sync_bwd_local", ptr(x), ptr(dy), n, c, h * w, c, 0, dy.shape[1], 0, ptr(mean), ptr(var), ptr(gamma), ptr(beta),
-             C.c_float(eps), act, C.c_float(slope), None, C.c_float(1.0), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(),
+             C.c_float(eps), act, C.c_float(slope), None, C.c_float(1.0), ptr(sums), ptr(dgamma), ptr(dbeta), ptr(gamma_sign), ptr(ws), ws.numel(),
              stream())
     local = sums.clone() if return_sums else None
     if extra_sums is not None:
         sums += extra_sums
     _allreduce_sum(sums, group)
-    dx = torch.empty_like(x)
     if want_planes:
         # (the bound uses this rank's maxima and the global sums: each rank scales its own dx)
-        slot = torch.empty(_hip.load().cl4_to_planes_f16_slot_floats(), dtype=torch.float32, device=x.device)
-        ps = Planes(n, c, h, w, x.device, planes=2, slot=slot)
-        call("cl4_bn_sync_bwd_apply_planes", ptr(x), ptr(dy), ptr(dx), ptr(ps.data), ptr(slot), n, c, h * w, dy.shape[1], 0, ptr(mean), ptr(var),
+        call("cl4_bn_sync_bwd_apply_planes", ptr(x), ptr(dy), ptr(dx), ptr(ps.data), ptr(ps.slot), n, c, h * w, dy.shape[1], 0, ptr(mean), ptr(var),
              ptr(gamma), ptr(beta), C.c_float(eps), act, C.c_float(slope), ptr(sums), C.c_double(count), ptr(maxima), ptr(ws), ws.numel(), stream())
         dx._cl4_planes = ps
     else:

@@ -210,7 +210,9 @@ int cl4_random_labels_dev(int* out, long n, uint64_t* seed_dev, uint64_t advance
  *             cl4_bn_sync_stats_final -> cl4_bn_apply;
  *   backward: cl4_bn_sync_bwd_local (local {sum dz, sum dz*xhat}; accumulates this rank's dgamma / dbeta) ->
  *             all-reduce(SUM) -> cl4_bn_sync_bwd_apply with the global count.
- * With one rank the pair reproduces cl4_bn_train_stats / cl4_bn_train_bwd (and adds the leaky-ReLU derivative). */
+ * With one rank the pair reproduces cl4_bn_train_stats / cl4_bn_train_bwd (and adds the leaky-ReLU derivative).
+ * gamma_sign_src (nullable; InPlaceABN, whose kernels run with gamma = |weight| + eps — cl4_abs_eps): the layer's raw weight; dgamma then
+ * receives d(weight) = (weight > 0 ? 1 : -1) * d(gamma) directly (what cl4_sign_axpy does as a separate pass). */
 int cl4_bn_sync_stats_local(const float* x, int n, int c, int hw, int ctot, int coff, double* sums, void* workspace,
                             size_t workspace_bytes, void* stream);
 int cl4_bn_sync_stats_final(const double* sums, double count, float* mean, float* var, float* running_mean, float* running_var,
@@ -218,7 +220,7 @@ int cl4_bn_sync_stats_final(const double* sums, double count, float* mean, float
 int cl4_bn_sync_bwd_local(const float* x, const float* dy, int n, int c, int hw, int x_ctot, int x_coff, int dy_ctot, int dy_coff,
                           const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act,
                           float slope, const uint8_t* keep, float keep_scale, double* sums, float* dgamma, float* dbeta,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          const float* gamma_sign_src, void* workspace, size_t workspace_bytes, void* stream);
 int cl4_bn_sync_bwd_apply(const float* x, const float* dy, float* dx, int n, int c, int hw, int x_ctot, int x_coff, int dy_ctot,
                           int dy_coff, const float* mean, const float* var, const float* gamma, const float* beta, float eps,
                           int act, float slope, const uint8_t* keep, float keep_scale, const double* sums, double count,
@@ -231,11 +233,19 @@ int cl4_bn_sync_bwd_apply(const float* x, const float* dy, float* dx, int n, int
 size_t cl4_bn_bwd_maxima_floats(int c);
 int cl4_bn_sync_bwd_local_max(const float* x, const float* dy, int n, int c, int hw, int dy_ctot, int dy_coff, const float* mean,
                               const float* var, const float* gamma, const float* beta, float eps, int act, float slope, double* sums,
-                              float* dgamma, float* dbeta, float* maxima, void* workspace, size_t workspace_bytes, void* stream);
+                              float* dgamma, float* dbeta, const float* gamma_sign_src, float* maxima, void* workspace, size_t workspace_bytes,
+                              void* stream);
 int cl4_bn_sync_bwd_apply_planes(const float* x, const float* dy, float* dx, void* dxs, float* slot, int n, int c, int hw, int dy_ctot,
                                  int dy_coff, const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act,
                                  float slope, const double* sums, double count, const float* maxima, void* workspace, size_t workspace_bytes,
                                  void* stream);
+/* The backward of a train-mode InPlaceABN on ONE rank (no exchange between reduction and elementwise pass: N = 1 runs of train.py:272-537)
+ * in two launches — reduction, then dx with the channel sums folded in place and dgamma / dbeta accumulated (sign rule: gamma_sign_src) —
+ * or three with the planes twin (dxs + slot non-null: see cl4_bn_sync_bwd_apply_planes). Results equal the two-phase pair's at world size 1. */
+size_t cl4_bn_train_bwd_act_workspace_bytes(int c);
+int cl4_bn_train_bwd_act(const float* x, const float* dy, float* dx, void* dxs, float* slot, int n, int c, int hw, int dy_ctot, int dy_coff,
+                         const float* mean, const float* var, const float* gamma, const float* beta, float eps, int act, float slope,
+                         float* dgamma, float* dbeta, const float* gamma_sign_src, void* workspace, size_t workspace_bytes, void* stream);
 /* db[c] += sum_{n,hw} dy — bias gradient of the classifier convs. */
 int cl4_bias_grad(const float* dy, float* db, int n, int c, int hw, int ctot, int coff, void* stream);
 /* Counter-based keep mask for nn.Dropout(p) — modules/panoptic_deeplab.py:123. */
@@ -633,6 +643,15 @@ int cl4_bn_apply_planes(const float* x, float* y, void* ys, int n, int c, int hw
                         /* ys may be null; post != null: y = act2(act(bn(x)) + post) (the residual add of a bottleneck in the same pass) */
 int cl4_add_act_planes(const float* a, const float* b, float* y, void* ys, int n, int c, int hw, int act, float slope, void* stream);
 int cl4_abs_eps(const float* w, float* out, int n, float eps, void* stream);
+/* ... of every InPlaceABN layer of a network in one launch: jobs in device memory, `first` = the channels of the jobs in front. */
+typedef struct cl4_abs_job {
+  const float* w;
+  float* out;
+  long first;
+  int n;
+  float eps;
+} cl4_abs_job;
+int cl4_abs_eps_batched(const cl4_abs_job* jobs, int njobs, long total_items, void* stream);
 int cl4_sign_axpy(float* y, const float* x, const float* w, int n, void* stream);
 
 /* --------------------------------------------------------------------------

@@ -233,3 +233,40 @@ def test_input_gradient_convolution_reads_the_abn_twin(gpu):
     e2 = ((converted.double().cpu() - ref).norm() / ref.norm()).item()
     print(f"input gradient 1024 -> 256 from the ABN twin {e1:.2e}, from a converted copy {e2:.2e}")
     assert e1 < 1e-6 and e2 < 1e-6
+
+
+@pytest.mark.parametrize("twin", [False, True])
+def test_one_rank_abn_equals_the_two_phase_pair_and_applies_the_sign_rule(gpu, monkeypatch, twin):
+    """r05: with nobody to exchange sums with, forward statistics come straight from the reduction's partials (cl4_bn_train_stats) and the
+    backward is cl4_bn_train_bwd_act (two launches, three with the planes twin); same numbers as the two-phase cl4_bn_sync_* pair. With
+    `gamma_sign` (InPlaceABN: the kernels see |weight| + eps) dgamma receives sign(weight) * d(gamma), what cl4_sign_axpy did as a pass."""
+    from cl4wsis_amd import ops
+    if twin and not ops.planes_f16():
+        pytest.skip("fp16 planes build only")
+    g = torch.Generator().manual_seed(13)
+    c = 64
+    x = (torch.randn(3, c, 21, 17, generator=g) * 1.5 + 0.3).to(gpu)
+    weight = torch.randn(c, generator=g).to(gpu)                       # negative entries: the sign rule matters
+    gamma = ops.abs_eps(weight, 1e-5)
+    beta = torch.randn(c, generator=g).to(gpu)
+    dy = torch.randn(x.shape, generator=g).to(gpu)
+    res = []
+    for one_rank in (False, True):
+        monkeypatch.setattr(ops, "ABN_ONE_RANK", one_rank)
+        rm, rv = torch.zeros(c, device=gpu), torch.ones(c, device=gpu)
+        y, mean, var, count = ops.abn_train_forward(x, gamma, beta, rm, rv, act=ops.ACT_LEAKY, slope=0.01)
+        dgamma, dbeta = torch.full((c,), 0.25, device=gpu), torch.full((c,), -0.5, device=gpu)      # accumulated into, not overwritten
+        dx = ops.abn_train_backward(x, dy, mean, var, gamma, beta, dgamma, dbeta, count, act=ops.ACT_LEAKY, slope=0.01, want_planes=twin, gamma_sign=weight)
+        res.append((y, mean, var, rm, rv, dx, dgamma, dbeta, getattr(dx, "_cl4_planes", None)))
+    a, b = res
+    for i, name in enumerate(("y", "mean", "var", "running_mean", "running_var", "dx")):
+        assert torch.equal(a[i], b[i]), name
+    # dgamma / dbeta: the one-rank kernels sum the 32 partials by a butterfly, the two-phase pair sequentially (float64 both): equal to 1e-6
+    assert _rel(a[6], b[6]) < 1e-6 and _rel(a[7], b[7]) < 1e-6
+    if twin:
+        assert float(a[8].slot[0]) == float(b[8].slot[0]) and torch.equal(a[8].data, b[8].data)
+    # the sign rule against the plain chain rule
+    dg_plain, db_plain = torch.zeros(c, device=gpu), torch.zeros(c, device=gpu)
+    ops.abn_train_backward(x, dy, a[1], a[2], gamma, beta, dg_plain, db_plain, float(x.numel() // c), act=ops.ACT_LEAKY, slope=0.01)
+    expect = 0.25 + torch.where(weight > 0, dg_plain, -dg_plain)
+    assert _rel(b[6], expect) < 1e-6 and _rel(b[7], db_plain - 0.5) < 1e-6
