@@ -66,6 +66,39 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float
   }
 }
 
+// The same gather with every window's argmax computed ONCE (r05): a workgroup owns MP_ROWS input rows of a plane, first leaves the argmax of the
+// <= MP_ROWS / 2 + 1 window rows that touch them in LDS (9 loads per window = 2.25 per input element), then every input element looks its <= 4
+// windows up there. maxpool3x3s2_bwd_kernel recomputes up to four 9-element argmaxes per input element: 1.56 ms for the stem of a 16-image
+// phase-1 step (68 M elements, ~25 cached loads each); this one is bound by its 0.6 GB of traffic. Same comparisons, same accumulation order:
+// bit-identical.
+constexpr int MP_ROWS = 16;
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_tile_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                                    int hin, int win, int hout, int wout) {
+  extern __shared__ int warg[];                // [MP_ROWS / 2 + 1][wout]
+  const long pl = blockIdx.x;
+  const int r0 = blockIdx.y * MP_ROWS, r1 = min(r0 + MP_ROWS, hin);
+  const float* xp = x + pl * hin * win;
+  const float* dp = dy + pl * hout * wout;
+  const int oy0 = r0 / 2, oy1 = min(hout - 1, r1 / 2);            // window rows touching input rows r0 .. r1 - 1: iy / 2 .. (iy + 1) / 2
+  const int nwin = (oy1 - oy0 + 1) * wout;
+  for (int t = threadIdx.x; t < nwin; t += blockDim.x) {
+    const int oy = oy0 + t / wout, ox = t - (t / wout) * wout;
+    warg[t] = window_argmax(xp, oy, ox, hin, win);
+  }
+  __syncthreads();
+  const int nel = (r1 - r0) * win;
+  for (int i = threadIdx.x; i < nel; i += blockDim.x) {
+    const int iy = r0 + i / win, ix = i - (i / win) * win;
+    const int oy_lo = iy / 2, oy_hi = min(hout - 1, (iy + 1) / 2);
+    const int ox_lo = ix / 2, ox_hi = min(wout - 1, (ix + 1) / 2);
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+      for (int ox = ox_lo; ox <= ox_hi; ++ox)
+        if (warg[(oy - oy0) * wout + ox] == iy * win + ix) acc += dp[oy * wout + ox];
+    dx[pl * hin * win + (long)iy * win + ix] = acc;
+  }
+}
+
 __global__ void add_act_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n, int act,
                                float slope) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -184,6 +217,13 @@ extern "C" int cl4_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, 
                                     void* stream) {
   CL4_REQUIRE(x && dy && dx && planes > 0, "maxpool_bwd: bad arguments");
   CL4_REQUIRE(hout == (hin + 2 - 3) / 2 + 1 && wout == (win + 2 - 3) / 2 + 1, "maxpool_bwd: output size mismatch");
+  static const bool tiled = [] { const char* e = getenv("CL4_MAXPOOL_BWD_TILE"); return !e || atoi(e) != 0; }();
+  const size_t lds = (size_t)(MP_ROWS / 2 + 1) * wout * sizeof(int);
+  if (tiled && lds <= 48 * 1024 && cl4::cdiv(hin, MP_ROWS) <= 65535) {
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_tile_kernel, dim3((unsigned)planes, cl4::cdiv(hin, MP_ROWS)), dim3(256), lds, cl4::as_stream(stream), x, dy, dx,
+                       hin, win, hout, wout);
+    return cl4::launch_status();
+  }
   const int chunks = cl4::cdiv((long)hin * win, 1024) < 64 ? cl4::cdiv((long)hin * win, 1024) : 64;
   hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((unsigned)planes, chunks), dim3(256), 0, cl4::as_stream(stream), x, dy, dx,
                      planes, hin, win, hout, wout);

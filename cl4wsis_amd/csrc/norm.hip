@@ -24,28 +24,50 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b) {
   b = sb[0] + sb[1] + sb[2] + sb[3];
 }
 
-// grid (c, SPLIT): partial[(c*SPLIT + s)*2 + {0,1}] = {sum x, sum x^2} over this block's share.
+// Reduction grids (r05): (c, nsplit) with nsplit <= SPLIT chosen so that a thread owns >= 8 elements where the tensor allows it — at 16 images
+// of 33 x 33 the fixed c x 32 grid left TWO elements per thread under a double-precision block reduction (res4: 2.0 TB/s, 8 ms per phase-1
+// step in these two kernels) — and four independent loads per thread and iteration instead of one. Consumers still read SPLIT partials per
+// channel: the entries no workgroup owns are written as zeros by the workgroups that exist.
+static int reduction_split(int per_c, int c) {
+  static const bool fixed = [] { const char* e = getenv("CL4_BN_SPLIT_FIXED"); return e && atoi(e) != 0; }();      // A/B: the r01-r04 grid
+  if (fixed) return SPLIT;
+  int sp = per_c / 2048;
+  if (sp > SPLIT) sp = SPLIT;
+  if (sp < 1) sp = 1;
+  while (sp < SPLIT && (long)c * sp < 1024) sp *= 2;      // >= ~4 workgroups per CU
+  return sp < SPLIT ? sp : SPLIT;
+}
+
+// grid (c, nsplit): partial[(c*SPLIT + s)*2 + {0,1}] = {sum x, sum x^2} over this block's share.
 __global__ void bn_stats_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, BnShape s) {
   const int c = blockIdx.x, sp = blockIdx.y;
   const int per_c = s.n * s.hw;                // checked on the host: < 2^31
-  const int step = SPLIT * blockDim.x;
+  const int step = gridDim.y * blockDim.x;
   double a = 0.0, b = 0.0;
-  // flattened (n, p) index walked without divisions: one division for the start, then carry p over image boundaries
-  int i = sp * blockDim.x + threadIdx.x;
-  int n = i / s.hw, p = i - n * s.hw;
   const float* xc = x + (long)(s.coff + c) * s.hw;
   const long img = (long)s.ctot * s.hw;
-  for (; i < per_c; i += step) {
-    const float v = xc[n * img + p];
-    a += (double)v;
-    b += (double)v * (double)v;
-    p += step;
-    while (p >= s.hw) { p -= s.hw; ++n; }
+  for (long i = sp * blockDim.x + threadIdx.x; i < per_c; i += 4L * step) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long j = i + (long)k * step;
+      const int n = j < per_c ? (int)j / s.hw : 0, p = (int)j - n * s.hw;
+      v[k] = j < per_c ? xc[n * img + p] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a += (double)v[k];
+      b += (double)v[k] * (double)v[k];
+    }
   }
   block_reduce2(a, b);
   if (threadIdx.x == 0) {
     partial[((long)c * SPLIT + sp) * 2 + 0] = a;
     partial[((long)c * SPLIT + sp) * 2 + 1] = b;
+    for (int z = sp + gridDim.y; z < SPLIT; z += gridDim.y) {
+      partial[((long)c * SPLIT + z) * 2 + 0] = 0.0;
+      partial[((long)c * SPLIT + z) * 2 + 1] = 0.0;
+    }
   }
 }
 
@@ -244,33 +266,46 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
                                       float keep_scale, float* __restrict__ maxima = nullptr) {
   const int c = blockIdx.x, sp = blockIdx.y;
   const int per_c = s.n * s.hw;
-  const int step = SPLIT * blockDim.x;
+  const int step = gridDim.y * blockDim.x;       // (c, nsplit) grid: reduction_split
   const float mu = mean[c], rstd = 1.f / sqrtf(var[c] + eps);
   const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
   double a = 0.0, b = 0.0;
   float md = 0.f, mx = 0.f;          // max |dz|, max |xhat| of this workgroup's share (r05: the bound behind cl4_bn_sync_bwd_apply_planes)
-  int i = sp * blockDim.x + threadIdx.x;
-  int n = i / s.hw, p = i - n * s.hw;
   const float* xc = x + (long)(s.coff + c) * s.hw;
   const float* dc = dy + (long)(dy_coff + c) * s.hw;
   const uint8_t* kc = keep ? keep + (long)c * s.hw : nullptr;
   const long ximg = (long)s.ctot * s.hw, dimg = (long)dy_ctot * s.hw, kimg = (long)s.c * s.hw;
-  for (; i < per_c; i += step) {
-    float xh = (xc[n * ximg + p] - mu) * rstd;
-    float d = dc[n * dimg + p];
-    if (kc) d = kc[n * kimg + p] ? d * keep_scale : 0.f;
-    d = act_grad(d, xh * g + bb, act, slope);
-    a += (double)d;
-    b += (double)d * (double)xh;
-    md = fmaxf(md, fabsf(d));
-    mx = fmaxf(mx, fabsf(xh));
-    p += step;
-    while (p >= s.hw) { p -= s.hw; ++n; }
+  for (long i = sp * blockDim.x + threadIdx.x; i < per_c; i += 4L * step) {
+    float xv[4], dv[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                // four independent (x, dy) loads in flight per thread
+      const long j = i + (long)k * step;
+      ok[k] = j < per_c;
+      const int n = ok[k] ? (int)j / s.hw : 0, p = ok[k] ? (int)j - n * s.hw : 0;
+      xv[k] = ok[k] ? xc[n * ximg + p] : 0.f;
+      dv[k] = ok[k] ? dc[n * dimg + p] : 0.f;
+      if (kc && ok[k]) dv[k] = kc[n * kimg + p] ? dv[k] * keep_scale : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!ok[k]) continue;
+      const float xh = (xv[k] - mu) * rstd;
+      const float d = act_grad(dv[k], xh * g + bb, act, slope);
+      a += (double)d;
+      b += (double)d * (double)xh;
+      md = fmaxf(md, fabsf(d));
+      mx = fmaxf(mx, fabsf(xh));
+    }
   }
   block_reduce2(a, b);
   if (threadIdx.x == 0) {
     partial[((long)c * SPLIT + sp) * 2 + 0] = a;
     partial[((long)c * SPLIT + sp) * 2 + 1] = b;
+    for (int z = sp + gridDim.y; z < SPLIT; z += gridDim.y) {
+      partial[((long)c * SPLIT + z) * 2 + 0] = 0.0;
+      partial[((long)c * SPLIT + z) * 2 + 1] = 0.0;
+    }
   }
   if (maxima) {                      // (uniform branch; block_reduce2's shared arrays are not reused)
     __shared__ float sm[8];
@@ -281,6 +316,10 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
     if (threadIdx.x == 0) {
       maxima[((long)c * SPLIT + sp) * 2 + 0] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
       maxima[((long)c * SPLIT + sp) * 2 + 1] = fmaxf(fmaxf(sm[4], sm[5]), fmaxf(sm[6], sm[7]));
+      for (int z = sp + gridDim.y; z < SPLIT; z += gridDim.y) {
+        maxima[((long)c * SPLIT + z) * 2 + 0] = 0.f;
+        maxima[((long)c * SPLIT + z) * 2 + 1] = 0.f;
+      }
     }
   }
 }
@@ -544,7 +583,7 @@ extern "C" int cl4_bn_train_stats(const float* x, int n, int c, int hw, int ctot
   CL4_REQUIRE(x && mean && var && workspace, "bn_train_stats: null pointer");
   if (workspace_bytes < cl4_bn_workspace_bytes(c)) { cl4::set_error("bn_train_stats: workspace too small"); return CL4_ENOSPC; }
   hipStream_t st = cl4::as_stream(stream);
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, (double*)workspace, s);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(c, reduction_split(n * hw, c)), dim3(256), 0, st, x, (double*)workspace, s);
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)workspace, mean, var,
                      running_mean, running_var, momentum, (long)n * hw, c);
   return cl4::launch_status();
@@ -589,7 +628,7 @@ extern "C" int cl4_bn_train_bwd(const float* x, const float* dy, float* dx, int 
   double* partial = (double*)workspace;
   float* sums = (float*)((char*)workspace + cl4_bn_workspace_bytes(c));
   hipStream_t st = cl4::as_stream(stream);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, reduction_split(n * hw, c)), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
                      0.f, s, dy_ctot, dy_coff, keep, keep_scale);
   static const bool fused = [] { const char* e = getenv("CL4_BN_FUSED_FINAL"); return !e || atoi(e) != 0; }();
   if (fused) {
@@ -618,7 +657,7 @@ extern "C" int cl4_bn_train_fwd(const float* x, float* y, int n, int c, int hw, 
   CL4_REQUIRE(y_coff >= 0 && y_coff + c <= y_ctot, "bn_train_fwd: output slice out of range");
   if (workspace_bytes < cl4_bn_workspace_bytes(c)) { cl4::set_error("bn_train_fwd: workspace too small"); return CL4_ENOSPC; }
   hipStream_t st = cl4::as_stream(stream);
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, (double*)workspace, s);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(c, reduction_split(n * hw, c)), dim3(256), 0, st, x, (double*)workspace, s);
   hipLaunchKernelGGL(bn_apply_fused_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, st, x, y,
                      (const double*)workspace, mean, var, running_mean, running_var, momentum, (long)n * hw, gamma, beta, eps, act, slope, s,
                      y_ctot, y_coff, keep, keep_scale, SPLIT);
@@ -651,7 +690,7 @@ extern "C" int cl4_bn_sync_stats_local(const float* x, int n, int c, int hw, int
   CL4_REQUIRE(x && sums && workspace, "bn_sync_stats_local: null pointer");
   if (workspace_bytes < cl4_bn_workspace_bytes(c)) { cl4::set_error("bn_sync_stats_local: workspace too small"); return CL4_ENOSPC; }
   hipStream_t st = cl4::as_stream(stream);
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, (double*)workspace, s);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(c, reduction_split(n * hw, c)), dim3(256), 0, st, x, (double*)workspace, s);
   hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)workspace, sums, c);
   return cl4::launch_status();
 }
@@ -679,7 +718,7 @@ extern "C" int cl4_bn_sync_bwd_local(const float* x, const float* dy, int n, int
   double* partial = (double*)workspace;
   float* fsum = (float*)((char*)workspace + cl4_bn_workspace_bytes(c));
   hipStream_t st = cl4::as_stream(stream);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, reduction_split(n * hw, c)), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
                      slope, s, dy_ctot, dy_coff, keep, keep_scale);
   hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, c);
   // the affine gradients are this rank's share (the gradient all-reduce averages them with everything else)
@@ -726,7 +765,7 @@ extern "C" int cl4_bn_sync_bwd_local_max(const float* x, const float* dy, int n,
   double* partial = (double*)workspace;
   float* fsum = (float*)((char*)workspace + cl4_bn_workspace_bytes(c));
   hipStream_t st = cl4::as_stream(stream);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, reduction_split(n * hw, c)), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
                      slope, s, dy_ctot, dy_coff, (const uint8_t*)nullptr, 1.f, maxima);
   hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, c);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, fsum, fsum + c, dgamma,
@@ -759,7 +798,7 @@ extern "C" int cl4_bn_train_bwd_act(const float* x, const float* dy, float* dx, 
   float* coef = maxima + (size_t)c * SPLIT * 2;
   hipStream_t st = cl4::as_stream(stream);
   const float invn = (float)(1.0 / (double)((long)n * hw));       // (as cl4_bn_sync_bwd_apply computes it from the global count)
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, SPLIT), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act, slope, s, dy_ctot,
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, reduction_split(n * hw, c)), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act, slope, s, dy_ctot,
                      dy_coff, (const uint8_t*)nullptr, 1.f, dxs ? maxima : (float*)nullptr);
   if (!dxs) {
     hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3(n * c, cl4::cdiv(hw, 1024) < 64 ? cl4::cdiv(hw, 1024) : 64), dim3(256), 0, st, x, dy, dx, mean,

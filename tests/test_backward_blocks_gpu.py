@@ -56,7 +56,7 @@ def test_maxpool_forward(gpu, shape):
 def test_maxpool_backward_with_ties(gpu):
     from cl4wsis_amd import ops
     g = torch.Generator().manual_seed(3)
-    for shape in [(2, 5, 17, 17), (1, 3, 18, 20), (1, 2, 5, 4)]:
+    for shape in [(2, 5, 17, 17), (1, 3, 18, 20), (1, 2, 5, 4), (1, 2, 65, 67), (2, 1, 48, 33)]:       # (several 16-row tiles of the r05 kernel)
         x = torch.randint(0, 4, shape, generator=g).float()     # many equal values inside every window
         x[0, 0, :2] = float("-inf")
         xr = x.clone().requires_grad_(True)
