@@ -70,6 +70,6 @@ int launch_conv_p(const ConvArgs& a, unsigned ntile, hipStream_t st);
 bool conv_b_eligible(const ConvArgs& a, int ks, int rows);
 // planes = 2, or 3 (bf16x6 operands; rows 128 / 8 waves only).
 // f16: fp16x3 operands (two fp16 planes, a.xs_scale set) instead of bf16x3; 8 waves, two planes only.
-int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, int planes, unsigned grid, hipStream_t st, bool f16 = false);
+int launch_conv_b(const ConvArgs& a, int ks, int rows, int waves, int planes, unsigned grid, hipStream_t st, bool f16 = false, bool split = false);
 
 }  // namespace cl4

@@ -48,7 +48,12 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, unsigned voff, __amdgpu
 // three K-tiles ahead, which is what the K-major GEMM of the weight gradient needs (both its operands miss L2 on every K-tile).
 // F16 (r05): the two planes hold fp16 hi / lo (planes_epilogue.h, fp16x3) — the same K loop with v_mfma_f32_16x16x32_f16, and the
 // accumulators scaled by 1 / (2^12 * *a.xs_scale) on their way into the parked tile. fp32 output (no planes residual / output yet).
-template <int KS, int BMB, int NW, int PB, bool GEMM = false, int NSTG = 3>
+// SPLITK (r05, <128, 8> two planes): the grid is ntile_l tiles x nsplit K ranges (as conv_s's SPLIT); a workgroup multiplies its range of the
+// tile's compacted K-tiles and leaves the raw fp32 partial tile in its slab of a.ws ([split][cout][ws_npix]); conv_splitk_epilogue_s sums the
+// slabs and runs the fused epilogue. For launches that cannot fill the chip with whole-K tiles (2-4 images of a 33 x 33 map = 62 tiles of
+// 72 K-tiles): conv_s's split kernel needs ~2 us per K-tile there (one workgroup per CU, nothing to hide its operand loads behind), this
+// kernel's three LDS-DMA stages ~0.5.
+template <int KS, int BMB, int NW, int PB, bool GEMM = false, int NSTG = 3, bool SPLITK = false>
 __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void conv_b_bf16x3(ConvArgs a) {
   // NSTG == 2 (r05 experiment, <128, 8> only): 70 KB of stages / 74 KB of parked tile -> TWO workgroups per CU, so that one's epilogue
   // (HBM streaming) can run under the other's K loop (MFMA + L2 -> LDS)
@@ -84,7 +89,8 @@ __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void co
   const unsigned total = gridDim.x, id = blockIdx.x;
   const unsigned q8 = total >> 3, r8 = total & 7, xcd = id & 7;
   const unsigned lid = a.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3) : id;
-  const unsigned tile_ = (unsigned)a.tile_base + lid;
+  const unsigned bz = SPLITK ? lid / (unsigned)a.ntile_l : 0u;            // K range of this workgroup
+  const unsigned tile_ = (unsigned)a.tile_base + (lid - bz * (unsigned)a.ntile_l);
   unsigned by_ = tile_ / (unsigned)a.gx, bx_ = tile_ - by_ * (unsigned)a.gx;
   if constexpr (GEMM) {
     // xcd_remap == 2 (cl4_gemm_kplanes): both operands are large matrices, so an XCD's workgroups should share rows AND columns:
@@ -124,10 +130,17 @@ __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void co
     nv = __builtin_amdgcn_readfirstlane(nv);
     vlist = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(vlist >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)vlist);
   }
+  int u0 = 0;                                              // first compacted K-tile of this workgroup
 #if CL4_B_DBG & 8
   const int nk = 0;
 #else
-  const int nk = (a.cin >> 5) * nv;
+  int nk = (a.cin >> 5) * nv;
+  if constexpr (SPLITK) {
+    const int nsplit = (a.K + a.kchunk - 1) / a.kchunk;
+    const int chunk_c = (nk + nsplit - 1) / nsplit;
+    u0 = (int)bz * chunk_c;
+    nk = max(0, min(nk - u0, chunk_c));
+  }
 #endif
   if (a.dbg_stagger != 0) {                                // experiments only (shader cycles): > 0: odd CUs of the first round start late;
     bool late = false;                                     // < 0: the second workgroup of every CU (first round) starts late
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void co
   // chip's vector-memory path sees an even stream instead of 50 pieces in one burst per K-tile. `prep_*` forms the addresses (K-tile
   // >= nk: every lane out of range -> zeros); `piece_*` issues one piece, between MFMA groups.
   struct Cursor { int cb, j; };
-  Cursor ca{0, 0}, cbt{0, 0};
+  Cursor ca{nv > 0 ? u0 / nv : 0, nv > 0 ? u0 % nv : 0}, cbt = ca;
   auto advance = [&](Cursor& c, int& cb, int& tap) {
     cb = c.cb;
     tap = KS == 3 ? (int)((vlist >> (4 * c.j)) & 15ull) : 0;
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void co
     return;
   }
 #endif
-  const int res_kind = a.post_s ? 2 : (a.post ? 1 : 0);
+  const int res_kind = SPLITK ? 0 : (a.post_s ? 2 : (a.post ? 1 : 0));
   if (res_kind == 2) {
     ep2.issue(a, m0h, g0, GST, px.valid, px.pn, px.phw, HWo);
     ex2.issue(a, m0h, erow, 0, xvalid, ex.pn, ex.phw, HWo);
@@ -438,6 +451,19 @@ __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void co
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if constexpr (SPLITK) {                                  // raw partial sums into this K range's slab: channel rows, lane = pixel
+    constexpr int RPW = BMB / NW;
+    float* wsb = a.ws + ((long)bz * a.cout) * a.ws_npix - a.ws_p0 + n0;
+#pragma unroll 4
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int co = m0 + wave * RPW + rr;
+      if (co >= a.cout) break;                             // wave-uniform
+#pragma unroll
+      for (int q = 0; q < (BNB + 63) / 64; ++q)
+        if (lane + 64 * q < BNB && n0 + lane + 64 * q < a.npix) wsb[(long)co * a.ws_npix + lane + 64 * q] = park[(wave * RPW + rr) * BNB + lane + 64 * q];
+    }
+    return;
+  }
   const float* stage = park + hsel * BM * BNB;
   const float* aff = affine[hsel];
   if (res_kind == 2) {
@@ -472,10 +498,21 @@ static int g_b_stagger = 0;
 extern "C" void cl4_conv_debug_stagger(int refclk_ticks) { cl4::g_b_stagger = refclk_ticks; }
 namespace cl4 {
 
-int launch_conv_b(const ConvArgs& a_, int ks, int rows, int waves, int planes, unsigned grid, hipStream_t st, bool f16) {
+int launch_conv_b(const ConvArgs& a_, int ks, int rows, int waves, int planes, unsigned grid, hipStream_t st, bool f16, bool split) {
   ConvArgs a = a_;
   a.dbg_stagger = g_b_stagger;
   const dim3 g(grid), b(64 * waves);
+  if (split) {                                             // K-split slabs: the 128-row / eight-wave tile on two planes only
+    if (planes != 2 || rows != 128 || waves != 8 || !a.ws || f16) { set_error("conv_b: K-split launches are built for 128 rows / 8 waves / two planes"); return CL4_EINVAL; }
+    ++g_b_launches;
+    static const int stagesS = [] { const char* e = getenv("CL4_CONV_B_STAGES"); return e ? atoi(e) : 3; }();
+    if (ks == 1 && stagesS == 4) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 2, false, 4, true>), g, b, 0, st, a);
+    else if (ks == 3 && stagesS == 4) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 8, 2, false, 4, true>), g, b, 0, st, a);
+    else if (ks == 1) hipLaunchKernelGGL((conv_b_bf16x3<1, 128, 8, 2, false, 3, true>), g, b, 0, st, a);
+    else if (ks == 3) hipLaunchKernelGGL((conv_b_bf16x3<3, 128, 8, 2, false, 3, true>), g, b, 0, st, a);
+    else { set_error("conv_b: kernel size %d not built", ks); return CL4_EINVAL; }
+    return launch_status();
+  }
   if (f16 && (!plfmt::F16 || !a.xs_scale || planes != 2)) {
     set_error("conv_b: a dynamically scaled fp16x3 launch needs an fp16 build (CL4_F16_PLANES), the operand scale and two planes");
     return CL4_EINVAL;

@@ -1321,8 +1321,14 @@ FwdPlan make_plan(int impl, int tile, int splits, int cout, int K, int precision
     p.impl = 3; p.tile = 128; p.splits = 1; p.kchunk = cl4::cdiv(K, BK2) * BK2;
     return p;
   }
-  if ((impl >= 4 && impl <= 6 && precision == 3) || (impl == 6 && precision == 4) || ((impl == 4 || impl == 6) && precision == 5)) {                            // LDS-DMA planes kernel (conv_b.hip): unsplit 256 x 144 (4) or 128 x 144 tiles (5: four waves, 6: eight)
+  if ((impl >= 4 && impl <= 6 && precision == 3) || (impl == 6 && precision == 4) || ((impl == 4 || impl == 6) && precision == 5)) {                            // LDS-DMA planes kernel (conv_b.hip): 256 x 144 (4) or 128 x 144 tiles (5: four waves, 6: eight)
     p.impl = impl; p.tile = 128; p.bn = 144; p.splits = 1; p.kchunk = cl4::cdiv(K, BK2) * BK2;
+    if (impl == 6 && precision == 3 && splits > 1) {       // r05: K-split slabs on the eight-wave tile (two planes): launches that cannot fill the chip
+      const int ktiles = cl4::cdiv(K, BK2);
+      const int sp = splits > ktiles ? ktiles : splits;
+      p.kchunk = cl4::cdiv(ktiles, sp) * BK2;
+      p.splits = cl4::cdiv(K, p.kchunk);
+    }
     return p;
   }
   if (impl != 2 || cout % 4 != 0 || cout < 64) return p;
@@ -1501,6 +1507,15 @@ int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace
       a.gx = cl4::cdiv(a.cout, rows);
       a.ntile_l = a.gx * cl4::cdiv(a.npix, 144);
       a.tile_base = 0; a.ws = nullptr; a.ws_p0 = 0; a.ws_npix = a.npix; a.kchunk = pl.kchunk;
+      if (pl.impl == 6 && pcode == 3 && pl.splits > 1) {    // K-split slabs + the planes split-K epilogue (as the conv_s plans below)
+        const size_t need = (size_t)pl.splits * a.cout * a.ws_npix * sizeof(float);
+        if (!workspace || workspace_bytes < need) { cl4::set_error("conv2d_fwd_planes: workspace too small for split-K"); return CL4_ENOSPC; }
+        a.ws = (float*)workspace;
+        const int rc = cl4::launch_conv_b(a, KS, 128, 8, 2, (unsigned)a.ntile_l * (unsigned)pl.splits, st, false, true);
+        if (rc != CL4_OK) return rc;
+        hipLaunchKernelGGL(conv_splitk_epilogue_s, dim3(cl4::cdiv(a.ws_npix, 256), cl4::cdiv(a.cout, 8)), dim3(256), 0, st, a, pl.splits);
+        return cl4::launch_status();
+      }
       return cl4::launch_conv_b(a, KS, rows, pl.impl == 5 ? 4 : 8, pcode == 4 ? 3 : 2, (unsigned)a.ntile_l, st);
     }
     const TailGeom tg = tail_geometry(pl, a.cout, a.npix, pcode);
@@ -2151,7 +2166,9 @@ extern "C" size_t cl4_conv2d_fwd_workspace_bytes(const cl4_conv_desc* d) {
   va.pad = d->pad; va.in_ctot = d->in_ctot; va.dil = d->dil;
   if (pl.impl == 2 && (vec_gather_plan(va, d->kh, d->precision, pl.tile) || u_plan(va, d->kh, d->precision, pl.tile)))
     npix = d->n * ((d->hout * d->wout + 3) & ~3);
-  if (planes_code(d->precision) && (pl.impl != 2 || pl.tile != 128)) return 0;      // also impl 3 ... 6 (persistent / LDS-DMA kernels): no slabs
+  if (planes_code(d->precision) && pl.impl == 6 && d->precision == 3 && pl.splits > 1)                        // r05: K-split slabs of the LDS-DMA kernel
+    return (size_t)pl.splits * d->cout * npix * sizeof(float);
+  if (planes_code(d->precision) && (pl.impl != 2 || pl.tile != 128)) return 0;      // impl 3 ... 6 unsplit (persistent / LDS-DMA kernels): no slabs
   if (d->precision != 0 && pl.impl == 2 && pl.tail > 0) {
     const TailGeom tg = tail_geometry(pl, d->cout, npix, d->precision);
     return (tg.main > 0 && pl.tail > 1) ? (size_t)pl.tail * d->cout * (npix - tg.p0) * sizeof(float) : 0;   // small-tile tail / degenerate: no slabs

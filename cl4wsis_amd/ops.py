@@ -328,6 +328,7 @@ TAIL_MARGIN_MS = float(os.environ.get("CL4_TUNE_TAIL_MARGIN_US", "0")) * 1e-3   
 CONV_P = os.environ.get("CL4_CONV_P", "1") != "0"      # 0: never pick the persistent pipelined planes kernel (A/B measurements)
 SMALL_TILE_BELOW = int(os.environ.get("CL4_SMALL_TILE_BELOW", "384"))    # planes launches with fewer 128 x 128 tiles than this also try 64-pixel tiles (0: never)
 CONV_B = os.environ.get("CL4_CONV_B", "1") != "0"      # r03: the tuner may pick the big-tile LDS-DMA planes kernel (plan impl 4)
+CONV_B_SPLIT = os.environ.get("CL4_CONV_B_SPLIT", "1") != "0"      # r05: ... and its K-split variant (plan impl 6 with splits > 1)
 PLANES_TILES = [int(v) for v in os.environ.get("CL4_PLANES_TILES", "128,144").split(",")]   # pixel widths of the planes kernel's tiles the tuner may pick (64 is built too: three workgroups per CU, measured no faster — profiles/r03_conv_s_tile64.txt)
 
 
@@ -369,6 +370,8 @@ def _autotune_planes(d, args, reps=6):
         if d.cout >= 128:
             cands.append((6, 144, 1))       # 128-row tiles of the same kernel, eight waves of 32 rows: launches with too few 256-row tiles to fill
                                             # the chip (impl 5 = the same tile as four waves of 64 rows is built and tested, but never faster)
+            if CONV_B_SPLIT:                # r05: ... and K-split over workgroups (slabs + the split-K epilogue) where even those cannot (2-8 images per GPU)
+                cands.extend((6, 144, sp) for sp in _SPLITS if sp > 1)
     for impl, tile, splits in cands:
         tiles = -(-d.cout // 128) * -(-npix // tile)
         if splits == -1 or abs(splits) > max(1, K // 64):

@@ -383,3 +383,49 @@ def test_x6_route_scope_sends_plain_bf16x6_convolutions_through_three_planes(gpu
     assert routed == (0 if (k == 1 and cout < cin) else 1)
     assert _rel_err(y1.cpu(), ref) < 2e-6 and _rel_err(y0.cpu(), ref) < 2e-6
     assert ops._x6_scope == 0
+
+
+# (n, cin, h, w, cout, k, pad, dil, splits)
+B_SPLIT_SHAPES = [
+    (4, 256, 33, 33, 256, 3, 1, 1, 4),        # res4 conv2 at 2 images per GPU + flip: 62 tiles of 72 K-tiles
+    (2, 1024, 33, 33, 256, 1, 0, 1, 3),       # 1x1, 32 K-tiles over 3 ranges (11 + 11 + 10)
+    (3, 96, 33, 31, 136, 3, 18, 18, 8),       # most taps dropped, more ranges than some tiles have K-tiles, partial M tile
+]
+
+
+@pytest.mark.parametrize("residual", [False, True])
+@pytest.mark.parametrize("shape", B_SPLIT_SHAPES)
+def test_conv_b_split_k_equals_the_planes_kernel_split_the_same_way(gpu, shape, residual):
+    """r05: K-split slabs on the LDS-DMA kernel (plan impl 6, splits > 1) for launches that cannot fill the chip. The K ranges, the
+    products inside a range and the slab sum (conv_splitk_epilogue_s) are those of the planes kernel's split plan (2, 144, s): planes
+    output bit-identical; against float64 within the x3 tolerance."""
+    from cl4wsis_amd import _hip, ops
+    n, cin, h, w, cout, k, pad, dil, splits = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    post = torch.randn(n, cout, h, w, generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), padding=pad, dilation=dil) * scale[None, :, None, None] + shift[None, :, None, None], 0.01)
+    if residual:
+        ref = F.relu(ref + post.double())
+    xs, wp = ops.to_planes(x.to(gpu)), ops.pack_conv_weight(wt.to(gpu), 1)
+    d = ops.ConvDescFor(n, cin, h, w, cin, 0, cout, k, 1, pad, dil, cout, 0, ops.ACT_LEAKY, 0.01, ops.ACT_RELU if residual else 0, 0.0, 3)
+    outs = {}
+    for plan in ((6, 144, splits), (2, 144, splits), (6, 144, 1)):
+        _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), *plan)
+        b0, s0 = _hip.load().cl4_conv_debug_b_launches(), _hip.load().cl4_conv_debug_s_launches()
+        try:
+            kw = dict(scale=scale.to(gpu), shift=shift.to(gpu), act1=ops.ACT_LEAKY, slope1=0.01, want_fp32=True, want_planes=True)
+            if residual:
+                kw.update(post=ops.to_planes(post.to(gpu)), act2=ops.ACT_RELU)
+            y, ys = ops.conv2d_planes(xs, wp, k, pad=pad, dil=dil, **kw)
+            torch.cuda.synchronize()
+        finally:
+            _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 0, 64, 1)
+        launched_b = _hip.load().cl4_conv_debug_b_launches() > b0
+        assert launched_b == (plan[0] == 6), plan
+        outs[plan] = (y.clone(), ys.data.clone())
+    yb, ysb = outs[(6, 144, splits)]
+    assert torch.equal(ysb, outs[(2, 144, splits)][1]) and torch.equal(yb, outs[(2, 144, splits)][0])
+    assert _rel_err(yb.cpu(), ref.float()) < TOL and _rel_err(outs[(6, 144, 1)][0].cpu(), ref.float()) < TOL
