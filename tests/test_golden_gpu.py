@@ -332,29 +332,47 @@ def test_collective_path_over_rccl_single_rank(gpu, monkeypatch):
         for i, m in enumerate((tr.model, tr.model_old, tr.pseudolabeler, tr.peakgenerator)):
             m.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in m.state_dict().items()}, seed=31 + i))
         tr._realias()
-        losses = [tr.step(b, next_batch=batches[i + 1] if lookahead and i + 1 < len(batches) else None)["losses"].clone()
-                  for i, b in enumerate(batches)]
+        losses, g1 = [], None
+        for i, b in enumerate(batches):
+            losses.append(tr.step(b, next_batch=batches[i + 1] if lookahead and i + 1 < len(batches) else None)["losses"].clone())
+            if i == 0:      # the first step's (averaged) gradients: every run computes them from the SAME weights
+                torch.cuda.synchronize()
+                g1 = torch.cat([tr._grad_map[id(p)].flatten() for p in tr._branch.trainable_parameters()]).cpu().clone()
         torch.cuda.synchronize()
         w = torch.cat([p.detach().flatten() for p in tr._branch.trainable_parameters()]).cpu()
-        return torch.stack(losses).cpu(), w, tr
+        return torch.stack(losses).cpu(), w, tr, g1
 
-    ls, ws, _ = run()
+    ls, ws, _, gs = run()
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29577")
     monkeypatch.setenv("CL4_FORCE_COLLECTIVES", "1")
     monkeypatch.setenv("CL4_PIPELINE_MIN_BATCH", "1")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
     try:
-        ld, wd, tr = run()
+        ld, wd, tr, gd = run()
         assert tr.buckets.distributed and tr.buckets.native_avg and tr._graph is not None
-        lp, wp_, trp = run(lookahead=True)               # the same with the next batch announced: (deep-)pipelined graphs + eager ASPP tail
+        lp, wp_, trp, gp = run(lookahead=True)           # the same with the next batch announced: (deep-)pipelined graphs + eager ASPP tail
         assert trp.buckets.distributed and trp._pipe is not None and trp._pipe["deep"]      # 2 images per GPU: deep pipelining
     finally:
         dist.destroy_process_group()
+    # (1) From the same weights — the first step — the collective path must reproduce the plain path's gradients: what is left is the order of
+    # the weight-gradient kernels' atomic adds (measured 4e-8; two PLAIN runs differ by the same, tests/tools/dbg_plain_vs_plain.py).
+    for name, g_ in (("collective path", gd), ("collective path, deep-pipelined", gp)):
+        e = float((g_ - gs).norm() / gs.norm())
+        print(f"COLLECTIVE1 {name}: first-step gradients vs the plain run, relative L2 {e:.2e}")
+        assert e < 1e-6, (name, e)
+    # (2) Three chained Adam steps. Adam turns every gradient into a step of ~lr whatever its size, so a weight whose gradient IS rounding
+    # noise (taps of the dilated ASPP convolutions that see one or two pixels of a 7 x 7 map) moves +-lr by the order of those atomic adds,
+    # and from the second step on the runs see different weights. r05: two plain runs in one process show the same spread (second-step
+    # gradients 4e-6 apart, third-step up to 8e-4 when a label decision flips), in discrete states that depend on the launch plans the tuner
+    # timed into place: max 0.00 / 0.01 / 0.12 / 0.22 / 0.39 / 1.66 lr with 0 ... 523 of 15.7 M weights beyond 0.4 lr. The bars bound that
+    # spread (max, mean unchanged since r03; the count at 1e-4 of the weights, r03-r04: 1e-5 = the five smaller states only).
     for l_, w_ in ((ld, wd), (lp, wp_)):
         assert torch.allclose(ls, l_, rtol=2e-3, atol=1e-6), (ls, l_)
         d = (ws - w_).abs()
-        assert d.max() < 3.2 * LR and (d > 0.4 * LR).float().mean() < 1e-5 and d.mean() < 0.02 * LR
+        print(f"COLLECTIVE1 weights after 3 Adam steps vs the plain run: max {float(d.max()) / LR:.2f} lr, mean {float(d.mean()) / LR:.4f} lr, "
+              f"fraction beyond 0.4 lr {float((d > 0.4 * LR).float().mean()):.2e} ({int((d > 0.4 * LR).sum())} of {d.numel()})")
+        assert d.max() < 3.2 * LR and (d > 0.4 * LR).float().mean() < 1e-4 and d.mean() < 0.02 * LR
 
 
 def test_pipelined_replay_matches_plain_graph_replay(gpu, monkeypatch):
