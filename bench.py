@@ -368,7 +368,7 @@ def run_p1(a, device, rank, world, b, steps, warmup):
     res = None
     if rank == 0:
         peaks = {"conv_fwd_bf16x6": PEAK_BF16_MFMA_TFLOPS / 6.0, "conv_fwd_bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0, "conv_fwd_f32": PEAK_FP32_MFMA_TFLOPS,
-                 "conv_fwd_f16x3": PEAK_BF16_MFMA_TFLOPS / 3.0,      # fp16 MFMA = the bf16 rate (tools/f16x3_probe.hip), three products per MAC
+                 "conv_fwd_f16x3": PEAK_BF16_MFMA_TFLOPS / 3.0,      # fp16 MFMA = the bf16 rate (tools/probes/f16x3_probe.hip), three products per MAC
                  "conv_wgrad": PEAK_BF16_MFMA_TFLOPS / 3.0 if body_train.WGRAD_PRECISION == 1 else PEAK_FP32_MFMA_TFLOPS}
         kinds = {k: {"achieved": fl / (ms * 1e-3) / 1e12, "peak": peaks.get(k), "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peaks[k] if k in peaks else None,
                      "ms_per_step": ms, "launches_per_step": n} for k, (n, fl, ms) in summ.items()}

@@ -28,7 +28,7 @@ struct ConvArgs {
   // bf16 kernels (1-D launches): logical tile = tile_base + (workgroup % ntile_l), M index fastest over gx tiles; the split-K
   // slabs cover the pixels [ws_p0, ws_p0 + ws_npix) only ("main + split tail" plans split just the last partial round)
   int gx, ntile_l, tile_base, ws_p0, ws_npix;
-  // Experiments only (tools/probe_timeline.py): when set, every workgroup of a bf16 launch records s_memtime stamps and its
+  // Experiments only (tools/probes/probe_timeline.py): when set, every workgroup of a bf16 launch records s_memtime stamps and its
   // XCC / CU ids into timeline[blockIdx * 8 ..]: [0] start, [1] first K-tile ready, [2] K loop done, [3] accumulators parked,
   // [4] epilogue done (MFMA wave 0), [5] loader wave 0 done, [6] (xcc << 8) | cu, [7] logical tile.
   unsigned long long* timeline;
@@ -43,7 +43,7 @@ struct ConvArgs {
   // w * 2^12; *xs_scale = s (a power of two written by cl4_to_planes_f16), and the accumulators are multiplied by 1 / (2^12 * s)
   // before the epilogue. Null for every bf16 launch.
   const float* xs_scale;
-  // Experiments only (cl4_conv_debug_stagger, tools/probe_b.py): first-round workgroups on odd CUs start this many REFCLK ticks (10 ns)
+  // Experiments only (cl4_conv_debug_stagger, tools/probes/probe_b.py): first-round workgroups on odd CUs start this many REFCLK ticks (10 ns)
   // late, so that neighbouring CUs run their K loops and their epilogues in anti-phase. 0 in every product launch.
   int dbg_stagger;
 };

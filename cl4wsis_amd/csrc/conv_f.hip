@@ -28,7 +28,7 @@
 #include "planes_epilogue.h"
 
 #ifndef CL4_F_DBG
-#define CL4_F_DBG 0   // experiments only (tools/probe_f.py): 1 = no x loads in phase 1, 2 = no residual loads, 4 = no output stores, 8 = no MFMAs,
+#define CL4_F_DBG 0   // experiments only (tools/probes/probe_f.py): 1 = no x loads in phase 1, 2 = no residual loads, 4 = no output stores, 8 = no MFMAs,
                       // 16 = no weight loads
 #endif
 

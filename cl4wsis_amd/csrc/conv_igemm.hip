@@ -465,7 +465,7 @@ __global__ void conv_splitk_epilogue(ConvArgs a, int splits) {
 #define CL4_DBG 0   // experiments only: 1 = loader issues no loads in the loop, 2 = no convert/LDS stores, 4 = no MFMA
 #endif
 #ifndef CL4_TL2
-#define CL4_TL2 0   // experiments only (tools/probe_phases.py): per-K-tile phase times of loader wave 0 / MFMA wave 0, summed per workgroup
+#define CL4_TL2 0   // experiments only (tools/probes/probe_phases.py): per-K-tile phase times of loader wave 0 / MFMA wave 0, summed per workgroup
 #endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -491,11 +491,11 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // PERS (non-split only): a PERSISTENT workgroup walks several output tiles. Its K-tile stream is continuous across tiles —
 // the loaders' register sets already hold the first K-tiles of the next tile while the MFMA waves drain the accumulators of
 // the previous one — so the pipeline is filled once per workgroup instead of once per tile and no workgroup is re-dispatched
-// per tile (short-K 1x1 layers spent more time on those two than in their eight K-tiles, tools/probe_epilogue.py).
+// per tile (short-K 1x1 layers spent more time on those two than in their eight K-tiles, tools/probes/probe_epilogue.py).
 // VEC (1x1, stride 1, cin % 32 == 0, unsplit 128x128 launches): the activation loader fetches FOUR CONSECUTIVE PIXELS of one
 // channel per lane and load (buffer_load_dwordx4) instead of one pixel of eight channels with eight dword loads. The CU's
 // vector-memory front end retires a 256-byte dword wave-load in the same ~16 cycles as a 1-KB dwordx4 one, and with 2 x 4
-// loader waves x 20 wave-loads per K-tile it — not L2, HBM or the MFMA pipe — set the K-tile period (tools/probe_timeline.py:
+// loader waves x 20 wave-loads per K-tile it — not L2, HBM or the MFMA pipe — set the K-tile period (tools/probes/probe_timeline.py:
 // 2.1-2.5 us per K-tile and workgroup for 0.64 us of MFMA work). 4 dwordx4 + 4 weight loads per lane and K-tile instead of
 // 16 + 4. The GEMM column order inside a tile is permuted (column = (pixel % 4) * 32 + pixel / 4) so that the loader's
 // ds_writes and the MFMA waves' ds_read_b128 stay bank-conflict free; the wide epilogue undoes it when it streams rows out.
@@ -2076,7 +2076,7 @@ int launch_wgrad(WgradArgs& a, hipStream_t st) {
   const int kpix = vec ? a.n * a.hw_pad : a.npix;
   const int tiles = cl4::cdiv(kpix, BKP);
   const int slots = (a.precision == 2 && KS > 1 && !small_m) ? 256 : 512;
-  // r04: one round of the 512 slots, not two (tools/probe_wgrad_split.py: 3x3 256 -> 256 at 33 x 33 x 16 132.7 -> 110.4 us, 1x1 1280 -> 256
+  // r04: one round of the 512 slots, not two (tools/probes/probe_wgrad_split.py: 3x3 256 -> 256 at 33 x 33 x 16 132.7 -> 110.4 us, 1x1 1280 -> 256
   // 83.9 -> 65.4 us, every other shape of the steps within 2 %; 256 is no better, 2048 is 10-30 % worse: each split is one more 64 KB
   // atomic pass over the tile of dW)
   static const int target_wgs = env_int("CL4_WGRAD_TARGET_WGS", 512);

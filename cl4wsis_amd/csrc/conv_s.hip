@@ -4,7 +4,7 @@
 //   planes format of a tensor [n][c][h][w] (c % 8 == 0):   [n][c/8][plane: hi, lo][h*w][8 x bf16]
 //   hi = bf16(x), lo = bf16(x - hi); one 16-byte chunk = 8 consecutive channels of one pixel of one plane.
 //
-// tools/probe_clock.py on the unified-wave kernel (profiles/r02c_u_clock.txt) showed what bounds a bf16x3 K-tile once loads are wide and
+// tools/probes/probe_clock.py on the unified-wave kernel (profiles/r02c_u_clock.txt) showed what bounds a bf16x3 K-tile once loads are wide and
 // every wave does everything: with the MFMAs REMOVED the loop still takes ~2200 cycles per K-tile — its ~95 VALU instructions per
 // wave (three per activation element for the split, masks, addresses) plus LDS stores, against 1412 cycles for the MFMAs alone, and the
 // shader clock falls from 2.34 to 1.8-1.9 GHz when both run together. A chunk of the planes format is exactly what one lane hands to

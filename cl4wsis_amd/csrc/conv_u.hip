@@ -1,6 +1,6 @@
 // Unified-wave bf16x3 forward convolution ("U" kernel): the same arithmetic, packed-weight format, K order, LDS image, tile
 // mapping, split-K slabs and fused epilogue as conv_igemm_bf16x3<128, 128, KS, SPLIT, true, 2> in conv_igemm.hip — but without
-// the loader / MFMA role split. tools/probe_phases.py (profiles/r02c_phase_probe_*.txt) showed where that kernel's time goes:
+// the loader / MFMA role split. tools/probes/probe_phases.py (profiles/r02c_phase_probe_*.txt) showed where that kernel's time goes:
 // its four loader waves never wait for memory; they are bound by their own instruction stream — vector-memory issue (the CU's
 // texture-address unit retires ONE wave-load per ~16 cycles whatever its width, so 64 dword gathers + 16 dwordx4 weight loads per
 // K-tile cost 1280 cycles against 768 cycles of MFMA work) and the convert / ds_write burst — while the four MFMA waves sit at

@@ -323,7 +323,7 @@ constexpr int SEG_REGC = 24;   // class counts up to this keep the per-pixel log
 
 // No per-thread arrays with run-time indices here. The r02 kernel kept `float v[SEG_MAXC], mask[SEG_MAXC]` per thread = 784 bytes of
 // scratch (private segment) per lane, ~410 MB for a full chip of waves. Removing them is a register / scratch optimisation (0.66 -> 0.26 ms,
-// and no kernel of the step path uses private-segment scratch any more: tools/kernel_resources.py). It was NOT the cause of the r02
+// and no kernel of the step path uses private-segment scratch any more: tools/probes/kernel_resources.py). It was NOT the cause of the r02
 // single-stream graph fault — that was the runtime's hipMemsetAsync graph nodes (FINDINGS.md finding 23, cl4::fill_bytes_async): the fault
 // came back with these arrays already gone and disappears with kernel fills alone. REGC > 0:
 // fully unrolled loops over REGC classes with compile-time indices (registers); REGC == 0: the logits are re-sampled from LDS in each

@@ -75,7 +75,7 @@ __device__ __forceinline__ void join8(const u32x4& hi, const u32x4& lo, float (&
 }
 
 // ---- fp16x3 (r05): x = h + l with h = fp16(x * s), l = fp16(x * s - h): 22 significant bits for three MFMA products (hh + hl + lh), the
-// accuracy of bf16x6's six (tools/f16x3_probe.hip: 5.3e-7 against 7.8e-7 relative L2 on a K = 2304 dot product; bf16x3 4.6e-6) — provided
+// accuracy of bf16x6's six (tools/probes/f16x3_probe.hip: 5.3e-7 against 7.8e-7 relative L2 on a K = 2304 dot product; bf16x3 4.6e-6) — provided
 // the operands sit inside fp16's range, hence the power-of-two scales: 2^12 on weights (|w| < 16), 2^4 on activations of O(1) networks,
 // and 2^(14 - exponent of max |x|) on gradients (cl4_to_planes_f16, dynamic). fp16 subnormals are honoured by the MFMA (same probe).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

@@ -67,7 +67,7 @@ def conv_out_size(h, k, stride, pad, dil):
 # 2 = "bf16x6" (hi + mid + lo, six products: fp32-level accuracy at 6/16 of the fp32 MFMA cycles).
 CONV_PRECISION = int(os.environ.get("CL4_CONV_PRECISION", "1"))
 # r04: plain bf16x6 convolutions with a long K loop via cl4_to_planes3 + the three-plane LDS-DMA kernel; thresholds
-# from tools/probe_x6_planes.py (the extra pass over the input has to be paid back by the kernel)
+# from tools/probes/probe_x6_planes.py (the extra pass over the input has to be paid back by the kernel)
 # Scope: the call sites of the differentiated body / DeepLabV3 head / PseudoLabeler (body_train.py, heads_train.py: phase 1, step 0 and the
 # autograd module surface) ask for it with `x6=True`; `x6_route_scope` switches it on for everything inside a `with`. Phase 2's instance
 # branch does not: its precision-2 convolutions share the chip with the frozen networks' stream and the extra pass costs more than it
@@ -865,7 +865,7 @@ def pack_stem_weight(w):
 FUSED_BLOCK = os.environ.get("CL4_FUSED_BLOCK", "1") != "0"    # r04: identity bottlenecks of res2 / res3 as one launch (csrc/conv_f.hip)
 # Middle widths that run fused (built: 64 = res2, 128 = res3). Default 64 only: the 128-channel variant (one 8-wave workgroup per CU, 116 KB of
 # y1 in LDS, 800 / 400 tiles = 3.1 / 1.6 rounds) is bit-exact but no faster than the three tuned launches — 385 vs 367 us at 32 images, 183 vs
-# 182 us at 16 (tools/probe_f.py, FINDINGS.md finding 38) — so res3 stays on three launches; CL4_FUSED_CM=64,128 selects it for experiments.
+# 182 us at 16 (tools/probes/probe_f.py, FINDINGS.md finding 38) — so res3 stays on three launches; CL4_FUSED_CM=64,128 selects it for experiments.
 FUSED_CM = tuple(int(v) for v in os.environ.get("CL4_FUSED_CM", "64").split(",") if v)
 FUSED_PROJ = os.environ.get("CL4_FUSED_PROJ", "1") != "0"      # the stage's first block (projection shortcut, width 64) fused as well
 

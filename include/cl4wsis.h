@@ -545,7 +545,7 @@ int cl4_target_generation(const long long* seg_map, const uint8_t* mask, int b, 
 /* InPlaceABN(Sync) (segmentation_module.py:19-27; mapillary/inplace_abn, not vendored) scales with |weight| + eps, not with
  * weight: cl4_abs_eps writes that effective scale (out[i] = |w[i]| + eps), cl4_sign_axpy applies its chain rule
  * (y[i] += w[i] > 0 ? x[i] : -x[i]) to a gradient computed with respect to the effective scale. */
-/* Experiments only: phase time stamps of the bf16 forward kernels (tools/probe_timeline.py); NULL = off. */
+/* Experiments only: phase time stamps of the bf16 forward kernels (tools/probes/probe_timeline.py); NULL = off. */
 int cl4_conv_debug_timeline(void* buf);
 /* Experiments / tests only: number of launches this process has sent to the unified-wave bf16x3 kernel (csrc/conv_u.hip) and to
  * the planes-input kernel (csrc/conv_s.hip). */
@@ -603,7 +603,7 @@ int cl4_conv2d_fwd_planes(const cl4_conv_desc* d, const void* xs, const float* w
                           const float* pre, const float* post, const void* post_s, float* y, void* ys, void* workspace,
                           size_t workspace_bytes, void* stream);
 /* fp16x3 (r05): the differentiated convolutions (train.py:272 forward, train.py:537 input gradients) as THREE MFMA products per MAC on
- * split-fp16 operands — x = h + l, both fp16, 22 significant bits: the accuracy of bf16x6's six products (tools/f16x3_probe.hip) —
+ * split-fp16 operands — x = h + l, both fp16, 22 significant bits: the accuracy of bf16x6's six products (tools/probes/f16x3_probe.hip) —
  * with power-of-two operand scales that keep both halves inside fp16's range:
  *   cl4_pack_conv_weight_f16x3: w [cout][cin][kh][kw] -> [K/8][hi, lo][cout][8 x fp16] of w * 2^12 (cin % 32 == 0, cout % 8 == 0, |w| < 16);
  *   cl4_to_planes_f16: fp32 NCHW channel slice -> [n][c/8][hi, lo][h*w][8 x fp16] of x * s; s = 2^4 (dynamic == 0: activations), or

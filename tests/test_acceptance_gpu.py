@@ -123,7 +123,7 @@ def test_phase2_gradients_well_conditioned(gpu, monkeypatch, frozen_precision, t
     # The oracle's own distance depends on the host CPU it runs on (oneDNN kernels, thread count: median 1.43e-3 on the r03 boxes, 9.7e-4 on
     # an r04 box), so the multiples carry that spread:
     #   0  exact fp32 products everywhere: 4x (measured 2.3x-2.7x median, 1.9x-2.1x maximum)
-    #   2  bf16x6 frozen networks (fp32-level per convolution, tools/dbg_x6.py) + bf16x3 weight gradients: 7x (3.5x-5.0x, 2.9x-3x)
+    #   2  bf16x6 frozen networks (fp32-level per convolution, tools/probes/dbg_x6.py) + bf16x3 weight gradients: 7x (3.5x-5.0x, 2.9x-3x)
     #   1  the DEFAULT, bf16x3 frozen networks: 20x (8.3x-13.9x, 6.6x-7x). Their features are 1e-4 off through ~100 layers (bar: 1e-3), which batch-
     #      statistics BN + ReLU turn into percent-level gradient differences. What that costs where it matters is measured below in mAP
     #      points (test_map_...: HIP at both settings inside the reference runs' distribution); the reference itself trains under fp16

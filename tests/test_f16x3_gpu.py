@@ -3,7 +3,7 @@ bits, power-of-two operand scales) instead of bf16x6's six bf16 products — cl4
 cl4_conv2d_fwd_planes_f16 (csrc/conv_b.hip, F16). Every case is compared with a float64 convolution and with the bf16x6 kernel on the
 same operands. The bar is fp32-level agreement: 1e-6 relative L2 and no worse than 2.5x bf16x6 (measured 0.8e-7 ... 5.3e-7 against
 bf16x6's 0.5e-7 ... 3.6e-7 and bf16x3's 4.4e-6: three products keep terms down to 2^-22, six down to 2^-24; an fp32 FMA chain of the
-same K = 2304 dot products sits at 8e-7, tools/f16x3_probe.hip)."""
+same K = 2304 dot products sits at 8e-7, tools/probes/f16x3_probe.hip)."""
 import ctypes as C
 
 import pytest

@@ -1,5 +1,5 @@
 # A/B of the deep-pipelined replay (CL4_DEEP_PIPE) at the per-GPU batches an N = 1 / 2 / 4 / 8 run executes, on the one-process path and on the
-# N > 1 code path rehearsed at world size 1 (CL4_FORCE_COLLECTIVES=1). usage: bash tools/ab_deep_pipe.sh TAG
+# N > 1 code path rehearsed at world size 1 (CL4_FORCE_COLLECTIVES=1). usage: bash tools/probes/ab_deep_pipe.sh TAG
 set -e
 R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the root of the repository copy)}
 cd $R

@@ -1,5 +1,5 @@
 """Per-kernel resources of the BUILT library (cl4wsis_amd/libcl4wsis_hip.so): scratch bytes per lane, VGPRs, SGPRs, LDS — read from the
-code objects' metadata notes (no recompilation). `python tools/kernel_resources.py [--scratch]`; tests/test_cabi.py uses
+code objects' metadata notes (no recompilation). `python tools/probes/kernel_resources.py [--scratch]`; tests/test_cabi.py uses
 `kernel_table()` to hold the library to "no kernel uses scratch" (see csrc/label.hip, seg_pseudo_gt_kernel, for why that matters)."""
 import os, re, struct, subprocess, sys, tempfile
 

@@ -1,5 +1,5 @@
 """Experiments: the fused identity bottleneck (csrc/conv_f.hip) against the same block as three tuned planes launches, res2 shape.
-usage: python tools/probe_f.py [n ...]"""
+usage: python tools/probes/probe_f.py [n ...]"""
 import os
 import sys
 

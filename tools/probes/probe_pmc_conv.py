@@ -1,4 +1,4 @@
-"""Three res4 conv shapes, 10 launches each, for a rocprofv3 --pmc pass (tools/prof_pmc_conv.sh)."""
+"""Three res4 conv shapes, 10 launches each, for a rocprofv3 --pmc pass (tools/probes/prof_pmc_conv.sh)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.sweep_conv import run

@@ -1,6 +1,6 @@
 """Experiment: HBM-side traffic of res4's three planes convolutions as the frozen networks launch them (tuned plan, in-place trunk), one shape
-per kernel-name / grid pair so that a rocprofv3 --pmc pass can be read per shape. usage: python tools/probe_res4_pmc.py [n]
-(tools/prof_pmc_res4.sh runs it under FETCH_SIZE / WRITE_SIZE / TCC hit-miss passes and prints bytes per launch against the algorithmic bytes)"""
+per kernel-name / grid pair so that a rocprofv3 --pmc pass can be read per shape. usage: python tools/probes/probe_res4_pmc.py [n]
+(tools/probes/prof_pmc_res4.sh runs it under FETCH_SIZE / WRITE_SIZE / TCC hit-miss passes and prints bytes per launch against the algorithmic bytes)"""
 import os
 import sys
 

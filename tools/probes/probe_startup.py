@@ -1,5 +1,5 @@
 """Where does a child process's start-up time go on a fresh GPU box? (tests that spawn ranks / loader workers take 40-200 s there)
-usage: python tools/probe_startup.py"""
+usage: python tools/probes/probe_startup.py"""
 import subprocess
 import sys
 import time

@@ -1,5 +1,5 @@
 """Experiment: the role-split weight-gradient kernel's K-split target (CL4_WGRAD_TARGET_WGS workgroups per launch) on the shapes of the
-phase-1 / phase-2 steps. usage: CL4_WGRAD_TARGET_WGS=512 python tools/probe_wgrad_split.py"""
+phase-1 / phase-2 steps. usage: CL4_WGRAD_TARGET_WGS=512 python tools/probes/probe_wgrad_split.py"""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 """Experiments: bf16x6 convolutions of the phase-1 step (body / head / PseudoLabeler, forward and input-gradient shapes) on the role-split
-kernel (fp32 input) against cl4_to_planes3 + the three-plane LDS-DMA kernel (conv_b). usage: python tools/probe_x6_planes.py"""
+kernel (fp32 input) against cl4_to_planes3 + the three-plane LDS-DMA kernel (conv_b). usage: python tools/probes/probe_x6_planes.py"""
 import os
 import sys
 

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 cd /tmp
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
   tag=$(echo $set | cut -d" " -f1)
-  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_conv/$tag -- python3 $R/tools/probe_pmc_conv.py > $R/gpurun_out/pmc_conv/$tag.log 2>&1 || echo "pass $tag failed"
+  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmc_conv/$tag -- python3 $R/tools/probes/probe_pmc_conv.py > $R/gpurun_out/pmc_conv/$tag.log 2>&1 || echo "pass $tag failed"
 done
 python3 - <<'PY'
 import csv, glob, collections, os

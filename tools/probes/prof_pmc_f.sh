@@ -1,5 +1,5 @@
 #!/bin/bash
-# Experiments: HBM-side traffic and L2 hit rate of the fused bottleneck kernel (csrc/conv_f.hip) on tools/probe_f.py, one counter set per pass.
+# Experiments: HBM-side traffic and L2 hit rate of the fused bottleneck kernel (csrc/conv_f.hip) on tools/probes/probe_f.py, one counter set per pass.
 R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the root of the repository copy)}
 O=$R/gpurun_out/${1:-r04}_pmc_f
 mkdir -p $O
@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   tag=$(echo $c | tr ' ' '_')
-  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $O/$tag -- python3 $R/tools/probe_f.py ${PROBE_N:-32} > $O/$tag.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $O/$tag -- python3 $R/tools/probes/probe_f.py ${PROBE_N:-32} > $O/$tag.log 2>&1
   echo "pass $c done"
 done
 python3 - <<PY

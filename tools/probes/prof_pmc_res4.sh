@@ -1,5 +1,5 @@
 #!/bin/bash
-# Experiments: HBM-side traffic and L2 hit rate of res4's planes convolutions (tools/probe_res4_pmc.py), one counter set per pass.
+# Experiments: HBM-side traffic and L2 hit rate of res4's planes convolutions (tools/probes/probe_res4_pmc.py), one counter set per pass.
 R=${GRAFT_REPO_ROOT:?run under gpurun (GRAFT_REPO_ROOT is the root of the repository copy)}
 O=$R/gpurun_out/${1:-r04}_pmc_res4
 mkdir -p $O
@@ -8,7 +8,7 @@ cd /tmp
 for n in 32 16; do
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=n${n}_$(echo $c | tr ' ' '_')
-  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $O/$tag -- python3 $R/tools/probe_res4_pmc.py $n > $O/$tag.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $O/$tag -- python3 $R/tools/probes/probe_res4_pmc.py $n > $O/$tag.log 2>&1
   echo "pass n=$n $c done"
 done
 tail -2 $O/n${n}_FETCH_SIZE.log
