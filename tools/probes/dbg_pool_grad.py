@@ -6,7 +6,7 @@ over images AND pixels is exactly zero, the per-image sums are what is left of a
 operands of that reduction and redoes it in float64 on the host: if the float64 redo agrees with the HIP kernels, the kernels are
 exact for their inputs and the deviation is element noise of the incoming gradient map amplified by the cancellation factor."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from util import QuietLogger, p2_opts

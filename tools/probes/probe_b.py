@@ -4,7 +4,7 @@ back to back for ~0.6 s, HIP events around the last 100 launches). usage: probe_
 Run it against library variants (CL4_LIB; tools/run_probe_b.sh): CL4_B_DBG=8 no K loop, 16 no epilogue traffic, 1 no LDS-DMA, 4 no MFMA.
 `stagger`: first-round workgroups on odd CUs start that many REFCLK ticks (10 ns) late (cl4_conv_debug_stagger)."""
 import ctypes as C, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cl4wsis_amd import _hip, ops
 

@@ -2,7 +2,7 @@
 for ~1.5 s, then one more launch records s_memtime / s_memrealtime stamps (cl4_conv_debug_timeline) — MI355X_MICROARCH.md,
 'DVFS give-back' item 6. usage: probe_clock.py [n]"""
 import ctypes as C, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from cl4wsis_amd import _hip, ops

@@ -3,7 +3,7 @@ run with CL4_LIB=cl4wsis_amd/libcl4wsis_tl2.so): loader wave 0 and MFMA wave 0 o
 phase of their K-tile loop. Printed per K-tile and workgroup, in shader cycles and (calibrated on the launch time) in ns.
 usage: probe_phases.py [tag]"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from cl4wsis_amd import _hip, ops

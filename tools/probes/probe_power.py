@@ -1,7 +1,7 @@
 """Is a conv launch power-bound? Runs one shape back to back for ~3 s and samples board power and shader clock from sysfs /
 rocm-smi meanwhile. usage: probe_power.py [name ...]   (CL4_CONV_U / CL4_LIB select the kernel as usual)"""
 import glob, os, subprocess, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ctypes as C
 import torch
 from cl4wsis_amd import _hip, ops

@@ -2,7 +2,7 @@
 (each shape is launched back to back for ~1 s; the last 100 launches are timed), with the in-kernel clock and cycles per K-tile from
 one stamped launch. CL4_CONV_S_MFMA=16|32 selects the MFMA shape of the planes kernel. usage: probe_s.py [planes|fp32] [n ...]"""
 import ctypes as C, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from cl4wsis_amd import _hip, ops

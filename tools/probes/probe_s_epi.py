@@ -1,7 +1,7 @@
 """Multi-round / epilogue-heavy shapes of the planes kernel under sustained load (r03: up-front residual loads, anti-phase stagger).
 Run once per CL4_S_STAGGER setting (the library reads it at its first launch). usage: probe_s_epi.py [n ...]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ctypes as C
 import torch
 from cl4wsis_amd import _hip, ops

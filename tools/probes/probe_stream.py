@@ -1,6 +1,6 @@
 """Practical streaming rates on this box for the res4 conv3 output tensor (143 MB): elementwise read+write, write-only fill."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cl4wsis_amd import ops
 dev = torch.device("cuda:0")

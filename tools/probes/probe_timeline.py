@@ -2,7 +2,7 @@
 phase durations (prologue / K loop / park / epilogue), workgroups resident per CU over time, idle gaps per CU slot.
 usage: probe_timeline.py  (res4 shapes at the bench batch)"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from cl4wsis_amd import _hip, ops

@@ -1,6 +1,6 @@
 """Pieces of the GEMM weight gradient (csrc/wgrad_gemm.hip) on the ASPP shape: x pack, dy pack, GEMM, scatter; and the role-split kernel."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cl4wsis_amd import _hip, ops
 from cl4wsis_amd.ops import call, ptr, stream

@@ -1,6 +1,6 @@
 """bf16x6 kernel with compile-time knock-outs (CL4_LIB=build/probe/lib_dbgN.so: 1 no loads, 2 no convert/LDS stores, 4 no MFMA)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cl4wsis_amd import _hip, ops
 dev = torch.device("cuda:0")
