@@ -88,7 +88,7 @@ __device__ __forceinline__ unsigned pack_f16(float lo, float hi) {    // {fp16(l
 __device__ __forceinline__ void split8_f16(const float (&v)[8], float s, u32x4& hi, u32x4& lo) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float a = fminf(fmaxf(v[2 * i] * s, -F16_MAX), F16_MAX), b = fminf(fmaxf(v[2 * i + 1] * s, -F16_MAX), F16_MAX);      // saturating
+    const float a = plfmt::sat_f16(v[2 * i] * s), b = plfmt::sat_f16(v[2 * i + 1] * s);      // saturating
     const unsigned hp = pack_f16(a, b);
     const f16x2 h = __builtin_bit_cast(f16x2, hp);
     const float ha = (float)h[0], hb = (float)h[1];

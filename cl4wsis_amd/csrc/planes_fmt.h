@@ -37,7 +37,8 @@ __device__ __forceinline__ unsigned pk_f16(float lo, float hi) {        // {fp16
   f32x2 t = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2));
 }
-__device__ __forceinline__ float sat_f16(float x) { return fminf(fmaxf(x, -F16_MAX), F16_MAX); }
+// one v_med3_f32 (fminf(fmaxf()) costs a canonicalising v_max in front of it; a NaN comes out as -65504 either way it is clamped)
+__device__ __forceinline__ float sat_f16(float x) { return __builtin_amdgcn_fmed3f(x, -F16_MAX, F16_MAX); }
 __device__ __forceinline__ float sub_asm(float a, float b) {            // one v_sub_f32 (keeps hipcc's SLP pass from forming v_pk_add_f32)
   float r;
   asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

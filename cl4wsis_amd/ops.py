@@ -129,11 +129,16 @@ F16X3_MIN_COUT = int(os.environ.get("CL4_F16X3_MIN_COUT", "128"))
 def f16x3_ok(cin, cout, k=3):
     """Shapes the fp16x3 route takes: what conv_b needs (32-channel K-tiles, 8-channel output groups, at least one 128-row tile), and only
     where the conversion pass of the input pays — every 3x3 layer, 1x1 layers that do not shrink the channel count (a 1024 -> 256 1x1
-    convolution reads 4x the elements it writes: converting them costs more than the bf16x6 launch it replaces, profiles/r05_f16x3_ab.txt)."""
-    return cin % 32 == 0 and cout % 8 == 0 and cout >= F16X3_MIN_COUT and (k > 1 or cout >= cin or F16X3_ALL_1X1)
+    convolution reads 4x the elements it writes: converting them costs more than the bf16x6 launch it replaces, profiles/r05_f16x3_ab.txt)
+    and have at least F16X3_MIN_K1 input channels."""
+    return cin % 32 == 0 and cout % 8 == 0 and cout >= F16X3_MIN_COUT and (k > 1 or (cout >= cin and cin >= F16X3_MIN_K1) or F16X3_ALL_1X1)
 
 
 F16X3_ALL_1X1 = os.environ.get("CL4_F16X3_ALL_1X1", "0") != "0"
+# ... and 1x1 layers with a K loop long enough to carry the conversion of their input: the decoder's 128 -> 128 / 144 layers at 129 x 129 took
+# 0.36 / 0.27 ms through the route against 0.23 / 0.15 as bf16x6 launches (profiles/r05_f16_planes_cost_per_layer.txt); with a producer-made
+# twin (force_f16) there is no conversion and the limit does not apply
+F16X3_MIN_K1 = int(os.environ.get("CL4_F16X3_MIN_K1", "256"))
 
 
 def pack_conv_weight(w, precision=None, force_f16=False):
