@@ -182,6 +182,8 @@ _decl("cl4_bn_sync_stats_final", _P, _D, _P, _P, _P, _P, _F, _I, _P)
 _decl("cl4_bn_sync_bwd_local", _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _F, _P, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_bn_sync_bwd_apply", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _F, _P, _D, _P, C.c_size_t, _P)
 _decl("cl4_pack_conv_weights_f16x3_batched", _P, _I, _L, _P)
+_decl("cl4_conv2d_fwd_planes_stats", _P, _P, _P, _P, _P, _P, _I, _P, C.c_size_t, _P)
+_decl("cl4_bn_stats_from_partials", _P, _I, _L, _I, _P, _P, _P, _P, _F, _P)
 _decl("cl4_abs_eps_batched", _P, _I, _L, _P)
 _decl("cl4_bn_sync_bwd_local_max", _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_bn_train_bwd_act", _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, C.c_size_t, _P)
@@ -231,6 +233,8 @@ def load():
     lib.cl4_last_error.restype = C.c_char_p
     lib.cl4_bn_workspace_bytes.restype = C.c_size_t
     lib.cl4_bn_workspace_bytes.argtypes = [C.c_int]
+    lib.cl4_conv2d_fwd_planes_stats_parts.restype = C.c_int
+    lib.cl4_conv2d_fwd_planes_stats_parts.argtypes = [C.POINTER(ConvDesc)]
     lib.cl4_bn_bwd_maxima_floats.restype = C.c_size_t
     lib.cl4_bn_bwd_maxima_floats.argtypes = [C.c_int]
     lib.cl4_bn_train_bwd_act_workspace_bytes.restype = C.c_size_t

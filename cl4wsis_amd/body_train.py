@@ -65,12 +65,14 @@ def conv_abn_train(x, conv, bn, group=None, xs_cache=None, emit_planes=False, po
     r = _Rec()
     r.x = x
     has_twin = getattr(x, "_cl4_planes", None) is not None
+    st = []           # r05: (partial sums, nparts) of z from the convolution's own epilogue, when its launch plan can leave them
     r.z = ops.conv2d(x, packed_weight(conv, PRECISION, force_f16=PRECISION == 3 and has_twin), k, stride=conv.stride[0], pad=conv.padding[0],
-                     dil=conv.dilation[0], x6=True, xs_cache=xs_cache)
+                     dil=conv.dilation[0], x6=True, xs_cache=xs_cache, stats_out=st)
     act, slope = bn.act_code()
     r.y, r.mean, r.var, r.count = ops.abn_train_forward(r.z, gamma_of(bn), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                         bn.momentum, bn.eps, act, slope, group,
-                                                        want_planes=emit_planes and _twin_pays(conv.out_channels), post=post, act2=act2, slope2=slope2)
+                                                        want_planes=emit_planes and _twin_pays(conv.out_channels), post=post, act2=act2, slope2=slope2,
+                                                        partials=st[0] if st else None)
     CACHE.touch(bn.running_mean)
     CACHE.touch(bn.running_var)
     return r.y, r

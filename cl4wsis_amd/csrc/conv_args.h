@@ -46,7 +46,45 @@ struct ConvArgs {
   // Experiments only (cl4_conv_debug_stagger, tools/probes/probe_b.py): first-round workgroups on odd CUs start this many REFCLK ticks (10 ns)
   // late, so that neighbouring CUs run their K loops and their epilogues in anti-phase. 0 in every product launch.
   int dbg_stagger;
+  // r05: per-channel partial sums of the OUTPUT for the train-mode BatchNorm behind the convolution (cl4_conv2d_fwd_planes_stats): every
+  // workgroup of an unsplit planes launch adds up the rows of its parked tile — stats[(channel * stats_np + pixel tile) * 2 + {0, 1}] =
+  // {sum, sum of squares} in double, the layout the BatchNorm kernels' channel_sums folds. Null otherwise.
+  double* stats;
+  int stats_np;
 };
+
+// {sum, sum of squares} of every row of a parked fp32 tile [rows][BNT] (LDS) -> a.stats; RPW rows per wave starting at wave * RPW, row r of the
+// tile = output channel m0 + r; columns past the tensor's last pixel hold zeros (their operands were zero-filled). Called by all waves.
+// A lane owns a PART of one row (64 / RPW lanes per row) and walks its 16-byte chunks with a per-row skew (lanes of different rows on different
+// banks); the parts are combined by one or two shuffles. (The first version reduced one row at a time across the lanes — 12 dependent
+// double-precision shuffle steps per row, ~9 us per 256 x 144 tile: the convolutions lost more than the statistics pass had cost.)
+template <int BNT, int RPW>
+__device__ __forceinline__ void tile_row_stats(const ConvArgs& a, const float* __restrict__ tile, int m0, int pixel_tile, int wave, int lane) {
+  typedef float f32x4s __attribute__((ext_vector_type(4)));
+  constexpr int Q = BNT / 4, LPR = 64 / RPW, QS = Q / LPR;      // chunks per row, lanes per row, chunks per lane
+  static_assert(BNT % 4 == 0 && 64 % RPW == 0 && Q % LPR == 0, "tile_row_stats: row parts");
+  const int r = lane % RPW, part = lane / RPW;
+  const int row = wave * RPW + r, co = m0 + row;
+  const f32x4s* src = reinterpret_cast<const f32x4s*>(tile + (long)row * BNT) + part * QS;
+  float s = 0.f, s2 = 0.f;
+#pragma unroll 4
+  for (int j = 0; j < QS; ++j) {
+    int q = j + r;
+    q = q >= QS ? q - QS * (q / QS) : q;
+    const f32x4s v = src[q];
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+#pragma unroll
+  for (int o = RPW; o < 64; o <<= 1) {
+    s += __shfl_xor(s, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if (part == 0 && co < a.cout) {
+    a.stats[((long)co * a.stats_np + pixel_tile) * 2 + 0] = (double)s;
+    a.stats[((long)co * a.stats_np + pixel_tile) * 2 + 1] = (double)s2;
+  }
+}
 
 // conv_u.hip: the unified-wave bf16x3 kernel (every wave loads, splits and multiplies). One launch of `grid` workgroups of 256
 // threads; ks = 1 | 3, split = K-split slabs (a.ws) instead of the fused epilogue.

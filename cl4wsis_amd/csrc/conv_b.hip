@@ -464,6 +464,7 @@ __global__ __launch_bounds__(64 * NW, NSTG == 2 ? 4 : (NW == 8 ? 2 : 1)) void co
     }
     return;
   }
+  if (a.stats) cl4::tile_row_stats<BNB, BMB / NW>(a, park, m0, (int)by_, wave, lane);     // (kernel argument: uniform)
   const float* stage = park + hsel * BM * BNB;
   const float* aff = affine[hsel];
   if (res_kind == 2) {

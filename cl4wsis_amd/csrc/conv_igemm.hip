@@ -1494,7 +1494,7 @@ int launch_planes(ConvArgs& a, hipStream_t st, void* workspace, size_t workspace
     }
     if (pl.impl < 2 || pl.impl > 6 || pl.tile != 128) { cl4::set_error("conv2d_fwd_planes: no 128x128 plan for this shape"); return CL4_EINVAL; }
     if (pl.impl == 3) {
-      if (pcode == 3 && cl4::conv_p_eligible(a, KS)) {
+      if (pcode == 3 && !a.stats && cl4::conv_p_eligible(a, KS)) {
         a.gx = cl4::cdiv(a.cout, 128);
         a.ntile_l = a.gx * cl4::cdiv(a.npix, 128);
         a.tile_base = 0; a.ws = nullptr; a.ws_p0 = 0; a.ws_npix = a.npix; a.kchunk = pl.kchunk;
@@ -2201,10 +2201,13 @@ extern "C" int cl4_conv2d_fwd_clear_plans(void) {
 
 static int conv2d_fwd_common(const cl4_conv_desc* d, const float* x, const void* xs, const float* wp, const float* scale,
                              const float* shift, const float* pre, const float* post, const void* post_s, float* y, void* ys,
-                             void* workspace, size_t workspace_bytes, void* stream, const float* xs_scale = nullptr) {
+                             void* workspace, size_t workspace_bytes, void* stream, const float* xs_scale = nullptr, double* stats = nullptr,
+                             int stats_np = 0) {
   ConvArgs a;
   a.xs_scale = xs_scale;
   a.dbg_stagger = 0;
+  a.stats = stats;
+  a.stats_np = stats_np;
   a.x = x; a.wp = wp; a.scale = scale; a.shift = shift; a.pre = pre; a.post = post; a.y = y;
   a.n = d->n; a.cin = d->cin; a.hin = d->hin; a.win = d->win; a.cout = d->cout;
   a.stride = d->stride; a.pad = d->pad; a.dil = d->dil; a.hout = d->hout; a.wout = d->wout;
@@ -2272,6 +2275,39 @@ extern "C" int cl4_conv2d_fwd_planes_f16(const cl4_conv_desc* d, const void* xs,
   CL4_REQUIRE(d->cout % 8 == 0 && d->cout >= 128, "conv2d_fwd_planes_f16: cout %% 8 == 0 and cout >= 128");
   CL4_REQUIRE((long)d->n * d->in_ctot * d->hin * d->win * 4 < 0x7FFFFFFFL, "conv2d_fwd_planes_f16: input >= 2 GiB is not addressable by the 32-bit buffer offsets");
   return conv2d_fwd_common(d, nullptr, xs, wp, scale, shift, pre, post, nullptr, y, nullptr, workspace, workspace_bytes, stream, xs_scale);
+}
+
+// r05: a plain planes convolution (no affine, activation or residual: the differentiated networks' conv in front of a train-mode ABN) that
+// also leaves the per-channel partial sums of its output for that ABN. stats_parts(d) = partial slots per channel the CURRENT launch plan of
+// this shape produces (its pixel tiles), 0 when the plan cannot (K-split slabs, main + tail plans): the caller then runs the separate pass.
+static int stats_parts_of(const cl4_conv_desc* d) {
+  if (!(d->precision == 3 || d->precision == 5) || !(d->kh == 1 || d->kh == 3)) return 0;
+  const int K = d->cin * d->kh * d->kw, npix = d->n * d->hout * d->wout;
+  const FwdPlan pl = plan_fwd(PlanKey{d->cout, npix, K, d->kh, d->stride, d->dil, d->hin * 8 + d->precision});
+  if (d->precision == 5) return cl4::cdiv(npix, 144);                           // always the LDS-DMA kernel, unsplit
+  if (pl.impl >= 4 && pl.impl <= 6) return pl.splits > 1 ? 0 : cl4::cdiv(npix, 144);
+  if (pl.impl == 3) return cl4::cdiv(npix, 128);                               // (runs on the plain planes kernel when statistics are asked for)
+  if (pl.impl == 2 && pl.tile == 128 && pl.splits == 1 && pl.tail == 0) return cl4::cdiv(npix, pl.pix());
+  return 0;
+}
+extern "C" int cl4_conv2d_fwd_planes_stats_parts(const cl4_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  return stats_parts_of(d);
+}
+extern "C" int cl4_conv2d_fwd_planes_stats(const cl4_conv_desc* d, const void* xs, const float* xs_scale, const float* wp, float* y, double* stats,
+                                           int stats_np, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  CL4_REQUIRE(xs && wp && y && stats, "conv2d_fwd_planes_stats: null tensor");
+  CL4_REQUIRE((d->precision == 3 && !xs_scale) || (d->precision == 5 && xs_scale), "conv2d_fwd_planes_stats: precision 3 (the build's planes) or 5 (fp16 planes with their scale)");
+  CL4_REQUIRE(d->act1 == CL4_ACT_NONE && d->act2 == CL4_ACT_NONE, "conv2d_fwd_planes_stats: a plain convolution (the statistics are those of the accumulators)");
+  CL4_REQUIRE(d->kh == 1 || d->kh == 3, "conv2d_fwd_planes_stats: 1x1 and 3x3 kernels only");
+  CL4_REQUIRE(d->cin % 32 == 0 && d->in_ctot % 8 == 0 && d->in_coff % 8 == 0, "conv2d_fwd_planes_stats: cin %% 32 == 0 and 8-aligned input channel slices");
+  CL4_REQUIRE(d->cout % 8 == 0 && d->cout >= (d->precision == 5 ? 128 : 64), "conv2d_fwd_planes_stats: cout %% 8 == 0 and cout >= 64 (128 for fp16 planes with a scale)");
+  CL4_REQUIRE((long)d->n * d->in_ctot * d->hin * d->win * 4 < 0x7FFFFFFFL, "conv2d_fwd_planes_stats: input >= 2 GiB is not addressable by the 32-bit buffer offsets");
+  const int np = stats_parts_of(d);
+  CL4_REQUIRE(np > 0 && np == stats_np, "conv2d_fwd_planes_stats: stats_np %d != cl4_conv2d_fwd_planes_stats_parts() = %d (0: this shape's plan cannot produce them)", stats_np, np);
+  return conv2d_fwd_common(d, nullptr, xs, wp, nullptr, nullptr, nullptr, nullptr, nullptr, y, nullptr, workspace, workspace_bytes, stream, xs_scale, stats, np);
 }
 
 // Experiments only (not part of the drop-in boundary): device buffer of 8 x uint64 per workgroup that the bf16 forward kernels

@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256, PL == 3 ? 1 : (BNT == 64 ? 3 : 2)) void conv_s
     }
     return;
   }
+  if (a.stats) cl4::tile_row_stats<BNT, BM / 4>(a, stage, m0, (int)by_, wave, lane);     // r05 (kernel argument: uniform)
 
   {
 #if !CL4_S_NO_AFFINE_LDS

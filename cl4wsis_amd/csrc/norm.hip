@@ -108,6 +108,28 @@ __global__ void bn_stats_final_kernel(const double* __restrict__ partial, float*
   }
 }
 
+// bn_stats_final_kernel for partials that came from somewhere else (r05: the producing convolution's epilogue, cl4_conv2d_fwd_planes_stats:
+// `nparts` = its pixel tiles, up to ~1,850 per channel): one wave per channel folds them (channel_sums) and finalises.
+__global__ __launch_bounds__(256) void bn_stats_from_partials_kernel(const double* __restrict__ partial, int nparts, float* __restrict__ mean,
+                                                                     float* __restrict__ var, float* running_mean, float* running_var,
+                                                                     float momentum, long count, int c) {
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ch >= c) return;
+  double a, b;
+  channel_sums(partial, ch, a, b, nparts);
+  if ((threadIdx.x & 63) != 0) return;
+  double m = a / (double)count;
+  double v = b / (double)count - m * m;
+  if (v < 0.0) v = 0.0;
+  mean[ch] = (float)m;
+  var[ch] = (float)v;
+  if (running_mean) {
+    double unb = count > 1 ? v * (double)count / (double)(count - 1) : v;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+  }
+}
+
 // Cross-rank (InPlaceABNSync) form: the SPLIT partials are folded to sums[c][2] doubles, which the host all-reduces over the
 // ranks before the statistics are finalised with the global element count.
 __global__ void bn_fold_partials_kernel(const double* __restrict__ partial, double* __restrict__ sums, int c) {
@@ -586,6 +608,14 @@ extern "C" int cl4_bn_train_stats(const float* x, int n, int c, int hw, int ctot
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(c, reduction_split(n * hw, c)), dim3(256), 0, st, x, (double*)workspace, s);
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)workspace, mean, var,
                      running_mean, running_var, momentum, (long)n * hw, c);
+  return cl4::launch_status();
+}
+
+extern "C" int cl4_bn_stats_from_partials(const double* partial, int nparts, long count, int c, float* mean, float* var, float* running_mean,
+                                          float* running_var, float momentum, void* stream) {
+  CL4_REQUIRE(partial && mean && var && nparts > 0 && count > 0 && c > 0, "bn_stats_from_partials: bad arguments");
+  hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3(cl4::cdiv(c, 4)), dim3(256), 0, cl4::as_stream(stream), partial, nparts, mean, var, running_mean,
+                     running_var, momentum, count, c);
   return cl4::launch_status();
 }
 

@@ -441,11 +441,12 @@ def gradient_scope(fn):
 
 def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, post=None,
            act1=ACT_NONE, slope1=0.01, act2=ACT_NONE, slope2=0.01,
-           out=None, out_coff=0, in_coff=0, cin=None, x6=False, xdyn=False, xs_cache=None):
+           out=None, out_coff=0, in_coff=0, cin=None, x6=False, xdyn=False, xs_cache=None, stats_out=None):
     """Fused conv (+affine +act +residual +act). `wp` comes from pack_conv_weight. `x6`: see X6_ROUTE. `xdyn`: `x` is a gradient (any
     magnitude): an fp16x3 launch then scales it by a power of two taken from its maximum (to_planes_f16(dynamic=True)). `xs_cache`: a
     dict the caller shares between convolutions that read the SAME input tensor (the ASPP branches, a block's conv1 and projection):
-    the fp16x3 operand is converted once.
+    the fp16x3 operand is converted once. `stats_out` (a list): a plain fp16x3 launch whose plan allows it also leaves the per-channel
+    partial sums of its output — (partials, nparts) is appended — for the train-mode ABN behind it (abn_train_forward(partials=...)).
 
     `out`/`out_coff` write into a channel slice of a wider tensor (replaces torch.cat);
     `in_coff`/`cin` read a channel slice of `x`.
@@ -487,10 +488,10 @@ def conv2d(x, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, p
                     xs_cache[ckey] = xs
             if xs.slot is not None:
                 y = conv2d_planes_f16(xs, wp, k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift, pre=pre, post=post, act1=act1, slope1=slope1,
-                                      act2=act2, slope2=slope2, out=out, out_coff=out_coff)
+                                      act2=act2, slope2=slope2, out=out, out_coff=out_coff, stats_out=stats_out)
             else:
                 y = conv2d_planes(xs, wp, k, stride=stride, pad=pad, dil=dil, scale=scale, shift=shift, pre=pre, post=post, act1=act1, slope1=slope1,
-                                  act2=act2, slope2=slope2, out=out, out_coff=out_coff, want_fp32=True)[0]
+                                  act2=act2, slope2=slope2, out=out, out_coff=out_coff, want_fp32=True, stats_out=stats_out)[0]
         finally:
             TIMER = timer
         if e1 is not None:
@@ -585,8 +586,25 @@ def to_planes_f16(x, dynamic=False, in_coff=0, c=None):
     return ps
 
 
+CONV_STATS = os.environ.get("CL4_CONV_STATS", "1") != "0"      # r05: a convolution in front of a train-mode ABN also leaves the ABN's partial sums
+
+
+def _launch_with_stats(d, xs, wp_ptr, out, stats_out):
+    """cl4_conv2d_fwd_planes_stats when the launch plan of this shape can produce the statistics: appends (partials, nparts) to `stats_out`
+    and returns True; False: the caller launches the plain entry (and the ABN makes its own pass)."""
+    parts = _hip.load().cl4_conv2d_fwd_planes_stats_parts(C.byref(d)) if CONV_STATS else 0
+    if parts <= 0:
+        return False
+    partial = torch.empty(d.cout * parts * 2, dtype=torch.float64, device=out.device)
+    need = _hip.load().cl4_conv2d_fwd_workspace_bytes(C.byref(d))
+    ws = _conv_workspace(out.device, need) if need else None
+    call("cl4_conv2d_fwd_planes_stats", C.byref(d), ptr(xs.data), ptr(xs.slot), wp_ptr, ptr(out), ptr(partial), parts, ptr(ws), need, stream())
+    stats_out.append((partial, parts))
+    return True
+
+
 def conv2d_planes_f16(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, post=None,
-                      act1=ACT_NONE, slope1=0.01, act2=ACT_NONE, slope2=0.01, out=None, out_coff=0):
+                      act1=ACT_NONE, slope1=0.01, act2=ACT_NONE, slope2=0.01, out=None, out_coff=0, stats_out=None):
     """conv2d on an fp16x3 operand (to_planes_f16) with pack_conv_weight(w, 3) weights: three fp16 MFMA products per MAC, fp32
     accumulation, the accuracy of bf16x6 (csrc/conv_b.hip, F16). fp32 NCHW output (optionally a channel slice of `out`)."""
     if not isinstance(xs, Planes) or xs.slot is None:
@@ -616,7 +634,9 @@ def conv2d_planes_f16(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None,
     args = (ptr(xs.data), ptr(xs.slot), ptr(wp.data), ptr(scale), ptr(shift), ptr(pre), ptr(post), ptr(out))
     if AUTOTUNE and not _planes_tuned(d):
         _autotune_f16(d, args)
-    call("cl4_conv2d_fwd_planes_f16", C.byref(d), *args, None, 0, stream())
+    plain = scale is None and shift is None and pre is None and post is None and act1 == ACT_NONE and act2 == ACT_NONE
+    if not (stats_out is not None and plain and out_coff == 0 and out.shape[1] == cout and _launch_with_stats(d, xs, ptr(wp.data), out, stats_out)):
+        call("cl4_conv2d_fwd_planes_f16", C.byref(d), *args, None, 0, stream())
     if TIMER is not None:
         e1.record()
     return out
@@ -658,7 +678,7 @@ def from_planes(ps, out=None, out_coff=0):
 
 def conv2d_planes(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre=None, post=None,
                   act1=ACT_NONE, slope1=0.01, act2=ACT_NONE, slope2=0.01, in_coff=0, cin=None,
-                  out=None, out_coff=0, want_fp32=True, out_planes=None, want_planes=False):
+                  out=None, out_coff=0, want_fp32=True, out_planes=None, want_planes=False, stats_out=None):
     """conv2d on a Planes input (csrc/conv_s.hip). `post` may be an fp32 tensor or a Planes tensor. Returns (y, ys): the fp32 NCHW
     output (None unless want_fp32 / out) and the Planes output (None unless want_planes / out_planes). `out` / `out_coff` /
     `out_planes` write channel slices of wider tensors (both outputs use the same slice offsets)."""
@@ -712,9 +732,12 @@ def conv2d_planes(xs, wp, k, stride=1, pad=0, dil=1, scale=None, shift=None, pre
             targs = args[:8] + (ptr(scratch.data),)
         _autotune_planes(d, targs)
         del scratch
-    need = _hip.load().cl4_conv2d_fwd_workspace_bytes(C.byref(d))
-    ws = _conv_workspace(dev, need) if need else None
-    call("cl4_conv2d_fwd_planes", C.byref(d), *args, ptr(ws), need, stream())
+    plain = (scale is None and shift is None and pre is None and post is None and act1 == ACT_NONE and act2 == ACT_NONE and not x6
+             and out is not None and out_planes is None and out_coff == 0 and out.shape[1] == cout and xs.slot is None)
+    if not (stats_out is not None and plain and _launch_with_stats(d, xs, ptr(wp.for_planes()), out, stats_out)):
+        need = _hip.load().cl4_conv2d_fwd_workspace_bytes(C.byref(d))
+        ws = _conv_workspace(dev, need) if need else None
+        call("cl4_conv2d_fwd_planes", C.byref(d), *args, ptr(ws), need, stream())
     if TIMER is not None:
         e1.record()
     return out, out_planes
@@ -1171,7 +1194,7 @@ def _allreduce_sum(t, group):
 
 
 def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act=ACT_LEAKY, slope=0.01,
-                      group=None, extra_sums=None, want_planes=False, post=None, act2=ACT_NONE, slope2=0.01):
+                      group=None, extra_sums=None, want_planes=False, post=None, act2=ACT_NONE, slope2=0.01, partials=None):
     """InPlaceABNSync in training mode (segmentation_module.py:17-29): batch statistics over every rank of
     `group`, then BN + leaky-ReLU / identity. Returns (y, mean, var, count). `extra_sums` ([c*2] doubles, count) adds the
     statistics of shards held elsewhere — used by the tests to emulate a second rank on one GPU."""
@@ -1179,7 +1202,14 @@ def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momen
     if ABN_ONE_RANK and extra_sums is None and not STAT_EXCHANGE._active(group):
         # r05: nobody to exchange sums with — statistics straight from the reduction's partials (cl4_bn_train_stats: the same arithmetic
         # as fold + all-reduce + final, one launch less per layer)
-        mean, var = bn_train_stats(x, running_mean=running_mean, running_var=running_var, momentum=momentum)
+        if partials is not None:      # the producing convolution left the partial sums (conv2d(stats_out=...)): no pass over x
+            part, nparts = partials
+            mean = torch.empty(c, dtype=torch.float32, device=x.device)
+            var = torch.empty_like(mean)
+            call("cl4_bn_stats_from_partials", ptr(part), int(nparts), n * h * w, c, ptr(mean), ptr(var), ptr(running_mean), ptr(running_var),
+                 C.c_float(momentum), stream())
+        else:
+            mean, var = bn_train_stats(x, running_mean=running_mean, running_var=running_var, momentum=momentum)
         y = bn_apply(x, mean, var, gamma, beta, eps=eps, act=act, slope=slope, want_planes=want_planes, post=post, act2=act2, slope2=slope2)
         return y, mean, var, float(n * h * w)
     # the count slot exists only when a caller brings extra shards (an uninitialised double must not go through the all-reduce)

@@ -625,6 +625,17 @@ typedef struct cl4_pack_job {
   int cout, cin, khw, transposed;
 } cl4_pack_job;
 int cl4_pack_conv_weights_f16x3_batched(const cl4_pack_job* jobs, int njobs, long total_items, void* stream);
+/* r05: the convolution in front of a train-mode ABN (train.py:272: conv -> InPlaceABNSync) also leaves the per-channel partial sums of its
+ * output, so the ABN needs no statistics pass over the tensor: a plain planes convolution (no affine / activation / residual), fp32 NCHW output
+ * y, stats[(channel * stats_np + pixel tile) * 2 + {0, 1}] = {sum, sum of squares} in double. stats_np must equal
+ * cl4_conv2d_fwd_planes_stats_parts(d) — the pixel tiles of the launch plan this shape currently has, 0 when that plan cannot produce them
+ * (K-split plans: run cl4_bn_train_stats instead). precision 3 (xs_scale null) or 5 (fp16 planes with their scale). cl4_bn_stats_from_partials
+ * turns such partials (any nparts) into mean / biased variance and updates the running statistics like cl4_bn_train_stats. */
+int cl4_conv2d_fwd_planes_stats_parts(const cl4_conv_desc* d);
+int cl4_conv2d_fwd_planes_stats(const cl4_conv_desc* d, const void* xs, const float* xs_scale, const float* wp, float* y, double* stats,
+                                int stats_np, void* workspace, size_t workspace_bytes, void* stream);
+int cl4_bn_stats_from_partials(const double* partial, int nparts, long count, int c, float* mean, float* var, float* running_mean,
+                               float* running_var, float momentum, void* stream);
 /* Which two-plane format / arithmetic this build of the library uses for EVERY planes tensor (cl4_to_planes, the ys / post_s operands, the
  * fused bottleneck and stem outputs): 1 = fp16x3 (fp16 hi / lo of 16 x; weights from cl4_pack_conv_weight_f16x3 — the default build),
  * 0 = bf16x3 (bf16 hi / lo of x; weights from cl4_pack_conv_weight_bf16x3; hipcc -DCL4_F16_PLANES=0: the r02-r04 format). */

@@ -32,7 +32,7 @@ def test_ctypes_prototypes_cover_header():
                 "cl4_pamr_workspace_bytes", "cl4_ngwp_workspace_bytes", "cl4_balanced_ce_workspace_bytes",
                 "cl4_bce_ignore_workspace_bytes", "cl4_p1loss_workspace_bytes", "cl4_cam_smooth_workspace_bytes", "cl4_cam_normalize_workspace_bytes", "cl4_abi_version", "cl4_last_error",
                 "cl4_input_ksize", "cl4_input_workspace_bytes", "cl4_target_generation_workspace_bytes", "cl4_conv_debug_u_launches", "cl4_conv_debug_s_launches", "cl4_conv_debug_b_launches", "cl4_conv_debug_f_launches", "cl4_kpack_bytes", "cl4_dwconv5_stats_parts",
-                "cl4_stem_weight_bytes", "cl4_to_planes_f16_slot_floats", "cl4_bn_bwd_maxima_floats", "cl4_bn_train_bwd_act_workspace_bytes"}
+                "cl4_stem_weight_bytes", "cl4_to_planes_f16_slot_floats", "cl4_bn_bwd_maxima_floats", "cl4_bn_train_bwd_act_workspace_bytes", "cl4_conv2d_fwd_planes_stats_parts"}
     for n in _declared():
         assert n in _hip.PROTOTYPES or n in size_fns, f"{n} has no ctypes prototype"
     assert lib.cl4_label_workspace_bytes(1, 65, 65) > 65 * 65 * 40

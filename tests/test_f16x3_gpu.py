@@ -159,3 +159,70 @@ def test_batched_weight_packs_equal_the_single_layer_launches(gpu):
         ref_d = ops.dgrad_weight(c.weight.detach(), 3, force_f16=True)
         assert torch.equal(a1.data, ref_f.data), tuple(c.weight.shape)
         assert torch.equal(b1.data, ref_d.data), tuple(c.weight.shape)
+
+
+@pytest.mark.parametrize("plan", [(6, 144, 1), (4, 144, 1), (2, 128, 1), (2, 144, 1), (2, 64, 1), (3, 128, 1), (2, 144, 3)])
+@pytest.mark.parametrize("shape", [(2, 256, 33, 33, 256, 3, 1), (3, 128, 21, 19, 136, 1, 0), (2, 64, 40, 40, 256, 1, 0)])
+def test_convolution_leaves_the_batchnorm_partial_sums(gpu, shape, plan):
+    """r05 (cl4_conv2d_fwd_planes_stats): the workgroups of an unsplit planes launch add up the rows of their parked tile, so the train-mode
+    ABN behind the convolution needs no statistics pass. Per channel the partials must sum to the sums of the fp32 output the same launch
+    wrote (1e-6: fp32 row sums of <= 144 elements, folded in double); a K-split plan reports 0 parts and the caller falls back."""
+    from cl4wsis_amd import _hip, ops
+    if not ops.planes_f16():
+        pytest.skip("fp16 planes build only")
+    n, cin, h, w, cout, k, pad = shape
+    if plan[0] == 4 and cout < 256:
+        pytest.skip("256-row tiles need cout >= 256")
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w, generator=g) + 0.3
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    xs = ops.to_planes(x.to(gpu))
+    wp = ops.pack_conv_weight(wt.to(gpu), 3, force_f16=True)
+    d = ops.ConvDescFor(n, cin, h, w, cin, 0, cout, k, 1, pad, 1, cout, 0, 0, 0.0, 0, 0.0, 3)
+    _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), *plan)
+    try:
+        parts = _hip.load().cl4_conv2d_fwd_planes_stats_parts(C.byref(d))
+        st = []
+        y = ops.conv2d_planes(xs, wp, k, pad=pad, want_fp32=True, stats_out=st)[0]
+        torch.cuda.synchronize()
+    finally:
+        _hip.call("cl4_conv2d_fwd_set_plan", C.byref(d), 0, 64, 1)
+    if plan[2] > 1:
+        assert parts == 0 and not st
+        return
+    tile = {6: 144, 4: 144, 3: 128}.get(plan[0], plan[1])
+    assert parts == -(-(n * h * w) // tile) and len(st) == 1 and st[0][1] == parts
+    part = st[0][0].view(cout, parts, 2).sum(1).cpu()
+    yd = y.double().cpu()
+    ref = torch.stack([yd.sum((0, 2, 3)), (yd * yd).sum((0, 2, 3))], 1)
+    assert ((part - ref).abs() <= 1e-6 * ref.abs() + 1e-6 * yd.abs().sum((0, 2, 3))[:, None] * 1e-1 + 1e-9).all(), (part - ref).abs().max()
+    ref64 = F.conv2d(x.double(), wt.double(), padding=pad)
+    assert _rel(yd, ref64) < 1e-6
+
+
+def test_train_mode_abn_reads_the_convolutions_partial_sums(gpu, monkeypatch):
+    """conv -> train-mode ABN of the differentiated networks (body_train.conv_abn_train) with and without the fused statistics: the same
+    mean / variance (1e-6 relative to the standard deviation), running statistics and activation."""
+    import torch.nn as tnn
+    from cl4wsis_amd import body_train, nn as cnn, ops
+    if not ops.planes_f16() or body_train.PRECISION != 3:
+        pytest.skip("fp16x3 training arithmetic only")
+    g = torch.Generator().manual_seed(31)
+    conv = tnn.Conv2d(256, 256, 3, padding=1, bias=False)
+    conv.weight.data = torch.randn(256, 256, 3, 3, generator=g) / 48.0
+    conv = conv.to(gpu)
+    x = (torch.randn(4, 256, 33, 33, generator=g) * 1.3 + 0.2).to(gpu)
+    outs = []
+    for fused in (False, True):
+        monkeypatch.setattr(ops, "CONV_STATS", fused)
+        bn = cnn.InPlaceABNSync(256).to(gpu)
+        bn.weight.data = (torch.rand(256, generator=torch.Generator().manual_seed(5)) + 0.5).to(gpu)
+        bn.train()
+        y, r = body_train.conv_abn_train(x, conv, bn)
+        torch.cuda.synchronize()
+        outs.append((y, r.mean, r.var, bn.running_mean.clone(), bn.running_var.clone()))
+    (y0, m0, v0, rm0, rv0), (y1, m1, v1, rm1, rv1) = outs
+    sd = v0.sqrt()
+    assert ((m0 - m1).abs() <= 1e-6 * sd + 1e-7).all() and ((v0 - v1).abs() <= 2e-6 * v0).all()
+    assert torch.allclose(rm0, rm1, rtol=1e-5, atol=1e-7) and torch.allclose(rv0, rv1, rtol=1e-5)
+    assert torch.allclose(y0, y1, rtol=1e-4, atol=1e-5)
