@@ -598,14 +598,24 @@ class Trainer:
                     for prm in grp["params"]:
                         CACHE.touch(prm)
 
+            # opt-in (see _deep_step): the frozen stage of the next batch as a graph of its own, replayed on the side stream (own memory
+            # pool: the two graphs of a step run concurrently)
+            split = P["deep"] and self.buckets.distributed and os.environ.get("CL4_SPLIT_SIDE_GRAPH", "0") != "0"
+            if split:
+                P["gB"], P["pool_side"] = [], torch.cuda.graph_pool_handle()
             for q in range(2):
                 stale_trainable()
+                if split:
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb, pool=P["pool_side"]):
+                        self._deep_step(P, q, part="frozen")
+                    P["gB"].append(gb)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
                     if getattr(self, "_stamps", None) is not None:
                         self._stamps["prefix"] = f"g{q}."
                     if P["deep"]:
-                        out = self._deep_step(P, q)
+                        out = self._deep_step(P, q, part="trainable" if split else "all")
                     else:
                         out = self._forward_backward(P["x"][q], P["l"][q], None, split_tail=self.buckets.distributed,
                                                      old_outputs=P["old"][q], prefetch_old=(P["x"][1 - q], P["old"][1 - q]))
@@ -645,6 +655,11 @@ class Trainer:
                 announced = True
         P["announced"] = next_batch if announced else None       # identity of the promise (held, so that its id cannot be reused)
         opt.upload_lr()
+        if P.get("gB"):
+            main = torch.cuda.current_stream()
+            self._side_stream.wait_stream(main)          # the batch copies above; the previous step's readers of FZ / OLD[1 - p]
+            with torch.cuda.stream(self._side_stream):
+                P["gB"][p].replay()
         P["g"][p].replay()
         P["have_old"][p] = False
         P["have_old"][1 - p] = announced
@@ -657,6 +672,8 @@ class Trainer:
             for prm in self._branch.aspp_parameters():    # the eager ASPP tail derives its operands from the current weights itself
                 CACHE.touch(prm)
             self._distributed_tail(P["out"][p], P.get("pool"))
+        if P.get("gB"):
+            torch.cuda.current_stream().wait_stream(self._side_stream)      # the step ends when the next batch's frozen stage has
         return P["out"][p]
 
     def enable_chain_stamps(self, slots=64):
@@ -685,15 +702,27 @@ class Trainer:
         v = S["buf"].cpu().tolist()
         return {n: v[i] * 0.01 for i, n in enumerate(S["names"])}
 
-    def _deep_step(self, P, q):
+    def _deep_step(self, P, q, part="all"):
         """Body of the deep-pipelined graph of parity q: the trainable stage of batch X[q] on its handed-over frozen results FZ[q] / OLD[q]
-        (main stream), beside the whole frozen stage of X[1 - q] into FZ[1 - q] / OLD[1 - q] (two side streams), joined at the end."""
+        (main stream), beside the whole frozen stage of X[1 - q] into FZ[1 - q] / OLD[1 - q] (two side streams), joined at the end.
+        `part` (r05, N > 1, opt-in: CL4_SPLIT_SIDE_GRAPH=1): "frozen" / "trainable" capture the two halves as SEPARATE graphs — the frozen
+        one is replayed on the side stream, so that everything enqueued behind the trainable graph (the eager ASPP tail, the bucketed
+        all-reduce, Adam) runs while the frozen chains are still busy; one graph is one stream-ordered unit, behind which the all-reduce
+        of 63 MB (~2 ms over xGMI at N = 8 by the ring estimate) would be fully exposed. At world size 1, where the all-reduce costs
+        nothing, two graph launches are 0.3-0.5 ms SLOWER than one (FINDINGS.md finding 60): hence off by default, for a node to try."""
         main = torch.cuda.current_stream()
         r = 1 - q
         H, W = P["x"][q].shape[2:]
         if getattr(self, "_stamps", None) is not None:
             self._stamps["prefix"] = f"g{q}."
-        self._stamp("main.head")
+        if part == "trainable":
+            self._stamp("main.head")
+            self.optimizer.zero_grad()
+            out = self._trainable_stage(P["fz"][q], P["old"][q], P["l"][q], None, (H, W), split_tail=self.buckets.distributed)
+            self._stamp("main.trainable_tail")
+            return out
+        if part == "all":
+            self._stamp("main.head")
         self._side_stream.wait_stream(main)
         self._side2.wait_stream(main)
 
@@ -718,6 +747,10 @@ class Trainer:
         order = (old_chain, frozen_chain) if os.environ.get("CL4_DEEP_ORDER", "frozen") == "old" else (frozen_chain, old_chain)
         for chain in order:
             chain()
+        if part == "frozen":
+            main.wait_stream(self._side_stream)
+            main.wait_stream(self._side2)
+            return None
         self.optimizer.zero_grad()
 
         def join_end():

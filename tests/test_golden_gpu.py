@@ -353,11 +353,14 @@ def test_collective_path_over_rccl_single_rank(gpu, monkeypatch):
         assert tr.buckets.distributed and tr.buckets.native_avg and tr._graph is not None
         lp, wp_, trp, gp = run(lookahead=True)           # the same with the next batch announced: (deep-)pipelined graphs + eager ASPP tail
         assert trp.buckets.distributed and trp._pipe is not None and trp._pipe["deep"]      # 2 images per GPU: deep pipelining
+        monkeypatch.setenv("CL4_SPLIT_SIDE_GRAPH", "1")  # opt-in: the next batch's frozen stage as a graph of its own on the side stream
+        l2, w2, tr2, g2 = run(lookahead=True)
+        assert tr2._pipe.get("gB") and len(tr2._pipe["gB"]) == 2
     finally:
         dist.destroy_process_group()
     # (1) From the same weights — the first step — the collective path must reproduce the plain path's gradients: what is left is the order of
     # the weight-gradient kernels' atomic adds (measured 4e-8; two PLAIN runs differ by the same, tests/tools/dbg_plain_vs_plain.py).
-    for name, g_ in (("collective path", gd), ("collective path, deep-pipelined", gp)):
+    for name, g_ in (("collective path", gd), ("collective path, deep-pipelined", gp), ("collective path, deep-pipelined, two graphs per step", g2)):
         e = float((g_ - gs).norm() / gs.norm())
         print(f"COLLECTIVE1 {name}: first-step gradients vs the plain run, relative L2 {e:.2e}")
         assert e < 1e-6, (name, e)
@@ -367,7 +370,7 @@ def test_collective_path_over_rccl_single_rank(gpu, monkeypatch):
     # gradients 4e-6 apart, third-step up to 8e-4 when a label decision flips), in discrete states that depend on the launch plans the tuner
     # timed into place: max 0.00 / 0.01 / 0.12 / 0.22 / 0.39 / 1.66 lr with 0 ... 523 of 15.7 M weights beyond 0.4 lr. The bars bound that
     # spread (max, mean unchanged since r03; the count at 1e-4 of the weights, r03-r04: 1e-5 = the five smaller states only).
-    for l_, w_ in ((ld, wd), (lp, wp_)):
+    for l_, w_ in ((ld, wd), (lp, wp_), (l2, w2)):
         assert torch.allclose(ls, l_, rtol=2e-3, atol=1e-6), (ls, l_)
         d = (ws - w_).abs()
         print(f"COLLECTIVE1 weights after 3 Adam steps vs the plain run: max {float(d.max()) / LR:.2f} lr, mean {float(d.mean()) / LR:.4f} lr, "
