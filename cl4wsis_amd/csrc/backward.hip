@@ -112,9 +112,10 @@ __global__ void add_act_planes_kernel(const float* __restrict__ a, const float* 
   const int c8 = c >> 3;
   const long total = (long)n * c8 * hw;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % hw);
-    const long r = i / hw;
-    const int g = (int)(r % c8), im = (int)(r / c8);
+    // (32-bit index arithmetic: the launchers check total < 2^31; the 64-bit divisions were ~250 of this loop's ~700 VALU instructions)
+    const unsigned iu = (unsigned)i, r = iu / (unsigned)hw;
+    const int px = (int)(iu - r * (unsigned)hw);
+    const int im = (int)(r / (unsigned)c8), g = (int)(r - (unsigned)im * (unsigned)c8);
     const long base = ((long)im * c + g * 8) * hw + px;
     float v[8];
 #pragma unroll
@@ -239,6 +240,7 @@ extern "C" int cl4_add_act(const float* a, const float* b, float* y, long n, int
 extern "C" int cl4_add_act_planes(const float* a, const float* b, float* y, void* ys, int n, int c, int hw, int act, float slope, void* stream) {
   CL4_REQUIRE(a && b && y && ys && n > 0 && c > 0 && hw > 0 && c % 8 == 0, "add_act_planes: bad arguments (c %% 8 == 0)");
   const long total = (long)n * (c >> 3) * hw;
+  CL4_REQUIRE(total < (1L << 31), "planes pass: n * c / 8 * hw = %ld work items exceed the 32-bit index arithmetic of the kernel", total);
   hipLaunchKernelGGL(add_act_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), a, b, y, (u32x4b*)ys, n, c, hw, act, slope);
   return cl4::launch_status();
 }

@@ -447,9 +447,10 @@ __global__ void to_planes_kernel(const float* __restrict__ x, u32x4* __restrict_
   const int c8 = c >> 3;
   const long total = (long)n * c8 * hw;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % hw);
-    const long r = i / hw;
-    const int g = (int)(r % c8), im = (int)(r / c8);
+    // (32-bit index arithmetic: the launchers check total < 2^31; the 64-bit divisions were ~250 of this loop's ~700 VALU instructions)
+    const unsigned iu = (unsigned)i, r = iu / (unsigned)hw;
+    const int px = (int)(iu - r * (unsigned)hw);
+    const int im = (int)(r / (unsigned)c8), g = (int)(r - (unsigned)im * (unsigned)c8);
     const float* src = x + ((long)im * ctot + coff + g * 8) * hw + px;
     float v[8];
 #pragma unroll
@@ -467,9 +468,10 @@ __global__ void from_planes_kernel(const u32x4* __restrict__ xs, float* __restri
   const int c8 = c >> 3;
   const long total = (long)n * c8 * hw;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % hw);
-    const long r = i / hw;
-    const int g = (int)(r % c8), im = (int)(r / c8);
+    // (32-bit index arithmetic: the launchers check total < 2^31; the 64-bit divisions were ~250 of this loop's ~700 VALU instructions)
+    const unsigned iu = (unsigned)i, r = iu / (unsigned)hw;
+    const int px = (int)(iu - r * (unsigned)hw);
+    const int im = (int)(r / (unsigned)c8), g = (int)(r - (unsigned)im * (unsigned)c8);
     const u32x4* src = xs + (((long)im * c8 + g) * 2) * hw + px;
     float v[8];
     join8(src[0], src[hw], v);
@@ -485,9 +487,10 @@ __global__ void to_planes3_kernel(const float* __restrict__ x, u32x4* __restrict
   const int c8 = c >> 3;
   const long total = (long)n * c8 * hw;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % hw);
-    const long r = i / hw;
-    const int g = (int)(r % c8), im = (int)(r / c8);
+    // (32-bit index arithmetic: the launchers check total < 2^31; the 64-bit divisions were ~250 of this loop's ~700 VALU instructions)
+    const unsigned iu = (unsigned)i, r = iu / (unsigned)hw;
+    const int px = (int)(iu - r * (unsigned)hw);
+    const int im = (int)(r / (unsigned)c8), g = (int)(r - (unsigned)im * (unsigned)c8);
     const float* src = x + ((long)im * ctot + coff + g * 8) * hw + px;
     float v[8], rest[8];
 #pragma unroll
@@ -552,9 +555,10 @@ __global__ __launch_bounds__(256) void to_planes_f16_kernel(const float* __restr
   const int c8 = c >> 3;
   const long total = (long)n * c8 * hw;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % hw);
-    const long r = i / hw;
-    const int g = (int)(r % c8), im = (int)(r / c8);
+    // (32-bit index arithmetic: the launchers check total < 2^31; the 64-bit divisions were ~250 of this loop's ~700 VALU instructions)
+    const unsigned iu = (unsigned)i, r = iu / (unsigned)hw;
+    const int px = (int)(iu - r * (unsigned)hw);
+    const int im = (int)(r / (unsigned)c8), g = (int)(r - (unsigned)im * (unsigned)c8);
     const float* src = x + ((long)im * ctot + coff + g * 8) * hw + px;
     float v[8];
 #pragma unroll
@@ -639,6 +643,7 @@ extern "C" int cl4_to_planes(const float* x, void* xs, int n, int ctot, int coff
   CL4_REQUIRE(x && xs, "to_planes: null tensor");
   CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0 && coff >= 0 && coff + c <= ctot, "to_planes: bad channel slice (c %% 8 == 0 required)");
   const long total = (long)n * (c >> 3) * hw;
+  CL4_REQUIRE(total < (1L << 31), "planes pass: n * c / 8 * hw = %ld work items exceed the 32-bit index arithmetic of the kernel", total);
   hipLaunchKernelGGL(to_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, (u32x4*)xs, n, ctot, coff, c, hw);
   return cl4::launch_status();
 }
@@ -647,6 +652,7 @@ extern "C" int cl4_to_planes3(const float* x, void* xs, int n, int ctot, int cof
   CL4_REQUIRE(x && xs, "to_planes3: null tensor");
   CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0 && coff >= 0 && coff + c <= ctot, "to_planes3: bad channel slice (c %% 8 == 0 required)");
   const long total = (long)n * (c >> 3) * hw;
+  CL4_REQUIRE(total < (1L << 31), "planes pass: n * c / 8 * hw = %ld work items exceed the 32-bit index arithmetic of the kernel", total);
   hipLaunchKernelGGL(to_planes3_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, (u32x4*)xs, n, ctot, coff, c, hw);
   return cl4::launch_status();
 }
@@ -665,6 +671,7 @@ extern "C" int cl4_to_planes_f16(const float* x, void* xs, int n, int ctot, int 
     hipLaunchKernelGGL(absmax_kernel, dim3(nparts), dim3(256), 0, st, x, slot + 4, n, ctot, coff, c, (long)hw);
   }
   const long total = (long)n * (c >> 3) * hw;
+  CL4_REQUIRE(total < (1L << 31), "planes pass: n * c / 8 * hw = %ld work items exceed the 32-bit index arithmetic of the kernel", total);
   hipLaunchKernelGGL(to_planes_f16_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, x, (u32x4*)xs, n, ctot, coff, c, hw, F16_XSCALE, slot, nparts);
   return cl4::launch_status();
 }
@@ -690,6 +697,7 @@ extern "C" int cl4_from_planes(const void* xs, float* y, int n, int c, int hw, i
   CL4_REQUIRE(xs && y, "from_planes: null tensor");
   CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0 && out_coff >= 0 && out_coff + c <= out_ctot, "from_planes: bad channel slice");
   const long total = (long)n * (c >> 3) * hw;
+  CL4_REQUIRE(total < (1L << 31), "planes pass: n * c / 8 * hw = %ld work items exceed the 32-bit index arithmetic of the kernel", total);
   hipLaunchKernelGGL(from_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), (const u32x4*)xs, y, n, c, hw, out_ctot, out_coff);
   return cl4::launch_status();
 }

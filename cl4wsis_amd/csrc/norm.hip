@@ -202,9 +202,10 @@ __global__ void bn_apply_planes_kernel(const float* __restrict__ x, float* __res
   const int c8 = c >> 3;
   const long total = (long)n * c8 * hw;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % hw);
-    const long r = i / hw;
-    const int g = (int)(r % c8), im = (int)(r / c8);
+    // (32-bit index arithmetic: the launchers check total < 2^31; the 64-bit divisions were ~250 of this loop's ~700 VALU instructions)
+    const unsigned iu = (unsigned)i, r = iu / (unsigned)hw;
+    const int px = (int)(iu - r * (unsigned)hw);
+    const int im = (int)(r / (unsigned)c8), g = (int)(r - (unsigned)im * (unsigned)c8);
     const long base = ((long)im * c + g * 8) * hw + px;
     float v[8];
 #pragma unroll
@@ -494,9 +495,10 @@ __global__ void bn_bwd_apply_planes_kernel(const float* __restrict__ x, const fl
   const int c8 = c >> 3;
   const long total = (long)n * c8 * hw;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int px = (int)(i % hw);
-    const long r = i / hw;
-    const int g8 = (int)(r % c8), im = (int)(r / c8);
+    // (32-bit index arithmetic: the launchers check total < 2^31; the 64-bit divisions were ~250 of this loop's ~700 VALU instructions)
+    const unsigned iu = (unsigned)i, r = iu / (unsigned)hw;
+    const int px = (int)(iu - r * (unsigned)hw);
+    const int im = (int)(r / (unsigned)c8), g8 = (int)(r - (unsigned)im * (unsigned)c8);
     const long base = ((long)im * c + g8 * 8) * hw + px;
     const long dbase = ((long)im * dy_ctot + dy_coff + g8 * 8) * hw + px;
     float xv[8], dv[8], v[8];
@@ -639,6 +641,7 @@ extern "C" int cl4_bn_apply_planes(const float* x, float* y, void* ys, int n, in
   CL4_REQUIRE(x && y && mean && var, "bn_apply_planes: null pointer");
   CL4_REQUIRE(n > 0 && c > 0 && hw > 0 && c % 8 == 0, "bn_apply_planes: c %% 8 == 0 required");
   const long total = (long)n * (c >> 3) * hw;
+  CL4_REQUIRE(total < (1L << 31), "planes pass: n * c / 8 * hw = %ld work items exceed the 32-bit index arithmetic of the kernel", total);
   hipLaunchKernelGGL(bn_apply_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, cl4::as_stream(stream), x, y, (u32x4n*)ys, mean, var,
                      gamma, beta, eps, act, slope, n, c, hw, post, act2, slope2);
   return cl4::launch_status();
@@ -839,6 +842,7 @@ extern "C" int cl4_bn_train_bwd_act(const float* x, const float* dy, float* dx, 
   hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3(cl4::cdiv(c, 4)), dim3(256), 0, st, (const double*)nullptr, (const float*)maxima, mean, var, gamma, beta, eps,
                      invn, c, coef, coef + 8 * (long)c, (const double*)partial, dgamma, dbeta, gamma_sign_src);
   const long total = (long)n * (c >> 3) * hw;
+  CL4_REQUIRE(total < (1L << 31), "planes pass: n * c / 8 * hw = %ld work items exceed the 32-bit index arithmetic of the kernel", total);
   hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, x, dy, dx, (u32x4n*)dxs, (const float*)coef, act, slope,
                      n, c, hw, dy_ctot, dy_coff, (const float*)(coef + 8 * (long)c), slot);
   return cl4::launch_status();
@@ -860,6 +864,7 @@ extern "C" int cl4_bn_sync_bwd_apply_planes(const float* x, const float* dy, flo
   const float invn = (float)(1.0 / count);
   hipLaunchKernelGGL(bn_bwd_prep_kernel, dim3(cl4::cdiv(c, 4)), dim3(256), 0, st, sums, maxima, mean, var, gamma, beta, eps, invn, c, coef, coef + 8 * (long)c);
   const long total = (long)n * (c >> 3) * hw;
+  CL4_REQUIRE(total < (1L << 31), "planes pass: n * c / 8 * hw = %ld work items exceed the 32-bit index arithmetic of the kernel", total);
   hipLaunchKernelGGL(bn_bwd_apply_planes_kernel, dim3(cl4::stream_grid(total, 256)), dim3(256), 0, st, x, dy, dx, (u32x4n*)dxs, (const float*)coef, act, slope,
                      n, c, hw, dy_ctot, dy_coff, (const float*)(coef + 8 * (long)c), slot);
   return cl4::launch_status();
