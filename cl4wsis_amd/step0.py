@@ -31,7 +31,11 @@ class Step0:
         hy, htape = heads_train.deeplab_forward(model.head, outs[-1])
         seg, cx = heads_train.cls_forward(model.cls, hy)
         branch = tr._branch
-        pred, itape = branch.forward_train(feats, dropout_keep=dropout_keep, seed=int(tr._iter * 2654435761 + tr.opts.random_seed))
+        if dropout_keep is None:      # the trainer's device-resident seed, advanced by the launch: the same code path eager and under graph replay
+            n5, _, h5, w5 = feats["res5"].shape
+            drop = model.decoder.instance_decoder.aspp.project
+            dropout_keep = ops.dropout_mask_dev((n5, drop[0].out_channels, h5, w5), drop[3].p, tr._seed_dev, 1, tr.device)
+        pred, itape = branch.forward_train(feats, dropout_keep=dropout_keep)
 
         # semantic loss on the upsampled logits (train.py:281-282,296-299)
         seg_up = ops.resize_bilinear(seg, (H, W), False)

@@ -164,6 +164,7 @@ class Trainer:
         self._side_stream = (torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CL4_SIDE_PRIORITY", "0")))
                              if os.environ.get("CL4_OVERLAP", "1") != "0" else None)
         self._use_graph = os.environ.get("CL4_GRAPH", "1") != "0"
+        self._s0_static = None
         # N > 1: the ASPP tail as a chain of per-bucket graphs (_distributed_tail). Built and tested (world-size-1 RCCL rehearsal, two gloo ranks),
         # measured at world size 1: 34.57 / 19.53 / 11.95 / 8.27 ms per step at 16 / 8 / 4 / 2 images against 34.57 / 19.44 / 11.96 / 8.21 with the
         # eager tail (profiles/r04_solo_collectives.txt) — the host runs ahead of the device either way, so it is OFF by default: the only real
@@ -321,20 +322,62 @@ class Trainer:
         images, seg_maps, center_maps, offset_maps, weights = batch[:5]
         f32 = lambda t: t.to(self.device, dtype=torch.float32).contiguous()
         self.model.train()
-        ops.AUTOTUNE = self._iter == 0 and os.environ.get("CL4_AUTOTUNE", "1") != "0"
-        try:
-            losses = self._s0.run(f32(images), seg_maps.to(self.device, dtype=torch.long).contiguous(), f32(center_maps),
-                                  f32(offset_maps), f32(weights), dropout_keep)
-        finally:
-            ops.AUTOTUNE = False
-        for i in range(len(self.buckets.fb.sizes)):
-            self.buckets.ready(i)
-        self.buckets.finish()
-        self.optimizer.step()
+        tensors = (f32(images), seg_maps.to(self.device, dtype=torch.long).contiguous(), f32(center_maps), f32(offset_maps), f32(weights))
+        # r05: on one GPU the step is HIP-graph replayed from its third call on, like phase 1 (the first two run eagerly: launch plans are
+        # timed in iteration 0, the one-launch weight packs get their job table in iteration 1). The Dropout mask then comes from the
+        # trainer's device-resident seed, which every launch advances. Injected masks (the parity tests), N > 1, the WiderResNet body
+        # (Dropout2d seeds drawn on the host) and CL4_GRAPH=0 take the eager path.
+        use_graph = (self._use_graph and dropout_keep is None and self._iter >= 2 and ops.TIMER is None and not self.buckets.distributed
+                     and not hasattr(self.model.body, "bn_out") and os.environ.get("CL4_S0_GRAPH", "1") != "0"
+                     and (self._s0_static is None or all(tuple(a.shape) == tuple(b.shape) for a, b in zip(tensors, self._s0_static["in"]))))
+        if use_graph:
+            losses = self._replay_step0(tensors)
+        else:
+            ops.AUTOTUNE = self._iter == 0 and os.environ.get("CL4_AUTOTUNE", "1") != "0"
+            try:
+                losses = self._s0.run(*tensors, dropout_keep)
+            finally:
+                ops.AUTOTUNE = False
+            for i in range(len(self.buckets.fb.sizes)):
+                self.buckets.ready(i)
+            self.buckets.finish()
+            self.optimizer.step()
         if self.scheduler is not None:
             self.scheduler.step()
         self._iter += 1
         return {"losses": losses}
+
+    def _replay_step0(self, tensors):
+        from .nn import CACHE
+        opt = self.optimizer
+        if self._s0_static is None:
+            def stale_trainable():       # the graph re-derives (packs / folds) what it reads from the trainable weights itself (as _replay_phase1)
+                for grp in opt.param_groups:
+                    for prm in grp["params"]:
+                        CACHE.touch(prm)
+                for buf in self.model.buffers():
+                    CACHE.touch(buf)
+            S = {"in": [t.clone() for t in tensors], "pool": torch.cuda.graph_pool_handle()}
+            opt.upload_lr()
+            torch.cuda.synchronize()
+            stale_trainable()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=S["pool"]):
+                losses = self._s0.run(*S["in"], None)
+                opt.step(upload=False)
+            if hasattr(opt, "_step"):
+                opt._step -= 1                            # capture only recorded the kernels
+            stale_trainable()
+            S["g"], S["losses"], S["keep"] = g, losses, self._derived_snapshot()
+            self._s0_static = S
+        S = self._s0_static
+        for dst, src in zip(S["in"], tensors):
+            dst.copy_(src)
+        opt.upload_lr()
+        S["g"].replay()
+        self._graph_active = True
+        opt.note_replayed_step()
+        return S["losses"]
 
     def _step_phase1(self, batch, cur_epoch=None, flac_angle=None, randrop_neg=None):
         """One phase-1 iteration (train.py:241-566 with --phase 1) — see cl4wsis_amd/phase1.py.

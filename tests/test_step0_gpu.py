@@ -76,3 +76,64 @@ def test_step0_matches_oracle(gpu, monkeypatch, precision):
         assert ratios.median() < 2 and (ratios > 3).float().mean() < 0.03, (ratios.median(), (ratios > 3).float().mean())
     else:
         assert so ** 0.5 < 5 * sc ** 0.5 + 1e-4, (so, sc)
+
+
+def test_step0_graph_replay_matches_eager(gpu):
+    """r05: on one GPU the supervised step is HIP-graph replayed from its third call on (Trainer._replay_step0; Dropout mask from the
+    device-resident seed). ONE step from ONE state, replayed and — weights, Adam moments and step count, running statistics and the seed
+    restored — run eagerly: the same losses (1e-4) and the same update (Adam turns noise-level gradients into +-lr: relative to the update)."""
+    from cl4wsis_amd.train import Trainer
+    from oracle import weights
+    crop = 97
+    opts = s0_opts(crop)
+    opts.max_iters, opts.start_decay = 1000, 1000
+    torch.manual_seed(0)
+    tr = Trainer(_Log(), gpu, opts)
+    tr.model.load_state_dict(weights.fill_({k: v.cpu().clone() for k, v in tr.model.state_dict().items()}, seed=43))
+    tr._realias()
+    g = torch.Generator().manual_seed(8)
+    b = 3
+
+    def batch():
+        seg = torch.randint(0, 16, (b, crop, crop), generator=g)
+        seg[torch.rand(b, crop, crop, generator=g) < 0.1] = 255
+        return (torch.randn(b, 3, crop, crop, generator=g), seg, torch.rand(b, 15, crop, crop, generator=g), torch.randn(b, 2, crop, crop, generator=g) * 5,
+                (torch.rand(b, 1, crop, crop, generator=g) < 0.4).float(), torch.zeros(b, 15))
+
+    for _ in range(4):
+        out = tr.step(batch())
+        assert all(torch.isfinite(v).all() for v in out["losses"].values())
+    assert tr._s0_static is not None                       # iterations 2 and 3 were replays
+    torch.cuda.synchronize()
+    opt = tr.optimizer
+    snap = {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
+    m0, v0, sd0, st0, seed0 = opt.m_fb.flat.clone(), opt.v_fb.flat.clone(), opt.step_dev.clone(), opt._step, tr._seed_dev.clone()
+    w0 = opt.params_fb.flat.clone()
+    bt = batch()
+
+    def restore():
+        tr.model.load_state_dict(snap)
+        tr._realias()
+        opt.m_fb.flat.copy_(m0); opt.v_fb.flat.copy_(v0); opt.step_dev.copy_(sd0); opt._step = st0
+        tr._seed_dev.copy_(seed0)
+
+    it = tr._iter
+    restore()
+    lg = {k: float(v) for k, v in tr.step(bt)["losses"].items()}                    # a replay
+    torch.cuda.synchronize()
+    wg = opt.params_fb.flat.clone()
+    assert opt._step == st0 + 1 and int(opt.step_dev) == int(sd0) + 1
+    restore()
+    tr._iter = it
+    tr._use_graph = False
+    try:
+        le = {k: float(v) for k, v in tr.step(bt)["losses"].items()}                # the same step, eager
+    finally:
+        tr._use_graph = True
+    torch.cuda.synchronize()
+    we = opt.params_fb.flat.clone()
+    for k in le:
+        assert abs(le[k] - lg[k]) <= 1e-4 * max(abs(le[k]), 1e-3), (k, le[k], lg[k])
+    rel = ((we - wg).norm() / (we - w0).norm()).item()
+    print("S0GRAPH update difference relative to the update", rel)
+    assert rel < 2e-2, rel
