@@ -29,7 +29,7 @@ center = torch.rand(b, 15, H, H, generator=g).to(dev)
 offset = torch.randn(b, 2, H, H, generator=g).to(dev)
 weights = (torch.rand(b, 1, H, H, generator=g) > 0.5).float().to(dev)
 batch = (images, seg, center, offset, weights)
-for _ in range(2):
+for _ in range(4):          # iteration 0 times the launch plans, 1 builds the pack table, 2 captures the step graph (r05)
     tr.step(batch)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
