@@ -38,7 +38,7 @@ for _ in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 arith = {0: "exact fp32 MFMA", 1: "bf16x3", 2: "bf16x6", 3: "fp16x3 (bf16x6 where not routed)"}[body_train.PRECISION]
-print(json.dumps({"workload": f"VOC 15-5 step 0 (BASELINE config 1: supervised, --bce, Adam), batch {b}, 513x513, Trainer.step eager, differentiated convolutions {arith}",
+print(json.dumps({"workload": f"VOC 15-5 step 0 (BASELINE config 1: supervised, --bce, Adam), batch {b}, 513x513, Trainer.step (HIP-graph replay from its third call on unless CL4_S0_GRAPH=0), differentiated convolutions {arith}",
                   "ms_per_step": 1e3 * dt, "images_per_s": b / dt, "algorithmic_tflops": 531.0 * b / dt / 1e3, "peak_mem_GB": torch.cuda.max_memory_allocated() / 2**30,
                   "losses": {k: float(v) for k, v in out["losses"].items()}}))
 if len(sys.argv) > 3:
