@@ -184,6 +184,7 @@ _decl("cl4_bn_sync_bwd_apply", _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _
 _decl("cl4_pack_conv_weights_f16x3_batched", _P, _I, _L, _P)
 _decl("cl4_conv2d_fwd_planes_stats", _P, _P, _P, _P, _P, _P, _I, _P, C.c_size_t, _P)
 _decl("cl4_bn_stats_from_partials", _P, _I, _L, _I, _P, _P, _P, _P, _F, _P)
+_decl("cl4_bn_sync_stats_from_partials", _P, _I, _P, _I, _P)
 _decl("cl4_abs_eps_batched", _P, _I, _L, _P)
 _decl("cl4_bn_sync_bwd_local_max", _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _P, C.c_size_t, _P)
 _decl("cl4_bn_train_bwd_act", _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _F, _P, _P, _P, _P, C.c_size_t, _P)

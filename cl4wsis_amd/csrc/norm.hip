@@ -352,13 +352,18 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ x, const float* 
 __device__ __forceinline__ float gamma_sign(const float* __restrict__ sign_src, int c) { return (sign_src && !(sign_src[c] > 0.f)) ? -1.f : 1.f; }
 
 __global__ void bn_bwd_final_kernel(const double* __restrict__ partial, float* __restrict__ sum_dz, float* __restrict__ sum_dz_xh,
-                                    float* dgamma, float* dbeta, int c, const float* __restrict__ sign_src = nullptr) {
+                                    float* dgamma, float* dbeta, int c, const float* __restrict__ sign_src = nullptr,
+                                    double* __restrict__ sums_out = nullptr) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c) return;
   double a = 0.0, b = 0.0;
   for (int s = 0; s < SPLIT; ++s) {
     a += partial[((long)i * SPLIT + s) * 2 + 0];
     b += partial[((long)i * SPLIT + s) * 2 + 1];
+  }
+  if (sums_out) {                    // r05: the packed vector of the cross-rank exchange (bn_fold_partials_kernel's job, one launch less)
+    sums_out[2 * i] = a;
+    sums_out[2 * i + 1] = b;
   }
   sum_dz[i] = (float)a;
   sum_dz_xh[i] = (float)b;
@@ -613,6 +618,24 @@ extern "C" int cl4_bn_train_stats(const float* x, int n, int c, int hw, int ctot
   return cl4::launch_status();
 }
 
+// ... and their cross-rank form: the same partials folded into the packed vector sums[c][2] that the ranks exchange (cl4_bn_sync_stats_local
+// without its pass over the tensor); cl4_bn_sync_stats_final follows the all-reduce.
+__global__ __launch_bounds__(256) void bn_fold_partials_n_kernel(const double* __restrict__ partial, int nparts, double* __restrict__ sums, int c) {
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ch >= c) return;
+  double a, b;
+  channel_sums(partial, ch, a, b, nparts);
+  if ((threadIdx.x & 63) == 0) {
+    sums[2 * ch] = a;
+    sums[2 * ch + 1] = b;
+  }
+}
+extern "C" int cl4_bn_sync_stats_from_partials(const double* partial, int nparts, double* sums, int c, void* stream) {
+  CL4_REQUIRE(partial && sums && nparts > 0 && c > 0, "bn_sync_stats_from_partials: bad arguments");
+  hipLaunchKernelGGL(bn_fold_partials_n_kernel, dim3(cl4::cdiv(c, 4)), dim3(256), 0, cl4::as_stream(stream), partial, nparts, sums, c);
+  return cl4::launch_status();
+}
+
 extern "C" int cl4_bn_stats_from_partials(const double* partial, int nparts, long count, int c, float* mean, float* var, float* running_mean,
                                           float* running_var, float momentum, void* stream) {
   CL4_REQUIRE(partial && mean && var && nparts > 0 && count > 0 && c > 0, "bn_stats_from_partials: bad arguments");
@@ -753,10 +776,10 @@ extern "C" int cl4_bn_sync_bwd_local(const float* x, const float* dy, int n, int
   hipStream_t st = cl4::as_stream(stream);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, reduction_split(n * hw, c)), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
                      slope, s, dy_ctot, dy_coff, keep, keep_scale);
-  hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, c);
-  // the affine gradients are this rank's share (the gradient all-reduce averages them with everything else)
+  // the affine gradients are this rank's share (the gradient all-reduce averages them with everything else); the same kernel folds the partials
+  // into the exchange's packed vector
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, fsum, fsum + c, dgamma,
-                     dbeta, c, gamma_sign_src);
+                     dbeta, c, gamma_sign_src, sums);
   return cl4::launch_status();
 }
 
@@ -800,9 +823,8 @@ extern "C" int cl4_bn_sync_bwd_local_max(const float* x, const float* dy, int n,
   hipStream_t st = cl4::as_stream(stream);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(c, reduction_split(n * hw, c)), dim3(256), 0, st, x, dy, partial, mean, var, gamma, beta, eps, act,
                      slope, s, dy_ctot, dy_coff, (const uint8_t*)nullptr, 1.f, maxima);
-  hipLaunchKernelGGL(bn_fold_partials_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, sums, c);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cl4::cdiv(c, 64)), dim3(64), 0, st, (const double*)partial, fsum, fsum + c, dgamma,
-                     dbeta, c, gamma_sign_src);
+                     dbeta, c, gamma_sign_src, sums);
   return cl4::launch_status();
 }
 

@@ -1215,7 +1215,10 @@ def abn_train_forward(x, gamma, beta, running_mean=None, running_var=None, momen
     # the count slot exists only when a caller brings extra shards (an uninitialised double must not go through the all-reduce)
     sums = torch.empty(2 * c + (1 if extra_sums is not None else 0), dtype=torch.float64, device=x.device)
     ws = _workspace(x.device, bn_workspace_bytes(c))
-    call("cl4_bn_sync_stats_local", ptr(x), n, c, h * w, c, 0, ptr(sums), ptr(ws), ws.numel(), stream())
+    if partials is not None:          # the producing convolution's partial sums (conv2d(stats_out=...)): no pass over x on this rank
+        call("cl4_bn_sync_stats_from_partials", ptr(partials[0]), int(partials[1]), ptr(sums), c, stream())
+    else:
+        call("cl4_bn_sync_stats_local", ptr(x), n, c, h * w, c, 0, ptr(sums), ptr(ws), ws.numel(), stream())
     if extra_sums is not None:      # (a host scalar written into a device tensor is a synchronous copy: not inside a HIP-graph capture)
         sums[2 * c] = float(n * h * w)
         sums += extra_sums

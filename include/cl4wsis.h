@@ -636,6 +636,9 @@ int cl4_conv2d_fwd_planes_stats(const cl4_conv_desc* d, const void* xs, const fl
                                 int stats_np, void* workspace, size_t workspace_bytes, void* stream);
 int cl4_bn_stats_from_partials(const double* partial, int nparts, long count, int c, float* mean, float* var, float* running_mean,
                                float* running_var, float momentum, void* stream);
+/* ... cross-rank form (InPlaceABNSync, segmentation_module.py:17-19): the partials folded into the packed sums[c * 2] vector the ranks
+ * all-reduce — cl4_bn_sync_stats_local without its pass over the tensor; cl4_bn_sync_stats_final follows the exchange. */
+int cl4_bn_sync_stats_from_partials(const double* partial, int nparts, double* sums, int c, void* stream);
 /* Which two-plane format / arithmetic this build of the library uses for EVERY planes tensor (cl4_to_planes, the ys / post_s operands, the
  * fused bottleneck and stem outputs): 1 = fp16x3 (fp16 hi / lo of 16 x; weights from cl4_pack_conv_weight_f16x3 — the default build),
  * 0 = bf16x3 (bf16 hi / lo of x; weights from cl4_pack_conv_weight_bf16x3; hipcc -DCL4_F16_PLANES=0: the r02-r04 format). */

@@ -200,9 +200,11 @@ def test_convolution_leaves_the_batchnorm_partial_sums(gpu, shape, plan):
     assert _rel(yd, ref64) < 1e-6
 
 
-def test_train_mode_abn_reads_the_convolutions_partial_sums(gpu, monkeypatch):
+@pytest.mark.parametrize("one_rank", [True, False])
+def test_train_mode_abn_reads_the_convolutions_partial_sums(gpu, monkeypatch, one_rank):
     """conv -> train-mode ABN of the differentiated networks (body_train.conv_abn_train) with and without the fused statistics: the same
-    mean / variance (1e-6 relative to the standard deviation), running statistics and activation."""
+    mean / variance (1e-6 relative to the standard deviation), running statistics and activation — on the one-rank path
+    (cl4_bn_stats_from_partials) and on the two-phase path of N > 1 (cl4_bn_sync_stats_from_partials -> exchange -> final)."""
     import torch.nn as tnn
     from cl4wsis_amd import body_train, nn as cnn, ops
     if not ops.planes_f16() or body_train.PRECISION != 3:
@@ -213,6 +215,7 @@ def test_train_mode_abn_reads_the_convolutions_partial_sums(gpu, monkeypatch):
     conv = conv.to(gpu)
     x = (torch.randn(4, 256, 33, 33, generator=g) * 1.3 + 0.2).to(gpu)
     outs = []
+    monkeypatch.setattr(ops, "ABN_ONE_RANK", one_rank)
     for fused in (False, True):
         monkeypatch.setattr(ops, "CONV_STATS", fused)
         bn = cnn.InPlaceABNSync(256).to(gpu)
