@@ -142,6 +142,7 @@ class PackBatch:
         self.entries = {}        # (id(conv), key) -> (conv, key, transposed, PackedWeight)
         self.scales = {}         # id(bn) -> (bn, |weight| + eps tensor): the InPlaceABN scales ride along (cl4_abs_eps_batched)
         self._table = None       # device job tables and what they were built for
+        self._retired = []       # earlier tables (graphs captured with them keep replaying them)
         self.launches = 0
 
     def __enter__(self):
@@ -184,6 +185,8 @@ class PackBatch:
             j.w, j.out, j.first, j.n, j.eps = bn.weight.data_ptr(), val.data_ptr(), afirst, bn.weight.numel(), bn.eps
             afirst += bn.weight.numel()
             dev = bn.weight.device
+        if self._table is not None:      # a captured graph may still read the table it was captured with: retired, never freed (as ops._Scratch)
+            self._retired.append(self._table)
         self._table = {"packs": (upload(jobs, dev), len(self.entries), first), "scales": (upload(ajobs, dev), len(self.scales), afirst),
                        "sig": self._signature()}
 
