@@ -714,7 +714,13 @@ class Trainer:
             from .nn import CACHE
             for prm in self._branch.aspp_parameters():    # the eager ASPP tail derives its operands from the current weights itself
                 CACHE.touch(prm)
-            self._distributed_tail(P["out"][p], P.get("pool"))
+            if "_tail" in P["out"][p]:
+                self._distributed_tail(P["out"][p], P.get("pool"))
+            else:                                        # the whole backward ran inside the graph: every bucket goes out now
+                for i in range(len(self.buckets.fb.sizes)):
+                    self.buckets.ready(i)
+                self.buckets.finish()
+                self.optimizer.step()
         if P.get("gB"):
             torch.cuda.current_stream().wait_stream(self._side_stream)      # the step ends when the next batch's frozen stage has
         return P["out"][p]
@@ -802,7 +808,14 @@ class Trainer:
             main.wait_stream(self._side2)
             self._stamp("main.joined")
 
-        return self._trainable_stage(P["fz"][q], P["old"][q], P["l"][q], None, (H, W), split_tail=self.buckets.distributed, join_end=join_end)
+        # r05, N > 1 at the smallest per-GPU batches: the ASPP backward stays INSIDE the graph (beside the frozen chains, like the one-process
+        # path) and the gradient buckets go out behind the graph. The eager tail behind the graph could hide at most its own ~0.4 ms of the
+        # all-reduce (63 MB: ~2 ms over xGMI at N = 8 by the ring estimate) and costs 0.45 ms of exposed kernels, because one graph is one
+        # stream-ordered unit and the frozen chains end ~1 ms after the trainable stage (finding 49). Larger per-GPU batches (N = 2: a tail of
+        # ~1 ms against an all-reduce of ~1.3 ms) keep the overlapped tail. CL4_TAIL_IN_GRAPH_MAX_BATCH [4]; 0 = always the eager tail.
+        in_graph = self.buckets.distributed and P["x"][q].shape[0] <= int(os.environ.get("CL4_TAIL_IN_GRAPH_MAX_BATCH", "4"))
+        return self._trainable_stage(P["fz"][q], P["old"][q], P["l"][q], None, (H, W), split_tail=self.buckets.distributed and not in_graph,
+                                     join_end=join_end)
 
     def _frozen_new(self, images, l1h, fork=None):
         """The part of the step that only the FROZEN new model and the batch feed (train.py:259-263, 421-449): semantic forward on
