@@ -607,7 +607,9 @@ def worker(a):
                                    "513x513, ResNet101+DeepLabV3+Panoptic-DeepLab, run_refine on, random-init weights, "
                                    "label stage fed by the networks' own outputs (e2e-random mode)",
                        "global_batch": GLOBAL_BATCH, "per_gpu_batch": b, "crop": CROP, "parallelism": f"dp{world}",
-                       "arithmetic": "fp32 tensors; convolutions as split 16-bit MFMA products with fp32 accumulation: bf16x3 frozen networks; differentiated "
+                       "arithmetic": "fp32 tensors; convolutions as split 16-bit MFMA products with fp32 accumulation: frozen networks x3 (three products per MAC: "
+                                     + ("fp16 hi / lo planes, 22-bit operands" if __import__("cl4wsis_amd.ops", fromlist=["x"]).planes_f16() else "bf16 hi / lo planes, 16-17-bit operands")
+                                     + "; bf16x3 on the fp32-input kernels of the thin layers); differentiated "
                                      "convs " + {0: "exact fp32 MFMA", 1: "bf16x3", 2: "bf16x6 (six bf16 products, fp32-level)",
                                                  3: "fp16x3 (three fp16 products on split-fp16 operands with power-of-two scales, fp32-level; bf16x6 where "
                                                     "the shape is not routed)"}[__import__("cl4wsis_amd.heads", fromlist=["x"]).TRAIN_PRECISION]
